@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training meshes/s of the plain spiral autoencoder at 6890 vertices,
+batch 64 per GPU, fp32 (BASELINE.json configs[1]); synthetic meshes resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL gradient all-reduce)
+
+One "step" = the reference's training iteration (train_funcs.py:495-510): zero_grad, forward,
+L1 + 1e-2 * edge-ratio loss, backward, [gradient all-reduce], Adam(lr 1e-3, wd 5e-5) step.
+Prints ONE JSON line (rank 0) with the whole-job throughput, the roofline of the dominant HIP
+kernel (HIP events recorded by the library on the launch stream) and a CPU baseline (the
+oracle = the reference's formulation, on this box's host cores; a reported number, not a
+target).  Nothing here reads /root/reference.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import re
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FE = [[3, 16, 32, 64, 128], [[], [], [], [], []]]
+FD = [[128, 64, 32, 32, 16], [[], [], [], [], 3]]
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+def conv_launch_table(model, B):
+    """Algorithmic FLOPs / bytes per launch of every conv kernel instance, keyed by the kernel
+    name the library's profiler reports (DESIGN.md 'Roofline accounting')."""
+    out = {}
+
+    def add(name, flops, nbytes):
+        e = out.setdefault(name, {"flops": 0.0, "bytes": 0.0, "launches": 0})
+        e["flops"] += flops; e["bytes"] += nbytes; e["launches"] += 1
+
+    def nt(c):
+        t = (c + 15) // 16
+        return 1 if t <= 1 else 2 if t <= 2 else 4 if t <= 4 else 8
+    first = True
+    for stack in (model._enc_stack, model._dec_stack):
+        for st in stack.steps:
+            if st.kind != "conv":
+                continue
+            K = st.S * st.cin
+            fl = 2.0 * B * st.R * K * st.cout
+            vec = "true" if st.cin % 4 == 0 else "false"
+            # fwd: read each needed input row once + weights, write output
+            byt = 4.0 * (B * st.n_in * st.cin + B * st.R * st.cout + st.cout * K)
+            add("gather_gemm_kernel<%d, %s, false, false>" % (nt(st.cout), vec), fl, byt)
+            vecb = "true" if st.cout % 4 == 0 else "false"
+            if not (first and stack is model._enc_stack):
+                add("gather_gemm_kernel<%d, %s, true, true>" % (nt(st.cin), vecb), fl, byt)
+            ctw = 2 if K > 64 else 1
+            add("wgrad_kernel<%d, %d, %s>" % (nt(st.cout), ctw, vec), fl, byt)
+            first = False
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE: 64)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured hipGraph")
+    ap.add_argument("--cpu-iters", type=int, default=2)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import semantichuman_amd as sh
+    from semantichuman_amd import _lib, synthetic
+    from semantichuman_amd.hierarchy import load_hierarchy
+    from semantichuman_amd.parallel import GradientAllReducer
+    _lib.load()                                   # fail loudly if the HIP library is missing
+
+    h = load_hierarchy(os.path.join(ROOT, "tests", "golden", "template6890.npz"))
+    B = args.batch
+    torch.manual_seed(2)                          # cfgs.py:46 seed; identical replicas on every rank
+    model = sh.SpiralAutoencoder(FE, FD, 256, h.sizes, h.spiral_sizes, h.spirals, h.D, h.U, dev)
+    init_state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    optim = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-5, capturable=True, foreach=True)   # main.py:262
+    ft = sh.FaceTables(h.faces, h.sizes[0] + 1, dev)
+    reducer = GradientAllReducer(model, bucket_cap_mb=64.0) if world > 1 else None
+
+    n_data = 16 * B                               # resident synthetic set, disjoint per rank
+    data = torch.from_numpy(synthetic.synth_batch(h.verts, n_data, seed=100 + rank)).to(dev)
+    test = torch.from_numpy(synthetic.synth_batch(h.verts, B, seed=7)).to(dev)
+
+    xin = torch.empty((B, h.sizes[0] + 1, 3), dtype=torch.float32, device=dev)
+    loss_out = torch.zeros((), device=dev)
+
+    def fwd_bwd():
+        optim.zero_grad(set_to_none=True)
+        x_hat, _ = model(xin)
+        loss = sh.l1_loss(xin, x_hat) + 1e-2 * sh.edge_ratio_loss(x_hat, xin, ft)     # traincfg.yaml:41
+        if reducer:
+            reducer.prepare()
+        loss.backward()
+        loss_out.copy_(loss.detach())
+
+    use_graph = (not args.no_graph) and world == 1
+    graph = None
+    if use_graph:
+        # capture forward+backward+Adam once, replay per step: removes ~100 host launches/step
+        xin.copy_(data[:B])
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(3):                    # warm allocator, Adam state
+                fwd_bwd(); optim.step()
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            fwd_bwd(); optim.step()
+        # capture must not change what is measured: restore the initial weights / optimizer
+        model.load_state_dict(init_state)
+        for st in optim.state.values():
+            for v in st.values():
+                if torch.is_tensor(v):
+                    v.zero_()
+
+    def step(i):
+        o = (i * B) % n_data
+        xin.copy_(data[o:o + B])
+        if graph is not None:
+            graph.replay()
+        else:
+            fwd_bwd()
+            if reducer:
+                reducer.finish()
+            optim.step()
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss_out.item())
+
+    with torch.no_grad():
+        xh, _ = model(test)
+        l2mm = float(sh.vertex_l2_mm(xh, test).item())
+
+    result = {
+        "metric": "training meshes/sec at 6890 verts, batch=64",
+        "value": world * B * args.steps / elapsed,
+        "unit": "meshes/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "plain spiral AE training step (fwd + L1 + 1e-2*edge loss + bwd + Adam), box_sphere(42,42,20) "
+                               "6890-vertex template, levels %s, spiral sizes %s, nz 256, 28.55M params" % (h.sizes, h.spiral_sizes[:-1]),
+                   "global_batch": world * B, "per_gpu_batch": B, "parallelism": "dp%d" % world,
+                   "launch": "hipGraph replay" if graph is not None else "eager"},
+        "train_loss_last": final_loss,
+        "recon_l2_mm_after_run": l2mm,
+    }
+
+    # ---- roofline of the dominant kernel: HIP events recorded by the library around every launch
+    if rank == 0 and not args.no_roofline:
+        nprof = 5
+        _lib.profile_enable(True)
+        for i in range(nprof):
+            o = (i * B) % n_data
+            xin.copy_(data[o:o + B])
+            fwd_bwd()
+            if reducer:
+                reducer.finish()
+            optim.step()
+        torch.cuda.synchronize()
+        recs = _lib.profile_records()
+        _lib.profile_enable(False)
+        agg = {}
+        for name, ms in recs:
+            a = agg.setdefault(name, [0, 0.0])
+            a[0] += 1; a[1] += ms
+        table = conv_launch_table(model, B)
+        kernels = []
+        for name, (cnt, tot) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            e = {"kernel": name, "launches_per_step": cnt / nprof, "avg_ms": tot / cnt, "ms_per_step": tot / nprof}
+            if name in table and table[name]["launches"] == cnt / nprof:
+                e["tflops"] = table[name]["flops"] / (tot / nprof * 1e-3) / 1e12
+            kernels.append(e)
+        dom = kernels[0]
+        if "tflops" in dom:
+            result["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
+                                  "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                                  "avg_launch_ms": dom["avg_ms"], "launches_per_step": dom["launches_per_step"]}
+        else:
+            result["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                  "frac": None, "traffic": None, "avg_launch_ms": dom["avg_ms"]}
+        result["kernel_breakdown"] = kernels[:8]
+        result["hip_kernel_ms_per_step"] = sum(k["ms_per_step"] for k in kernels)
+
+    # ---- CPU baseline: the oracle (reference formulation) on this box's host cores, rank 0, N=1
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import ref_cpu
+        ncores = os.cpu_count() or 1
+        torch.set_num_threads(ncores)
+        S, D, U = h.dense_constants()
+        om = ref_cpu.SpiralAEOracle(FE, FD, 256, h.sizes, h.spiral_sizes, S, D, U)
+        om.load_state_dict(init_state)
+        oopt = torch.optim.Adam(om.parameters(), lr=1e-3, weight_decay=5e-5)
+        xc = data[:B].cpu()
+        ref_cpu.train_step(om, oopt, xc, faces=h.faces, edgereg_w=1e-2)          # warm-up
+        t0 = time.perf_counter()
+        for _ in range(args.cpu_iters):
+            ref_cpu.train_step(om, oopt, xc, faces=h.faces, edgereg_w=1e-2)
+        ct = time.perf_counter() - t0
+        result["cpu_baseline"] = {"value": B * args.cpu_iters / ct, "unit": "meshes/s", "cores": ncores, "kind": "port",
+                                  "sample": "%d training steps at batch %d (same template, same init) after 1 warm-up, "
+                                            "torch CPU fp32, oracle/ref_cpu.py" % (args.cpu_iters, B)}
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,167 @@
+/*
+ * sh_kernels.h - C ABI of libsh_kernels.so: the MI355X (gfx950) kernels behind the
+ * spiral-convolution mesh-autoencoder training path of SemanticHuman.
+ *
+ * The reference (pure Python/PyTorch) has no FFI layer; its boundary for this path is the
+ * nn.Module surface of models.py.  Each entry point below names the reference lines whose
+ * ATen dispatches it replaces.  A maintainer binds them with ctypes;
+ * semantichuman_amd/_lib.py is exactly that binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc / torch caching allocator); tables are
+ *     int32, tensors fp32; nothing is allocated, freed or retained by the library
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it
+ *     (no synchronisation, no hipMalloc: safe under hipGraph capture)
+ *   - activations are addressed with explicit element strides so one kernel serves both
+ *       batch-major  [B][rows][C]  (the reference layout):  sv = C,     sb = rows*C
+ *       vertex-major [rows][B][C]  (the fast internal layout): sv = B*C, sb = C
+ *     element (row r, batch b, channel c) lives at  base + r*sv + b*sb + c
+ *   - return value: 0 on success, negative sh_status on failure (never throws);
+ *     sh_last_error() gives a thread-local message
+ */
+#ifndef SH_KERNELS_H
+#define SH_KERNELS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* sh_stream_t;
+
+#if defined(__GNUC__)
+#define SH_API __attribute__((visibility("default")))
+#else
+#define SH_API
+#endif
+
+enum sh_status {
+    SH_OK = 0,
+    SH_ERR_INVALID_ARG = -1,   /* null pointer, negative size, misaligned stride */
+    SH_ERR_UNSUPPORTED = -2,   /* shape outside what the kernels were built for */
+    SH_ERR_WORKSPACE = -3,     /* workspace too small */
+    SH_ERR_LAUNCH = -4         /* hipLaunchKernel reported an error */
+};
+
+/* activation ids: the strings reference models.py:19-32 accepts */
+enum sh_act {
+    SH_ACT_IDENTITY = 0,
+    SH_ACT_RELU = 1,
+    SH_ACT_ELU = 2,         /* alpha = 1 */
+    SH_ACT_LEAKY_RELU = 3,  /* slope 0.02 (models.py:24) */
+    SH_ACT_SIGMOID = 4,
+    SH_ACT_TANH = 5
+};
+
+SH_API int sh_version(void);
+SH_API const char* sh_last_error(void);
+
+/* Optional per-kernel timing with HIP events recorded on the launch stream, immediately before
+ * and after each kernel launch (used by bench.py for the roofline figures; off by default, must
+ * be off while a hipGraph is being captured).  sh_profile_get synchronises on the events. */
+SH_API int sh_profile_enable(int on);                 /* on=1 start recording (clears), on=0 stop */
+SH_API int sh_profile_count(void);
+SH_API int sh_profile_get(int i, char* name, int name_len, float* ms);
+
+/* ---------------------------------------------------------------------------------------------
+ * SpiralConv forward.  Replaces models.py:40-51 (aten::index gather, aten::addmm, activation,
+ * dummy-row mask) with one fused kernel; the gathered [B*(N+1), S*Cin] matrix is never
+ * materialised.
+ *   y[r,b,:] = act( sum_s x[table[r,s], b, :] . W[:, s*Cin:(s+1)*Cin]^T + bias )      r < R
+ *   y[zero_row,b,:] = 0   (zero_row < 0: no masking)
+ * table: int32 [R][S], values in [0, n_in) - the caller has already mapped the reference's -1
+ * to the dummy row (torch negative-index wrap, models.py:42).  R may be smaller than n_in: a
+ * row-select down-sampling D (models.py:127) is fused by passing table = spirals[sel].
+ * weight: [Cout][S*Cin] row-major = nn.Linear.weight (models.py:17); bias may be NULL.
+ */
+SH_API int sh_spiral_conv_fwd(const float* x, int64_t x_sv, int64_t x_sb,
+                       const int32_t* table, const float* weight, const float* bias,
+                       float* y, int64_t y_sv, int64_t y_sb,
+                       int B, int R, int S, int Cin, int Cout, int act, int zero_row,
+                       sh_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * SpiralConv backward w.r.t. the input.  Replaces autograd's aten::mm (dG = dY.W) +
+ * aten::_index_put_impl_(accumulate=True) scatter-add by a gather over the
+ * transposed table - no atomics, fixed summation order, bitwise reproducible:
+ *   dx[u,b,:] = sum_s ( sum_{e in [lptr[u*S+s], lptr[u*S+s+1])} dpre[lsrc[e], b, :] ) . W[:, s*Cin:(s+1)*Cin]
+ * weight_t: [Cin][S*Cout], weight_t[ci][s*Cout+co] = weight[co][s*Cin+ci]  (sh_weight_transpose).
+ * Optional epilogue (yprev != NULL): dx is multiplied by act_prev'(yprev) evaluated from the
+ * OUTPUT yprev of the layer that produced x, and row zero_row is forced to 0, so dx is directly
+ * that layer's pre-activation gradient (aten::elu_backward + mask backward).
+ */
+SH_API int sh_spiral_conv_bwd_data(const float* dpre, int64_t dp_sv, int64_t dp_sb,
+                            const int32_t* lptr, const int32_t* lsrc, const float* weight_t,
+                            float* dx, int64_t dx_sv, int64_t dx_sb,
+                            const float* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row,
+                            int B, int n_in, int S, int Cin, int Cout,
+                            sh_stream_t stream);
+
+/* weight [Cout][S*Cin] -> weight_t [Cin][S*Cout] (see above). */
+SH_API int sh_weight_transpose(const float* weight, float* weight_t, int S, int Cin, int Cout, sh_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * SpiralConv backward w.r.t. weight and bias.  Replaces aten::mm dW = dY^T.G; the
+ * gathered matrix G is re-gathered on the fly.  Two-stage, deterministic: per-block partial
+ * slabs in `workspace`, then a fixed-order reduction.
+ *   dW[co, s*Cin+ci] = sum_{r,b} dpre[r,b,co] * x[table[r,s], b, ci];   dbias[co] = sum_{r,b} dpre[r,b,co]
+ * dbias may be NULL.  Results OVERWRITE dW/dbias.
+ */
+SH_API size_t sh_spiral_conv_bwd_wgt_workspace(int B, int R, int S, int Cin, int Cout);
+SH_API int sh_spiral_conv_bwd_wgt(const float* dpre, int64_t dp_sv, int64_t dp_sb,
+                           const float* x, int64_t x_sv, int64_t x_sb, const int32_t* table,
+                           float* dW, float* dbias, void* workspace, size_t workspace_bytes,
+                           int B, int R, int S, int Cin, int Cout,
+                           sh_stream_t stream);
+
+/* dpre = dy * act'(y) with row zero_row forced to 0 (aten::elu_backward + mask, models.py:46-51). */
+SH_API int sh_act_backward(const float* dy, int64_t dy_sv, int64_t dy_sb,
+                    const float* y, int64_t y_sv, int64_t y_sb,
+                    float* dpre, int64_t dp_sv, int64_t dp_sb,
+                    int B, int R, int C, int act, int zero_row, sh_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Sparse mesh re-sampling.  Replaces the dense aten::bmm of models.py:127 (D) and :148 (U), and
+ * with the transposed CSR their backward:
+ *   y[r,b,:] = sum_{e in [rowptr[r], rowptr[r+1])} val[e] * x[col[e], b, :]
+ * Optional epilogue as in sh_spiral_conv_bwd_data (yprev != NULL).
+ */
+SH_API int sh_spmm(const int32_t* rowptr, const int32_t* col, const float* val,
+            const float* x, int64_t x_sv, int64_t x_sb,
+            float* y, int64_t y_sv, int64_t y_sb,
+            const float* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row,
+            int B, int rows, int C, sh_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Losses / metric.  All reductions are two-stage with a fixed order (no atomics).
+ * workspace: at least sh_reduce_workspace() bytes.
+ */
+SH_API size_t sh_reduce_workspace(void);
+
+/* loss[0] = mean |a - b| over n elements           (F.l1_loss, train_funcs.py:501) */
+SH_API int sh_l1_loss_fwd(const float* a, const float* b, int64_t n, float* loss, void* workspace, sh_stream_t stream);
+/* grad_b[i] = sign(b[i]-a[i]) * gscale[0] / n      (gscale: device scalar = upstream gradient) */
+SH_API int sh_l1_loss_bwd(const float* a, const float* b, int64_t n, const float* gscale, float* grad_b, sh_stream_t stream);
+
+/* out[0] = mean_{b<B, v<N} | scale * (a[b,v,:3] - b[b,v,:3]) |_2  for contiguous [B][N1][3] tensors,
+ * rows v >= N (the dummy row) excluded                           (test_funcs.py:41-49) */
+SH_API int sh_vertex_l2(const float* a, const float* b, int B, int N1, int N, float scale, float* out,
+                 void* workspace, sh_stream_t stream);
+
+/* Edge-length-ratio regulariser (train_funcs.py:12-39, 503-508), batched on device:
+ *   loss[0] = mean_{b,f} sum_{e in 3 edges} | |e_rec| / (|e_gt| + 1e-5) - 1 |
+ * x_hat, x: contiguous [B][N1][3]; faces int32 [F][3].
+ * bwd: corner lists (vptr [N1+1], vcorner [3F], entries f*3+k) give an atomic-free gradient
+ *   grad[b,v,:] = gscale[0]/(B*F) * sum_{corners of v} d score / d x_hat[b,v,:] */
+SH_API int sh_edge_ratio_loss_fwd(const float* x_hat, const float* x, const int32_t* faces, int B, int N1, int F,
+                           float* loss, void* workspace, sh_stream_t stream);
+SH_API int sh_edge_ratio_loss_bwd(const float* x_hat, const float* x, const int32_t* faces,
+                           const int32_t* vptr, const int32_t* vcorner, int B, int N1, int F,
+                           const float* gscale, float* grad, sh_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SH_KERNELS_H */

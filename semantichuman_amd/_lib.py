@@ -1,0 +1,105 @@
+"""ctypes binding of libsh_kernels.so (the C ABI declared in include/sh_kernels.h).
+
+This is the binding a maintainer of the reference would add.  There is NO
+fallback: if the shared library is missing or a call fails, a RuntimeError is raised - the
+product path never silently runs on a CPU/PyTorch substitute.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsh_kernels.so")
+
+ACT_IDS = {"identity": 0, "relu": 1, "elu": 2, "leaky_relu": 3, "sigmoid": 4, "tanh": 5}
+
+# name -> (restype, argtypes); must list every symbol of include/sh_kernels.h
+_P, _I, _L = c_void_p, c_int, c_int64
+SIGNATURES = {
+    "sh_version": (c_int, []),
+    "sh_last_error": (c_char_p, []),
+    "sh_profile_enable": (c_int, [_I]),
+    "sh_profile_count": (c_int, []),
+    "sh_profile_get": (c_int, [_I, c_char_p, _I, ctypes.POINTER(c_float)]),
+    "sh_spiral_conv_fwd": (c_int, [_P, _L, _L, _P, _P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "sh_spiral_conv_bwd_data": (c_int, [_P, _L, _L, _P, _P, _P, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "sh_weight_transpose": (c_int, [_P, _P, _I, _I, _I, _P]),
+    "sh_spiral_conv_bwd_wgt_workspace": (c_size_t, [_I, _I, _I, _I, _I]),
+    "sh_spiral_conv_bwd_wgt": (c_int, [_P, _L, _L, _P, _L, _L, _P, _P, _P, _P, c_size_t, _I, _I, _I, _I, _I, _P]),
+    "sh_act_backward": (c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _P]),
+    "sh_spmm": (c_int, [_P, _P, _P, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _P]),
+    "sh_reduce_workspace": (c_size_t, []),
+    "sh_l1_loss_fwd": (c_int, [_P, _P, _L, _P, _P, _P]),
+    "sh_l1_loss_bwd": (c_int, [_P, _P, _L, _P, _P, _P]),
+    "sh_vertex_l2": (c_int, [_P, _P, _I, _I, _I, c_float, _P, _P, _P]),
+    "sh_edge_ratio_loss_fwd": (c_int, [_P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "sh_edge_ratio_loss_bwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
+}
+
+_lib = None
+
+
+class KernelLibraryError(RuntimeError):
+    pass
+
+
+def load(path: str | None = None):
+    """Load (once) and return the ctypes library.  Raises KernelLibraryError if it is absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise KernelLibraryError(
+            "semantichuman_amd: HIP kernel library not found at %s. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C semantichuman_amd/csrc`). "
+            "There is no CPU fallback." % p)
+    try:
+        lib = ctypes.CDLL(p)
+    except OSError as e:
+        raise KernelLibraryError("semantichuman_amd: cannot load %s: %s" % (p, e)) from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise KernelLibraryError("semantichuman_amd: %s does not export %s" % (p, name)) from e
+        fn.restype, fn.argtypes = res, args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().sh_last_error()
+        raise RuntimeError("%s failed (status %d): %s" % (what, rc, msg.decode() if msg else ""))
+
+
+def stream_ptr():
+    """hipStream_t of torch's current stream (kernels are only ever enqueued there, so they
+    are ordered with torch's own work and can be captured into a hipGraph)."""
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def profile_enable(on: bool):
+    check(load().sh_profile_enable(1 if on else 0), "sh_profile_enable")
+
+
+def profile_records():
+    """[(kernel name, milliseconds)] recorded since profile_enable(True); synchronises."""
+    lib = load()
+    out = []
+    buf = ctypes.create_string_buffer(128)
+    ms = c_float(0)
+    for i in range(lib.sh_profile_count()):
+        check(lib.sh_profile_get(i, buf, 128, ctypes.byref(ms)), "sh_profile_get")
+        out.append((buf.value.decode(), ms.value))
+    return out
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return c_void_p(0 if t is None else t.data_ptr())

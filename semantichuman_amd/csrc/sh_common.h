@@ -1,0 +1,77 @@
+// Shared device helpers for the gfx950 kernels of libsh_kernels.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/sh_kernels.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------- error plumbing
+void sh_set_error(const char* fmt, ...);
+
+#define SH_REQUIRE(cond, code, ...)            \
+    do {                                       \
+        if (!(cond)) {                         \
+            sh_set_error(__VA_ARGS__);         \
+            return (code);                     \
+        }                                      \
+    } while (0)
+
+#define SH_CHECK_LAUNCH(name)                                                       \
+    do {                                                                            \
+        hipError_t e_ = hipGetLastError();                                          \
+        if (e_ != hipSuccess) {                                                     \
+            sh_set_error("%s: launch failed: %s", (name), hipGetErrorString(e_));   \
+            return SH_ERR_LAUNCH;                                                   \
+        }                                                                           \
+    } while (0)
+
+// ---------------------------------------------------------------------------- kernel timing
+// RAII: records a hipEvent pair on `st` around the launches made inside its scope (only when
+// profiling was enabled through sh_profile_enable).
+bool sh_profile_on();
+void sh_profile_push(const char* name, hipEvent_t a, hipEvent_t b);
+struct ShProfScope {
+    hipStream_t st; hipEvent_t a, b; bool on; char name[96];
+    ShProfScope(hipStream_t s, const char* fmt, ...);
+    ~ShProfScope();
+};
+
+// ---------------------------------------------------------------------------- activations
+// Forward activation (reference models.py:19-32) ...
+__device__ __forceinline__ float sh_act_fwd(float v, int act) {
+    switch (act) {
+        case SH_ACT_RELU: return v > 0.f ? v : 0.f;
+        case SH_ACT_ELU: return v > 0.f ? v : expm1f(v);
+        case SH_ACT_LEAKY_RELU: return v > 0.f ? v : 0.02f * v;
+        case SH_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        case SH_ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+// ... and its derivative expressed through the activation OUTPUT y, so the backward pass needs
+// nothing but the tensor the next layer consumed anyway (no saved pre-activation).
+__device__ __forceinline__ float sh_act_grad_from_out(float y, int act) {
+    switch (act) {
+        case SH_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+        case SH_ACT_ELU: return y > 0.f ? 1.f : y + 1.f;          // exp(x) = elu(x) + 1 for x <= 0
+        case SH_ACT_LEAKY_RELU: return y > 0.f ? 1.f : 0.02f;
+        case SH_ACT_SIGMOID: return y * (1.f - y);
+        case SH_ACT_TANH: return 1.f - y * y;
+        default: return 1.f;
+    }
+}
+
+__device__ __forceinline__ float sh_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+static inline int sh_ilog2_floor(int v) {
+    int l = 0;
+    while ((1 << (l + 1)) <= v) ++l;
+    return l;
+}
+static inline int sh_cdiv(int a, int b) { return (a + b - 1) / b; }

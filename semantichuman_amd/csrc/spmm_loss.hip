@@ -1,0 +1,267 @@
+// HBM-bound companions of the spiral convolution: sparse mesh re-sampling (D / U and their
+// transposes) and the loss / metric reductions.  All are streaming kernels: 16-byte accesses
+// where the layout allows, grid capped at ~8 workgroups per CU with grid-stride loops, two-stage
+// fixed-order reductions (no atomics -> bitwise reproducible).
+#include "sh_common.h"
+
+namespace {
+
+constexpr int RED_BLOCKS = 1024;   // partial sums of the first reduction stage
+
+// y[r,b,:] = sum_e val[e] * x[col[e],b,:]   (+ optional act'(yprev) epilogue, zero_row)
+template <bool VEC>
+__global__ void spmm_kernel(const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ val,
+                            const float* __restrict__ x, long x_sv, long x_sb, float* __restrict__ y, long y_sv, long y_sb,
+                            const float* __restrict__ yprev, long yp_sv, long yp_sb, int act, int zero_row, int B, int rows,
+                            int C) {
+    const int CW = VEC ? C / 4 : C;
+    const long n = (long)rows * B * CW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int cw = (int)(i % CW);
+        const long t = i / CW;
+        const int b = (int)(t % B);
+        const int r = (int)(t / B);
+        const int e0 = rowptr[r], e1 = rowptr[r + 1];
+        const long xo = (long)b * x_sb + (VEC ? 4 * cw : cw);
+        const long yo = (long)r * y_sv + (long)b * y_sb + (VEC ? 4 * cw : cw);
+        if (VEC) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int e = e0; e < e1; ++e) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (long)col[e] * x_sv + xo);
+                const float w = val[e];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = fmaf(w, xv[j], acc[j]);
+            }
+            if (yprev) {
+                const f32x4 yv = *reinterpret_cast<const f32x4*>(yprev + (long)r * yp_sv + (long)b * yp_sb + 4 * cw);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] *= sh_act_grad_from_out(yv[j], act);
+            }
+            if (r == zero_row) acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(y + yo) = acc;
+        } else {
+            float acc = 0.f;
+            for (int e = e0; e < e1; ++e) acc = fmaf(val[e], x[(long)col[e] * x_sv + xo], acc);
+            if (yprev) acc *= sh_act_grad_from_out(yprev[(long)r * yp_sv + (long)b * yp_sb + cw], act);
+            y[yo] = r == zero_row ? 0.f : acc;
+        }
+    }
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = sh_wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+    if (threadIdx.x == 0)
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+    return t;   // valid in thread 0
+}
+
+__global__ void l1_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, long n, float* __restrict__ part) {
+    __shared__ float red[16];
+    float s = 0.f;
+    const long n4 = n >> 2;
+    const f32x4* a4 = reinterpret_cast<const f32x4*>(a);
+    const f32x4* b4 = reinterpret_cast<const f32x4*>(b);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 d = a4[i] - b4[i];
+        s += (fabsf(d[0]) + fabsf(d[1])) + (fabsf(d[2]) + fabsf(d[3]));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) s += fabsf(a[(n4 << 2) + threadIdx.x] - b[(n4 << 2) + threadIdx.x]);
+    const float t = block_sum(s, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+// out[0] = (sum of part[0..np)) * scale, summed in a fixed order in double
+__global__ void final_sum_kernel(const float* __restrict__ part, int np, double scale, float* __restrict__ out) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < np; i += 256) s += (double)part[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)(red[0] * scale);
+}
+
+__global__ void l1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, long n, const float* __restrict__ gscale,
+                              float* __restrict__ g) {
+    const float sc = gscale[0] / (float)n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float d = b[i] - a[i];
+        g[i] = d > 0.f ? sc : (d < 0.f ? -sc : 0.f);
+    }
+}
+
+__global__ void vertex_l2_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, int B, int N1, int N, float scale,
+                                         float* __restrict__ part) {
+    __shared__ float red[16];
+    float s = 0.f;
+    const long n = (long)B * N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long bb = i / N, v = i - bb * N;
+        const long o = (bb * N1 + v) * 3;
+        const float dx = (a[o] - b[o]) * scale, dy = (a[o + 1] - b[o + 1]) * scale, dz = (a[o + 2] - b[o + 2]) * scale;
+        s += sqrtf(dx * dx + dy * dy + dz * dz);
+    }
+    const float t = block_sum(s, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+__device__ __forceinline__ float edge_len(const float* p, int i, int j) {
+    const float dx = p[3 * i] - p[3 * j], dy = p[3 * i + 1] - p[3 * j + 1], dz = p[3 * i + 2] - p[3 * j + 2];
+    return sqrtf(dx * dx + dy * dy + dz * dz);
+}
+
+__global__ void edge_loss_partial_kernel(const float* __restrict__ xh, const float* __restrict__ x, const int* __restrict__ faces,
+                                         int B, int N1, int F, float* __restrict__ part) {
+    __shared__ float red[16];
+    float s = 0.f;
+    const long n = (long)B * F;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long bb = i / F;
+        const int f = (int)(i - bb * F);
+        const int ia = faces[3 * f], ib = faces[3 * f + 1], ic = faces[3 * f + 2];
+        const float* ph = xh + bb * N1 * 3;
+        const float* pg = x + bb * N1 * 3;
+        s += fabsf(edge_len(ph, ia, ib) / (edge_len(pg, ia, ib) + 0.00001f) - 1.f);
+        s += fabsf(edge_len(ph, ib, ic) / (edge_len(pg, ib, ic) + 0.00001f) - 1.f);
+        s += fabsf(edge_len(ph, ia, ic) / (edge_len(pg, ia, ic) + 0.00001f) - 1.f);
+    }
+    const float t = block_sum(s, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+// d/dp_i | |p_i - p_j| / t - 1 |  accumulated into g[3]
+__device__ __forceinline__ void edge_grad(const float* ph, const float* pg, int i, int j, float* g) {
+    const float dx = ph[3 * i] - ph[3 * j], dy = ph[3 * i + 1] - ph[3 * j + 1], dz = ph[3 * i + 2] - ph[3 * j + 2];
+    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float t = edge_len(pg, i, j) + 0.00001f;
+    const float r = len / t - 1.f;
+    const float sg = r > 0.f ? 1.f : (r < 0.f ? -1.f : 0.f);
+    if (len > 0.f) {
+        const float k = sg / (len * t);
+        g[0] += k * dx; g[1] += k * dy; g[2] += k * dz;
+    }
+}
+
+__global__ void edge_loss_bwd_kernel(const float* __restrict__ xh, const float* __restrict__ x, const int* __restrict__ faces,
+                                     const int* __restrict__ vptr, const int* __restrict__ vcorner, int B, int N1, int F,
+                                     const float* __restrict__ gscale, float* __restrict__ grad) {
+    const float sc = gscale[0] / ((float)B * (float)F);
+    const long n = (long)B * N1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long bb = i / N1;
+        const int v = (int)(i - bb * N1);
+        const float* ph = xh + bb * N1 * 3;
+        const float* pg = x + bb * N1 * 3;
+        float g[3] = {0.f, 0.f, 0.f};
+        for (int e = vptr[v]; e < vptr[v + 1]; ++e) {
+            const int c = vcorner[e], f = c / 3, kx = c - 3 * f;
+            // the two face edges incident to corner kx
+            const int o1 = faces[3 * f + (kx + 1) % 3], o2 = faces[3 * f + (kx + 2) % 3];
+            edge_grad(ph, pg, v, o1, g);
+            edge_grad(ph, pg, v, o2, g);
+        }
+        grad[i * 3] = sc * g[0]; grad[i * 3 + 1] = sc * g[1]; grad[i * 3 + 2] = sc * g[2];
+    }
+}
+
+inline int grid_for(long n, int per_block) {
+    long g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    return (int)(g < 2048 ? g : 2048);
+}
+
+}  // namespace
+
+extern "C" {
+
+int sh_spmm(const int32_t* rowptr, const int32_t* col, const float* val, const float* x, int64_t x_sv, int64_t x_sb, float* y,
+            int64_t y_sv, int64_t y_sb, const float* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row, int B,
+            int rows, int C, sh_stream_t stream) {
+    SH_REQUIRE(rowptr && col && val && x && y, SH_ERR_INVALID_ARG, "sh_spmm: null pointer");
+    SH_REQUIRE(B > 0 && rows > 0 && C > 0, SH_ERR_INVALID_ARG, "sh_spmm: non-positive size");
+    SH_REQUIRE(act_prev >= SH_ACT_IDENTITY && act_prev <= SH_ACT_TANH, SH_ERR_INVALID_ARG, "sh_spmm: unknown activation %d", act_prev);
+    const bool vec = (C % 4 == 0) && (x_sv % 4 == 0) && (x_sb % 4 == 0) && (y_sv % 4 == 0) && (y_sb % 4 == 0) &&
+                     ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) % 16 == 0) &&
+                     (!yprev || (yp_sv % 4 == 0 && yp_sb % 4 == 0 && reinterpret_cast<uintptr_t>(yprev) % 16 == 0));
+    const long n = (long)rows * B * (vec ? C / 4 : C);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ShProfScope ps(st, "spmm_kernel<%s>", vec ? "true" : "false");
+    if (vec)
+        hipLaunchKernelGGL(spmm_kernel<true>, dim3(grid_for(n, 256)), dim3(256), 0, st, rowptr, col, val, x, x_sv, x_sb, y, y_sv, y_sb,
+                           yprev, yp_sv, yp_sb, act_prev, zero_row, B, rows, C);
+    else
+        hipLaunchKernelGGL(spmm_kernel<false>, dim3(grid_for(n, 256)), dim3(256), 0, st, rowptr, col, val, x, x_sv, x_sb, y, y_sv, y_sb,
+                           yprev, yp_sv, yp_sb, act_prev, zero_row, B, rows, C);
+    SH_CHECK_LAUNCH("spmm");
+    return SH_OK;
+}
+
+size_t sh_reduce_workspace(void) { return (size_t)RED_BLOCKS * sizeof(float); }
+
+int sh_l1_loss_fwd(const float* a, const float* b, int64_t n, float* loss, void* workspace, sh_stream_t stream) {
+    SH_REQUIRE(a && b && loss && workspace && n > 0, SH_ERR_INVALID_ARG, "sh_l1_loss_fwd: bad argument");
+    SH_REQUIRE((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) % 16 == 0, SH_ERR_INVALID_ARG,
+               "sh_l1_loss_fwd: inputs must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* part = static_cast<float*>(workspace);
+    const int nb = grid_for(n / 4 + 1, 1024) < RED_BLOCKS ? grid_for(n / 4 + 1, 1024) : RED_BLOCKS;
+    hipLaunchKernelGGL(l1_partial_kernel, dim3(nb), dim3(256), 0, st, a, b, (long)n, part);
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, st, part, nb, 1.0 / (double)n, loss);
+    SH_CHECK_LAUNCH("l1_loss_fwd");
+    return SH_OK;
+}
+
+int sh_l1_loss_bwd(const float* a, const float* b, int64_t n, const float* gscale, float* grad_b, sh_stream_t stream) {
+    SH_REQUIRE(a && b && gscale && grad_b && n > 0, SH_ERR_INVALID_ARG, "sh_l1_loss_bwd: bad argument");
+    hipLaunchKernelGGL(l1_bwd_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, static_cast<hipStream_t>(stream), a, b, (long)n, gscale,
+                       grad_b);
+    SH_CHECK_LAUNCH("l1_loss_bwd");
+    return SH_OK;
+}
+
+int sh_vertex_l2(const float* a, const float* b, int B, int N1, int N, float scale, float* out, void* workspace,
+                 sh_stream_t stream) {
+    SH_REQUIRE(a && b && out && workspace && B > 0 && N > 0 && N1 >= N, SH_ERR_INVALID_ARG, "sh_vertex_l2: bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* part = static_cast<float*>(workspace);
+    const long n = (long)B * N;
+    const int nb = grid_for(n, 1024) < RED_BLOCKS ? grid_for(n, 1024) : RED_BLOCKS;
+    hipLaunchKernelGGL(vertex_l2_partial_kernel, dim3(nb), dim3(256), 0, st, a, b, B, N1, N, scale, part);
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, st, part, nb, 1.0 / (double)n, out);
+    SH_CHECK_LAUNCH("vertex_l2");
+    return SH_OK;
+}
+
+int sh_edge_ratio_loss_fwd(const float* x_hat, const float* x, const int32_t* faces, int B, int N1, int F, float* loss,
+                           void* workspace, sh_stream_t stream) {
+    SH_REQUIRE(x_hat && x && faces && loss && workspace && B > 0 && N1 > 0 && F > 0, SH_ERR_INVALID_ARG,
+               "sh_edge_ratio_loss_fwd: bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* part = static_cast<float*>(workspace);
+    const long n = (long)B * F;
+    const int nb = grid_for(n, 1024) < RED_BLOCKS ? grid_for(n, 1024) : RED_BLOCKS;
+    hipLaunchKernelGGL(edge_loss_partial_kernel, dim3(nb), dim3(256), 0, st, x_hat, x, faces, B, N1, F, part);
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, st, part, nb, 1.0 / (double)n, loss);
+    SH_CHECK_LAUNCH("edge_ratio_loss_fwd");
+    return SH_OK;
+}
+
+int sh_edge_ratio_loss_bwd(const float* x_hat, const float* x, const int32_t* faces, const int32_t* vptr, const int32_t* vcorner,
+                           int B, int N1, int F, const float* gscale, float* grad, sh_stream_t stream) {
+    SH_REQUIRE(x_hat && x && faces && vptr && vcorner && gscale && grad && B > 0 && N1 > 0 && F > 0, SH_ERR_INVALID_ARG,
+               "sh_edge_ratio_loss_bwd: bad argument");
+    const long n = (long)B * N1;
+    hipLaunchKernelGGL(edge_loss_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x_hat, x, faces,
+                       vptr, vcorner, B, N1, F, gscale, grad);
+    SH_CHECK_LAUNCH("edge_ratio_loss_bwd");
+    return SH_OK;
+}
+
+}  // extern "C"

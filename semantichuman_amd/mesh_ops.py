@@ -1,0 +1,237 @@
+"""Host-side (numpy) construction of the constant index tables the HIP kernels read.
+
+The reference hands its model three kinds of per-level constants
+(main.py:183-205): `spirals[l]` int64 [1, N_l+1, S_l] with -1 padding,
+and dense fp32 `D[l]`, `U[l]` of shape [1, rows+1, cols+1].  The kernels never
+touch those forms.  At module construction they are turned, once, into
+
+  * gather tables   int32 [R, S]         (-1 -> the dummy row N, Appendix D-1)
+  * CSR matrices    rowptr/col/val       (D: one 1.0 per row, U: <=3 nnz per row)
+  * transposed ("who references me") tables for the atomic-free backward passes
+
+All functions are pure numpy and run on the CPU; they are exercised by the
+`not gpu` tests against the golden fixtures.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+
+# ----------------------------------------------------------------------------- spirals
+def spirals_to_table(spiral_adj) -> np.ndarray:
+    """[1|B, N+1, S] (any int/float dtype, -1 = padding) -> int32 [N+1, S] with
+    -1 mapped to N, which is what torch's negative-index wrap does in
+    reference models.py:42 (`x[batch_index, spirals_index, :]`)."""
+    a = np.asarray(spiral_adj)
+    if a.ndim == 3:
+        a = a[0]
+    n1 = a.shape[0]
+    t = a.astype(np.int64)
+    if t.min() < -n1 or t.max() >= n1:
+        raise IndexError("spiral index out of range for %d rows" % n1)
+    t = np.where(t < 0, t + n1, t)
+    return np.ascontiguousarray(t.astype(np.int32))
+
+
+@dataclass
+class CSR:
+    """Row-compressed sparse matrix, int32 indices, float32 values."""
+    rows: int
+    cols: int
+    rowptr: np.ndarray   # int32 [rows+1]
+    col: np.ndarray      # int32 [nnz]
+    val: np.ndarray      # float32 [nnz]
+
+    @property
+    def nnz(self) -> int:
+        return int(self.col.shape[0])
+
+    def is_row_select(self) -> bool:
+        """True when every row has exactly one entry whose value is exactly 1.0
+        (the padded down-sampling matrices, mesh_sampling.py:214-227 +
+        main.py:190)."""
+        return (self.nnz == self.rows
+                and np.array_equal(self.rowptr, np.arange(self.rows + 1, dtype=np.int32))
+                and bool(np.all(self.val == np.float32(1.0))))
+
+    def transpose(self) -> "CSR":
+        """CSR of the transposed matrix; entries of each output row are in
+        increasing source-row order, so the backward sums have a fixed order."""
+        order = np.argsort(self.col, kind="stable")
+        src_row = np.repeat(np.arange(self.rows, dtype=np.int32), np.diff(self.rowptr))
+        counts = np.bincount(self.col, minlength=self.cols)
+        rowptr = np.zeros(self.cols + 1, dtype=np.int32)
+        np.cumsum(counts, out=rowptr[1:])
+        return CSR(self.cols, self.rows, rowptr, src_row[order].astype(np.int32),
+                   self.val[order].astype(np.float32))
+
+    def todense(self) -> np.ndarray:
+        m = np.zeros((self.rows, self.cols), dtype=np.float32)
+        r = np.repeat(np.arange(self.rows), np.diff(self.rowptr))
+        np.add.at(m, (r, self.col), self.val)
+        return m
+
+
+def dense_to_csr(m) -> CSR:
+    """Dense [1,R,C] or [R,C] matrix -> CSR keeping exact fp32 values.  Entries
+    are kept in increasing column order (the order a dense dot product visits
+    them), zeros are dropped."""
+    a = np.asarray(m)
+    if a.ndim == 3:
+        a = a[0]
+    a = a.astype(np.float32)
+    r, c = np.nonzero(a)           # row-major order: sorted by row, then column
+    rowptr = np.zeros(a.shape[0] + 1, dtype=np.int32)
+    np.cumsum(np.bincount(r, minlength=a.shape[0]), out=rowptr[1:])
+    return CSR(a.shape[0], a.shape[1], rowptr, c.astype(np.int32), a[r, c].astype(np.float32))
+
+
+def compose_select(table: np.ndarray, sel: np.ndarray) -> np.ndarray:
+    """Fuse a row-select down-sampling into the convolution that precedes it.
+
+    reference encode (models.py:122-127) computes y = conv(x, spirals_l) on all
+    N_l+1 rows and then keeps rows `sel` (x_{l+1} = D_l y).  Because D_l is an
+    exact row select, only the kept rows need computing:
+        x_{l+1}[r] = conv_row(x, spirals_l[sel[r]])
+    so the fused gather table is spirals_l[sel]  (int32 [N_{l+1}+1, S_l])."""
+    return np.ascontiguousarray(table[sel.astype(np.int64)])
+
+
+@dataclass
+class GatherLists:
+    """Transposed gather table, grouped by (input row u, spiral position s).
+
+    For the backward-data pass  dX[u] = sum_s ( sum_{r : table[r,s]==u} dPre[r] ) W_s.
+    `ptr` has U*S+1 entries; entries ptr[u*S+s] .. ptr[u*S+s+1] of `src` list
+    the output rows r that read input row u at position s, in increasing r (a
+    fixed order -> bitwise reproducible sums, no atomics)."""
+    n_in: int
+    S: int
+    ptr: np.ndarray      # int32 [n_in*S + 1]
+    src: np.ndarray      # int32 [R*S]
+    max_len: int
+
+
+def transpose_table(table: np.ndarray, n_in: int, skip_row: int = -1) -> GatherLists:
+    """Build GatherLists for `table` int32 [R,S] whose values are in [0,n_in).
+    `skip_row`: an input row whose gradient is known to be dead (the dummy row
+    after a masked SpiralConv) gets empty lists, so its huge fan-in costs
+    nothing."""
+    R, S = table.shape
+    key = table.astype(np.int64) * S + np.arange(S, dtype=np.int64)[None, :]
+    key = key.ravel()
+    src = np.repeat(np.arange(R, dtype=np.int32), S)
+    if skip_row >= 0:
+        keep = table.ravel() != skip_row
+        key, src = key[keep], src[keep]
+    order = np.argsort(key, kind="stable")
+    counts = np.bincount(key, minlength=n_in * S)
+    ptr = np.zeros(n_in * S + 1, dtype=np.int32)
+    np.cumsum(counts, out=ptr[1:])
+    return GatherLists(n_in, S, ptr, np.ascontiguousarray(src[order]),
+                       int(counts.max()) if counts.size else 0)
+
+
+# ----------------------------------------------------------------------------- U (up-sampling)
+def _closest_point_barycentric(p, a, b, c):
+    """Closest point to p on triangles (a,b,c) (all [M,3]); returns barycentric
+    weights [M,3] and squared distance [M].  Region-based method (Ericson,
+    Real-Time Collision Detection 5.1.5), vectorised."""
+    ab, ac, ap = b - a, c - a, p - a
+    d1 = np.einsum("ij,ij->i", ab, ap)
+    d2 = np.einsum("ij,ij->i", ac, ap)
+    bp = p - b
+    d3 = np.einsum("ij,ij->i", ab, bp)
+    d4 = np.einsum("ij,ij->i", ac, bp)
+    cp = p - c
+    d5 = np.einsum("ij,ij->i", ab, cp)
+    d6 = np.einsum("ij,ij->i", ac, cp)
+    vc = d1 * d4 - d3 * d2
+    vb = d5 * d2 - d1 * d6
+    va = d3 * d6 - d5 * d4
+    w = np.zeros((p.shape[0], 3))
+    done = np.zeros(p.shape[0], dtype=bool)
+
+    def put(mask, wa, wb, wc):
+        nonlocal done
+        m = mask & ~done
+        w[m, 0], w[m, 1], w[m, 2] = wa[m], wb[m], wc[m]
+        done |= m
+
+    one, zero = np.ones_like(d1), np.zeros_like(d1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        put((d1 <= 0) & (d2 <= 0), one, zero, zero)
+        put((d3 >= 0) & (d4 <= d3), zero, one, zero)
+        t = d1 / (d1 - d3)
+        put((vc <= 0) & (d1 >= 0) & (d3 <= 0), 1 - t, t, zero)
+        put((d6 >= 0) & (d5 <= d6), zero, zero, one)
+        t = d2 / (d2 - d6)
+        put((vb <= 0) & (d2 >= 0) & (d6 <= 0), 1 - t, zero, t)
+        t = (d4 - d3) / ((d4 - d3) + (d5 - d6))
+        put((va <= 0) & ((d4 - d3) >= 0) & ((d5 - d6) >= 0), zero, 1 - t, t)
+        denom = 1.0 / (va + vb + vc)
+        v_, w_ = vb * denom, vc * denom
+        put(np.ones_like(done), 1 - v_ - w_, v_, w_)
+    q = w[:, :1] * a + w[:, 1:2] * b + w[:, 2:3] * c
+    return w, np.sum((p - q) ** 2, axis=1)
+
+
+def barycentric_upsample(src_v, src_f, tgt_v, k: int = 8) -> CSR:
+    """Up-sampling operator U (tgt rows, src cols): each target vertex is
+    expressed in barycentric coordinates of its closest point on the source
+    (coarser) surface - the role of mesh_sampling.setup_deformation_transfer
+    (mesh_sampling.py:47-95).  The reference delegates the closest-point search
+    to psbody-mesh's C++ AABB tree (psbody-mesh 0.4, absent here), so
+    this construction is our own: candidate triangles = those incident to the k
+    nearest source vertices.  At most 3 non-zeros per row, rows sum to 1."""
+    from scipy.spatial import cKDTree
+    src_v = np.asarray(src_v, dtype=np.float64)
+    tgt_v = np.asarray(tgt_v, dtype=np.float64)
+    src_f = np.asarray(src_f, dtype=np.int64)
+    nv = src_v.shape[0]
+    # vertex -> incident faces (padded)
+    order = np.argsort(src_f.ravel(), kind="stable")
+    vert_of = src_f.ravel()[order]
+    face_of = (order // 3)
+    vptr = np.zeros(nv + 1, dtype=np.int64)
+    np.cumsum(np.bincount(vert_of, minlength=nv), out=vptr[1:])
+    _, nn = cKDTree(src_v).query(tgt_v, k=min(k, nv))
+    nn = nn.reshape(tgt_v.shape[0], -1)
+    best_d = np.full(tgt_v.shape[0], np.inf)
+    best_f = np.zeros(tgt_v.shape[0], dtype=np.int64)
+    best_w = np.zeros((tgt_v.shape[0], 3))
+    maxdeg = int(np.diff(vptr).max())
+    for j in range(nn.shape[1]):
+        v = nn[:, j]
+        for t in range(maxdeg):
+            has = (vptr[v] + t) < vptr[v + 1]
+            if not has.any():
+                continue
+            rows = np.nonzero(has)[0]
+            f = face_of[vptr[v[rows]] + t]
+            tri = src_f[f]
+            w, d = _closest_point_barycentric(tgt_v[rows], src_v[tri[:, 0]], src_v[tri[:, 1]], src_v[tri[:, 2]])
+            better = d < best_d[rows]
+            rr = rows[better]
+            best_d[rr], best_f[rr], best_w[rr] = d[better], f[better], w[better]
+    cols = src_f[best_f]                       # [T,3]
+    vals = best_w.astype(np.float32)
+    keep = vals != 0
+    rowptr = np.zeros(tgt_v.shape[0] + 1, dtype=np.int32)
+    np.cumsum(keep.sum(1), out=rowptr[1:])
+    # entries in increasing column order inside a row (dense dot-product order)
+    o = np.argsort(np.where(keep, cols, np.iinfo(np.int64).max), axis=1, kind="stable")
+    cols_s = np.take_along_axis(cols, o, 1)
+    vals_s = np.take_along_axis(vals, o, 1)
+    keep_s = np.take_along_axis(keep, o, 1)
+    return CSR(tgt_v.shape[0], nv, rowptr, cols_s[keep_s].astype(np.int32), vals_s[keep_s].astype(np.float32))
+
+
+def pad_dummy(m: CSR) -> CSR:
+    """Append the dummy row/column with a 1 at [-1,-1] (main.py:186-191)."""
+    rowptr = np.concatenate([m.rowptr, [m.rowptr[-1] + 1]]).astype(np.int32)
+    col = np.concatenate([m.col, [m.cols]]).astype(np.int32)
+    val = np.concatenate([m.val, [1.0]]).astype(np.float32)
+    return CSR(m.rows + 1, m.cols + 1, rowptr, col, val)

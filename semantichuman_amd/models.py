@@ -1,0 +1,179 @@
+"""Drop-in replacements for the nn.Modules of reference models.py, running on HIP kernels.
+
+Same constructor signatures, method names, attribute names and `state_dict` keys as the
+reference, so a reference checkpoint
+(`{'epoch','autoencoder_state_dict','optimizer_state_dict','scheduler_state_dict'}`,
+train_funcs.py:562-567) loads unchanged and the reference training loops can drive them.
+
+  SpiralConv          reference models.py:10-53    one fused gather+GEMM kernel per call
+  SpiralAutoencoder   reference models.py:55-162   encoder / decoder = one autograd node each
+                                                   (semantichuman_amd.stack), nn.Linear latent FCs
+
+Constants (`spirals`, `D`, `U`) are accepted exactly as main.py:203-205 prepares them (int64
+[1,N+1,S] with -1 padding; dense fp32 [1,rows+1,cols+1]) or, to skip densification, as
+int arrays / mesh_ops.CSR.  They are converted once, here, to int32 gather tables and CSR.
+There is no CPU execution path: calling forward on CPU tensors raises.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import mesh_ops, ops
+from .mesh_ops import CSR
+from .stack import ConvStep, SpmmStep, Stack, StackFunction, run_stack
+
+
+def _as_csr(m) -> CSR:
+    if isinstance(m, CSR):
+        return m
+    if torch.is_tensor(m):
+        m = m.detach().cpu().numpy()
+    return mesh_ops.dense_to_csr(m)
+
+
+def _as_table(s) -> np.ndarray:
+    if torch.is_tensor(s):
+        s = s.detach().cpu().numpy()
+    return mesh_ops.spirals_to_table(s)
+
+
+class SpiralConv(nn.Module):
+    """reference models.py:10-53.  forward(x [B,N+1,Cin], spiral_adj int [B,N+1,S]) -> [B,N+1,Cout]."""
+
+    def __init__(self, in_c, spiral_size, out_c, activation='elu', bias=True, device=None):
+        super().__init__()
+        self.in_c, self.out_c, self.device = in_c, out_c, device
+        self.spiral_size = spiral_size
+        self.conv = nn.Linear(in_c * spiral_size, out_c, bias=bias)
+        self.act_name = activation
+        self.act_id = ops.act_id(activation)          # NotImplementedError for unknown names (models.py:31-32)
+        self._cache_key, self._cache_stack = None, None
+
+    def _stack_for(self, spiral_adj) -> Stack:
+        key = (spiral_adj.data_ptr(), tuple(spiral_adj.shape), spiral_adj._version, str(spiral_adj.device))
+        if key != self._cache_key:
+            adj = spiral_adj.detach()
+            if adj.shape[0] > 1 and not bool((adj == adj[:1]).all()):
+                raise NotImplementedError("per-sample spiral indices are not supported (the reference always "
+                                          "passes one index repeated over the batch, models.py:122)")
+            table = _as_table(adj[:1])
+            st = ConvStep(param=0, table=table, n_in=table.shape[0], cin=self.in_c, cout=self.out_c, act=self.act_id)
+            self._cache_stack = Stack([st]).to(spiral_adj.device)
+            self._cache_key = key
+        return self._cache_stack
+
+    def forward(self, x, spiral_adj):
+        if x.shape[1] != spiral_adj.shape[1] or spiral_adj.shape[2] != self.spiral_size:
+            raise RuntimeError("SpiralConv: x %s does not match spiral_adj %s" % (tuple(x.shape), tuple(spiral_adj.shape)))
+        return run_stack(self._stack_for(spiral_adj), x, "bm", "bm", [self])
+
+
+def conv_layout(filters_enc, filters_dec, spiral_sizes, activation):
+    """(in_c, spiral_size, out_c, activation, level) of every SpiralConv, in ModuleList order,
+    as the reference constructor creates them (models.py:69-113)."""
+    levels = len(spiral_sizes) - 1
+    enc, c = [], filters_enc[0][0]
+    for lvl in range(levels):
+        widths = ([filters_enc[1][lvl]] if filters_enc[1][lvl] else []) + [filters_enc[0][lvl + 1]]
+        for w in widths:
+            enc.append((c, spiral_sizes[lvl], w, activation, lvl))
+            c = w
+    dec, c = [], filters_dec[0][0]
+    for i in range(levels):
+        lvl = levels - 1 - i
+        widths = [filters_dec[0][i + 1]] + ([filters_dec[1][i + 1]] if filters_dec[1][i + 1] else [])
+        for k, w in enumerate(widths):
+            final = (i == levels - 1) and (k == len(widths) - 1)      # the very last conv is linear (:105-110)
+            dec.append((c, spiral_sizes[lvl], w, 'identity' if final else activation, lvl))
+            c = w
+    return enc, dec
+
+
+def build_encoder_stack(enc_layout, tables, Ds, sizes) -> Stack:
+    steps = []
+    levels = len(Ds)
+    for lvl in range(levels):
+        convs = [(j, l) for j, l in enumerate(enc_layout) if l[4] == lvl]
+        D = Ds[lvl]
+        fuse = D.is_row_select()
+        for k, (j, (cin, S, cout, act, _)) in enumerate(convs):
+            table = tables[lvl]
+            if fuse and k == len(convs) - 1:
+                table = mesh_ops.compose_select(table, D.col)       # conv + row-select D in one kernel
+            steps.append(ConvStep(param=j, table=table, n_in=sizes[lvl] + 1, cin=cin, cout=cout, act=ops.act_id(act)))
+        if not fuse or not convs:
+            steps.append(SpmmStep(D))
+    return Stack(steps, input_dummy_dead=False)
+
+
+def build_decoder_stack(dec_layout, tables, Us, sizes) -> Stack:
+    steps = []
+    levels = len(Us)
+    for lvl in range(levels - 1, -1, -1):
+        steps.append(SpmmStep(Us[lvl]))
+        for j, (cin, S, cout, act, l) in enumerate(dec_layout):
+            if l == lvl:
+                steps.append(ConvStep(param=j, table=tables[lvl], n_in=sizes[lvl] + 1, cin=cin, cout=cout, act=ops.act_id(act)))
+    # the decoder input's dummy row is a live slice of fc_latent_dec's output
+    return Stack(steps, input_dummy_dead=False)
+
+
+class SpiralAutoencoder(nn.Module):
+    """reference models.py:55-162."""
+
+    def __init__(self, filters_enc, filters_dec, latent_size, sizes, spiral_sizes, spirals, D, U, device,
+                 VAE_flag=False, activation='elu'):
+        super().__init__()
+        self.latent_size, self.sizes, self.spirals = latent_size, sizes, spirals
+        self.filters_enc, self.filters_dec, self.spiral_sizes = filters_enc, filters_dec, spiral_sizes
+        self.D, self.U, self.device = D, U, device
+        self.activation, self.VAE_flag = activation, VAE_flag
+        levels = len(spiral_sizes) - 1
+        enc_layout, dec_layout = conv_layout(filters_enc, filters_dec, spiral_sizes, activation)
+        self.conv = nn.ModuleList([SpiralConv(c, S, o, activation=a, device=device) for (c, S, o, a, _) in enc_layout])
+        feat = enc_layout[-1][2]
+        self.fc_latent_enc = nn.Linear((sizes[-1] + 1) * feat, (2 if VAE_flag else 1) * latent_size)
+        self.fc_latent_dec = nn.Linear(latent_size, (sizes[-1] + 1) * filters_dec[0][0])
+        self.dconv = nn.ModuleList([SpiralConv(c, S, o, activation=a, device=device) for (c, S, o, a, _) in dec_layout])
+
+        tables = [_as_table(spirals[l]) for l in range(levels)]
+        for l in range(levels):
+            if tables[l].shape != (sizes[l] + 1, spiral_sizes[l]):
+                raise ValueError("spirals[%d] has shape %s, expected %s" % (l, tables[l].shape, (sizes[l] + 1, spiral_sizes[l])))
+        Ds = [_as_csr(D[l]) for l in range(levels)]
+        Us = [_as_csr(U[l]) for l in range(levels)]
+        self._enc_stack = build_encoder_stack(enc_layout, tables, Ds, sizes)
+        self._dec_stack = build_decoder_stack(dec_layout, tables, Us, sizes)
+        if device is not None:
+            self.to(device)
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        dev = self.fc_latent_enc.weight.device          # tables follow the parameters' device
+        if self._enc_stack.device != dev:
+            self._enc_stack.to(dev)
+            self._dec_stack.to(dev)
+            self.device = dev
+        return out
+
+    def encode(self, x, VAE_flag=None):
+        bsize = x.size(0)
+        h = run_stack(self._enc_stack, x, "bm", "bm", self.conv)        # [B, N_last+1, C]
+        z = self.fc_latent_enc(h.reshape(bsize, -1))
+        if VAE_flag if VAE_flag is not None else self.VAE_flag:         # models.py:131-136
+            self.z_mu = z[..., :self.latent_size]
+            self.z_var = z[..., self.latent_size:]
+            std = torch.exp(self.z_var / 2)
+            z = torch.randn_like(std).mul(std).add_(self.z_mu)
+        return z
+
+    def decode(self, z):
+        bsize = z.size(0)
+        h = self.fc_latent_dec(z).view(bsize, self.sizes[-1] + 1, -1)
+        return run_stack(self._dec_stack, h, "bm", "bm", self.dconv)
+
+    def forward(self, x):
+        z = self.encode(x, self.VAE_flag)
+        return self.decode(z), z

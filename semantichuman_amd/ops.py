@@ -1,0 +1,148 @@
+"""Typed Python wrappers around the C ABI (one function per entry point of sh_kernels.h).
+
+Tensors are fp32, contiguous, on a HIP device.  A 3-D activation has one of two layouts:
+    'bm'  batch-major  [B, rows, C]   - the reference layout (models.py:37)
+    'vm'  vertex-major [rows, B, C]   - the internal fast layout (a gathered neighbour is one
+                                        contiguous B*C block -> coalesced 16-byte reads)
+The kernels take explicit strides, so both layouts go through the same code.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import ACT_IDS, check, ptr, stream_ptr
+
+
+def _dims(t: torch.Tensor, layout: str):
+    """-> (B, rows, C, stride_row, stride_batch) for a contiguous 3-D tensor."""
+    if t.dim() != 3 or not t.is_contiguous() or t.dtype != torch.float32:
+        raise ValueError("expected a contiguous fp32 3-D tensor, got %s %s" % (tuple(t.shape), t.dtype))
+    if not t.is_cuda:
+        raise RuntimeError("semantichuman_amd kernels need a HIP device tensor (got %s); there is no CPU path" % t.device)
+    if layout == "bm":
+        B, R, C = t.shape
+        return B, R, C, C, R * C
+    if layout == "vm":
+        R, B, C = t.shape
+        return B, R, C, B * C, C
+    raise ValueError("layout must be 'bm' or 'vm'")
+
+
+def alloc(B: int, rows: int, C: int, layout: str, device, extra_rows: int = 0) -> torch.Tensor:
+    if layout == "bm":
+        if extra_rows:
+            raise ValueError("extra rows need the vertex-major layout")
+        return torch.empty((B, rows, C), dtype=torch.float32, device=device)
+    return torch.empty((rows + extra_rows, B, C), dtype=torch.float32, device=device)
+
+
+def act_id(name: str) -> int:
+    if name not in ACT_IDS:
+        raise NotImplementedError(name)          # same error type as reference models.py:31-32
+    return ACT_IDS[name]
+
+
+def spiral_conv_fwd(x, x_layout, table, weight, bias, y, y_layout, R, S, act, zero_row):
+    B, _, Cin, xsv, xsb = _dims(x, x_layout)
+    B2, Ry, Cout, ysv, ysb = _dims(y, y_layout)
+    assert B == B2 and Ry >= R and weight.shape == (Cout, S * Cin) and table.dtype == torch.int32
+    check(_lib.load().sh_spiral_conv_fwd(ptr(x), xsv, xsb, ptr(table), ptr(weight), ptr(bias), ptr(y), ysv, ysb,
+                                         B, R, S, Cin, Cout, act, zero_row, stream_ptr()), "sh_spiral_conv_fwd")
+
+
+def spiral_conv_bwd_data(dpre, dp_layout, lptr, lsrc, weight_t, dx, dx_layout, yprev, yp_layout, act_prev, zero_row,
+                         n_in, S, Cin, Cout):
+    B, _, C1, dsv, dsb = _dims(dpre, dp_layout)
+    B2, Rx, C2, xsv, xsb = _dims(dx, dx_layout)
+    assert B == B2 and C1 == Cout and C2 == Cin and Rx >= n_in and weight_t.shape == (Cin, S * Cout)
+    if yprev is not None:
+        _, _, C3, ysv, ysb = _dims(yprev, yp_layout)
+        assert C3 == Cin
+    else:
+        ysv = ysb = 0
+    check(_lib.load().sh_spiral_conv_bwd_data(ptr(dpre), dsv, dsb, ptr(lptr), ptr(lsrc), ptr(weight_t), ptr(dx), xsv, xsb,
+                                              ptr(yprev), ysv, ysb, act_prev, zero_row, B, n_in, S, Cin, Cout,
+                                              stream_ptr()), "sh_spiral_conv_bwd_data")
+
+
+def weight_transpose(weight, S, Cin, Cout):
+    wt = torch.empty((Cin, S * Cout), dtype=torch.float32, device=weight.device)
+    check(_lib.load().sh_weight_transpose(ptr(weight), ptr(wt), S, Cin, Cout, stream_ptr()), "sh_weight_transpose")
+    return wt
+
+
+def spiral_conv_bwd_wgt(dpre, dp_layout, x, x_layout, table, R, S, Cin, Cout, want_bias=True):
+    B, _, C1, dsv, dsb = _dims(dpre, dp_layout)
+    B2, _, C2, xsv, xsb = _dims(x, x_layout)
+    assert B == B2 and C1 == Cout and C2 == Cin
+    lib = _lib.load()
+    nbytes = lib.sh_spiral_conv_bwd_wgt_workspace(B, R, S, Cin, Cout)
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
+    dW = torch.empty((Cout, S * Cin), dtype=torch.float32, device=x.device)
+    db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
+    check(lib.sh_spiral_conv_bwd_wgt(ptr(dpre), dsv, dsb, ptr(x), xsv, xsb, ptr(table), ptr(dW), ptr(db), ptr(ws),
+                                     nbytes, B, R, S, Cin, Cout, stream_ptr()), "sh_spiral_conv_bwd_wgt")
+    return dW, db
+
+
+def act_backward(dy, dy_layout, y, y_layout, dpre, dp_layout, R, act, zero_row):
+    B, _, C, asv, asb = _dims(dy, dy_layout)
+    _, _, _, ysv, ysb = _dims(y, y_layout)
+    _, _, _, psv, psb = _dims(dpre, dp_layout)
+    check(_lib.load().sh_act_backward(ptr(dy), asv, asb, ptr(y), ysv, ysb, ptr(dpre), psv, psb, B, R, C, act, zero_row,
+                                      stream_ptr()), "sh_act_backward")
+
+
+def spmm(csr_dev, x, x_layout, y, y_layout, rows, yprev=None, yp_layout="vm", act_prev=0, zero_row=-1):
+    """csr_dev = (rowptr, col, val) device tensors."""
+    B, _, C, xsv, xsb = _dims(x, x_layout)
+    B2, Ry, C2, ysv, ysb = _dims(y, y_layout)
+    assert B == B2 and C == C2 and Ry >= rows
+    if yprev is not None:
+        _, _, _, psv, psb = _dims(yprev, yp_layout)
+    else:
+        psv = psb = 0
+    rowptr, col, val = csr_dev
+    check(_lib.load().sh_spmm(ptr(rowptr), ptr(col), ptr(val), ptr(x), xsv, xsb, ptr(y), ysv, ysb, ptr(yprev), psv, psb,
+                              act_prev, zero_row, B, rows, C, stream_ptr()), "sh_spmm")
+
+
+def _ws(device):
+    return torch.empty(_lib.load().sh_reduce_workspace() // 4, dtype=torch.float32, device=device)
+
+
+def l1_loss_fwd(a, b):
+    assert a.shape == b.shape and a.is_contiguous() and b.is_contiguous() and a.is_cuda
+    out = torch.empty((), dtype=torch.float32, device=a.device)
+    check(_lib.load().sh_l1_loss_fwd(ptr(a), ptr(b), a.numel(), ptr(out), ptr(_ws(a.device)), stream_ptr()), "sh_l1_loss_fwd")
+    return out
+
+
+def l1_loss_bwd(a, b, gscale):
+    g = torch.empty_like(b)
+    check(_lib.load().sh_l1_loss_bwd(ptr(a), ptr(b), a.numel(), ptr(gscale), ptr(g), stream_ptr()), "sh_l1_loss_bwd")
+    return g
+
+
+def vertex_l2(a, b, n_real, scale=1000.0):
+    assert a.shape == b.shape and a.dim() == 3 and a.shape[2] == 3 and a.is_contiguous() and b.is_contiguous()
+    out = torch.empty((), dtype=torch.float32, device=a.device)
+    check(_lib.load().sh_vertex_l2(ptr(a), ptr(b), a.shape[0], a.shape[1], n_real, scale, ptr(out), ptr(_ws(a.device)),
+                                   stream_ptr()), "sh_vertex_l2")
+    return out
+
+
+def edge_ratio_loss_fwd(x_hat, x, faces):
+    assert x_hat.shape == x.shape and x.shape[2] == 3 and x_hat.is_contiguous() and x.is_contiguous()
+    out = torch.empty((), dtype=torch.float32, device=x.device)
+    check(_lib.load().sh_edge_ratio_loss_fwd(ptr(x_hat), ptr(x), ptr(faces), x.shape[0], x.shape[1], faces.shape[0], ptr(out),
+                                             ptr(_ws(x.device)), stream_ptr()), "sh_edge_ratio_loss_fwd")
+    return out
+
+
+def edge_ratio_loss_bwd(x_hat, x, faces, vptr, vcorner, gscale):
+    g = torch.empty_like(x_hat)
+    check(_lib.load().sh_edge_ratio_loss_bwd(ptr(x_hat), ptr(x), ptr(faces), ptr(vptr), ptr(vcorner), x.shape[0], x.shape[1],
+                                             faces.shape[0], ptr(gscale), ptr(g), stream_ptr()), "sh_edge_ratio_loss_bwd")
+    return g

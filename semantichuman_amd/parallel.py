@@ -1,0 +1,137 @@
+"""Data-parallel training over the GPUs of one node: one process per GPU, RCCL over xGMI.
+
+The reference is single-process / single-GPU (main.py:197-201; no torch.distributed anywhere).
+The training path shards on the batch axis only: every mesh is independent through
+forward and backward, the only cross-sample coupling is the mean in the losses and the sum in
+the weight gradients.  So each rank holds a full replica, works on its own batch shard, and the
+ONE collective per step is the gradient all-reduce (sum, pre-scaled by 1/world = mean).
+
+Design for xGMI (point-to-point links, no switch): few, large messages.
+  * gradients are packed into contiguous buckets in BACKWARD order; the plain autoencoder's
+    114 MB of gradients are 99 % two latent FC matrices (2 x 56.6 MB), which become ready in
+    the middle of backward (decoder stack -> fc_latent_dec -> fc_latent_enc -> encoder stack);
+  * a bucket's all-reduce is launched asynchronously the moment its last gradient has been
+    produced (post-accumulate-grad hooks), so the FC buckets travel while the encoder-stack
+    backward kernels run; `finish()` waits and re-points .grad at the reduced bucket views.
+
+Backend "nccl" is RCCL on ROCm; on CPU (tests) the same code runs over gloo.
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+import torch.distributed as dist
+
+
+class GradBucket:
+    def __init__(self, params: List[torch.nn.Parameter]):
+        self.params = params
+        self.numel = sum(p.numel() for p in params)
+        p0 = params[0]
+        self.flat = torch.zeros(self.numel, dtype=p0.dtype, device=p0.device)
+        self.views, o = [], 0
+        for p in params:
+            self.views.append(self.flat[o:o + p.numel()].view_as(p))
+            o += p.numel()
+        self.pending = 0
+        self.work = None
+
+
+class GradientAllReducer:
+    """Bucketed, overlapped gradient averaging for a replicated nn.Module."""
+
+    def __init__(self, module: torch.nn.Module, process_group=None, bucket_cap_mb: float = 64.0, overlap: bool = True):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.overlap = overlap
+        params = [p for p in module.parameters() if p.requires_grad]
+        # backward produces gradients roughly in reverse registration order
+        cap = int(bucket_cap_mb * 1024 * 1024)
+        self.buckets: List[GradBucket] = []
+        cur, cur_bytes = [], 0
+        for p in reversed(params):
+            nbytes = p.numel() * p.element_size()
+            if cur and cur_bytes + nbytes > cap:
+                self.buckets.append(GradBucket(cur))
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            self.buckets.append(GradBucket(cur))
+        self._where = {}
+        for b in self.buckets:
+            for i, p in enumerate(b.params):
+                self._where[p] = (b, i)
+        self._hooks = []
+        if self.world > 1 and overlap:
+            for p in params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        self._armed = False
+
+    @property
+    def message_bytes(self) -> int:
+        return sum(b.numel * b.flat.element_size() for b in self.buckets)
+
+    def prepare(self):
+        """Call before backward (after zero_grad)."""
+        for b in self.buckets:
+            b.pending = len(b.params)
+            b.work = None
+        self._armed = True
+
+    def _launch(self, b: GradBucket):
+        scale = 1.0 / self.world
+        for p, v in zip(b.params, b.views):
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                torch.mul(p.grad, scale, out=v)
+            else:
+                v.mul_(scale)
+        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _on_grad(self, p):
+        if not self._armed:
+            return
+        b, _ = self._where[p]
+        b.pending -= 1
+        if b.pending == 0:
+            self._launch(b)
+
+    def finish(self):
+        """Call after backward, before optimizer.step(): waits for the collectives and makes
+        every .grad the averaged gradient."""
+        if self.world == 1:
+            return
+        for b in self.buckets:
+            if b.work is None:           # not launched by a hook (overlap off, or unused params)
+                self._launch(b)
+        for b in self.buckets:
+            b.work.wait()
+            for p, v in zip(b.params, b.views):
+                p.grad = v
+        self._armed = False
+
+    def remove_hooks(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
+def shard_batch(n_total: int, rank: int, world: int):
+    """Even split of a global batch (config 3: 512 -> 64 per GPU).  Returns the slice of this
+    rank; the global batch must divide evenly so every rank's loss mean has the same weight."""
+    if n_total % world:
+        raise ValueError("global batch %d is not divisible by world size %d" % (n_total, world))
+    per = n_total // world
+    return slice(rank * per, (rank + 1) * per)
+
+
+def all_reduce_mean_scalar(t: torch.Tensor, group=None) -> torch.Tensor:
+    """Average a scalar metric (loss, L1, L2) over ranks - logging / evaluation only."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        t = t.clone()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        t /= dist.get_world_size(group)
+    return t

@@ -1,0 +1,289 @@
+"""Plans and executes a stack of spiral convolutions and mesh re-sampling steps on the GPU.
+
+The reference runs encode/decode as a Python loop of small autograd ops
+(models.py:115-154).  Here each stack (encoder, decoder) is ONE autograd node:
+
+  forward   conv -> conv -> ...   every step one fused HIP kernel, activations kept in the
+            vertex-major layout between steps, only the first input / last output use the
+            caller's layout (strides, no transposes).  A row-select down-sampling D is folded
+            into the gather table of the convolution in front of it (mesh_ops.compose_select),
+            so the rows D would discard are never computed.
+  backward  a hand-scheduled chain: for every conv, the weight-gradient kernel and the
+            backward-data kernel; the activation derivative of the PREVIOUS layer is applied in
+            the epilogue of whichever kernel produces that layer's output gradient, so no
+            separate elementwise pass and no saved pre-activations.  No atomics anywhere.
+
+Plan construction is pure numpy (testable without a GPU); `to(device)` uploads the tables.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import mesh_ops, ops
+from .mesh_ops import CSR
+
+LONG_LIST = 8     # (input row, spiral position) lists longer than this are pre-reduced by an SpMM
+
+
+def _dev(a: np.ndarray, device):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def _csr_dev(m: CSR, device):
+    return (_dev(m.rowptr, device), _dev(m.col, device), _dev(m.val, device))
+
+
+@dataclass
+class ConvStep:
+    """One SpiralConv (optionally with a fused row-select down-sampling)."""
+    param: int                 # index of the SpiralConv module in its ModuleList
+    table: np.ndarray          # int32 [R, S], values in [0, n_in)
+    n_in: int
+    cin: int
+    cout: int
+    act: int
+    dead_dummy_grad: bool = False   # gradient w.r.t. input row n_in-1 is provably zero
+    kind: str = "conv"
+    # filled by finalize()
+    R: int = 0
+    S: int = 0
+    zero_row: int = -1
+    lptr: Optional[np.ndarray] = None
+    lsrc: Optional[np.ndarray] = None
+    long_csr: Optional[CSR] = None
+    n_extra: int = 0
+    dev: dict = field(default_factory=dict)
+
+    def finalize(self):
+        self.R, self.S = self.table.shape
+        self.zero_row = self.R - 1                       # the dummy row of the output (models.py:49-51)
+        gl = mesh_ops.transpose_table(self.table, self.n_in,
+                                      skip_row=self.n_in - 1 if self.dead_dummy_grad else -1)
+        lengths = np.diff(gl.ptr)
+        long_pairs = np.nonzero(lengths > LONG_LIST)[0]
+        if long_pairs.size == 0:
+            self.lptr, self.lsrc, self.long_csr, self.n_extra = gl.ptr, gl.src, None, 0
+            return self
+        # divert long lists: they are summed first by an SpMM (ones) into extra rows R..R+n_long-1
+        # of the dpre buffer, and the list is replaced by the single entry pointing there.
+        new_len = lengths.copy()
+        new_len[long_pairs] = 1
+        ptr = np.zeros_like(gl.ptr)
+        np.cumsum(new_len, out=ptr[1:])
+        src = np.empty(int(ptr[-1]), dtype=np.int32)
+        is_long = np.zeros(lengths.shape[0], dtype=bool)
+        is_long[long_pairs] = True
+        keep_entry = ~np.repeat(is_long, lengths)
+        short_dst = np.ones(int(ptr[-1]), dtype=bool)
+        short_dst[ptr[:-1][long_pairs]] = False
+        src[short_dst] = gl.src[keep_entry]
+        src[ptr[:-1][long_pairs]] = self.R + np.arange(long_pairs.size, dtype=np.int32)
+        rowptr = np.zeros(long_pairs.size + 1, dtype=np.int32)
+        np.cumsum(lengths[long_pairs], out=rowptr[1:])
+        col = np.concatenate([gl.src[gl.ptr[p]:gl.ptr[p + 1]] for p in long_pairs]).astype(np.int32)
+        self.long_csr = CSR(long_pairs.size, self.R, rowptr, col, np.ones(col.shape[0], dtype=np.float32))
+        self.lptr, self.lsrc, self.n_extra = ptr.astype(np.int32), src, int(long_pairs.size)
+        return self
+
+    def to(self, device):
+        self.dev = {"table": _dev(self.table, device), "lptr": _dev(self.lptr, device), "lsrc": _dev(self.lsrc, device)}
+        if self.long_csr is not None:
+            self.dev["long"] = _csr_dev(self.long_csr, device)
+        return self
+
+
+@dataclass
+class SpmmStep:
+    """y = M x for a sparse re-sampling matrix (U, or a D that is not a pure row select)."""
+    csr: CSR
+    kind: str = "spmm"
+    csr_t: Optional[CSR] = None
+    dev: dict = field(default_factory=dict)
+
+    def finalize(self):
+        self.csr_t = self.csr.transpose()
+        return self
+
+    def to(self, device):
+        self.dev = {"m": _csr_dev(self.csr, device), "mt": _csr_dev(self.csr_t, device)}
+        return self
+
+    def passes_dummy_only_to_dummy(self) -> bool:
+        """True if the last input column feeds only the last output row (the padded 1 of
+        main.py:190-191), i.e. a dead gradient on the output dummy row stays confined."""
+        t = self.csr_t
+        lo, hi = t.rowptr[t.rows - 1], t.rowptr[t.rows]
+        return hi - lo == 1 and t.col[lo] == self.csr.rows - 1
+
+
+def mark_dead_dummy(steps, input_dummy_dead: bool = False):
+    """Decide for every conv whether the gradient w.r.t. its input's dummy row is provably zero:
+    it is when that row was produced by a masked SpiralConv, possibly handed through
+    re-sampling steps that map dummy -> dummy only."""
+    dead = input_dummy_dead
+    for st in steps:
+        if st.kind == "conv":
+            st.dead_dummy_grad = dead
+            dead = True                      # its own output dummy row is masked
+        else:
+            dead = dead and st.passes_dummy_only_to_dummy()
+    return steps
+
+
+class Stack:
+    def __init__(self, steps, input_dummy_dead: bool = False):
+        for s in steps:
+            if s.kind == "spmm":
+                s.finalize()
+        mark_dead_dummy(steps, input_dummy_dead)
+        for s in steps:
+            if s.kind == "conv":
+                s.finalize()
+        self.steps = list(steps)
+        self.device = None
+
+    def to(self, device):
+        for s in self.steps:
+            s.to(device)
+        self.device = torch.empty(0, device=device).device      # normalised ('cuda' -> 'cuda:0')
+        return self
+
+    def conv_steps(self):
+        return [s for s in self.steps if s.kind == "conv"]
+
+    # ------------------------------------------------------------------ forward
+    def run_forward(self, x, in_layout, out_layout, weights, biases, keep: bool):
+        """-> (output, [activation of every step]) ; activations are only kept when `keep`."""
+        B = x.shape[0] if in_layout == "bm" else x.shape[1]
+        cur, cur_layout = x, in_layout
+        acts = []
+        last = len(self.steps) - 1
+        for i, st in enumerate(self.steps):
+            lay = out_layout if i == last else "vm"
+            if st.kind == "conv":
+                y = ops.alloc(B, st.R, st.cout, lay, x.device)
+                ops.spiral_conv_fwd(cur, cur_layout, st.dev["table"], weights[st.param], biases[st.param], y, lay,
+                                    st.R, st.S, st.act, st.zero_row)
+            else:
+                C = cur.shape[2]
+                y = ops.alloc(B, st.csr.rows, C, lay, x.device)
+                ops.spmm(st.dev["m"], cur, cur_layout, y, lay, st.csr.rows)
+            if keep:
+                acts.append(y)
+            cur, cur_layout = y, lay
+        return cur, acts
+
+    # ------------------------------------------------------------------ backward
+    def run_backward(self, x, in_layout, out_layout, acts, g, weights, need_x_grad: bool, need_bias):
+        """g: gradient w.r.t. the stack output (layout out_layout).
+        -> (grad_x or None, {param: (dW, db)})"""
+        steps = self.steps
+        last = len(steps) - 1
+        B = x.shape[0] if in_layout == "bm" else x.shape[1]
+        dev = x.device
+        grads = {}
+
+        def in_of(i):
+            return (x, in_layout) if i == 0 else (acts[i - 1], "vm")
+
+        # gradient entering the last step
+        st = steps[last]
+        if st.kind == "conv":
+            dpre = ops.alloc(B, st.R, st.cout, "vm", dev, extra_rows=st.n_extra)
+            ops.act_backward(g, out_layout, acts[last], out_layout, dpre, "vm", st.R, st.act, st.zero_row)
+            cur, cur_layout = dpre, "vm"
+        else:
+            cur, cur_layout = g, out_layout
+
+        for i in range(last, -1, -1):
+            st = steps[i]
+            inp, inp_layout = in_of(i)
+            prev = steps[i - 1] if i > 0 else None
+            want_in = i > 0 or need_x_grad
+            # where the input gradient goes: previous conv's dpre buffer (vm, maybe extra rows),
+            # previous spmm's output gradient (vm), or the caller's x gradient (in_layout)
+            g_in = None
+            if want_in:
+                rows_in = st.n_in if st.kind == "conv" else st.csr.cols
+                cin = st.cin if st.kind == "conv" else cur.shape[2]
+                if i == 0:
+                    g_in, g_layout = ops.alloc(B, rows_in, cin, in_layout, dev), in_layout
+                else:
+                    extra = prev.n_extra if prev.kind == "conv" else 0
+                    g_in, g_layout = ops.alloc(B, rows_in, cin, "vm", dev, extra_rows=extra), "vm"
+            ep = dict(yprev=None, yp_layout="vm", act_prev=0, zero_row=-1)
+            if prev is not None and prev.kind == "conv":
+                ep = dict(yprev=acts[i - 1], yp_layout="vm", act_prev=prev.act, zero_row=prev.zero_row)
+
+            if st.kind == "conv":
+                if st.n_extra:          # pre-reduce the long lists into the extra rows of dpre
+                    ops.spmm(st.dev["long"], cur, "vm", cur[st.R:], "vm", st.n_extra)
+                dW, db = ops.spiral_conv_bwd_wgt(cur, cur_layout, inp, inp_layout, st.dev["table"], st.R, st.S,
+                                                 st.cin, st.cout, want_bias=need_bias[st.param])
+                grads[st.param] = (dW, db)
+                if want_in:
+                    wt = ops.weight_transpose(weights[st.param], st.S, st.cin, st.cout)
+                    ops.spiral_conv_bwd_data(cur, cur_layout, st.dev["lptr"], st.dev["lsrc"], wt, g_in, g_layout,
+                                             ep["yprev"], ep["yp_layout"], ep["act_prev"], ep["zero_row"],
+                                             st.n_in, st.S, st.cin, st.cout)
+            elif want_in:
+                ops.spmm(st.dev["mt"], cur, cur_layout, g_in, g_layout, st.csr.cols, yprev=ep["yprev"],
+                         yp_layout=ep["yp_layout"], act_prev=ep["act_prev"], zero_row=ep["zero_row"])
+            if want_in:
+                cur, cur_layout = g_in, g_layout
+        return (cur if need_x_grad else None), grads
+
+
+class StackFunction(torch.autograd.Function):
+    """autograd node for a whole Stack.  params = (w_0, b_0, w_1, b_1, ...) for the SpiralConv
+    modules in ModuleList order (b_j may be None)."""
+
+    @staticmethod
+    def forward(ctx, stack: Stack, in_layout: str, out_layout: str, x, *params):
+        weights, biases = list(params[0::2]), list(params[1::2])
+        x = x.contiguous()
+        need = any(ctx.needs_input_grad[3:])
+        out, acts = stack.run_forward(x, in_layout, out_layout, weights, biases, keep=need)
+        ctx.stack, ctx.layouts = stack, (in_layout, out_layout)
+        ctx.acts = acts[:-1]                 # internal activations; the output itself goes through
+        ctx.save_for_backward(x, out, *weights)   # save_for_backward (no ctx <-> output cycle)
+        ctx.has_bias = [b is not None for b in biases]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        stack = ctx.stack
+        in_layout, out_layout = ctx.layouts
+        x, out, *weights = ctx.saved_tensors
+        g = g.contiguous()
+        # forward args: (stack, in_layout, out_layout, x, w_0, b_0, w_1, b_1, ...)
+        need_bias = [hb and ctx.needs_input_grad[5 + 2 * j] for j, hb in enumerate(ctx.has_bias)]
+        gx, grads = stack.run_backward(x, in_layout, out_layout, ctx.acts + [out], g, weights,
+                                       ctx.needs_input_grad[3], need_bias)
+        ctx.acts = None
+        out = [None, None, None, gx]
+        for j in range(len(weights)):
+            dW, db = grads.get(j, (None, None))
+            out += [dW, db]
+        return tuple(out)
+
+
+def run_stack(stack: Stack, x, in_layout, out_layout, convs):
+    """convs: the ModuleList of SpiralConv modules this stack's ConvSteps index into."""
+    if not x.is_cuda:
+        raise RuntimeError("semantichuman_amd: input is on %s; the spiral-convolution kernels run on a HIP device "
+                           "only (there is no CPU fallback)" % x.device)
+    if stack.device is None or stack.device != x.device:
+        raise RuntimeError("semantichuman_amd: model tables are on %s but the input is on %s - move the module with "
+                           ".to(device)" % (stack.device, x.device))
+    params = []
+    for m in convs:
+        params += [m.conv.weight, m.conv.bias]
+    if torch.is_grad_enabled() and (x.requires_grad or any(p is not None and p.requires_grad for p in params)):
+        return StackFunction.apply(stack, in_layout, out_layout, x, *params)
+    out, _ = stack.run_forward(x.contiguous(), in_layout, out_layout, params[0::2], params[1::2], keep=False)
+    return out

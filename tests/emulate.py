@@ -1,0 +1,87 @@
+"""numpy (float64) emulation of the FORMULATION the HIP kernels use - gather tables, fused
+row-select, transposed lists, long-list pre-reduction, CSR re-sampling.  It lets the CPU test
+suite prove that the tables built by semantichuman_amd.mesh_ops / stack are right (against the
+oracle's autograd) without a GPU.  Test infrastructure only."""
+import numpy as np
+
+ACT = {0: lambda v: v, 1: lambda v: np.maximum(v, 0), 2: lambda v: np.where(v > 0, v, np.expm1(np.minimum(v, 0))),
+       3: lambda v: np.where(v > 0, v, 0.02 * v), 4: lambda v: 1 / (1 + np.exp(-v)), 5: np.tanh}
+DACT = {0: lambda y: np.ones_like(y), 1: lambda y: (y > 0).astype(y.dtype), 2: lambda y: np.where(y > 0, 1.0, y + 1.0),
+        3: lambda y: np.where(y > 0, 1.0, 0.02), 4: lambda y: y * (1 - y), 5: lambda y: 1 - y * y}
+
+
+def conv_fwd(x, table, W, b, act, zero_row):
+    """x [n_in,B,Cin] (vertex-major) -> y [R,B,Cout]"""
+    R, S = table.shape
+    G = x[table]                                        # [R,S,B,Cin]
+    G = G.transpose(0, 2, 1, 3).reshape(R, x.shape[1], -1)
+    y = ACT[act](G @ W.T + (0 if b is None else b))
+    if zero_row >= 0:
+        y[zero_row] = 0
+    return y
+
+
+def conv_bwd_data(dpre_ext, lptr, lsrc, W, n_in, S, cin, cout):
+    """dpre_ext [R+extra,B,Cout]; -> dx [n_in,B,Cin] via the (u,s) lists"""
+    B = dpre_ext.shape[1]
+    dx = np.zeros((n_in, B, cin))
+    for u in range(n_in):
+        for s in range(S):
+            e0, e1 = lptr[u * S + s], lptr[u * S + s + 1]
+            if e1 > e0:
+                a = dpre_ext[lsrc[e0:e1]].sum(0)         # [B,Cout]
+                dx[u] += a @ W[:, s * cin:(s + 1) * cin]
+    return dx
+
+
+def conv_bwd_wgt(dpre, x, table):
+    R, S = table.shape
+    G = x[table].transpose(0, 2, 1, 3).reshape(R * x.shape[1], -1)
+    P = dpre[:R].reshape(R * x.shape[1], -1)
+    return P.T @ G, P.sum(0)
+
+
+def spmm(csr, x):
+    y = np.zeros((csr.rows,) + x.shape[1:])
+    for r in range(csr.rows):
+        for e in range(csr.rowptr[r], csr.rowptr[r + 1]):
+            y[r] += csr.val[e] * x[csr.col[e]]
+    return y
+
+
+def stack_forward(stack, x, weights, biases):
+    acts, cur = [], x
+    for st in stack.steps:
+        if st.kind == "conv":
+            cur = conv_fwd(cur, st.table, weights[st.param], biases[st.param], st.act, st.zero_row)
+        else:
+            cur = spmm(st.csr, cur)
+        acts.append(cur)
+    return acts
+
+
+def stack_backward(stack, x, acts, g, weights):
+    """Mirror of semantichuman_amd.stack.Stack.run_backward in numpy. -> (gx, {param: (dW, db)})"""
+    steps, grads = stack.steps, {}
+    last = len(steps) - 1
+    st = steps[last]
+    cur = g * DACT[st.act](acts[last]) if st.kind == "conv" else g
+    if st.kind == "conv":
+        cur[st.zero_row] = 0
+    for i in range(last, -1, -1):
+        st = steps[i]
+        inp = x if i == 0 else acts[i - 1]
+        prev = steps[i - 1] if i > 0 else None
+        if st.kind == "conv":
+            ext = cur
+            if st.n_extra:
+                ext = np.concatenate([cur[:st.R], spmm(st.long_csr, cur[:st.R])], 0)
+            grads[st.param] = conv_bwd_wgt(cur, inp, st.table)
+            g_in = conv_bwd_data(ext, st.lptr, st.lsrc, weights[st.param], st.n_in, st.S, st.cin, st.cout)
+        else:
+            g_in = spmm(st.csr_t, cur)
+        if prev is not None and prev.kind == "conv":
+            g_in = g_in * DACT[prev.act](acts[i - 1])
+            g_in[prev.zero_row] = 0
+        cur = g_in
+    return cur, grads

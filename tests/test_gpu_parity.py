@@ -1,0 +1,314 @@
+"""GPU parity tests: every HIP kernel, through the C ABI, against the CPU oracle and the
+reference's golden vectors.  Run with `pytest -m gpu` on an MI355X.
+
+Tolerances (fp32):
+  forward tensors      max-abs-err <= 1e-5 * max|ref|      (the reference's own fp32-vs-fp64
+                                                           noise is 5e-7 relative)
+  gradients            max-abs-err <= 1e-4 * max|g_ref|    per tensor
+  row-select / gather  bit-exact
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import semantichuman_amd as sh
+from oracle import ref_cpu
+from semantichuman_amd import mesh_ops, ops
+from semantichuman_amd.hierarchy import load_hierarchy
+
+pytestmark = pytest.mark.gpu
+FE = [[3, 16, 32, 64, 128], [[], [], [], [], []]]
+FD = [[128, 64, 32, 32, 16], [[], [], [], [], 3]]
+FWD_TOL, GRAD_TOL = 1e-5, 1e-4
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def close(got, ref, tol, what=""):
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+    ref = ref.detach().cpu().numpy() if torch.is_tensor(ref) else np.asarray(ref)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err, scale = np.abs(got - ref).max(), np.abs(ref).max()
+    assert np.isfinite(got).all(), what
+    assert err <= tol * scale + 1e-30, "%s: err %.3e > %.1e * %.3e" % (what, err, tol, scale)
+
+
+def test_native_library_is_loaded():
+    from semantichuman_amd import _lib
+    lib = _lib.load()
+    assert lib.sh_version() >= 100
+    with open("/proc/self/maps") as f:
+        assert "libsh_kernels.so" in f.read()
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("act", ["relu", "elu", "leaky_relu", "sigmoid", "tanh", "identity"])
+def test_spiral_conv_module_vs_reference_golden(golden_dir, act):
+    g = np.load(os.path.join(golden_dir, "conv_acts.npz"))
+    B, N1, cin = g["x"].shape
+    S = g["spirals"].shape[1]
+    cout = g["w"].shape[0]
+    m = sh.SpiralConv(cin, S, cout, activation=act, device=dev()).to(dev())
+    with torch.no_grad():
+        m.conv.weight.copy_(torch.from_numpy(g["w"]))
+        m.conv.bias.copy_(torch.from_numpy(g["b"]))
+    x = torch.from_numpy(g["x"]).to(dev()).requires_grad_(True)
+    adj = torch.from_numpy(g["spirals"].astype(np.int64))[None].repeat(B, 1, 1).to(dev())     # int64, -1 padded
+    y = m(x, adj)
+    (y * torch.from_numpy(g["gy"]).to(dev())).sum().backward()
+    close(y, g[act + "/y"], FWD_TOL, "y")
+    assert float(y[:, -1].abs().max()) == 0.0                       # dummy row is masked (models.py:49-51)
+    close(x.grad, g[act + "/gx"], GRAD_TOL, "gx")
+    close(m.conv.weight.grad, g[act + "/gw"], GRAD_TOL, "gw")
+    close(m.conv.bias.grad, g[act + "/gb"], GRAD_TOL, "gb")
+
+
+SHAPES = [  # (B, n_rows, S, Cin, Cout)  - ragged / odd cases on purpose
+    (1, 7, 1, 4, 4), (3, 50, 5, 3, 16), (5, 171, 11, 12, 20), (2, 300, 8, 16, 3), (70, 33, 9, 32, 32),
+    (4, 129, 7, 64, 128), (130, 20, 3, 8, 64), (2, 64, 4, 5, 7),
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("layouts", [("bm", "bm"), ("vm", "vm"), ("bm", "vm")])
+def test_conv_kernels_vs_oracle(shape, layouts):
+    B, N1, S, cin, cout = shape
+    rs = np.random.RandomState(hash(shape) % 1000)
+    table = rs.randint(0, N1, size=(N1, S)).astype(np.int32)
+    table[:, 0] = np.arange(N1)
+    table[rs.rand(N1, S) < 0.15] = N1 - 1                       # padding -> dummy row
+    table[-1] = N1 - 1
+    x = torch.from_numpy(rs.randn(B, N1, cin).astype(np.float32))
+    x[:, -1] = 0.3                                              # a NON-zero dummy row (decoder input case)
+    W = torch.from_numpy((rs.randn(cout, S * cin) / np.sqrt(S * cin)).astype(np.float32))
+    b = torch.from_numpy(rs.randn(cout).astype(np.float32))
+    gy = torch.from_numpy(rs.randn(B, N1, cout).astype(np.float32))
+    # oracle
+    xo, Wo, bo = x.clone().requires_grad_(True), W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    adj = torch.from_numpy(table.astype(np.int64))[None]
+    yo = ref_cpu.spiral_conv(xo, adj, Wo, bo, "elu")
+    (yo * gy).sum().backward()
+    # HIP
+    lin, lout = layouts
+    d = dev()
+    xd = (x if lin == "bm" else x.permute(1, 0, 2)).contiguous().to(d)
+    y = ops.alloc(B, N1, cout, lout, d)
+    tab = torch.from_numpy(table).to(d)
+    Wd, bd = W.to(d), b.to(d)
+    ops.spiral_conv_fwd(xd, lin, tab, Wd, bd, y, lout, N1, S, ops.act_id("elu"), N1 - 1)
+    y_bm = y if lout == "bm" else y.permute(1, 0, 2)
+    close(y_bm, yo, FWD_TOL, "fwd")
+    # backward: dpre -> wgrad, bwd-data
+    gyd = (gy if lout == "bm" else gy.permute(1, 0, 2)).contiguous().to(d)
+    dpre = ops.alloc(B, N1, cout, "vm", d)
+    ops.act_backward(gyd, lout, y, lout, dpre, "vm", N1, ops.act_id("elu"), N1 - 1)
+    dW, db = ops.spiral_conv_bwd_wgt(dpre, "vm", xd, lin, tab, N1, S, cin, cout)
+    close(dW, Wo.grad, GRAD_TOL, "dW")
+    close(db, bo.grad, GRAD_TOL, "db")
+    gl = mesh_ops.transpose_table(table, N1)
+    dx = ops.alloc(B, N1, cin, lin, d)
+    ops.spiral_conv_bwd_data(dpre, "vm", torch.from_numpy(gl.ptr).to(d), torch.from_numpy(gl.src).to(d),
+                             ops.weight_transpose(Wd, S, cin, cout), dx, lin, None, "vm", 0, -1, N1, S, cin, cout)
+    close(dx if lin == "bm" else dx.permute(1, 0, 2), xo.grad, GRAD_TOL, "dx")
+
+
+def test_gather_is_bit_exact():
+    """Identity weights, identity activation: the kernel output is a pure copy of the gathered
+    rows (north_star: bit-exact spiral index gathers)."""
+    B, N1, S, C = 3, 200, 6, 16
+    rs = np.random.RandomState(3)
+    table = rs.randint(0, N1, size=(N1, S)).astype(np.int32)
+    x = torch.from_numpy(rs.randn(B, N1, C).astype(np.float32))
+    d = dev()
+    for s in range(S):
+        W = torch.zeros(C, S * C)
+        W[:, s * C:(s + 1) * C] = torch.eye(C)
+        y = ops.alloc(B, N1, C, "bm", d)
+        ops.spiral_conv_fwd(x.to(d), "bm", torch.from_numpy(table).to(d), W.to(d), None, y, "bm", N1, S, 0, -1)
+        assert torch.equal(y.cpu(), x[:, table[:, s].astype(np.int64)])
+
+
+def test_fused_row_select_is_exact_and_matches_dense_D(golden_dir):
+    h = load_hierarchy(os.path.join(golden_dir, "small_ae.npz"))
+    S, D, U = h.dense_constants()
+    rs = np.random.RandomState(5)
+    B, cin, cout = 4, 16, 32
+    x = torch.from_numpy(rs.randn(B, h.sizes[1] + 1, cin).astype(np.float32)); x[:, -1] = 0
+    W = torch.from_numpy((rs.randn(cout, h.spiral_sizes[1] * cin) * 0.1).astype(np.float32))
+    b = torch.from_numpy(rs.randn(cout).astype(np.float32))
+    yo = torch.matmul(D[1], ref_cpu.spiral_conv(x, S[1], W, b, "elu"))       # conv then dense D (models.py:122-127)
+    d = dev()
+    full = mesh_ops.spirals_to_table(h.spirals[1])
+    fused = mesh_ops.compose_select(full, h.D[1].col)
+    yf = ops.alloc(B, fused.shape[0], cout, "bm", d)
+    ops.spiral_conv_fwd(x.to(d), "bm", torch.from_numpy(fused).to(d), W.to(d), b.to(d), yf, "bm", fused.shape[0],
+                        h.spiral_sizes[1], 2, fused.shape[0] - 1)
+    ya = ops.alloc(B, full.shape[0], cout, "bm", d)
+    ops.spiral_conv_fwd(x.to(d), "bm", torch.from_numpy(full).to(d), W.to(d), b.to(d), ya, "bm", full.shape[0],
+                        h.spiral_sizes[1], 2, full.shape[0] - 1)
+    assert torch.equal(yf, ya[:, torch.from_numpy(h.D[1].col.astype(np.int64)).to(d)])    # fusion is bit-exact
+    close(yf, yo, FWD_TOL, "fused conv+D vs dense")
+
+
+def test_spmm_vs_dense(golden_dir):
+    h = load_hierarchy(os.path.join(golden_dir, "small_ae.npz"))
+    d = dev()
+    rs = np.random.RandomState(7)
+    for m in (h.U[0], h.U[2], h.D[1], h.U[1].transpose()):
+        for C in (3, 32):
+            x = torch.from_numpy(rs.randn(5, m.cols, C).astype(np.float32))
+            ref = torch.matmul(torch.from_numpy(m.todense())[None], x)
+            md = tuple(torch.from_numpy(a).to(d) for a in (m.rowptr, m.col, m.val))
+            for lay in ("bm", "vm"):
+                xd = (x if lay == "bm" else x.permute(1, 0, 2)).contiguous().to(d)
+                y = ops.alloc(5, m.rows, C, lay, d)
+                ops.spmm(md, xd, lay, y, lay, m.rows)
+                close(y if lay == "bm" else y.permute(1, 0, 2), ref, FWD_TOL, "spmm")
+    # a row-select applied by spmm is a bit-exact copy
+    m = h.D[0]
+    x = torch.from_numpy(rs.randn(2, m.cols, 8).astype(np.float32))
+    y = ops.alloc(2, m.rows, 8, "bm", d)
+    ops.spmm(tuple(torch.from_numpy(a).to(d) for a in (m.rowptr, m.col, m.val)), x.to(d), "bm", y, "bm", m.rows)
+    assert torch.equal(y.cpu(), x[:, m.col.astype(np.int64)])
+
+
+def test_losses_and_metric_vs_oracle(golden_dir):
+    h = load_hierarchy(os.path.join(golden_dir, "small_ae.npz"))
+    rs = np.random.RandomState(11)
+    B, N1 = 5, h.sizes[0] + 1
+    x = torch.from_numpy(np.concatenate([rs.randn(B, N1 - 1, 3), np.zeros((B, 1, 3))], 1).astype(np.float32))
+    xh = (x + 0.05 * torch.from_numpy(rs.randn(B, N1, 3).astype(np.float32)))
+    xh[:, -1] = 0
+    d = dev()
+    xd, xhd = x.to(d), xh.to(d).requires_grad_(True)
+    xho = xh.clone().requires_grad_(True)
+    ft = sh.FaceTables(h.faces, N1, d)
+    lo = torch.nn.functional.l1_loss(x, xho) * 0.7 + 0.01 * ref_cpu.edge_ratio_loss(xho, x, h.faces)
+    lo.backward()
+    l = sh.l1_loss(xd, xhd) * 0.7 + 0.01 * sh.edge_ratio_loss(xhd, xd, ft)
+    l.backward()
+    assert l.item() == pytest.approx(lo.item(), rel=2e-6)
+    close(xhd.grad, xho.grad, GRAD_TOL, "loss grad")
+    l1o, l2o = ref_cpu.eval_metrics(xh, x)
+    assert sh.vertex_l2_mm(xhd, xd).item() == pytest.approx(l2o.item(), rel=2e-6)
+    assert sh.eval_l1(xhd, xd).item() == pytest.approx(l1o.item(), rel=2e-6)
+    # odd element count for the vector tail path
+    a, b = torch.from_numpy(rs.randn(1031).astype(np.float32)), torch.from_numpy(rs.randn(1031).astype(np.float32))
+    assert ops.l1_loss_fwd(a.to(d), b.to(d)).item() == pytest.approx((a - b).abs().mean().item(), rel=2e-6)
+
+
+# ------------------------------------------------------------------------------------------
+def make_models(h, g, latent):
+    S, D, U = h.dense_constants()
+    om = ref_cpu.SpiralAEOracle(FE, FD, latent, h.sizes, h.spiral_sizes, S, D, U)
+    m = sh.SpiralAutoencoder(FE, FD, latent, h.sizes, h.spiral_sizes, h.spirals, h.D, h.U, dev())
+    if g is not None:
+        sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w0/")}
+        om.load_state_dict(sd)
+    m.load_state_dict(om.state_dict())
+    return m, om
+
+
+def test_autoencoder_vs_reference_golden(golden_dir):
+    """models.SpiralAutoencoder of the REFERENCE (run in the build container, vectors committed):
+    outputs, latent, loss, every parameter gradient, weights after one Adam step, eval metric."""
+    p = os.path.join(golden_dir, "small_ae.npz")
+    g, h = np.load(p), load_hierarchy(p)
+    m, om = make_models(h, g, 16)
+    x = torch.from_numpy(g["x"]).to(dev())
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-5)
+    opt.zero_grad()
+    x_hat, z = m(x)
+    close(x_hat, g["x_hat"], FWD_TOL, "x_hat")
+    close(z, g["z"], FWD_TOL, "z")
+    close(m.decode(torch.from_numpy(g["z_in"]).to(dev())), g["decode_out"], FWD_TOL, "decode")
+    assert sh.eval_l1(x_hat, x).item() == pytest.approx(float(g["eval_l1_w0"]), rel=1e-5)
+    assert sh.vertex_l2_mm(x_hat, x).item() == pytest.approx(float(g["eval_l2mm_w0"]), rel=1e-5)
+    ft = sh.FaceTables(h.faces, h.sizes[0] + 1, dev())
+    rec, edge = sh.l1_loss(x, x_hat), sh.edge_ratio_loss(x_hat, x, ft)
+    assert rec.item() == pytest.approx(float(g["loss_rec"]), rel=1e-5)
+    assert edge.item() == pytest.approx(float(g["loss_edge"]), rel=1e-5)
+    (rec + 1e-2 * edge).backward()
+    for name, prm in m.named_parameters():
+        close(prm.grad, g["grad/" + name], GRAD_TOL, "grad " + name)
+    opt.step()
+    for name, prm in m.named_parameters():
+        dlt = np.abs(prm.detach().cpu().numpy() - g["w1/" + name])
+        assert dlt.max() <= 1e-4 and dlt.mean() <= 1e-7, (name, dlt.max(), dlt.mean())
+
+
+def test_state_dict_and_checkpoint_roundtrip(golden_dir, tmp_path):
+    p = os.path.join(golden_dir, "small_ae.npz")
+    g, h = np.load(p), load_hierarchy(p)
+    m, om = make_models(h, g, 16)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-5)
+    sched = torch.optim.lr_scheduler.StepLR(opt, 1, gamma=0.99)
+    ck = {"epoch": 3, "autoencoder_state_dict": m.cpu().state_dict(), "optimizer_state_dict": opt.state_dict(),
+          "scheduler_state_dict": sched.state_dict()}                      # train_funcs.py:562-567 layout
+    torch.save(ck, tmp_path / "checkpoint3.pth.tar")
+    m.to(dev())
+    ld = torch.load(tmp_path / "checkpoint3.pth.tar", map_location="cpu")
+    om.load_state_dict(ld["autoencoder_state_dict"])                        # oracle == reference names
+    m2, _ = make_models(h, None, 16)
+    m2.load_state_dict(ld["autoencoder_state_dict"])
+    x = torch.from_numpy(g["x"]).to(dev())
+    assert torch.equal(m2(x)[0], m(x)[0])
+
+
+def test_full_size_6890_vs_oracle_and_reference_probe(golden_dir):
+    """6890-vertex template (BASELINE config sizes), B=2: against the oracle on the same
+    inputs, and against the probe of the REFERENCE's own output stored in the fixture."""
+    p = os.path.join(golden_dir, "template6890.npz")
+    g, h = np.load(p), load_hierarchy(p)
+    from semantichuman_amd import synthetic
+    m, om = make_models(h, None, 256)
+    import math
+    with torch.no_grad():                       # the closed-form weights the fixture was made with
+        for j, (name, prm) in enumerate(om.named_parameters()):
+            fan_in = prm.shape[1] if prm.dim() == 2 else prm.shape[0]
+            prm.copy_(torch.from_numpy(synthetic.closed_form_fill(tuple(prm.shape), 1.0 / math.sqrt(fan_in), 0.37 + 0.011 * j, 0.1 * j)))
+    m.load_state_dict(om.state_dict())
+    x = torch.from_numpy(synthetic.synth_batch(h.verts, 2, seed=0))
+    xd = x.to(dev())
+    x_hat, z = m(xd)
+    close(z, g["z_B2"], FWD_TOL, "z vs reference")
+    close(x_hat[:, ::97], g["x_hat_B2_probe"], FWD_TOL, "x_hat probe vs reference")
+    xo, zo = om(x)
+    close(x_hat, xo, FWD_TOL, "x_hat vs oracle")
+    sh.l1_loss(xd, x_hat).backward()
+    torch.nn.functional.l1_loss(x, xo).backward()
+    for (name, prm), po in zip(m.named_parameters(), om.parameters()):
+        close(prm.grad, po.grad, GRAD_TOL, "grad " + name)
+
+
+def test_batch64_properties(golden_dir):
+    """BASELINE batch size (64) at 6890 vertices, through size-independent properties:
+    per-sample independence (sample b of a batch == that sample alone, bitwise), determinism
+    (two runs bitwise equal, no atomics), dummy row stays exactly zero."""
+    p = os.path.join(golden_dir, "template6890.npz")
+    h = load_hierarchy(p)
+    from semantichuman_amd import synthetic
+    torch.manual_seed(0)
+    m, _ = make_models(h, None, 256)
+    x = torch.from_numpy(synthetic.synth_batch(h.verts, 64, seed=1)).to(dev())
+    x_hat, z = m(x)
+    x_hat2, z2 = m(x)
+    assert torch.equal(x_hat, x_hat2) and torch.equal(z, z2)
+    assert float(x_hat[:, -1].abs().max()) == 0.0
+    with torch.no_grad():
+        h1 = m._enc_stack.run_forward(x[5:6].contiguous(), "bm", "bm", [c.conv.weight for c in m.conv],
+                                      [c.conv.bias for c in m.conv], keep=False)[0]
+        h64 = m._enc_stack.run_forward(x, "bm", "bm", [c.conv.weight for c in m.conv], [c.conv.bias for c in m.conv],
+                                       keep=False)[0]
+    assert torch.equal(h1[0], h64[5])            # conv stack: no cross-sample coupling, same summation order
+    sh.l1_loss(x, x_hat).backward()
+    g1 = [prm.grad.clone() for prm in m.parameters()]
+    m.zero_grad()
+    xh3, _ = m(x)
+    sh.l1_loss(x, xh3).backward()
+    for a, prm in zip(g1, m.parameters()):
+        assert torch.equal(a, prm.grad)          # deterministic backward (fixed-order slab reduction)

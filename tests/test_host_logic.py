@@ -1,0 +1,206 @@
+"""Host-side table construction (mesh_ops, stack planning) checked on CPU against the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu
+from semantichuman_amd import mesh_ops, models, synthetic
+from semantichuman_amd.hierarchy import load_hierarchy
+from semantichuman_amd.losses import FaceTables
+from semantichuman_amd.stack import ConvStep, Stack
+from tests import emulate
+
+FE = [[3, 16, 32, 64, 128], [[], [], [], [], []]]
+FD = [[128, 64, 32, 32, 16], [[], [], [], [], 3]]
+
+
+@pytest.fixture(scope="module")
+def small(golden_dir):
+    return np.load(os.path.join(golden_dir, "small_ae.npz")), load_hierarchy(os.path.join(golden_dir, "small_ae.npz"))
+
+
+def test_spirals_to_table_wraps_minus_one(small):
+    g, h = small
+    t = mesh_ops.spirals_to_table(h.spirals[1][None])
+    n1 = h.sizes[1] + 1
+    assert t.dtype == np.int32 and t.min() >= 0 and t.max() == n1 - 1
+    assert np.array_equal(t[h.spirals[1] >= 0], h.spirals[1][h.spirals[1] >= 0])
+    assert np.all(t[h.spirals[1] == -1] == n1 - 1) and np.all(t[-1] == n1 - 1)
+    with pytest.raises(IndexError):
+        mesh_ops.spirals_to_table(np.array([[[0, 5]]]))
+
+
+def test_csr_roundtrip_and_transpose(small):
+    g, h = small
+    for m in h.U + h.D:
+        dense = m.todense()
+        back = mesh_ops.dense_to_csr(dense[None])
+        assert np.array_equal(back.todense(), dense)
+        assert np.array_equal(m.transpose().todense(), dense.T)
+    assert all(d.is_row_select() for d in h.D) and not any(u.is_row_select() for u in h.U)
+    for u in h.U:
+        assert np.diff(u.rowptr).max() <= 3
+        np.testing.assert_allclose(u.todense().sum(1), 1.0, atol=1e-6)
+        assert u.todense()[-1, -1] == 1.0                    # padded dummy entry (main.py:190-191)
+
+
+def test_empty_and_ragged_rows():
+    d = np.zeros((4, 5), np.float32)
+    d[0, 1] = 2; d[0, 4] = -1; d[3, 0] = 0.5           # rows 1,2 empty
+    c = mesh_ops.dense_to_csr(d)
+    assert list(c.rowptr) == [0, 2, 2, 2, 3] and np.array_equal(c.todense(), d)
+    t = c.transpose()
+    assert t.rows == 5 and np.array_equal(t.todense(), d.T)
+    x = np.arange(10.0).reshape(5, 1, 2)
+    np.testing.assert_allclose(emulate.spmm(c, x)[:, 0], d.astype(np.float64) @ x[:, 0])
+
+
+def test_transpose_table_brute_force(small):
+    g, h = small
+    table = mesh_ops.spirals_to_table(h.spirals[2][None])
+    n_in, S = table.shape
+    gl = mesh_ops.transpose_table(table, n_in)
+    assert gl.ptr[-1] == table.size
+    for u in range(n_in):
+        for s in range(S):
+            want = np.nonzero(table[:, s] == u)[0]
+            assert np.array_equal(gl.src[gl.ptr[u * S + s]:gl.ptr[u * S + s + 1]], want)
+    gl2 = mesh_ops.transpose_table(table, n_in, skip_row=n_in - 1)
+    assert gl2.ptr[-1] == (table != n_in - 1).sum()
+    assert gl2.ptr[(n_in - 1) * S] == gl2.ptr[-1]
+
+
+def test_long_lists_are_diverted(small):
+    g, h = small
+    table = mesh_ops.spirals_to_table(h.spirals[1][None])
+    st = ConvStep(param=0, table=table, n_in=table.shape[0], cin=4, cout=5, act=2).finalize()
+    assert st.n_extra > 0 and st.long_csr.rows == st.n_extra       # the dummy row has a huge fan-in
+    assert np.diff(st.lptr).max() <= 8
+    rs = np.random.RandomState(0)
+    dpre = rs.randn(st.R, 2, 5)
+    W = rs.randn(5, st.S * 4)
+    ext = np.concatenate([dpre, emulate.spmm(st.long_csr, dpre)], 0)
+    got = emulate.conv_bwd_data(ext, st.lptr, st.lsrc, W, st.n_in, st.S, 4, 5)
+    plain = mesh_ops.transpose_table(table, table.shape[0])
+    want = emulate.conv_bwd_data(dpre, plain.ptr, plain.src, W, st.n_in, st.S, 4, 5)
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)
+
+
+def test_conv_layout_matches_reference_keys(small):
+    g, h = small
+    enc, dec = models.conv_layout(FE, FD, h.spiral_sizes, "elu")
+    keys = [str(k) for k in g["state_dict_keys"]]
+    for j, (cin, S, cout, act, lvl) in enumerate(enc):
+        assert g["w0/conv.%d.conv.weight" % j].shape == (cout, cin * S)
+    for j, (cin, S, cout, act, lvl) in enumerate(dec):
+        assert g["w0/dconv.%d.conv.weight" % j].shape == (cout, cin * S)
+    assert dec[-1][3] == "identity" and all(l[3] == "elu" for l in enc + dec[:-1])
+    assert len(enc) + len(dec) == sum(k.endswith("conv.weight") for k in keys)
+    # optional second convolution per level (models.py:72-75, :96-99)
+    enc2, dec2 = models.conv_layout([[3, 16, 32, 64, 128], [8, [], 48, [], []]], [[128, 64, 32, 32, 16], [[], 64, [], [], 3]],
+                                    h.spiral_sizes, "relu")
+    assert [(l[0], l[2]) for l in enc2] == [(3, 8), (8, 16), (16, 32), (32, 48), (48, 64), (64, 128)]
+    assert [(l[0], l[2], l[3]) for l in dec2] == [(128, 64, "relu"), (64, 64, "relu"), (64, 32, "relu"), (32, 32, "relu"),
+                                                  (32, 16, "relu"), (16, 3, "identity")]
+    o = ref_cpu.layer_plan([[3, 16, 32, 64, 128], [8, [], 48, [], []]], [[128, 64, 32, 32, 16], [[], 64, [], [], 3]],
+                           h.spiral_sizes, "relu")
+    assert [tuple(l) for l in o[0]] == [tuple(l) for l in enc2] and [tuple(l) for l in o[1]] == [tuple(l) for l in dec2]
+
+
+def test_module_state_dict_is_drop_in(small):
+    g, h = small
+    import semantichuman_amd as sh
+    m = sh.SpiralAutoencoder(FE, FD, 16, h.sizes, h.spiral_sizes, h.spirals, h.D, h.U, None)
+    assert list(m.state_dict().keys()) == [str(k) for k in g["state_dict_keys"]]
+    m.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w0/")})      # strict
+    with pytest.raises(NotImplementedError):
+        sh.SpiralConv(3, 4, 5, activation="gelu")
+    with pytest.raises(RuntimeError):                        # no silent CPU fallback
+        m(torch.from_numpy(g["x"]))
+
+
+def test_stack_formulation_equals_oracle_autograd(small):
+    """Fused row-select, transposed lists, dead-dummy skipping, epilogue placement: the numpy
+    emulation of the kernel chain must reproduce the oracle's outputs and autograd gradients."""
+    g, h = small
+    import semantichuman_amd as sh
+    S, D, U = h.dense_constants()
+    om = ref_cpu.SpiralAEOracle(FE, FD, 16, h.sizes, h.spiral_sizes, S, D, U).double()
+    sd = {k[3:]: torch.from_numpy(g[k]).double() for k in g.files if k.startswith("w0/")}
+    om.load_state_dict(sd)
+    m = sh.SpiralAutoencoder(FE, FD, 16, h.sizes, h.spiral_sizes, h.spirals, h.D, h.U, None)
+    x = torch.from_numpy(g["x"]).double().requires_grad_(True)
+    for stack, convs, inp in ((m._enc_stack, "conv", x),):
+        W = [sd["%s.%d.conv.weight" % (convs, j)].numpy() for j in range(len(getattr(m, convs)))]
+        Bs = [sd["%s.%d.conv.bias" % (convs, j)].numpy() for j in range(len(getattr(m, convs)))]
+        xin = x.detach().numpy().transpose(1, 0, 2)                       # vertex-major
+        acts = emulate.stack_forward(stack, xin, W, Bs)
+        # oracle encoder activations
+        cur, j = x, 0
+        for lvl in range(4):
+            cur = ref_cpu.spiral_conv(cur, S[lvl], om.conv[j].conv.weight, om.conv[j].conv.bias, "elu")
+            cur = torch.matmul(D[lvl].double(), cur)
+            np.testing.assert_allclose(acts[j].transpose(1, 0, 2), cur.detach().numpy(), rtol=1e-10, atol=1e-12)
+            j += 1
+        gy = torch.from_numpy(np.random.RandomState(1).randn(*cur.shape))
+        om.zero_grad()
+        (cur * gy).sum().backward()
+        gx, grads = emulate.stack_backward(stack, xin, acts, gy.numpy().transpose(1, 0, 2).copy(), W)
+        np.testing.assert_allclose(gx.transpose(1, 0, 2), x.grad.numpy(), rtol=1e-9, atol=1e-12)
+        for j in range(4):
+            np.testing.assert_allclose(grads[j][0], om.conv[j].conv.weight.grad.numpy(), rtol=1e-9, atol=1e-11)
+            np.testing.assert_allclose(grads[j][1], om.conv[j].conv.bias.grad.numpy(), rtol=1e-9, atol=1e-11)
+    # decoder, including the LIVE dummy row of its input
+    hin = torch.from_numpy(np.random.RandomState(2).randn(2, h.sizes[-1] + 1, 128)).requires_grad_(True)
+    W = [sd["dconv.%d.conv.weight" % j].numpy() for j in range(5)]
+    Bs = [sd["dconv.%d.conv.bias" % j].numpy() for j in range(5)]
+    hv = hin.detach().numpy().transpose(1, 0, 2)
+    acts = emulate.stack_forward(m._dec_stack, hv, W, Bs)
+    cur, j = hin, 0
+    for lvl in (3, 2, 1, 0):
+        cur = torch.matmul(U[lvl].double(), cur)
+        for _ in range(2 if lvl == 0 else 1):
+            cur = ref_cpu.spiral_conv(cur, S[lvl], om.dconv[j].conv.weight, om.dconv[j].conv.bias, om.dconv[j].act)
+            j += 1
+    np.testing.assert_allclose(acts[-1].transpose(1, 0, 2), cur.detach().numpy(), rtol=1e-9, atol=1e-12)
+    gy = torch.from_numpy(np.random.RandomState(3).randn(*cur.shape))
+    om.zero_grad()
+    (cur * gy).sum().backward()
+    gx, grads = emulate.stack_backward(m._dec_stack, hv, acts, gy.numpy().transpose(1, 0, 2).copy(), W)
+    assert np.abs(hin.grad.numpy()[:, -1]).max() > 0                       # the dummy-row gradient is live here
+    np.testing.assert_allclose(gx.transpose(1, 0, 2), hin.grad.numpy(), rtol=1e-9, atol=1e-12)
+    for j in range(5):
+        np.testing.assert_allclose(grads[j][0], om.dconv[j].conv.weight.grad.numpy(), rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(grads[j][1], om.dconv[j].conv.bias.grad.numpy(), rtol=1e-9, atol=1e-11)
+    dead = [st.dead_dummy_grad for st in m._dec_stack.steps if st.kind == "conv"]
+    assert dead == [False, True, True, True, True]
+
+
+def test_barycentric_upsample_reproduces_vertices():
+    v, f = synthetic.box_sphere(6, 6, 4)
+    U = mesh_ops.barycentric_upsample(v, f, v)               # same mesh: every vertex maps to itself
+    np.testing.assert_allclose(U.todense() @ v, v, atol=1e-6)
+    p = (v[f[:, 0]] + v[f[:, 1]] + v[f[:, 2]]) / 3            # face centres lie on the surface
+    Uc = mesh_ops.barycentric_upsample(v, f, p)
+    np.testing.assert_allclose(Uc.todense() @ v, p, atol=1e-6)
+    np.testing.assert_allclose(Uc.todense().sum(1), 1.0, atol=1e-6)
+
+
+def test_face_tables():
+    v, f = synthetic.box_sphere(3, 3, 2)
+    ft = FaceTables(f, v.shape[0] + 1, "cpu")
+    vptr, vc = ft.vptr.numpy(), ft.vcorner.numpy()
+    assert vptr[-1] == f.size and vptr[v.shape[0]] == vptr[-1]          # dummy row has no corners
+    for vert in range(v.shape[0]):
+        corners = vc[vptr[vert]:vptr[vert + 1]]
+        assert np.all(f.ravel()[corners] == vert) and len(corners) == (f == vert).sum()
+
+
+def test_synthetic_batch_contract():
+    v, f = synthetic.box_sphere(42, 42, 20)
+    assert v.shape == (6890, 3) and f.shape == (13776, 3)
+    x = synthetic.synth_batch(v, 3, seed=0)
+    assert x.shape == (3, 6891, 3) and x.dtype == np.float32 and np.all(x[:, -1] == 0)
+    assert np.array_equal(x, synthetic.synth_batch(v, 3, seed=0))
