@@ -56,10 +56,12 @@ def conv_launch_table(model, B):
             vec = "true" if st.cin % 4 == 0 else "false"
             # fwd: read each needed input row once + weights, write output
             byt = 4.0 * (B * st.n_in * st.cin + B * st.R * st.cout + st.cout * K)
-            add("gather_gemm_kernel<%d, %s, false, false>" % (nt(st.cout), vec), fl, byt)
+            add("gather_gemm_kernel<%d, %s, false>" % (nt(st.cout), vec), fl, byt)
             vecb = "true" if st.cout % 4 == 0 else "false"
             if not (first and stack is model._enc_stack):
-                add("gather_gemm_kernel<%d, %s, true, true>" % (nt(st.cin), vecb), fl, byt)
+                # backward-data = the same kernel over the transposed table; algorithmic FLOPs are
+                # those of the R*S real (row, position) pairs, not of the padded n_in*S table
+                add("gather_gemm_kernel<%d, %s, true>" % (nt(st.cin), vecb), fl, byt)
             ctw = 2 if K > 64 else 1
             add("wgrad_kernel<%d, %d, %s>" % (nt(st.cout), ctw, vec), fl, byt)
             first = False
@@ -102,7 +104,7 @@ def main():
     torch.manual_seed(2)                          # cfgs.py:46 seed; identical replicas on every rank
     model = sh.SpiralAutoencoder(FE, FD, 256, h.sizes, h.spiral_sizes, h.spirals, h.D, h.U, dev)
     init_state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    optim = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-5, capturable=True, foreach=True)   # main.py:262
+    optim = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-5, capturable=True, fused=True)   # main.py:262
     ft = sh.FaceTables(h.faces, h.sizes[0] + 1, dev)
     reducer = GradientAllReducer(model, bucket_cap_mb=64.0) if world > 1 else None
 
@@ -204,10 +206,10 @@ def main():
                 reducer.finish()
             optim.step()
         torch.cuda.synchronize()
-        recs = _lib.profile_records()
+        recs = _lib.profile_records_by_kernel()
         _lib.profile_enable(False)
         agg = {}
-        for name, ms in recs:
+        for name, _shape, ms in recs:
             a = agg.setdefault(name, [0, 0.0])
             a[0] += 1; a[1] += ms
         table = conv_launch_table(model, B)

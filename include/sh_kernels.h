@@ -84,16 +84,21 @@ SH_API int sh_spiral_conv_fwd(const float* x, int64_t x_sv, int64_t x_sb,
 
 /* ---------------------------------------------------------------------------------------------
  * SpiralConv backward w.r.t. the input.  Replaces autograd's aten::mm (dG = dY.W) +
- * aten::_index_put_impl_(accumulate=True) scatter-add by a gather over the
- * transposed table - no atomics, fixed summation order, bitwise reproducible:
- *   dx[u,b,:] = sum_s ( sum_{e in [lptr[u*S+s], lptr[u*S+s+1])} dpre[lsrc[e], b, :] ) . W[:, s*Cin:(s+1)*Cin]
+ * aten::_index_put_impl_(accumulate=True) scatter-add by a GATHER over the
+ * transposed table - no atomics, fixed summation order, bitwise reproducible.  It is the same
+ * fused gather+MFMA kernel as the forward pass:
+ *   dx[u,b,:] = sum_s dpre[table_t[u,s], b, :] . W[:, s*Cin:(s+1)*Cin]            u < n_in
+ * table_t: int32 [n_in][S]; table_t[u,s] = the output row r with table[r,s] == u.  Where no such r
+ * exists it must point at a row of dpre that is zero (the masked dummy row); where several exist
+ * (irregular vertices, the dummy row) the caller first sums those rows of dpre into an extra row
+ * (sh_spmm with unit values) and points table_t at it - semantichuman_amd/stack.py does both.
  * weight_t: [Cin][S*Cout], weight_t[ci][s*Cout+co] = weight[co][s*Cin+ci]  (sh_weight_transpose).
  * Optional epilogue (yprev != NULL): dx is multiplied by act_prev'(yprev) evaluated from the
  * OUTPUT yprev of the layer that produced x, and row zero_row is forced to 0, so dx is directly
  * that layer's pre-activation gradient (aten::elu_backward + mask backward).
  */
 SH_API int sh_spiral_conv_bwd_data(const float* dpre, int64_t dp_sv, int64_t dp_sb,
-                            const int32_t* lptr, const int32_t* lsrc, const float* weight_t,
+                            const int32_t* table_t, const float* weight_t,
                             float* dx, int64_t dx_sv, int64_t dx_sb,
                             const float* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row,
                             int B, int n_in, int S, int Cin, int Cout,
@@ -133,6 +138,24 @@ SH_API int sh_spmm(const int32_t* rowptr, const int32_t* col, const float* val,
             float* y, int64_t y_sv, int64_t y_sb,
             const float* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row,
             int B, int rows, int C, sh_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense layers with one tiny and one huge dimension: the latent nn.Linear pair fc_latent_enc /
+ * fc_latent_dec (models.py:85-86, applied at :130 and :144) and their autograd.  Contiguous
+ * row-major tensors; weight is nn.Linear.weight [N][K].  All three stream the weight-shaped matrix
+ * once (HBM-bound); a reduction that is too long for one workgroup is split over workgroups into
+ * partial slabs in `workspace` (>= sh_linear_workspace bytes) and summed in a fixed order.
+ *   fwd       y[M,N]  = x[M,K] . weight^T + bias        (bias may be NULL)
+ *   bwd_data  dx[M,K] = dy[M,N] . weight
+ *   bwd_wgt   dW[N,K] = dy^T . x ;  dbias[N] = column sums of dy (dbias may be NULL)
+ */
+SH_API size_t sh_linear_workspace(int M, int N, int K);
+SH_API int sh_linear_fwd(const float* x, const float* weight, const float* bias, float* y, int M, int N, int K,
+                  void* workspace, size_t workspace_bytes, sh_stream_t stream);
+SH_API int sh_linear_bwd_data(const float* dy, const float* weight, float* dx, int M, int N, int K,
+                       void* workspace, size_t workspace_bytes, sh_stream_t stream);
+SH_API int sh_linear_bwd_wgt(const float* dy, const float* x, float* dW, float* dbias, int M, int N, int K,
+                      void* workspace, size_t workspace_bytes, sh_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Losses / metric.  All reductions are two-stage with a fixed order (no atomics).

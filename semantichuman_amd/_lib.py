@@ -24,12 +24,16 @@ SIGNATURES = {
     "sh_profile_count": (c_int, []),
     "sh_profile_get": (c_int, [_I, c_char_p, _I, ctypes.POINTER(c_float)]),
     "sh_spiral_conv_fwd": (c_int, [_P, _L, _L, _P, _P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "sh_spiral_conv_bwd_data": (c_int, [_P, _L, _L, _P, _P, _P, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "sh_spiral_conv_bwd_data": (c_int, [_P, _L, _L, _P, _P, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sh_weight_transpose": (c_int, [_P, _P, _I, _I, _I, _P]),
     "sh_spiral_conv_bwd_wgt_workspace": (c_size_t, [_I, _I, _I, _I, _I]),
     "sh_spiral_conv_bwd_wgt": (c_int, [_P, _L, _L, _P, _L, _L, _P, _P, _P, _P, c_size_t, _I, _I, _I, _I, _I, _P]),
     "sh_act_backward": (c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _P]),
     "sh_spmm": (c_int, [_P, _P, _P, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _P]),
+    "sh_linear_workspace": (c_size_t, [_I, _I, _I]),
+    "sh_linear_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, c_size_t, _P]),
+    "sh_linear_bwd_data": (c_int, [_P, _P, _P, _I, _I, _I, _P, c_size_t, _P]),
+    "sh_linear_bwd_wgt": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, c_size_t, _P]),
     "sh_reduce_workspace": (c_size_t, []),
     "sh_l1_loss_fwd": (c_int, [_P, _P, _L, _P, _P, _P]),
     "sh_l1_loss_bwd": (c_int, [_P, _P, _L, _P, _P, _P]),
@@ -98,6 +102,11 @@ def profile_records():
         check(lib.sh_profile_get(i, buf, 128, ctypes.byref(ms)), "sh_profile_get")
         out.append((buf.value.decode(), ms.value))
     return out
+
+
+def profile_records_by_kernel():
+    """[(kernel name without the '|shape' tag, shape tag, milliseconds)]."""
+    return [(n.split("|")[0], n.split("|")[1] if "|" in n else "", ms) for n, ms in profile_records()]
 
 
 def ptr(t):

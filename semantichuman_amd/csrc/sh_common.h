@@ -63,6 +63,17 @@ __device__ __forceinline__ float sh_act_grad_from_out(float y, int act) {
     }
 }
 
+// XCD-aware work-item order.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8
+// share an XCD and its 4 MiB L2); remapping so that each XCD owns a CONTIGUOUS range of work items
+// lets the S-fold reuse of gathered neighbour rows hit in that XCD's L2 instead of going to the
+// fabric.  Bijective for any grid size (cdna_hip_programming.md 5, 'XCD swizzle must be bijective').
+// Placement only changes speed, never results.
+__device__ __forceinline__ int sh_xcd_remap(int bid, int nwg) {
+    const int xcd = bid & 7, local = bid >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+}
+
 __device__ __forceinline__ float sh_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -75,3 +86,5 @@ static inline int sh_ilog2_floor(int v) {
     return l;
 }
 static inline int sh_cdiv(int a, int b) { return (a + b - 1) / b; }
+// tuning knob from the environment (read once by the caller through a function-local static)
+int sh_env_int(const char* name, int dflt, int lo, int hi);

@@ -1,5 +1,6 @@
 // Library-level plumbing of libsh_kernels.so: version and the thread-local error message.
 #include <stdarg.h>
+#include <stdlib.h>
 #include "sh_common.h"
 
 namespace {
@@ -11,6 +12,13 @@ void sh_set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+int sh_env_int(const char* name, int dflt, int lo, int hi) {
+    const char* v = getenv(name);
+    if (!v || !*v) return dflt;
+    int x = atoi(v);
+    return x < lo ? lo : (x > hi ? hi : x);
 }
 
 // ---- kernel timing -----------------------------------------------------------------------

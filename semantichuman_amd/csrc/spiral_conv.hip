@@ -32,8 +32,7 @@ constexpr int NTHREADS = 256;
 
 struct GGParams {
     const float* x; long x_sv, x_sb;
-    const int* table;   // forward: [R][S] gather rows; MULTI: lptr [R*S+1]
-    const int* lsrc;    // MULTI: list entries
+    const int* table;   // [R][S] rows of x to gather
     const float* w;     // [Nout][K] row-major
     const float* bias;  // [Nout] or null
     float* y; long y_sv, y_sb;
@@ -41,11 +40,11 @@ struct GGParams {
     int B, R, S, Cg, Nout, K;
     int act;            // forward: activation of this layer; backward: activation that produced x
     int zero_row;
-    int log2TB, n_btiles, nchunks;
+    int log2TB, n_btiles, n_vtiles, nchunks;
     int vec_out;        // Nout % 4 == 0 and output strides 16-B aligned
 };
 
-template <int NT, bool VEC4, bool MULTI, bool BWD_EPI>
+template <int NT, bool VEC4, bool BWD_EPI>
 __global__ __launch_bounds__(NTHREADS) void gather_gemm_kernel(const GGParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* As = reinterpret_cast<float*>(smem);            // [2][TM][KC]
@@ -54,88 +53,82 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_kernel(const GGParams p)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int TB = 1 << p.log2TB, TV = TM >> p.log2TB;
-    const int bt = blockIdx.x % p.n_btiles, vt = blockIdx.x / p.n_btiles;
+    const int tile = sh_xcd_remap(blockIdx.x, gridDim.x);
+    const int bt = tile / p.n_vtiles, vt = tile - bt * p.n_vtiles;     // batch-slice-major order
     const int v0 = vt * TV, b0 = bt * TB;
     const int S = p.S;
 
     {   // table tile: rows v0 .. v0+TV-1 are contiguous in the table
-        const int nT = TV * S + (MULTI ? 1 : 0);
-        const long lim = (long)p.R * S + (MULTI ? 1 : 0);
+        const int nT = TV * S;
+        const long lim = (long)p.R * S;
         for (int i = tid; i < nT; i += NTHREADS) {
             const long g = (long)v0 * S + i;
-            Ts[i] = g < lim ? p.table[g] : (MULTI ? p.table[lim - 1] : 0);
+            Ts[i] = g < lim ? p.table[g] : 0;
         }
     }
     __syncthreads();
 
     // ---- staging assignment: thread -> quad q of rows rbase + 32*i
+    // All hot-path loads are BRANCH-FREE: out-of-range rows / columns read a valid dummy address
+    // and are zeroed by a select afterwards, so the compiler can keep two chunks of loads in
+    // flight behind counted s_waitcnt vmcnt(N) (a load under a branch would force vmcnt(0)).
     const int q = tid & 7, rbase = tid >> 3;
-    int a_vl[4];
+    int a_ts[4];        // a_vl * S: offset of the row's table line
     long a_boff[4];
     bool a_ok[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = rbase + 32 * i;
         const int vl = row >> p.log2TB, bl = row & (TB - 1);
-        a_vl[i] = vl;
         a_ok[i] = (v0 + vl) < p.R && (b0 + bl) < p.B;
-        a_boff[i] = (long)(b0 + bl) * p.x_sb;
+        a_ts[i] = vl * S;
+        a_boff[i] = a_ok[i] ? (long)(b0 + bl) * p.x_sb : 0;
     }
     constexpr int WQ = NT >= 2 ? NT / 2 : 1;
     const bool w_thread = (NT >= 2) || tid < 128;
+    long w_off[WQ];
+    bool w_ok[WQ];
+#pragma unroll
+    for (int i = 0; i < WQ; ++i) {
+        const int n = rbase + 32 * i;
+        w_ok[i] = n < p.Nout;
+        w_off[i] = w_ok[i] ? (long)n * p.K : 0;
+    }
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-    f32x4 ra[4];
-    f32x4 rw[WQ];
-
+    // Loads return RAW values; zeroing (only needed for K columns past the end of K) is applied
+    // when the chunk is written to LDS, two phases later - a select placed next to the load would
+    // make the compiler wait for the load right away.  Rows outside the tile's valid range are not
+    // masked at all: they only feed output rows/channels the epilogue never stores.
     auto gather_quad = [&](int i, int s, int ch) -> f32x4 {
-        f32x4 r = {0.f, 0.f, 0.f, 0.f};
-        if (!MULTI) {
-            const int u = Ts[a_vl[i] * S + s];
-            r = *reinterpret_cast<const f32x4*>(p.x + (long)u * p.x_sv + a_boff[i] + ch);
-        } else {
-            const int e0 = Ts[a_vl[i] * S + s], e1 = Ts[a_vl[i] * S + s + 1];
-            for (int e = e0; e < e1; ++e) {
-                const int u = p.lsrc[e];
-                r += *reinterpret_cast<const f32x4*>(p.x + (long)u * p.x_sv + a_boff[i] + ch);
-            }
-        }
-        return r;
+        const int u = Ts[a_ts[i] + s];
+        return *reinterpret_cast<const f32x4*>(p.x + (long)u * p.x_sv + a_boff[i] + ch);
     };
     auto gather_scalar = [&](int i, int s, int ch) -> float {
-        float r = 0.f;
-        if (!MULTI) {
-            const int u = Ts[a_vl[i] * S + s];
-            r = p.x[(long)u * p.x_sv + a_boff[i] + ch];
-        } else {
-            const int e0 = Ts[a_vl[i] * S + s], e1 = Ts[a_vl[i] * S + s + 1];
-            for (int e = e0; e < e1; ++e) r += p.x[(long)p.lsrc[e] * p.x_sv + a_boff[i] + ch];
-        }
-        return r;
+        const int u = Ts[a_ts[i] + s];
+        return p.x[(long)u * p.x_sv + a_boff[i] + ch];
     };
 
-    auto load_chunk = [&](int c) {
+    // mask != 0: this thread's K columns are inside K
+    auto load_chunk = [&](int c, f32x4 (&ra)[4], f32x4 (&rw)[WQ], unsigned& mask) {
+        c = c < p.nchunks ? c : p.nchunks - 1;              // prefetches past the end re-read the last chunk
         const int k = c * KC + 4 * q;
+        mask = 0;
         if (VEC4) {
             const bool kok = k < p.K;
-            int s = 0, ch = 0;
-            if (kok) { s = k / p.Cg; ch = k - s * p.Cg; }
+            const int kc = kok ? k : 0;
+            const int s = kc / p.Cg, ch = kc - s * p.Cg;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ra[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (kok && a_ok[i]) ra[i] = gather_quad(i, s, ch);
-            }
+            for (int i = 0; i < 4; ++i) ra[i] = gather_quad(i, s, ch);
 #pragma unroll
-            for (int i = 0; i < WQ; ++i) {
-                const int n = rbase + 32 * i;
-                rw[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (w_thread && kok && n < p.Nout)
-                    rw[i] = *reinterpret_cast<const f32x4*>(p.w + (long)n * p.K + k);
-            }
+            for (int i = 0; i < WQ; ++i) rw[i] = *reinterpret_cast<const f32x4*>(p.w + w_off[i] + kc);
+            mask = kok ? 1u : 0u;
         } else {
+            mask = 1u;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ra[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < 4; ++i) ra[i] = zero4;
 #pragma unroll
-            for (int i = 0; i < WQ; ++i) rw[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < WQ; ++i) rw[i] = zero4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int kk = k + j;
@@ -145,23 +138,23 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_kernel(const GGParams p)
                     for (int i = 0; i < 4; ++i)
                         if (a_ok[i]) ra[i][j] = gather_scalar(i, s, ch);
 #pragma unroll
-                    for (int i = 0; i < WQ; ++i) {
-                        const int n = rbase + 32 * i;
-                        if (w_thread && n < p.Nout) rw[i][j] = p.w[(long)n * p.K + kk];
-                    }
+                    for (int i = 0; i < WQ; ++i)
+                        if (w_ok[i]) rw[i][j] = p.w[w_off[i] + kk];
                 }
             }
         }
     };
-    auto store_chunk = [&](int buf) {
+    auto store_chunk = [&](int buf, const f32x4 (&ra)[4], const f32x4 (&rw)[WQ], unsigned mask) {
         float* Ab = As + buf * TM * KC;
         float* Wb = Ws + buf * NT * 16 * KC;
         const int pq = (q ^ (rbase & 7)) << 2;     // (rbase + 32 i) & 7 == rbase & 7
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(Ab + (rbase + 32 * i) * KC + pq) = ra[i];
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<f32x4*>(Ab + (rbase + 32 * i) * KC + pq) = mask ? ra[i] : zero4;
         if (w_thread) {
 #pragma unroll
-            for (int i = 0; i < WQ; ++i) *reinterpret_cast<f32x4*>(Wb + (rbase + 32 * i) * KC + pq) = rw[i];
+            for (int i = 0; i < WQ; ++i)
+                *reinterpret_cast<f32x4*>(Wb + (rbase + 32 * i) * KC + pq) = mask ? rw[i] : zero4;
         }
     };
 
@@ -169,7 +162,7 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_kernel(const GGParams p)
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < NT; ++n) acc[m][n] = zero4;
 
     const int lrow = lane & 15, lq = lane >> 4;
     auto compute = [&](int buf) {
@@ -192,15 +185,27 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_kernel(const GGParams p)
         }
     };
 
-    // ---- main loop: one barrier per K-chunk, next chunk's global loads in flight during MFMAs
-    load_chunk(0);
-    store_chunk(0);
+    // ---- main loop.  LDS holds chunk c (buffer c&1); register set A/B hold the loads of chunks
+    // c+1 and c+2, so every load has two MFMA phases + a barrier to land (the kernel is otherwise
+    // bound by loaded-memory latency: 3 workgroups/CU x 20 KB in flight / ~2 us).  Unrolled by two so
+    // that both register sets are statically named.
+    f32x4 raA[4], raB[4], rwA[WQ], rwB[WQ];
+    unsigned mA, mB;
+    load_chunk(0, raA, rwA, mA);
+    store_chunk(0, raA, rwA, mA);
     __syncthreads();
-    for (int c = 0; c < p.nchunks; ++c) {
-        const bool more = c + 1 < p.nchunks;
-        if (more) load_chunk(c + 1);
-        compute(c & 1);
-        if (more) store_chunk((c + 1) & 1);
+    load_chunk(1, raA, rwA, mA);
+    for (int c = 0; c < p.nchunks; c += 2) {
+        load_chunk(c + 2, raB, rwB, mB);
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch loads AHEAD of the MFMA phase
+        compute(0);
+        store_chunk(1, raA, rwA, mA);        // chunk c+1 (a clamped duplicate past the end is never read)
+        __syncthreads();
+        if (c + 1 >= p.nchunks) break;
+        load_chunk(c + 3, raA, rwA, mA);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(1);
+        store_chunk(0, raB, rwB, mB);        // chunk c+2
         __syncthreads();
     }
 
@@ -249,29 +254,32 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_kernel(const GGParams p)
     }
 }
 
-template <int NT, bool VEC4, bool MULTI, bool BWD_EPI>
+template <int NT, bool VEC4, bool BWD_EPI>
 int launch_gg(const GGParams& p, int nblocks, hipStream_t st) {
     const int TV = TM >> p.log2TB;
-    const size_t smem = (size_t)(2 * TM * KC + 2 * NT * 16 * KC) * sizeof(float) + (size_t)(TV * p.S + 1) * sizeof(int);
+    const size_t smem = (size_t)(2 * TM * KC + 2 * NT * 16 * KC) * sizeof(float) + (size_t)(TV * p.S) * sizeof(int);
     {
-        ShProfScope ps(st, "gather_gemm_kernel<%d, %s, %s, %s>", NT, VEC4 ? "true" : "false", MULTI ? "true" : "false",
-                       BWD_EPI ? "true" : "false");
-        hipLaunchKernelGGL((gather_gemm_kernel<NT, VEC4, MULTI, BWD_EPI>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
+        ShProfScope ps(st, "gather_gemm_kernel<%d, %s, %s>|R=%d B=%d K=%d N=%d grid=%d", NT, VEC4 ? "true" : "false",
+                       BWD_EPI ? "true" : "false", p.R, p.B, p.K, p.Nout, nblocks);
+        hipLaunchKernelGGL((gather_gemm_kernel<NT, VEC4, BWD_EPI>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
     }
     SH_CHECK_LAUNCH("gather_gemm");
     return SH_OK;
 }
 
-template <bool MULTI, bool BWD_EPI>
+template <bool BWD_EPI>
 int dispatch_gg(GGParams& p, hipStream_t st) {
-    // batch tile: largest power of two <= min(B rounded up, TM)
+    // batch slice per tile: a power of two <= SH_GG_TB (default 16).  Narrow slices keep the
+    // working set of an XCD's sweep (neighbour rows x slice width) inside its 4 MiB L2.
+    static const int tb_pref = sh_env_int("SH_GG_TB", 16, 1, TM);
     int tb = 1;
-    while (tb < p.B && tb < TM) tb <<= 1;
+    while (tb < p.B && tb < tb_pref) tb <<= 1;
     p.log2TB = sh_ilog2_floor(tb);
     const int TV = TM >> p.log2TB;
     p.n_btiles = sh_cdiv(p.B, tb);
+    p.n_vtiles = sh_cdiv(p.R, TV);
     p.nchunks = sh_cdiv(p.K, KC);
-    const long nblocks = (long)sh_cdiv(p.R, TV) * p.n_btiles;
+    const long nblocks = (long)p.n_vtiles * p.n_btiles;
     SH_REQUIRE(nblocks > 0 && nblocks < (1L << 31), SH_ERR_UNSUPPORTED, "gather_gemm: grid %ld out of range", nblocks);
     SH_REQUIRE(p.Nout <= 128, SH_ERR_UNSUPPORTED, "gather_gemm: more than 128 output channels (%d) not built", p.Nout);
     SH_REQUIRE(p.S <= 64, SH_ERR_UNSUPPORTED, "gather_gemm: spiral length %d > 64", p.S);
@@ -283,8 +291,8 @@ int dispatch_gg(GGParams& p, hipStream_t st) {
                 (!p.yprev || ((p.yp_sv % 4 == 0) && (p.yp_sb % 4 == 0) && reinterpret_cast<uintptr_t>(p.yprev) % 16 == 0));
     const int nt = sh_cdiv(p.Nout, 16);
 #define SH_GG_CASE(NTV)                                                                  \
-    return vec4 ? launch_gg<NTV, true, MULTI, BWD_EPI>(p, (int)nblocks, st)              \
-                : launch_gg<NTV, false, MULTI, BWD_EPI>(p, (int)nblocks, st)
+    return vec4 ? launch_gg<NTV, true, BWD_EPI>(p, (int)nblocks, st)              \
+                : launch_gg<NTV, false, BWD_EPI>(p, (int)nblocks, st)
     if (nt <= 1) { SH_GG_CASE(1); }
     if (nt <= 2) { SH_GG_CASE(2); }
     if (nt <= 4) { SH_GG_CASE(4); }
@@ -300,6 +308,7 @@ int dispatch_gg(GGParams& p, hipStream_t st) {
 // dimension is the ROW index.  Each block ends by writing its partial to a slab; a second kernel
 // sums the slabs in a fixed order (no atomics -> bitwise reproducible).
 constexpr int TMW = 32;
+constexpr int WG_TABLE_CAP = 8192;      // ints of gather table a workgroup keeps in LDS (32 KiB)
 
 struct WGParams {
     const float* dpre; long dp_sv, dp_sb;
@@ -309,7 +318,7 @@ struct WGParams {
     long slab_stride;   // Cout*K
     long bias_off;      // nrc*Cout*K
     int B, R, S, Cin, Cout, K;
-    int log2TB, n_btiles, nsteps, steps_per_block;
+    int log2TB, n_btiles, n_vtiles, nvc, steps_per_block, ncg;
 };
 
 template <int COT, int CTW, bool VEC4>
@@ -326,110 +335,153 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(const WGParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Gs = reinterpret_cast<float*>(smem);          // [2][TMW][LDG]
     float* Ps = Gs + 2 * TMW * LDG;                      // [2][TMW][LDP]
+    int* Tl = reinterpret_cast<int*>(Ps + 2 * TMW * LDP);   // gather-table lines of this block's vertices
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cg = blockIdx.x, rc = blockIdx.y;
-    const int TB = 1 << p.log2TB;
-    const int step0 = rc * p.steps_per_block;
-    const int step1 = min(step0 + p.steps_per_block, p.nsteps);
+    // linear block id -> XCD-contiguous order, column group fastest: the column groups of one row
+    // chunk (same dpre rows, same gathered input rows) run on the same XCD, and an XCD sweeps a
+    // contiguous vertex range of one batch slice.
+    const int lin = sh_xcd_remap(blockIdx.x, gridDim.x);
+    const int rc = lin / p.ncg, cg = lin - rc * p.ncg;
+    const int bt = rc / p.nvc, vc = rc - bt * p.nvc;
+    const int TB = 1 << p.log2TB, TV = TMW >> p.log2TB;
+    const int step0 = vc * p.steps_per_block;
+    const int nsteps = min(p.steps_per_block, p.n_vtiles - step0);      // may be <= 0 for the last chunk
+    const int vbase = step0 * TV, b0 = bt * TB;
+    const int S = p.S;
 
-    // fixed (s, channel) of this thread's G quad: the column group never changes
+    {   // table lines of vertices vbase .. vbase + nsteps*TV - 1 (clipped to R; padding -> row 0)
+        const int nT = max(nsteps, 0) * TV * S;
+        const long lim = (long)p.R * S;
+        for (int i = tid; i < nT; i += NTHREADS) {
+            const long g = (long)vbase * S + i;
+            Tl[i] = g < lim ? p.table[g] : 0;
+        }
+    }
+    __syncthreads();
+
+    // fixed (s, channel) of this thread's G quad: the column group never changes.  Columns past
+    // K read (s=0, c=0): they only feed weight columns that are never stored.
     const int gq = tid % GQ, grow0 = tid / GQ;
     const int k = cg * KCW + 4 * gq;
     int s4[4], c4[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int kk = k + j;
-        s4[j] = kk < p.K ? kk / p.Cin : -1;
+        s4[j] = kk < p.K ? kk / p.Cin : 0;
         c4[j] = kk < p.K ? kk - s4[j] * p.Cin : 0;
     }
+    // per-pass row decomposition (does not depend on the step)
+    int g_vl[GP], p_vl[PP], p_q[PP], p_row[PP];
+    long g_boff[GP], p_boff[PP];
+    unsigned g_bok = 0, p_bok = 0;                       // bit i: batch index of pass i is < B
+#pragma unroll
+    for (int i = 0; i < GP; ++i) {
+        const int row = grow0 + GROWS * i;
+        const int bl = row & (TB - 1);
+        g_vl[i] = row >> p.log2TB;
+        const bool ok = b0 + bl < p.B;
+        g_bok |= (ok ? 1u : 0u) << i;
+        g_boff[i] = ok ? (long)(b0 + bl) * p.x_sb : 0;
+    }
+    const bool p_vec = (p.Cout & 3) == 0 && ((p.dp_sv | p.dp_sb) & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < PP; ++i) {
+        const int idx = tid + NTHREADS * i;
+        const int row = idx < PTOT ? idx / PQ : 0;
+        p_row[i] = row;
+        p_q[i] = idx < PTOT ? idx - row * PQ : 0;
+        p_vl[i] = row >> p.log2TB;
+        const int bl = row & (TB - 1);
+        const bool ok = idx < PTOT && b0 + bl < p.B && 4 * p_q[i] < p.Cout;
+        p_bok |= (ok ? 1u : 0u) << i;
+        p_boff[i] = ok ? (long)(b0 + bl) * p.dp_sb + 4 * p_q[i] : 0;
+    }
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-    f32x4 rg[GP];
-    f32x4 rp[PP];
-
-    auto load_step = [&](int step) {
-        const int vt = step / p.n_btiles, bt = step - vt * p.n_btiles;
-        const int v0 = vt * (TMW >> p.log2TB), b0 = bt * TB;
+    // Branch-free loads (addresses clamped to valid memory); the row-validity masks are applied
+    // when the tile is written to LDS two steps later.  Invalid rows MUST be zeroed here because
+    // rows are the reduction dimension.
+    auto load_step = [&](int st, f32x4 (&rg)[GP], f32x4 (&rp)[PP], unsigned& mg, unsigned& mp) {
+        st = st < nsteps ? st : nsteps - 1;
+        const int vloc = st * TV;                       // local vertex index of the step's first vertex
+        mg = 0; mp = 0;
 #pragma unroll
         for (int i = 0; i < GP; ++i) {
-            const int row = grow0 + GROWS * i;
-            const int v = v0 + (row >> p.log2TB), b = b0 + (row & (TB - 1));
-            rg[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (v < p.R && b < p.B) {
-                if (VEC4) {
-                    if (s4[0] >= 0) {
-                        const int u = p.table[(long)v * p.S + s4[0]];
-                        rg[i] = *reinterpret_cast<const f32x4*>(p.x + (long)u * p.x_sv + (long)b * p.x_sb + c4[0]);
-                    }
-                } else {
+            const int vl = vloc + g_vl[i];
+            const bool ok = vbase + vl < p.R && ((g_bok >> i) & 1u);
+            mg |= (ok ? 1u : 0u) << i;
+            if (VEC4) {
+                const int u = Tl[vl * S + s4[0]];
+                rg[i] = *reinterpret_cast<const f32x4*>(p.x + (long)u * p.x_sv + g_boff[i] + c4[0]);
+            } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (s4[j] >= 0) {
-                            const int u = p.table[(long)v * p.S + s4[j]];
-                            rg[i][j] = p.x[(long)u * p.x_sv + (long)b * p.x_sb + c4[j]];
-                        }
+                for (int j = 0; j < 4; ++j) {
+                    const int u = Tl[vl * S + s4[j]];
+                    rg[i][j] = p.x[(long)u * p.x_sv + g_boff[i] + c4[j]];
                 }
             }
         }
 #pragma unroll
         for (int i = 0; i < PP; ++i) {
-            const int idx = tid + NTHREADS * i;
-            rp[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (idx < PTOT) {
-                const int row = idx / PQ, pq = idx - row * PQ;
-                const int v = v0 + (row >> p.log2TB), b = b0 + (row & (TB - 1));
-                if (v < p.R && b < p.B) {
-                    const float* src = p.dpre + (long)v * p.dp_sv + (long)b * p.dp_sb + 4 * pq;
-                    if ((p.Cout & 3) == 0 && ((p.dp_sv | p.dp_sb) & 3) == 0) {
-                        if (4 * pq < p.Cout) rp[i] = *reinterpret_cast<const f32x4*>(src);
-                    } else {
+            const int vl = vloc + p_vl[i];
+            const bool ok = vbase + vl < p.R && ((p_bok >> i) & 1u);
+            mp |= (ok ? 1u : 0u) << i;
+            const int v = ok ? vbase + vl : 0;
+            const float* src = p.dpre + (long)v * p.dp_sv + p_boff[i];
+            if (p_vec) {
+                rp[i] = *reinterpret_cast<const f32x4*>(src);
+            } else {
+                rp[i] = zero4;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (4 * pq + j < p.Cout) rp[i][j] = src[j];
-                    }
-                }
+                for (int j = 0; j < 4; ++j)
+                    if (ok && 4 * p_q[i] + j < p.Cout) rp[i][j] = src[j];
             }
         }
     };
-    auto store_step = [&](int buf) {
+    auto store_step = [&](int buf, const f32x4 (&rg)[GP], const f32x4 (&rp)[PP], unsigned mg, unsigned mp) {
         float* Gb = Gs + buf * TMW * LDG;
         float* Pb = Ps + buf * TMW * LDP;
 #pragma unroll
-        for (int i = 0; i < GP; ++i) *reinterpret_cast<f32x4*>(Gb + (grow0 + GROWS * i) * LDG + 4 * gq) = rg[i];
+        for (int i = 0; i < GP; ++i)
+            *reinterpret_cast<f32x4*>(Gb + (grow0 + GROWS * i) * LDG + 4 * gq) = ((mg >> i) & 1u) ? rg[i] : zero4;
 #pragma unroll
-        for (int i = 0; i < PP; ++i) {
-            const int idx = tid + NTHREADS * i;
-            if (idx < PTOT) {
-                const int row = idx / PQ, pq = idx - row * PQ;
-                *reinterpret_cast<f32x4*>(Pb + row * LDP + 4 * pq) = rp[i];
-            }
-        }
+        for (int i = 0; i < PP; ++i)
+            if (tid + NTHREADS * i < PTOT)
+                *reinterpret_cast<f32x4*>(Pb + p_row[i] * LDP + 4 * p_q[i]) = ((mp >> i) & 1u) ? rp[i] : zero4;
     };
 
     f32x4 acc[CTW][COT];
 #pragma unroll
     for (int a = 0; a < CTW; ++a)
 #pragma unroll
-        for (int b = 0; b < COT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < COT; ++b) acc[a][b] = zero4;
     float bsum = 0.f;
 
     const int lcol = lane & 15, lk = lane >> 4;
     auto compute = [&](int buf) {
         const float* Gb = Gs + buf * TMW * LDG + (wave * CTW) * 16 + lcol;
         const float* Pb = Ps + buf * TMW * LDP + lcol;
+        // operands of 4 k-steps (16 rows) are read from LDS in one batch, then their MFMAs issue
+        // back to back: the ds_read latency is paid twice per tile instead of eight times
 #pragma unroll
-        for (int kk = 0; kk < TMW / 4; ++kk) {
-            const int row = 4 * kk + lk;
-            float gf[CTW], pf[COT];
+        for (int half = 0; half < 2; ++half) {
+            float gf[4][CTW], pf[4][COT];
 #pragma unroll
-            for (int a = 0; a < CTW; ++a) gf[a] = Gb[row * LDG + a * 16];
+            for (int kk = 0; kk < 4; ++kk) {
+                const int row = 16 * half + 4 * kk + lk;
 #pragma unroll
-            for (int b = 0; b < COT; ++b) pf[b] = Pb[row * LDP + b * 16];
+                for (int a = 0; a < CTW; ++a) gf[kk][a] = Gb[row * LDG + a * 16];
 #pragma unroll
-            for (int a = 0; a < CTW; ++a)
+                for (int b = 0; b < COT; ++b) pf[kk][b] = Pb[row * LDP + b * 16];
+            }
 #pragma unroll
-                for (int b = 0; b < COT; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(gf[a], pf[b], acc[a][b], 0, 0, 0);
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int a = 0; a < CTW; ++a)
+#pragma unroll
+                    for (int b = 0; b < COT; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(gf[kk][a], pf[kk][b], acc[a][b], 0, 0, 0);
         }
         if (cg == 0 && tid < COT * 16) {
             const float* Pc = Ps + buf * TMW * LDP + tid;
@@ -438,16 +490,25 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(const WGParams p) {
         }
     };
 
-    if (step0 < step1) {
-        load_step(step0);
-        store_step(0);
+    // two steps of loads in flight (register sets A/B), LDS double-buffered, one barrier per step
+    if (nsteps > 0) {
+        f32x4 rgA[GP], rgB[GP], rpA[PP], rpB[PP];
+        unsigned mgA, mgB, mpA, mpB;
+        load_step(0, rgA, rpA, mgA, mpA);
+        store_step(0, rgA, rpA, mgA, mpA);
         __syncthreads();
-        for (int st = step0; st < step1; ++st) {
-            const bool more = st + 1 < step1;
-            const int buf = (st - step0) & 1;
-            if (more) load_step(st + 1);
-            compute(buf);
-            if (more) store_step(buf ^ 1);
+        load_step(1, rgA, rpA, mgA, mpA);
+        for (int st = 0; st < nsteps; st += 2) {
+            load_step(st + 2, rgB, rpB, mgB, mpB);
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch loads AHEAD of the MFMA phase
+            compute(0);
+            store_step(1, rgA, rpA, mgA, mpA);
+            __syncthreads();
+            if (st + 1 >= nsteps) break;
+            load_step(st + 3, rgA, rpA, mgA, mpA);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(1);
+            store_step(0, rgB, rpB, mgB, mpB);
             __syncthreads();
         }
     }
@@ -474,36 +535,62 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(const WGParams p) {
     if (cg == 0 && tid < p.Cout) p.slab[p.bias_off + (long)rc * p.Cout + tid] = bsum;
 }
 
-__global__ void slab_reduce_kernel(const float* __restrict__ slab, long stride, int nslab, long n, float* __restrict__ out) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// out[i] = sum_r slab[r][i], r in increasing order within each of 16 interleaved lanes, lanes then
+// combined in a fixed order: deterministic.  Block = 64 outputs x 16 slab lanes.
+__global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restrict__ slab, long stride, int nslab, long n,
+                                                           float* __restrict__ out) {
+    __shared__ float red[16][64];
+    const int ox = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + ox;
     float s = 0.f;
-    for (int r = 0; r < nslab; ++r) s += slab[(long)r * stride + i];
-    out[i] = s;
+    if (i < n) {
+        int r = ry;
+        for (; r + 48 < nslab; r += 64) {
+            const float a = slab[(long)r * stride + i], b = slab[(long)(r + 16) * stride + i];
+            const float c = slab[(long)(r + 32) * stride + i], d = slab[(long)(r + 48) * stride + i];
+            s += (a + b) + (c + d);
+        }
+        for (; r < nslab; r += 16) s += slab[(long)r * stride + i];
+    }
+    red[ry][ox] = s;
+    __syncthreads();
+    if (ry == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][ox];
+        out[i] = t;
+    }
 }
 
 struct WGPlan {
-    int log2TB, n_btiles, nsteps, steps_per_block, nrc, ncg, ctw, cot;
+    int log2TB, n_btiles, n_vtiles, nvc, steps_per_block, nrc, ncg, ctw, cot;
 };
 
 WGPlan plan_wgrad(int B, int R, int S, int Cin, int Cout) {
     WGPlan w;
     const int K = S * Cin;
+    static const int tb_pref = sh_env_int("SH_WG_TB", 8, 1, TMW);
+    static const int blocks_target = sh_env_int("SH_WG_BLOCKS", 1024, 64, 65536);
     int tb = 1;
-    while (tb < B && tb < TMW) tb <<= 1;
+    while (tb < B && tb < tb_pref) tb <<= 1;
     w.log2TB = sh_ilog2_floor(tb);
     const int tv = TMW >> w.log2TB;
     w.n_btiles = sh_cdiv(B, tb);
-    w.nsteps = sh_cdiv(R, tv) * w.n_btiles;
+    w.n_vtiles = sh_cdiv(R, tv);
     w.ctw = K > 64 ? 2 : 1;
     w.ncg = sh_cdiv(K, 64 * w.ctw);
     const int cot = sh_cdiv(Cout, 16);
     w.cot = cot <= 1 ? 1 : cot <= 2 ? 2 : cot <= 4 ? 4 : 8;
-    int nrc = 512 / w.ncg;
-    if (nrc < 1) nrc = 1;
-    if (nrc > w.nsteps) nrc = w.nsteps;
-    w.steps_per_block = sh_cdiv(w.nsteps, nrc);
-    w.nrc = sh_cdiv(w.nsteps, w.steps_per_block);
+    // vertex chunks per batch slice: enough blocks to fill the chip, few enough that the partial
+    // slabs stay small, and a table slice that fits its LDS area
+    int nvc = blocks_target / (w.ncg * w.n_btiles);
+    if (nvc < 1) nvc = 1;
+    if (nvc > w.n_vtiles) nvc = w.n_vtiles;
+    const int max_steps = WG_TABLE_CAP / (tv * S) > 0 ? WG_TABLE_CAP / (tv * S) : 1;
+    w.steps_per_block = sh_cdiv(w.n_vtiles, nvc);
+    if (w.steps_per_block > max_steps) w.steps_per_block = max_steps;
+    w.nvc = sh_cdiv(w.n_vtiles, w.steps_per_block);
+    w.nrc = w.nvc * w.n_btiles;
     return w;
 }
 
@@ -512,9 +599,11 @@ int launch_wg(const WGParams& p, const WGPlan& w, bool vec4, hipStream_t st) {
     constexpr int KCW = 64 * CTW;
     constexpr int LDG = KCW + 16;
     constexpr int LDP = COT == 1 ? 16 : COT * 16 + 16;
-    const size_t smem = (size_t)2 * TMW * (LDG + LDP) * sizeof(float);
-    dim3 grid(w.ncg, w.nrc);
-    ShProfScope ps(st, "wgrad_kernel<%d, %d, %s>", COT, CTW, vec4 ? "true" : "false");
+    const int tv = TMW >> w.log2TB;
+    const size_t smem = (size_t)2 * TMW * (LDG + LDP) * sizeof(float) + (size_t)w.steps_per_block * tv * p.S * sizeof(int);
+    dim3 grid(w.ncg * w.nrc);
+    ShProfScope ps(st, "wgrad_kernel<%d, %d, %s>|R=%d B=%d K=%d N=%d grid=%d", COT, CTW, vec4 ? "true" : "false", p.R, p.B, p.K,
+                   p.Cout, w.ncg * w.nrc);
     if (vec4) hipLaunchKernelGGL((wgrad_kernel<COT, CTW, true>), grid, dim3(NTHREADS), smem, st, p);
     else hipLaunchKernelGGL((wgrad_kernel<COT, CTW, false>), grid, dim3(NTHREADS), smem, st, p);
     SH_CHECK_LAUNCH("wgrad");
@@ -561,29 +650,28 @@ int sh_spiral_conv_fwd(const float* x, int64_t x_sv, int64_t x_sb, const int32_t
     SH_REQUIRE(act >= SH_ACT_IDENTITY && act <= SH_ACT_TANH, SH_ERR_INVALID_ARG, "sh_spiral_conv_fwd: unknown activation %d", act);
     GGParams p{};
     p.x = x; p.x_sv = x_sv; p.x_sb = x_sb;
-    p.table = table; p.lsrc = nullptr; p.w = weight; p.bias = bias;
+    p.table = table; p.w = weight; p.bias = bias;
     p.y = y; p.y_sv = y_sv; p.y_sb = y_sb;
     p.yprev = nullptr;
     p.B = B; p.R = R; p.S = S; p.Cg = Cin; p.Nout = Cout; p.K = S * Cin;
     p.act = act; p.zero_row = zero_row;
-    return dispatch_gg<false, false>(p, static_cast<hipStream_t>(stream));
+    return dispatch_gg<false>(p, static_cast<hipStream_t>(stream));
 }
 
-int sh_spiral_conv_bwd_data(const float* dpre, int64_t dp_sv, int64_t dp_sb, const int32_t* lptr, const int32_t* lsrc,
-                            const float* weight_t, float* dx, int64_t dx_sv, int64_t dx_sb, const float* yprev,
-                            int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row, int B, int n_in, int S, int Cin,
-                            int Cout, sh_stream_t stream) {
-    SH_REQUIRE(dpre && lptr && lsrc && weight_t && dx, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_data: null pointer");
+int sh_spiral_conv_bwd_data(const float* dpre, int64_t dp_sv, int64_t dp_sb, const int32_t* table_t, const float* weight_t,
+                            float* dx, int64_t dx_sv, int64_t dx_sb, const float* yprev, int64_t yp_sv, int64_t yp_sb,
+                            int act_prev, int zero_row, int B, int n_in, int S, int Cin, int Cout, sh_stream_t stream) {
+    SH_REQUIRE(dpre && table_t && weight_t && dx, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_data: null pointer");
     SH_REQUIRE(B > 0 && n_in > 0 && S > 0 && Cin > 0 && Cout > 0, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_data: non-positive size");
     SH_REQUIRE(act_prev >= SH_ACT_IDENTITY && act_prev <= SH_ACT_TANH, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_data: unknown activation %d", act_prev);
     GGParams p{};
     p.x = dpre; p.x_sv = dp_sv; p.x_sb = dp_sb;
-    p.table = lptr; p.lsrc = lsrc; p.w = weight_t; p.bias = nullptr;
+    p.table = table_t; p.w = weight_t; p.bias = nullptr;
     p.y = dx; p.y_sv = dx_sv; p.y_sb = dx_sb;
     p.yprev = yprev; p.yp_sv = yp_sv; p.yp_sb = yp_sb;
     p.B = B; p.R = n_in; p.S = S; p.Cg = Cout; p.Nout = Cin; p.K = S * Cout;
     p.act = act_prev; p.zero_row = zero_row;
-    return dispatch_gg<true, true>(p, static_cast<hipStream_t>(stream));
+    return dispatch_gg<true>(p, static_cast<hipStream_t>(stream));
 }
 
 int sh_weight_transpose(const float* weight, float* weight_t, int S, int Cin, int Cout, sh_stream_t stream) {
@@ -618,7 +706,7 @@ int sh_spiral_conv_bwd_wgt(const float* dpre, int64_t dp_sv, int64_t dp_sb, cons
     p.B = B; p.R = R; p.S = S; p.Cin = Cin; p.Cout = Cout; p.K = S * Cin;
     p.slab_stride = (long)Cout * p.K;
     p.bias_off = (long)w.nrc * p.slab_stride;
-    p.log2TB = w.log2TB; p.n_btiles = w.n_btiles; p.nsteps = w.nsteps; p.steps_per_block = w.steps_per_block;
+    p.log2TB = w.log2TB; p.n_btiles = w.n_btiles; p.n_vtiles = w.n_vtiles; p.nvc = w.nvc; p.steps_per_block = w.steps_per_block; p.ncg = w.ncg;
     const bool vec4 = (Cin % 4 == 0) && (x_sv % 4 == 0) && (x_sb % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) &&
                       (reinterpret_cast<uintptr_t>(dpre) % 16 == 0);
     int rc;
@@ -632,9 +720,9 @@ int sh_spiral_conv_bwd_wgt(const float* dpre, int64_t dp_sv, int64_t dp_sb, cons
     if (rc != SH_OK) return rc;
     const long n = p.slab_stride;
     ShProfScope ps(st, "slab_reduce_kernel");
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p.slab, p.slab_stride, w.nrc, n, dW);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, st, p.slab, p.slab_stride, w.nrc, n, dW);
     if (dbias)
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((Cout + 255) / 256)), dim3(256), 0, st, p.slab + p.bias_off,
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((Cout + 63) / 64)), dim3(1024), 0, st, p.slab + p.bias_off,
                            (long)Cout, w.nrc, (long)Cout, dbias);
     SH_CHECK_LAUNCH("slab_reduce");
     return SH_OK;

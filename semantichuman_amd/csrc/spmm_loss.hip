@@ -9,41 +9,55 @@ namespace {
 constexpr int RED_BLOCKS = 1024;   // partial sums of the first reduction stage
 
 // y[r,b,:] = sum_e val[e] * x[col[e],b,:]   (+ optional act'(yprev) epilogue, zero_row)
+// One workgroup per output row (grid-stride over rows): the row's CSR entries are wave-uniform
+// scalars, threads sweep the row's B*C elements (contiguous in the vertex-major layout) with
+// 32-bit index math only.
 template <bool VEC>
-__global__ void spmm_kernel(const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ val,
-                            const float* __restrict__ x, long x_sv, long x_sb, float* __restrict__ y, long y_sv, long y_sb,
-                            const float* __restrict__ yprev, long yp_sv, long yp_sb, int act, int zero_row, int B, int rows,
-                            int C) {
-    const int CW = VEC ? C / 4 : C;
-    const long n = (long)rows * B * CW;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const int cw = (int)(i % CW);
-        const long t = i / CW;
-        const int b = (int)(t % B);
-        const int r = (int)(t / B);
+__global__ __launch_bounds__(256) void spmm_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                   const float* __restrict__ val, const float* __restrict__ x, long x_sv, long x_sb,
+                                                   float* __restrict__ y, long y_sv, long y_sb, const float* __restrict__ yprev,
+                                                   long yp_sv, long yp_sb, int act, int zero_row, int B, int rows, int C) {
+    const int CW = VEC ? C >> 2 : C;
+    const int per_row = B * CW;
+    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
         const int e0 = rowptr[r], e1 = rowptr[r + 1];
-        const long xo = (long)b * x_sb + (VEC ? 4 * cw : cw);
-        const long yo = (long)r * y_sv + (long)b * y_sb + (VEC ? 4 * cw : cw);
-        if (VEC) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (int e = e0; e < e1; ++e) {
-                const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (long)col[e] * x_sv + xo);
-                const float w = val[e];
+        const bool zero = r == zero_row;
+        for (int j = threadIdx.x; j < per_row; j += 256) {
+            const int b = j / CW, cw = j - b * CW;
+            const int co = VEC ? 4 * cw : cw;
+            const long xo = (long)b * x_sb + co;
+            const long yo = (long)r * y_sv + (long)b * y_sb + co;
+            if (VEC) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                int e = e0;
+                for (; e + 3 < e1; e += 4) {         // 4 independent 16-B loads in flight
+                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(x + (long)col[e] * x_sv + xo);
+                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(x + (long)col[e + 1] * x_sv + xo);
+                    const f32x4 x2 = *reinterpret_cast<const f32x4*>(x + (long)col[e + 2] * x_sv + xo);
+                    const f32x4 x3 = *reinterpret_cast<const f32x4*>(x + (long)col[e + 3] * x_sv + xo);
+                    const float w0 = val[e], w1 = val[e + 1], w2 = val[e + 2], w3 = val[e + 3];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = fmaf(w, xv[j], acc[j]);
-            }
-            if (yprev) {
-                const f32x4 yv = *reinterpret_cast<const f32x4*>(yprev + (long)r * yp_sv + (long)b * yp_sb + 4 * cw);
+                    for (int k = 0; k < 4; ++k) acc[k] = fmaf(w3, x3[k], fmaf(w2, x2[k], fmaf(w1, x1[k], fmaf(w0, x0[k], acc[k]))));
+                }
+                for (; e < e1; ++e) {
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (long)col[e] * x_sv + xo);
+                    const float w = val[e];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] *= sh_act_grad_from_out(yv[j], act);
+                    for (int k = 0; k < 4; ++k) acc[k] = fmaf(w, xv[k], acc[k]);
+                }
+                if (yprev) {
+                    const f32x4 yv = *reinterpret_cast<const f32x4*>(yprev + (long)r * yp_sv + (long)b * yp_sb + co);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[k] *= sh_act_grad_from_out(yv[k], act);
+                }
+                if (zero) acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(y + yo) = acc;
+            } else {
+                float acc = 0.f;
+                for (int e = e0; e < e1; ++e) acc = fmaf(val[e], x[(long)col[e] * x_sv + xo], acc);
+                if (yprev) acc *= sh_act_grad_from_out(yprev[(long)r * yp_sv + (long)b * yp_sb + co], act);
+                y[yo] = zero ? 0.f : acc;
             }
-            if (r == zero_row) acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4*>(y + yo) = acc;
-        } else {
-            float acc = 0.f;
-            for (int e = e0; e < e1; ++e) acc = fmaf(val[e], x[(long)col[e] * x_sv + xo], acc);
-            if (yprev) acc *= sh_act_grad_from_out(yprev[(long)r * yp_sv + (long)b * yp_sb + cw], act);
-            y[yo] = r == zero_row ? 0.f : acc;
         }
     }
 }
@@ -190,14 +204,14 @@ int sh_spmm(const int32_t* rowptr, const int32_t* col, const float* val, const f
     const bool vec = (C % 4 == 0) && (x_sv % 4 == 0) && (x_sb % 4 == 0) && (y_sv % 4 == 0) && (y_sb % 4 == 0) &&
                      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) % 16 == 0) &&
                      (!yprev || (yp_sv % 4 == 0 && yp_sb % 4 == 0 && reinterpret_cast<uintptr_t>(yprev) % 16 == 0));
-    const long n = (long)rows * B * (vec ? C / 4 : C);
+    const int grid = rows < 8192 ? rows : 8192;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    ShProfScope ps(st, "spmm_kernel<%s>", vec ? "true" : "false");
+    ShProfScope ps(st, "spmm_kernel<%s>|rows=%d B=%d C=%d", vec ? "true" : "false", rows, B, C);
     if (vec)
-        hipLaunchKernelGGL(spmm_kernel<true>, dim3(grid_for(n, 256)), dim3(256), 0, st, rowptr, col, val, x, x_sv, x_sb, y, y_sv, y_sb,
+        hipLaunchKernelGGL(spmm_kernel<true>, dim3(grid), dim3(256), 0, st, rowptr, col, val, x, x_sv, x_sb, y, y_sv, y_sb,
                            yprev, yp_sv, yp_sb, act_prev, zero_row, B, rows, C);
     else
-        hipLaunchKernelGGL(spmm_kernel<false>, dim3(grid_for(n, 256)), dim3(256), 0, st, rowptr, col, val, x, x_sv, x_sb, y, y_sv, y_sb,
+        hipLaunchKernelGGL(spmm_kernel<false>, dim3(grid), dim3(256), 0, st, rowptr, col, val, x, x_sv, x_sb, y, y_sv, y_sb,
                            yprev, yp_sv, yp_sb, act_prev, zero_row, B, rows, C);
     SH_CHECK_LAUNCH("spmm");
     return SH_OK;

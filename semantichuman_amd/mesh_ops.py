@@ -15,6 +15,7 @@ All functions are pure numpy and run on the CPU; they are exercised by the
 from __future__ import annotations
 
 from dataclasses import dataclass
+from typing import Optional
 
 import numpy as np
 
@@ -132,6 +133,63 @@ def transpose_table(table: np.ndarray, n_in: int, skip_row: int = -1) -> GatherL
     np.cumsum(counts, out=ptr[1:])
     return GatherLists(n_in, S, ptr, np.ascontiguousarray(src[order]),
                        int(counts.max()) if counts.size else 0)
+
+
+@dataclass
+class TransposedTable:
+    """Dense transposed gather table for the backward-data pass.
+
+    table_t[u, s] is the ONE row of the (extended) dpre buffer whose W_s-product contributes to
+    dx[u]:   dx[u] = sum_s dpre_ext[table_t[u,s]] . W_s.   Three cases per (u, s):
+      * exactly one output row r reads input row u at position s      -> r
+      * none does (or the gradient of row u is known dead)            -> none_row (a zero row of dpre)
+      * several do (irregular vertices; the dummy row, ~900 readers)  -> an EXTRA row R + k that the
+        caller fills beforehand with the sum of those rows: `csr2` (rows R+n1 .. R+n1+n2-1, unit
+        values) sums either original rows directly (<= chunk entries) or the chunk sums produced by
+        `csr1` (rows R .. R+n1-1) for very long lists.  Entries keep increasing-row order, so the
+        sums have a fixed order and the whole backward pass is bitwise reproducible (no atomics).
+    """
+    table_t: np.ndarray          # int32 [n_in, S]
+    csr1: Optional["CSR"]        # [n1, R]           chunk sums of very long lists
+    csr2: Optional["CSR"]        # [n2, R + n1]      one row per multi-entry list
+    n1: int
+    n2: int
+
+    @property
+    def n_extra(self) -> int:
+        return self.n1 + self.n2
+
+
+def transpose_table_dense(table: np.ndarray, n_in: int, none_row: int, skip_row: int = -1,
+                          chunk: int = 16) -> TransposedTable:
+    R, S = table.shape
+    gl = transpose_table(table, n_in, skip_row=skip_row)
+    lengths = np.diff(gl.ptr)
+    tt = np.full(n_in * S, none_row, dtype=np.int32)
+    single = lengths == 1
+    tt[single] = gl.src[gl.ptr[:-1][single]]
+    multi = np.nonzero(lengths > 1)[0]
+    if multi.size == 0:
+        return TransposedTable(tt.reshape(n_in, S), None, None, 0, 0)
+    rp1, col1, rp2, col2 = [0], [], [0], []
+    for p in multi:
+        ent = gl.src[gl.ptr[p]:gl.ptr[p + 1]]
+        if ent.size <= chunk:
+            col2.extend(int(e) for e in ent)
+        else:
+            for c in range(0, ent.size, chunk):
+                col2.append(R + len(rp1) - 1)
+                col1.extend(int(e) for e in ent[c:c + chunk])
+                rp1.append(len(col1))
+        rp2.append(len(col2))
+    n1, n2 = len(rp1) - 1, len(rp2) - 1
+    tt[multi] = R + n1 + np.arange(n2, dtype=np.int32)
+
+    def ones_csr(rows, cols, rp, col):
+        return CSR(rows, cols, np.asarray(rp, np.int32), np.asarray(col, np.int32), np.ones(len(col), np.float32))
+    csr1 = ones_csr(n1, R, rp1, col1) if n1 else None
+    csr2 = ones_csr(n2, R + n1, rp2, col2)
+    return TransposedTable(tt.reshape(n_in, S), csr1, csr2, n1, n2)
 
 
 # ----------------------------------------------------------------------------- U (up-sampling)

@@ -22,6 +22,7 @@ import torch.nn as nn
 
 from . import mesh_ops, ops
 from .mesh_ops import CSR
+from .linear import latent_linear
 from .stack import ConvStep, SpmmStep, Stack, StackFunction, run_stack
 
 
@@ -161,7 +162,7 @@ class SpiralAutoencoder(nn.Module):
     def encode(self, x, VAE_flag=None):
         bsize = x.size(0)
         h = run_stack(self._enc_stack, x, "bm", "bm", self.conv)        # [B, N_last+1, C]
-        z = self.fc_latent_enc(h.reshape(bsize, -1))
+        z = latent_linear(h.reshape(bsize, -1), self.fc_latent_enc.weight, self.fc_latent_enc.bias)
         if VAE_flag if VAE_flag is not None else self.VAE_flag:         # models.py:131-136
             self.z_mu = z[..., :self.latent_size]
             self.z_var = z[..., self.latent_size:]
@@ -171,7 +172,7 @@ class SpiralAutoencoder(nn.Module):
 
     def decode(self, z):
         bsize = z.size(0)
-        h = self.fc_latent_dec(z).view(bsize, self.sizes[-1] + 1, -1)
+        h = latent_linear(z, self.fc_latent_dec.weight, self.fc_latent_dec.bias).view(bsize, self.sizes[-1] + 1, -1)
         return run_stack(self._dec_stack, h, "bm", "bm", self.dconv)
 
     def forward(self, x):

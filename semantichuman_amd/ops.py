@@ -51,17 +51,18 @@ def spiral_conv_fwd(x, x_layout, table, weight, bias, y, y_layout, R, S, act, ze
                                          B, R, S, Cin, Cout, act, zero_row, stream_ptr()), "sh_spiral_conv_fwd")
 
 
-def spiral_conv_bwd_data(dpre, dp_layout, lptr, lsrc, weight_t, dx, dx_layout, yprev, yp_layout, act_prev, zero_row,
+def spiral_conv_bwd_data(dpre, dp_layout, table_t, weight_t, dx, dx_layout, yprev, yp_layout, act_prev, zero_row,
                          n_in, S, Cin, Cout):
     B, _, C1, dsv, dsb = _dims(dpre, dp_layout)
     B2, Rx, C2, xsv, xsb = _dims(dx, dx_layout)
     assert B == B2 and C1 == Cout and C2 == Cin and Rx >= n_in and weight_t.shape == (Cin, S * Cout)
+    assert table_t.dtype == torch.int32 and tuple(table_t.shape) == (n_in, S)
     if yprev is not None:
         _, _, C3, ysv, ysb = _dims(yprev, yp_layout)
         assert C3 == Cin
     else:
         ysv = ysb = 0
-    check(_lib.load().sh_spiral_conv_bwd_data(ptr(dpre), dsv, dsb, ptr(lptr), ptr(lsrc), ptr(weight_t), ptr(dx), xsv, xsb,
+    check(_lib.load().sh_spiral_conv_bwd_data(ptr(dpre), dsv, dsb, ptr(table_t), ptr(weight_t), ptr(dx), xsv, xsb,
                                               ptr(yprev), ysv, ysb, act_prev, zero_row, B, n_in, S, Cin, Cout,
                                               stream_ptr()), "sh_spiral_conv_bwd_data")
 
@@ -106,6 +107,53 @@ def spmm(csr_dev, x, x_layout, y, y_layout, rows, yprev=None, yp_layout="vm", ac
     rowptr, col, val = csr_dev
     check(_lib.load().sh_spmm(ptr(rowptr), ptr(col), ptr(val), ptr(x), xsv, xsb, ptr(y), ysv, ysb, ptr(yprev), psv, psb,
                               act_prev, zero_row, B, rows, C, stream_ptr()), "sh_spmm")
+
+
+def _linear_ws(M, N, K, device):
+    nbytes = _lib.load().sh_linear_workspace(M, N, K)
+    return torch.empty(max(1, (nbytes + 3) // 4), dtype=torch.float32, device=device), nbytes
+
+
+def _check2d(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise RuntimeError("semantichuman_amd linear kernels need contiguous fp32 HIP tensors (got %s %s %s); there is "
+                               "no CPU path" % (t.device, t.dtype, tuple(t.shape)))
+
+
+def linear_fwd(x, weight, bias):
+    """y = x @ weight.T + bias for x [M,K], weight [N,K] (nn.Linear layout)."""
+    _check2d(x, weight, bias)
+    M, K = x.shape
+    N = weight.shape[0]
+    assert weight.shape[1] == K
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    ws, nb = _linear_ws(M, N, K, x.device)
+    check(_lib.load().sh_linear_fwd(ptr(x), ptr(weight), ptr(bias), ptr(y), M, N, K, ptr(ws), nb, stream_ptr()), "sh_linear_fwd")
+    return y
+
+
+def linear_bwd_data(dy, weight):
+    _check2d(dy, weight)
+    M, N = dy.shape
+    K = weight.shape[1]
+    dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
+    ws, nb = _linear_ws(M, N, K, dy.device)
+    check(_lib.load().sh_linear_bwd_data(ptr(dy), ptr(weight), ptr(dx), M, N, K, ptr(ws), nb, stream_ptr()), "sh_linear_bwd_data")
+    return dx
+
+
+def linear_bwd_wgt(dy, x, want_bias=True):
+    _check2d(dy, x)
+    M, N = dy.shape
+    K = x.shape[1]
+    dW = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+    db = torch.empty((N,), dtype=torch.float32, device=dy.device) if want_bias else None
+    ws, nb = _linear_ws(M, N, K, dy.device)
+    check(_lib.load().sh_linear_bwd_wgt(ptr(dy), ptr(x), ptr(dW), ptr(db), M, N, K, ptr(ws), nb, stream_ptr()), "sh_linear_bwd_wgt")
+    return dW, db
 
 
 def _ws(device):

@@ -9,9 +9,10 @@ The reference runs encode/decode as a Python loop of small autograd ops
             into the gather table of the convolution in front of it (mesh_ops.compose_select),
             so the rows D would discard are never computed.
   backward  a hand-scheduled chain: for every conv, the weight-gradient kernel and the
-            backward-data kernel; the activation derivative of the PREVIOUS layer is applied in
-            the epilogue of whichever kernel produces that layer's output gradient, so no
-            separate elementwise pass and no saved pre-activations.  No atomics anywhere.
+            backward-data kernel (the forward kernel run over the TRANSPOSED gather table);
+            the activation derivative of the PREVIOUS layer is applied in the epilogue of
+            whichever kernel produces that layer's output gradient, so there is no separate
+            elementwise pass and no saved pre-activation.  No atomics anywhere.
 
 Plan construction is pure numpy (testable without a GPU); `to(device)` uploads the tables.
 """
@@ -24,9 +25,13 @@ import numpy as np
 import torch
 
 from . import mesh_ops, ops
-from .mesh_ops import CSR
+from .mesh_ops import CSR, TransposedTable
 
-LONG_LIST = 8     # (input row, spiral position) lists longer than this are pre-reduced by an SpMM
+
+import os
+
+# run weight-gradient kernels on a side stream, concurrently with the backward-data chain
+OVERLAP_WGRAD = os.environ.get("SH_OVERLAP_WGRAD", "1") != "0"
 
 
 def _dev(a: np.ndarray, device):
@@ -52,47 +57,26 @@ class ConvStep:
     R: int = 0
     S: int = 0
     zero_row: int = -1
-    lptr: Optional[np.ndarray] = None
-    lsrc: Optional[np.ndarray] = None
-    long_csr: Optional[CSR] = None
-    n_extra: int = 0
+    tt: Optional[TransposedTable] = None
+    n_extra: int = 0           # extra rows the dpre buffer needs behind its R real rows
     dev: dict = field(default_factory=dict)
 
     def finalize(self):
         self.R, self.S = self.table.shape
         self.zero_row = self.R - 1                       # the dummy row of the output (models.py:49-51)
-        gl = mesh_ops.transpose_table(self.table, self.n_in,
-                                      skip_row=self.n_in - 1 if self.dead_dummy_grad else -1)
-        lengths = np.diff(gl.ptr)
-        long_pairs = np.nonzero(lengths > LONG_LIST)[0]
-        if long_pairs.size == 0:
-            self.lptr, self.lsrc, self.long_csr, self.n_extra = gl.ptr, gl.src, None, 0
-            return self
-        # divert long lists: they are summed first by an SpMM (ones) into extra rows R..R+n_long-1
-        # of the dpre buffer, and the list is replaced by the single entry pointing there.
-        new_len = lengths.copy()
-        new_len[long_pairs] = 1
-        ptr = np.zeros_like(gl.ptr)
-        np.cumsum(new_len, out=ptr[1:])
-        src = np.empty(int(ptr[-1]), dtype=np.int32)
-        is_long = np.zeros(lengths.shape[0], dtype=bool)
-        is_long[long_pairs] = True
-        keep_entry = ~np.repeat(is_long, lengths)
-        short_dst = np.ones(int(ptr[-1]), dtype=bool)
-        short_dst[ptr[:-1][long_pairs]] = False
-        src[short_dst] = gl.src[keep_entry]
-        src[ptr[:-1][long_pairs]] = self.R + np.arange(long_pairs.size, dtype=np.int32)
-        rowptr = np.zeros(long_pairs.size + 1, dtype=np.int32)
-        np.cumsum(lengths[long_pairs], out=rowptr[1:])
-        col = np.concatenate([gl.src[gl.ptr[p]:gl.ptr[p + 1]] for p in long_pairs]).astype(np.int32)
-        self.long_csr = CSR(long_pairs.size, self.R, rowptr, col, np.ones(col.shape[0], dtype=np.float32))
-        self.lptr, self.lsrc, self.n_extra = ptr.astype(np.int32), src, int(long_pairs.size)
+        # "no source" entries point at dpre's own dummy row, which every producer of dpre forces to
+        # zero (act_backward / the zero_row epilogues).
+        self.tt = mesh_ops.transpose_table_dense(self.table, self.n_in, none_row=self.zero_row,
+                                                 skip_row=self.n_in - 1 if self.dead_dummy_grad else -1)
+        self.n_extra = self.tt.n_extra
         return self
 
     def to(self, device):
-        self.dev = {"table": _dev(self.table, device), "lptr": _dev(self.lptr, device), "lsrc": _dev(self.lsrc, device)}
-        if self.long_csr is not None:
-            self.dev["long"] = _csr_dev(self.long_csr, device)
+        self.dev = {"table": _dev(self.table, device), "table_t": _dev(self.tt.table_t, device)}
+        if self.tt.csr1 is not None:
+            self.dev["sum1"] = _csr_dev(self.tt.csr1, device)
+        if self.tt.csr2 is not None:
+            self.dev["sum2"] = _csr_dev(self.tt.csr2, device)
         return self
 
 
@@ -155,6 +139,12 @@ class Stack:
     def conv_steps(self):
         return [s for s in self.steps if s.kind == "conv"]
 
+    def _side_stream(self, dev):
+        s = getattr(self, "_side", None)
+        if s is None or s.device != dev:
+            s = self._side = torch.cuda.Stream(device=dev)
+        return s
+
     # ------------------------------------------------------------------ forward
     def run_forward(self, x, in_layout, out_layout, weights, biases, keep: bool):
         """-> (output, [activation of every step]) ; activations are only kept when `keep`."""
@@ -186,6 +176,14 @@ class Stack:
         B = x.shape[0] if in_layout == "bm" else x.shape[1]
         dev = x.device
         grads = {}
+        # Weight-gradient kernels only read (dpre_i, input_i) and are needed by nobody until the
+        # optimizer, so they run on a side stream concurrently with the backward-data chain on the
+        # main stream.  Each launch of this net has limited parallelism (a few hundred to a few
+        # thousand workgroups with long, barrier-paced tiles); two independent kernel streams fill
+        # each other's tails and stalls.  Under hipGraph capture this becomes two parallel branches.
+        main = torch.cuda.current_stream(dev)
+        side = self._side_stream(dev) if OVERLAP_WGRAD else None
+        keep_alive = []          # buffers the side stream still reads must outlive the join below
 
         def in_of(i):
             return (x, in_layout) if i == 0 else (acts[i - 1], "vm")
@@ -220,14 +218,26 @@ class Stack:
                 ep = dict(yprev=acts[i - 1], yp_layout="vm", act_prev=prev.act, zero_row=prev.zero_row)
 
             if st.kind == "conv":
-                if st.n_extra:          # pre-reduce the long lists into the extra rows of dpre
-                    ops.spmm(st.dev["long"], cur, "vm", cur[st.R:], "vm", st.n_extra)
-                dW, db = ops.spiral_conv_bwd_wgt(cur, cur_layout, inp, inp_layout, st.dev["table"], st.R, st.S,
-                                                 st.cin, st.cout, want_bias=need_bias[st.param])
+                if side is not None:
+                    side.wait_stream(main)                     # dpre_i (and input_i) are complete on main
+                    keep_alive.append(cur)
+                    with torch.cuda.stream(side):
+                        dW, db = ops.spiral_conv_bwd_wgt(cur, cur_layout, inp, inp_layout, st.dev["table"], st.R, st.S,
+                                                         st.cin, st.cout, want_bias=need_bias[st.param])
+                else:
+                    dW, db = ops.spiral_conv_bwd_wgt(cur, cur_layout, inp, inp_layout, st.dev["table"], st.R, st.S,
+                                                     st.cin, st.cout, want_bias=need_bias[st.param])
                 grads[st.param] = (dW, db)
                 if want_in:
+                    # rows referenced more than once per (input row, position): sum them into the
+                    # extra rows of the dpre buffer first (see mesh_ops.TransposedTable)
+                    n1, n2 = st.tt.n1, st.tt.n2
+                    if n1:
+                        ops.spmm(st.dev["sum1"], cur, "vm", cur[st.R:], "vm", n1)
+                    if n2:
+                        ops.spmm(st.dev["sum2"], cur, "vm", cur[st.R + n1:], "vm", n2)
                     wt = ops.weight_transpose(weights[st.param], st.S, st.cin, st.cout)
-                    ops.spiral_conv_bwd_data(cur, cur_layout, st.dev["lptr"], st.dev["lsrc"], wt, g_in, g_layout,
+                    ops.spiral_conv_bwd_data(cur, cur_layout, st.dev["table_t"], wt, g_in, g_layout,
                                              ep["yprev"], ep["yp_layout"], ep["act_prev"], ep["zero_row"],
                                              st.n_in, st.S, st.cin, st.cout)
             elif want_in:
@@ -235,6 +245,13 @@ class Stack:
                          yp_layout=ep["yp_layout"], act_prev=ep["act_prev"], zero_row=ep["zero_row"])
             if want_in:
                 cur, cur_layout = g_in, g_layout
+        if side is not None:
+            main.wait_stream(side)                             # join: gradients are consumed on main
+            for dW, db in grads.values():
+                dW.record_stream(main)
+                if db is not None:
+                    db.record_stream(main)
+            del keep_alive
         return (cur if need_x_grad else None), grads
 
 
@@ -265,11 +282,11 @@ class StackFunction(torch.autograd.Function):
         gx, grads = stack.run_backward(x, in_layout, out_layout, ctx.acts + [out], g, weights,
                                        ctx.needs_input_grad[3], need_bias)
         ctx.acts = None
-        out = [None, None, None, gx]
+        res = [None, None, None, gx]
         for j in range(len(weights)):
             dW, db = grads.get(j, (None, None))
-            out += [dW, db]
-        return tuple(out)
+            res += [dW, db]
+        return tuple(res)
 
 
 def run_stack(stack: Stack, x, in_layout, out_layout, convs):

@@ -1,7 +1,7 @@
 """numpy (float64) emulation of the FORMULATION the HIP kernels use - gather tables, fused
-row-select, transposed lists, long-list pre-reduction, CSR re-sampling.  It lets the CPU test
-suite prove that the tables built by semantichuman_amd.mesh_ops / stack are right (against the
-oracle's autograd) without a GPU.  Test infrastructure only."""
+row-select, dense transposed tables with pre-summed extra rows, CSR re-sampling.  It lets the
+CPU test suite prove that the tables built by semantichuman_amd.mesh_ops / stack are right
+(against the oracle's autograd) without a GPU.  Test infrastructure only."""
 import numpy as np
 
 ACT = {0: lambda v: v, 1: lambda v: np.maximum(v, 0), 2: lambda v: np.where(v > 0, v, np.expm1(np.minimum(v, 0))),
@@ -21,16 +21,24 @@ def conv_fwd(x, table, W, b, act, zero_row):
     return y
 
 
-def conv_bwd_data(dpre_ext, lptr, lsrc, W, n_in, S, cin, cout):
-    """dpre_ext [R+extra,B,Cout]; -> dx [n_in,B,Cin] via the (u,s) lists"""
-    B = dpre_ext.shape[1]
-    dx = np.zeros((n_in, B, cin))
-    for u in range(n_in):
-        for s in range(S):
-            e0, e1 = lptr[u * S + s], lptr[u * S + s + 1]
-            if e1 > e0:
-                a = dpre_ext[lsrc[e0:e1]].sum(0)         # [B,Cout]
-                dx[u] += a @ W[:, s * cin:(s + 1) * cin]
+def extend_dpre(dpre, tt):
+    """Append the pre-summed extra rows of a mesh_ops.TransposedTable (what the two sh_spmm
+    launches in stack.run_backward write behind the R real rows)."""
+    ext = dpre
+    if tt.csr1 is not None:
+        ext = np.concatenate([ext, spmm(tt.csr1, ext)], 0)
+    if tt.csr2 is not None:
+        ext = np.concatenate([ext, spmm(tt.csr2, ext)], 0)
+    return ext
+
+
+def conv_bwd_data(dpre_ext, table_t, W, cin):
+    """dx[u] = sum_s dpre_ext[table_t[u,s]] . W[:, s*cin:(s+1)*cin]  - the forward formulation
+    over the transposed table (sh_spiral_conv_bwd_data)."""
+    n_in, S = table_t.shape
+    dx = np.zeros((n_in, dpre_ext.shape[1], cin))
+    for s in range(S):
+        dx += dpre_ext[table_t[:, s]] @ W[:, s * cin:(s + 1) * cin]
     return dx
 
 
@@ -73,11 +81,8 @@ def stack_backward(stack, x, acts, g, weights):
         inp = x if i == 0 else acts[i - 1]
         prev = steps[i - 1] if i > 0 else None
         if st.kind == "conv":
-            ext = cur
-            if st.n_extra:
-                ext = np.concatenate([cur[:st.R], spmm(st.long_csr, cur[:st.R])], 0)
             grads[st.param] = conv_bwd_wgt(cur, inp, st.table)
-            g_in = conv_bwd_data(ext, st.lptr, st.lsrc, weights[st.param], st.n_in, st.S, st.cin, st.cout)
+            g_in = conv_bwd_data(extend_dpre(cur[:st.R], st.tt), st.tt.table_t, weights[st.param], st.cin)
         else:
             g_in = spmm(st.csr_t, cur)
         if prev is not None and prev.kind == "conv":

@@ -72,20 +72,34 @@ def test_transpose_table_brute_force(small):
     assert gl2.ptr[(n_in - 1) * S] == gl2.ptr[-1]
 
 
-def test_long_lists_are_diverted(small):
+def test_dense_transposed_table(small):
+    """table_t + pre-summed extra rows == the scatter-add the reference's autograd performs."""
     g, h = small
     table = mesh_ops.spirals_to_table(h.spirals[1][None])
-    st = ConvStep(param=0, table=table, n_in=table.shape[0], cin=4, cout=5, act=2).finalize()
-    assert st.n_extra > 0 and st.long_csr.rows == st.n_extra       # the dummy row has a huge fan-in
-    assert np.diff(st.lptr).max() <= 8
+    R, S = table.shape
+    st = ConvStep(param=0, table=table, n_in=R, cin=4, cout=5, act=2).finalize()
+    tt = st.tt
+    assert tt.table_t.shape == (R, S) and tt.table_t.dtype == np.int32
+    assert tt.n1 > 0 and tt.n2 > 0                        # the dummy row is read hundreds of times per position
+    assert np.diff(tt.csr1.rowptr).max() <= 16 and tt.csr2.rows == tt.n2 and tt.csr2.cols == R + tt.n1
+    assert tt.table_t.max() == R + tt.n_extra - 1
     rs = np.random.RandomState(0)
-    dpre = rs.randn(st.R, 2, 5)
-    W = rs.randn(5, st.S * 4)
-    ext = np.concatenate([dpre, emulate.spmm(st.long_csr, dpre)], 0)
-    got = emulate.conv_bwd_data(ext, st.lptr, st.lsrc, W, st.n_in, st.S, 4, 5)
-    plain = mesh_ops.transpose_table(table, table.shape[0])
-    want = emulate.conv_bwd_data(dpre, plain.ptr, plain.src, W, st.n_in, st.S, 4, 5)
+    dpre = rs.randn(R, 2, 5)
+    dpre[st.zero_row] = 0                                  # contract: the "no source" row of dpre is zero
+    W = rs.randn(5, S * 4)
+    got = emulate.conv_bwd_data(emulate.extend_dpre(dpre, tt), tt.table_t, W, 4)
+    want = np.zeros((R, 2, 4))                             # brute-force scatter-add
+    for r in range(R):
+        for s in range(S):
+            want[table[r, s]] += dpre[r] @ W[:, s * 4:(s + 1) * 4]
     np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)
+    # a dead dummy row gets no sources at all
+    tt2 = mesh_ops.transpose_table_dense(table, R, none_row=R - 1, skip_row=R - 1)
+    assert np.all(tt2.table_t[R - 1] == R - 1) and tt2.n1 == 0
+    # no multi-entry list at all -> no extra rows
+    ident = np.arange(6, dtype=np.int32).reshape(6, 1)
+    tt3 = mesh_ops.transpose_table_dense(ident, 6, none_row=5)
+    assert tt3.n_extra == 0 and np.array_equal(tt3.table_t, ident)
 
 
 def test_conv_layout_matches_reference_keys(small):
