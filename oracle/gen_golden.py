@@ -239,6 +239,60 @@ def gen_conv_acts():
     print("conv_acts.npz written")
 
 
+def gen_loop():
+    """The reference's OWN plain training loop (train_funcs.train_autoencoder_dataloader,
+    :474-583) and evaluation loop (test_funcs.test_autoencoder_dataloader), 3 epochs x 3
+    iterations at batch 2 on the 170-vertex hierarchy, edge regulariser on (epoch > 0, w = 1e-2),
+    Adam 1e-3 / 5e-5, StepLR(1, 0.99), checkpoint every epoch."""
+    import tempfile
+    from types import SimpleNamespace
+    from configure.cfgs import cfg
+    g = np.load(os.path.join(GOLD, "small_ae.npz"))
+    from semantichuman_amd.hierarchy import load_hierarchy
+    h = load_hierarchy(os.path.join(GOLD, "small_ae.npz"))
+    S, D, U = h.dense_constants()
+    dev = torch.device("cpu")
+    model = ref_models.SpiralAutoencoder(FILTERS_ENC, FILTERS_DEC, 16, h.sizes, h.spiral_sizes, S, D, U, dev)
+    model.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w0/")})
+    xtr = torch.from_numpy(synthetic.synth_batch(h.verts, 6, seed=10))
+    xva = torch.from_numpy(synthetic.synth_batch(h.verts, 4, seed=11))
+
+    class DS(torch.utils.data.Dataset):
+        dummy_node = True
+        def __init__(self, x): self.x = x
+        def __len__(self): return self.x.shape[0]
+        def __getitem__(self, i): return {"verts": self.x[i], "idx": i}
+
+    ltr = torch.utils.data.DataLoader(DS(xtr), batch_size=2, shuffle=False)
+    lva = torch.utils.data.DataLoader(DS(xva), batch_size=2, shuffle=False)
+    optim = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-5)
+    sched = torch.optim.lr_scheduler.StepLR(optim, 1, gamma=0.99)
+    scalars = []
+
+    class Writer:
+        def add_scalar(self, tag, value, step): scalars.append((tag, float(value), int(step)))
+
+    cfg.TRAIN.edgereg_epoch, cfg.TRAIN.edgereg_w, cfg.TRAIN.ck_frequency = 0, 1e-2, 1
+    shapedata = SimpleNamespace(reference_mesh=SimpleNamespace(f=h.faces))
+    ref_train.tqdm = lambda it: it
+    J = np.zeros((24, h.sizes[0]), np.float32)
+    with tempfile.TemporaryDirectory() as td:
+        ref_train.train_autoencoder_dataloader(ltr, lva, dev, model, optim, torch.nn.functional.l1_loss, 1, 3, 10, None, sched,
+                                               Writer(), shapedata, td, td, "checkpoint", J, None, None, False)
+        ck = torch.load(os.path.join(td, "checkpoint3.pth.tar"), map_location="cpu", weights_only=False)
+    assert sorted(ck.keys()) == ["autoencoder_state_dict", "epoch", "optimizer_state_dict", "scheduler_state_dict"]
+    ref_test.tqdm = lambda it: it
+    _, _, _, l1, l2 = ref_test.test_autoencoder_dataloader(dev, model, lva, None, J)
+    arrs = {"x_train": xtr.numpy(), "x_val": xva.numpy(), "eval_l1": l1, "eval_l2mm": l2, "ck_epoch": ck["epoch"],
+            "ck_keys": np.asarray(sorted(ck.keys())), "lr_after": optim.param_groups[0]["lr"],
+            "scalar_tags": np.asarray([s[0] for s in scalars]), "scalar_values": np.asarray([s[1] for s in scalars]),
+            "scalar_steps": np.asarray([s[2] for s in scalars])}
+    for name, p in model.named_parameters():
+        arrs["w_end/" + name] = p.detach().numpy().copy()
+    np.savez_compressed(os.path.join(GOLD, "small_loop.npz"), **arrs)
+    print("small_loop.npz:", [(t, round(v, 6), s) for t, v, s in scalars], "L1", l1, "L2mm", l2)
+
+
 def gen_template():
     t0 = time.time()
     v, f = synthetic.box_sphere(42, 42, 20)
@@ -281,5 +335,6 @@ if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     gen_small()
     gen_conv_acts()
+    gen_loop()
     if not a.skip_template:
         gen_template()

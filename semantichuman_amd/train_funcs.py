@@ -1,0 +1,130 @@
+"""Training loop of the plain spiral autoencoder - the outer loop stays PyTorch (north_star), the
+model and the losses underneath are HIP kernels.
+
+`train_autoencoder_dataloader` keeps the reference's name, positional signature, per-epoch
+logging tags and checkpoint layout (reference train_funcs.py:474-583), so `main.py` can call it
+unchanged.  Differences, all invisible in the numbers:
+
+  * the edge regulariser is ONE batched kernel instead of a per-sample Python loop with a
+    `.cpu().numpy()` synchronisation per sample (reference :503-508);
+  * the per-iteration `loss.item()` host syncs (:513) are replaced by on-device accumulation; the
+    host reads the running sums once per epoch (and at the `eval_freq` logging points);
+  * the global yacs `cfg` is replaced by keyword options (`edgereg_epoch`, `edgereg_w`,
+    `ck_frequency`; defaults = configure/traincfg.yaml:40-41,52);
+  * optional data-parallel training: pass `reducer=parallel.GradientAllReducer(model)` and give
+    every rank its own shard of the data.
+
+Checkpoints: `{'epoch','autoencoder_state_dict','optimizer_state_dict','scheduler_state_dict'}`
+with CPU tensors, at `<metadata_dir>/<checkpoint_path><epoch>.pth.tar` (reference :562-567).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import losses
+
+
+def _as_loss(loss_fn):
+    """The reference passes torch's F.l1_loss (main.py:296,311); route it to the HIP kernel."""
+    return losses.l1_loss if loss_fn is F.l1_loss or loss_fn is None else loss_fn
+
+
+def save_checkpoint(path, epoch, model, optim, scheduler):
+    """Reference layout and CPU tensors (train_funcs.py:554-569) without moving the live model."""
+    module = model.module if hasattr(model, "module") else model
+    state = {k: v.detach().cpu() for k, v in module.state_dict().items()}
+    torch.save({"epoch": epoch, "autoencoder_state_dict": state, "optimizer_state_dict": optim.state_dict(),
+                "scheduler_state_dict": scheduler.state_dict() if scheduler else None}, path)
+
+
+def load_checkpoint(path, model, optim=None, scheduler=None, finetune=False, map_location="cpu"):
+    """main.py:277-292: returns the epoch to start from."""
+    ck = torch.load(path, map_location=map_location, weights_only=False)
+    model.load_state_dict(ck["autoencoder_state_dict"])
+    if finetune:
+        return 1
+    if optim is not None:
+        optim.load_state_dict(ck["optimizer_state_dict"])
+    if scheduler is not None and ck.get("scheduler_state_dict") is not None:
+        scheduler.load_state_dict(ck["scheduler_state_dict"])
+    return ck["epoch"] + 1
+
+
+def train_autoencoder_dataloader(dataloader_train, dataloader_val, device, model, optim, loss_fn,
+                                 start_epoch, n_epochs, eval_freq, dataloader_interp, scheduler,
+                                 writer, shapedata, metadata_dir, samples_dir, checkpoint_path,
+                                 J_regressor=None, vert_part_index_dict=None, partname_list=None, save_recons=False,
+                                 *, edgereg_epoch=0, edgereg_w=1e-2, ck_frequency=50, reducer=None, verbose=True):
+    loss_fn = _as_loss(loss_fn)
+    f_np = np.asarray(shapedata.reference_mesh.f).astype(np.int32)
+    n_rows = None
+    face_tables = None
+    total_steps = (start_epoch - 1) * len(dataloader_train)
+    eval_freq = len(dataloader_train)                                    # reference :482
+    history = []
+
+    for epoch in range(start_epoch, n_epochs + 1):
+        model.train()
+        tloss = torch.zeros((), device=device)
+        rec_loss = torch.zeros((), device=device)
+        edgereg_loss = torch.zeros((), device=device)
+        for b, sample_dict in enumerate(dataloader_train):
+            optim.zero_grad()
+            tx = sample_dict["verts"].to(device)
+            cur_bsize = tx.shape[0]
+            tx_hat = model(tx)[0]
+            rec_loss = loss_fn(tx, tx_hat)
+            loss = rec_loss
+            if epoch > edgereg_epoch and edgereg_w > 0:
+                if face_tables is None or n_rows != tx.shape[1]:
+                    n_rows = tx.shape[1]
+                    face_tables = losses.FaceTables(f_np, n_rows, device)
+                edgereg_loss = losses.edge_ratio_loss(tx_hat, tx, face_tables)
+                loss = loss + edgereg_w * edgereg_loss
+            if reducer is not None:
+                reducer.prepare()
+            loss.backward()
+            if reducer is not None:
+                reducer.finish()
+            optim.step()
+            tloss += cur_bsize * loss.detach()
+            if writer and total_steps % eval_freq == 0:
+                writer.add_scalar("loss/loss/data_loss", loss.item(), total_steps)
+                writer.add_scalar("loss/loss/rec_loss", rec_loss.item(), total_steps)
+                writer.add_scalar("loss/loss/edgereg_loss", float(edgereg_loss), total_steps)
+            total_steps += 1
+
+        model.eval()
+        vloss = torch.zeros((), device=device)
+        with torch.no_grad():
+            for b, sample_dict in enumerate(dataloader_val):
+                tx = sample_dict["verts"].to(device)
+                tx_hat_val = model(tx)[0]
+                vloss += tx.shape[0] * loss_fn(tx[:, :-1, :], tx_hat_val[:, :-1, :])   # dummy row dropped (:535)
+
+        if scheduler:
+            scheduler.step()
+
+        epoch_tloss = float(tloss) / float(len(dataloader_train.dataset))
+        if writer:
+            writer.add_scalar("avg_epoch_train_loss", epoch_tloss, epoch)
+        epoch_vloss = None
+        if len(dataloader_val.dataset) > 0:
+            epoch_vloss = float(vloss) / float(len(dataloader_val.dataset))
+            if writer:
+                writer.add_scalar("avg_epoch_valid_loss", epoch_vloss, epoch)
+            if verbose:
+                print("epoch {0} | tr {1} | val {2}".format(epoch, epoch_tloss, epoch_vloss))
+        elif verbose:
+            print("epoch {0} | tr {1} ".format(epoch, epoch_tloss))
+        history.append((epoch, epoch_tloss, epoch_vloss))
+
+        if epoch % ck_frequency == 0 and metadata_dir is not None:
+            save_checkpoint(os.path.join(metadata_dir, checkpoint_path + "%s.pth.tar" % epoch), epoch, model, optim, scheduler)
+    if verbose:
+        print("~FIN~")
+    return history
