@@ -197,6 +197,8 @@ def main():
     # ---- roofline of the dominant kernel: HIP events recorded by the library around every launch
     if rank == 0 and not args.no_roofline:
         nprof = 5
+        from semantichuman_amd import stack as _stack
+        overlap_was, _stack.OVERLAP_WGRAD = _stack.OVERLAP_WGRAD, False     # serial launches: clean per-kernel durations
         _lib.profile_enable(True)
         for i in range(nprof):
             o = (i * B) % n_data
@@ -208,6 +210,7 @@ def main():
         torch.cuda.synchronize()
         recs = _lib.profile_records_by_kernel()
         _lib.profile_enable(False)
+        _stack.OVERLAP_WGRAD = overlap_was
         agg = {}
         for name, _shape, ms in recs:
             a = agg.setdefault(name, [0, 0.0])

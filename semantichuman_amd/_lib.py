@@ -11,7 +11,7 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsh_kernels.so")
+LIB_PATH = os.environ.get("SH_KERNEL_LIB") or os.path.join(_HERE, "lib", "libsh_kernels.so")   # override: diagnostic builds
 
 ACT_IDS = {"identity": 0, "relu": 1, "elu": 2, "leaky_relu": 3, "sigmoid": 4, "tanh": 5}
 

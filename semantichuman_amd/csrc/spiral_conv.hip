@@ -44,7 +44,7 @@ struct GGParams {
     int vec_out;        // Nout % 4 == 0 and output strides 16-B aligned
 };
 
-template <int NT, bool VEC4, bool BWD_EPI>
+template <int NT, bool VEC4, bool BWD_EPI, bool TB16>
 __global__ __launch_bounds__(NTHREADS) void gather_gemm_kernel(const GGParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* As = reinterpret_cast<float*>(smem);            // [2][TM][KC]
@@ -63,26 +63,36 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_kernel(const GGParams p)
         const long lim = (long)p.R * S;
         for (int i = tid; i < nT; i += NTHREADS) {
             const long g = (long)v0 * S + i;
-            Ts[i] = g < lim ? p.table[g] : 0;
+            Ts[i] = g < lim ? (int)(unsigned)((long)p.table[g] * p.x_sv) : 0;     // element offset of the gathered row (< 2^32)
         }
     }
     __syncthreads();
 
-    // ---- staging assignment: thread -> quad q of rows rbase + 32*i
-    // All hot-path loads are BRANCH-FREE: out-of-range rows / columns read a valid dummy address
-    // and are zeroed by a select afterwards, so the compiler can keep two chunks of loads in
-    // flight behind counted s_waitcnt vmcnt(N) (a load under a branch would force vmcnt(0)).
+    // ---- staging assignment.
+    // All hot-path loads are BRANCH-FREE: out-of-range rows / columns read a valid dummy address,
+    // so the compiler can keep two chunks of loads in flight behind counted s_waitcnt vmcnt(N) (a
+    // load under a branch would force vmcnt(0)).  Garbage in rows/channels outside the valid range
+    // only feeds outputs the epilogue never stores; only K columns past the end of K need zeroing,
+    // and that is done on the weight operand when the chunk is written to LDS.
+    //
+    // FAST path (TB16: batch slice of 16, vector loads): thread -> (vertex vl = tid>>5, batch rows
+    // bl0 + 4j, quad q).  One gather-table lookup and one base address per thread and chunk; the four
+    // loads differ only by a per-thread constant batch offset.  The generic path (any slice width,
+    // scalar channels) maps thread -> quad q of rows rbase + 32*i with a lookup per row.
+    constexpr bool FAST = TB16 && VEC4;
     const int q = tid & 7, rbase = tid >> 3;
-    int a_ts[4];        // a_vl * S: offset of the row's table line
-    long a_boff[4];
+    int a_ts[4];        // offset of the row's table line
+    long a_boff[4];     // batch offset (elements)
     bool a_ok[4];
+    int a_lds[4];       // LDS float offset of this thread's quad in row i (swizzled)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int row = rbase + 32 * i;
+        const int row = FAST ? ((tid >> 5) << 4) + ((tid & 31) >> 3) + 4 * i : rbase + 32 * i;
         const int vl = row >> p.log2TB, bl = row & (TB - 1);
         a_ok[i] = (v0 + vl) < p.R && (b0 + bl) < p.B;
         a_ts[i] = vl * S;
-        a_boff[i] = a_ok[i] ? (long)(b0 + bl) * p.x_sb : 0;
+        a_boff[i] = (b0 + bl) < p.B ? (long)(b0 + bl) * p.x_sb : 0;
+        a_lds[i] = row * KC + ((q ^ (row & 7)) << 2);
     }
     constexpr int WQ = NT >= 2 ? NT / 2 : 1;
     const bool w_thread = (NT >= 2) || tid < 128;
@@ -96,35 +106,30 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_kernel(const GGParams p)
     }
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-    // Loads return RAW values; zeroing (only needed for K columns past the end of K) is applied
-    // when the chunk is written to LDS, two phases later - a select placed next to the load would
-    // make the compiler wait for the load right away.  Rows outside the tile's valid range are not
-    // masked at all: they only feed output rows/channels the epilogue never stores.
-    auto gather_quad = [&](int i, int s, int ch) -> f32x4 {
-        const int u = Ts[a_ts[i] + s];
-        return *reinterpret_cast<const f32x4*>(p.x + (long)u * p.x_sv + a_boff[i] + ch);
-    };
-    auto gather_scalar = [&](int i, int s, int ch) -> float {
-        const int u = Ts[a_ts[i] + s];
-        return p.x[(long)u * p.x_sv + a_boff[i] + ch];
-    };
+    // running (k, s, channel) of this thread's quad for the NEXT chunk to be loaded: chunks are
+    // loaded strictly in order, so the split of k into (spiral position, channel) advances by
+    // additions instead of a division per chunk
+    int k_next = 4 * q, s_next = k_next / p.Cg, ch_next = k_next - s_next * p.Cg;
+    const int adv_s = KC / p.Cg, adv_c = KC - adv_s * p.Cg;
 
-    // mask != 0: this thread's K columns are inside K
-    auto load_chunk = [&](int c, f32x4 (&ra)[4], f32x4 (&rw)[WQ], unsigned& mask) {
-        c = c < p.nchunks ? c : p.nchunks - 1;              // prefetches past the end re-read the last chunk
-        const int k = c * KC + 4 * q;
-        mask = 0;
+    auto load_chunk = [&](f32x4 (&ra)[4], f32x4 (&rw)[WQ], unsigned& mask) {
+        const int k = k_next;
+        const bool kok = k < p.K;                           // also false for prefetches past the last chunk
+        mask = kok ? 1u : 0u;
         if (VEC4) {
-            const bool kok = k < p.K;
-            const int kc = kok ? k : 0;
-            const int s = kc / p.Cg, ch = kc - s * p.Cg;
+            const int s = kok ? s_next : 0, ch = kok ? ch_next : 0, kc = kok ? k : 0;
+            if (FAST) {
+                const float* src = p.x + (unsigned)Ts[a_ts[0] + s] + ch;      // Ts holds row * x_sv (element offsets)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ra[i] = gather_quad(i, s, ch);
+                for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const f32x4*>(src + a_boff[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    ra[i] = *reinterpret_cast<const f32x4*>(p.x + (unsigned)Ts[a_ts[i] + s] + a_boff[i] + ch);
+            }
 #pragma unroll
             for (int i = 0; i < WQ; ++i) rw[i] = *reinterpret_cast<const f32x4*>(p.w + w_off[i] + kc);
-            mask = kok ? 1u : 0u;
         } else {
-            mask = 1u;
 #pragma unroll
             for (int i = 0; i < 4; ++i) ra[i] = zero4;
 #pragma unroll
@@ -136,22 +141,29 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_kernel(const GGParams p)
                     const int s = kk / p.Cg, ch = kk - s * p.Cg;
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        if (a_ok[i]) ra[i][j] = gather_scalar(i, s, ch);
+                        if (a_ok[i]) ra[i][j] = p.x[(long)(unsigned)Ts[a_ts[i] + s] + a_boff[i] + ch];
 #pragma unroll
                     for (int i = 0; i < WQ; ++i)
                         if (w_ok[i]) rw[i][j] = p.w[w_off[i] + kk];
                 }
             }
+            mask = 1u;
         }
+        // branch-free advance by KC columns (a loop here would make hipcc drain vmcnt)
+        k_next += KC;
+        ch_next += adv_c;
+        s_next += adv_s;
+        const bool wrap = ch_next >= p.Cg;
+        ch_next = wrap ? ch_next - p.Cg : ch_next;
+        s_next = wrap ? s_next + 1 : s_next;
     };
     auto store_chunk = [&](int buf, const f32x4 (&ra)[4], const f32x4 (&rw)[WQ], unsigned mask) {
         float* Ab = As + buf * TM * KC;
         float* Wb = Ws + buf * NT * 16 * KC;
-        const int pq = (q ^ (rbase & 7)) << 2;     // (rbase + 32 i) & 7 == rbase & 7
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<f32x4*>(Ab + (rbase + 32 * i) * KC + pq) = mask ? ra[i] : zero4;
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(Ab + a_lds[i]) = ra[i];
         if (w_thread) {
+            const int pq = (q ^ (rbase & 7)) << 2;     // (rbase + 32 i) & 7 == rbase & 7
 #pragma unroll
             for (int i = 0; i < WQ; ++i)
                 *reinterpret_cast<f32x4*>(Wb + (rbase + 32 * i) * KC + pq) = mask ? rw[i] : zero4;
@@ -191,18 +203,18 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_kernel(const GGParams p)
     // that both register sets are statically named.
     f32x4 raA[4], raB[4], rwA[WQ], rwB[WQ];
     unsigned mA, mB;
-    load_chunk(0, raA, rwA, mA);
+    load_chunk(raA, rwA, mA);                // chunk 0
     store_chunk(0, raA, rwA, mA);
     __syncthreads();
-    load_chunk(1, raA, rwA, mA);
+    load_chunk(raA, rwA, mA);                // chunk 1
     for (int c = 0; c < p.nchunks; c += 2) {
-        load_chunk(c + 2, raB, rwB, mB);
+        load_chunk(raB, rwB, mB);            // chunk c+2
         __builtin_amdgcn_sched_barrier(0);   // keep the prefetch loads AHEAD of the MFMA phase
         compute(0);
         store_chunk(1, raA, rwA, mA);        // chunk c+1 (a clamped duplicate past the end is never read)
         __syncthreads();
         if (c + 1 >= p.nchunks) break;
-        load_chunk(c + 3, raA, rwA, mA);
+        load_chunk(raA, rwA, mA);            // chunk c+3
         __builtin_amdgcn_sched_barrier(0);
         compute(1);
         store_chunk(0, raB, rwB, mB);        // chunk c+2
@@ -261,7 +273,10 @@ int launch_gg(const GGParams& p, int nblocks, hipStream_t st) {
     {
         ShProfScope ps(st, "gather_gemm_kernel<%d, %s, %s>|R=%d B=%d K=%d N=%d grid=%d", NT, VEC4 ? "true" : "false",
                        BWD_EPI ? "true" : "false", p.R, p.B, p.K, p.Nout, nblocks);
-        hipLaunchKernelGGL((gather_gemm_kernel<NT, VEC4, BWD_EPI>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
+        if (p.log2TB == 4)
+            hipLaunchKernelGGL((gather_gemm_kernel<NT, VEC4, BWD_EPI, true>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
+        else
+            hipLaunchKernelGGL((gather_gemm_kernel<NT, VEC4, BWD_EPI, false>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
     }
     SH_CHECK_LAUNCH("gather_gemm");
     return SH_OK;

@@ -29,6 +29,12 @@ def _dims(t: torch.Tensor, layout: str):
     raise ValueError("layout must be 'bm' or 'vm'")
 
 
+def _check_index_range(t):
+    if t.numel() >= 2 ** 32:
+        raise RuntimeError("semantichuman_amd: gathered tensors are addressed with 32-bit element offsets; "
+                           "%d elements is too large - split the batch" % t.numel())
+
+
 def alloc(B: int, rows: int, C: int, layout: str, device, extra_rows: int = 0) -> torch.Tensor:
     if layout == "bm":
         if extra_rows:
@@ -47,6 +53,7 @@ def spiral_conv_fwd(x, x_layout, table, weight, bias, y, y_layout, R, S, act, ze
     B, _, Cin, xsv, xsb = _dims(x, x_layout)
     B2, Ry, Cout, ysv, ysb = _dims(y, y_layout)
     assert B == B2 and Ry >= R and weight.shape == (Cout, S * Cin) and table.dtype == torch.int32
+    _check_index_range(x)
     check(_lib.load().sh_spiral_conv_fwd(ptr(x), xsv, xsb, ptr(table), ptr(weight), ptr(bias), ptr(y), ysv, ysb,
                                          B, R, S, Cin, Cout, act, zero_row, stream_ptr()), "sh_spiral_conv_fwd")
 
@@ -57,6 +64,7 @@ def spiral_conv_bwd_data(dpre, dp_layout, table_t, weight_t, dx, dx_layout, ypre
     B2, Rx, C2, xsv, xsb = _dims(dx, dx_layout)
     assert B == B2 and C1 == Cout and C2 == Cin and Rx >= n_in and weight_t.shape == (Cin, S * Cout)
     assert table_t.dtype == torch.int32 and tuple(table_t.shape) == (n_in, S)
+    _check_index_range(dpre)
     if yprev is not None:
         _, _, C3, ysv, ysb = _dims(yprev, yp_layout)
         assert C3 == Cin
