@@ -184,6 +184,32 @@ SH_API int sh_edge_ratio_loss_bwd(const float* x_hat, const float* x, const int3
                            const int32_t* vptr, const int32_t* vcorner, int B, int N1, int F,
                            const float* gscale, float* grad, sh_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Part-wise pairwise-distance loss of the semantic training loop (train_funcs.py:243-284 and
+ * :353-389; utils_distance.calc_euclidean_dist_matrix :366-376; utils_SH.angle_skl :442-478).
+ * For every part p, batch entry b and ordered vertex pair (i,j), i != j, of the part:
+ *   De = |g_i-g_j| * scale[b,p];  De_r = |r_i-r_j|;  w from the angle between (g_i-g_j) and bone[b,p]
+ *   (w_mode 0 all_one, 1 angle/90, 2 sin(angle), 3 angle/90 thresholded at w_threshold; flags[p]&1
+ *   forces w = 1); pairs with w*De == 0 are dropped;
+ *   term = relat ? |w*De_r/De - w| : |w*De_r - w*De|;   loss = sum_p w_part[p] * mean_{kept pairs} term.
+ * x_rec, x_gt: contiguous [B][N1][3]; bone [B][P][3]; scale [B][P] or NULL (= 1); parts as CSR
+ * (part_ptr [P+1], part_vert), disjoint; tile_ptr [P+1] = cumulative ceil(n_p / sh_part_pairdist_tile_rows());
+ * T = tile_ptr[P]; max_part = largest n_p.  workspace >= B*T*2 floats.  part_sum / part_cnt [P] are
+ * outputs of fwd; bwd takes part_cnt, a device scalar gscale, and OVERWRITES grad [B][N1][3]
+ * (gradient w.r.t. x_rec; vertices outside every part get 0).  Deterministic (no atomics).
+ */
+SH_API int sh_part_pairdist_tile_rows(void);
+SH_API int sh_part_pairdist_loss_fwd(const float* x_rec, const float* x_gt, const float* bone, const float* scale,
+                              const int32_t* part_ptr, const int32_t* part_vert, const int32_t* tile_ptr,
+                              const int32_t* flags, const float* w_part, int B, int N1, int P, int T, int max_part,
+                              int w_mode, float w_threshold, int relat, float* loss, float* part_sum, float* part_cnt,
+                              void* workspace, size_t workspace_bytes, sh_stream_t stream);
+SH_API int sh_part_pairdist_loss_bwd(const float* x_rec, const float* x_gt, const float* bone, const float* scale,
+                              const int32_t* part_ptr, const int32_t* part_vert, const int32_t* tile_ptr,
+                              const int32_t* flags, const float* w_part, int B, int N1, int P, int T, int max_part,
+                              int w_mode, float w_threshold, int relat, const float* part_cnt, const float* gscale,
+                              float* grad, sh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -293,6 +293,127 @@ def gen_loop():
     print("small_loop.npz:", [(t, round(v, 6), s) for t, v, s in scalars], "L1", l1, "L2mm", l2)
 
 
+def gen_semantic():
+    """Semantic model + part losses on a 578-vertex hierarchy
+    [578,289,145,73,37]: reference models.SpiralAutoencoder_multiz_partkps forward/backward, and the
+    reference's loss primitives utils_distance.calc_euclidean_dist_matrix, utils_SH.angle_skl /
+    kps2skl / skl2kps, train_funcs.cal_volloss, combined exactly as train_funcs.py:243-284 combines
+    them (that loop itself cannot run on torch >= 2: `.next()`)."""
+    import utils_SH as ref_sh
+    import utils_distance as ref_ud
+    from configure.cfgs import cfg
+    from semantichuman_amd import constants as C
+    cfg.CONSTANTS.newskl_list = C.NEWSKL_LIST                      # traincfg.yaml:55-56 values
+    cfg.CONSTANTS.kps_index_list = C.KPS_INDEX_LIST
+    v, f = synthetic.box_sphere(12, 12, 6)
+    M, D, U, Fs, sizes, spirals_np, spiral_sizes = build_hierarchy(v, f, ref_point=100)
+    arrs = hierarchy_arrays(M, D, U, Fs, sizes, spirals_np, spiral_sizes)
+    tD, tU = dense_consts(D, U)
+    tS = [torch.from_numpy(s).long() for s in spirals_np]
+    dev = torch.device("cpu")
+    rs = np.random.RandomState(3)
+    names = C.PART_LIST
+    coarse = np.array_split(rs.permutation(sizes[-1]), 17)        # coarsest-level part -> vertex ids
+    # level-0 parts: 17 compact Voronoi patches around farthest-point seeds (parts must contain whole
+    # faces for the part-volume loss, like the body parts of the real template do)
+    vi = v / np.asarray((0.25, 0.15, 0.9))                       # undo the anisotropic scale: patches of equal size
+    seeds = [0]
+    dmin = np.linalg.norm(vi - vi[0], axis=1)
+    for _ in range(16):
+        seeds.append(int(np.argmax(dmin)))
+        dmin = np.minimum(dmin, np.linalg.norm(vi - vi[seeds[-1]], axis=1))
+    owner = np.argmin(np.linalg.norm(vi[:, None, :] - vi[None, seeds, :], axis=2), axis=1)
+    fine = [np.nonzero(owner == k)[0] for k in range(17)]
+    part_coarse = {n: np.sort(c) for n, c in zip(names, coarse)}
+    part_fine = {n: np.sort(c) for n, c in zip(names, fine)}
+    for k, n in enumerate(names):
+        arrs["part_coarse_%d" % k], arrs["part_fine_%d" % k] = part_coarse[n], part_fine[n]
+    model = ref_models.SpiralAutoencoder_multiz_partkps(C.KPS_INDEX_LIST, part_coarse, FILTERS_ENC, FILTERS_DEC, 8, 8, sizes,
+                                                        spiral_sizes, tS, tD, tU, dev)
+    fill_params(model, scale=1.5)
+    B = 3
+    x = torch.from_numpy(synthetic.synth_batch(v, B, seed=21))
+    J = np.abs(synthetic.closed_form_fill((35, sizes[0]), 1.0, 0.618, 0.3)) ** 8           # sparse-ish positive joint regressor
+    J = (J / J.sum(1, keepdims=True)).astype(np.float32)
+    Jt = torch.from_numpy(J)
+    kps_full = torch.matmul(Jt, x[:, :-1, :]).float()                                       # train_funcs.py:131
+    kps_keep = C.kps_keep()
+    kps = kps_full[:, kps_keep]
+    arrs.update(x=x.numpy(), J_regressor=J, kps=kps.numpy(), state_dict_keys=np.asarray(list(model.state_dict().keys())))
+    for name, p in model.named_parameters():
+        arrs["w0/" + name] = p.detach().numpy().copy()
+    x_hat, z, zk = model(x, kps)
+    torch.nn.functional.l1_loss(x, x_hat).backward()
+    arrs.update(x_hat=x_hat.detach().numpy(), z=z.detach().numpy(), z_part_kps=zk.detach().numpy())
+    for name, p in model.named_parameters():
+        arrs["grad/" + name] = p.grad.numpy().copy()
+    # edited decode (train_funcs.py:224-227): scale some part latents, decode
+    lat, lk, dummy = model.encode(x, kps)
+    a = torch.from_numpy(synthetic.closed_form_fill((B, 17), 0.2, 0.9, 0.1) + 1.0)
+    lat2 = lat.clone()
+    for k in range(17):
+        lat2[:, k, :] = lat2[:, k, :] * a[:, k][:, None]
+    rec = model.decode(lat2, lk, dummy)
+    arrs.update(edit_scale=a.numpy(), rec_edit=rec.detach().numpy())
+    arrs["kps2skl_model"] = model.kps2skl(kps).detach().numpy()
+    skl = ref_sh.kps2skl(kps_full, "ori_m")
+    arrs["kps2skl_ori_m"], arrs["skl2kps_ori_m"] = skl.numpy(), ref_sh.skl2kps(skl, "ori_m").numpy()
+
+    # ---- part pairwise-distance loss (train_funcs.py:243-284), threshold weights, both forms
+    xg, xr = x.detach(), rec.detach().clone().requires_grad_(True)
+    angle_w = ref_sh.angle_skl(xg[:, :-1, :], kps_full, names, part_fine, C.SKL_LIST)
+    leaf = [0, 7, 10, 13, 16]
+    edited = [1, 2, 3, 4, 5, 6, 8, 9, 11, 12, 14, 15]                                     # part_index_in_allpart ('equal' mode)
+    for relat in (True, False):
+        total = 0
+        for i, n in enumerate(names):
+            idx = part_fine[n]
+            De = ref_ud.calc_euclidean_dist_matrix(xg[:, idx, :])
+            De_r = ref_ud.calc_euclidean_dist_matrix(xr[:, idx, :])
+            if i in edited:
+                De = De * a[:, i][:, None, None]
+            w_part = 1 / len(names)
+            if i in leaf:
+                w = torch.ones_like(angle_w[i].squeeze(-1))
+            else:
+                w = angle_w[i].squeeze(-1).float() / 90
+                w = torch.where(w < 0.8, torch.full_like(w, 0), w)
+            for b in range(w.shape[0]):
+                w[b] = w[b] - torch.diag_embed(torch.diag(w[b]))
+            nz = torch.where((w * De) != 0)
+            if relat:
+                li = w_part * torch.nn.functional.l1_loss(w[nz] * De_r[nz].float() / De[nz], w[nz] * torch.ones_like(w[nz]))
+            else:
+                li = w_part * torch.nn.functional.l1_loss(w[nz] * De_r[nz].float(), w[nz] * De[nz])
+            total = total + li
+            if relat:
+                arrs["pair_count_%d" % i] = int(nz[0].shape[0])
+        xr.grad = None
+        total.backward()
+        tag = "relat" if relat else "abs"
+        arrs["pair_loss_" + tag], arrs["pair_grad_" + tag] = float(total), xr.grad.numpy().copy()
+    arrs["angle_w_part3"] = angle_w[3].squeeze(-1).numpy()
+    arrs["dist_part3"] = ref_ud.calc_euclidean_dist_matrix(xg[:, part_fine[names[3]], :]).numpy()
+
+    # ---- signed part-volume loss (train_funcs.py:56-71, called per sample at :323-329)
+    faces = torch.from_numpy(M[0].f.astype(np.int64))
+    vpi = torch.ones(sizes[0])
+    for k, vv in enumerate(part_fine.values()):
+        vpi[vv] = k
+    fpi = torch.ones(faces.shape[0])
+    for k, t in enumerate(faces):
+        fpi[k] = vpi[t[0]] if (vpi[t[0]] == vpi[t[1]] and vpi[t[0]] == vpi[t[2]]) else 100
+    xr2 = rec.detach().clone().requires_grad_(True)
+    vol = 0
+    for i in range(B):
+        vol = vol + ref_train.cal_volloss(xr2[i, :-1, :], xg[i, :-1, :], faces, vpi, fpi, part_fine, edited)
+    vol = vol / B
+    vol.backward()
+    arrs.update(vol_loss=float(vol), vol_grad=xr2.grad.numpy().copy(), face_part_index=fpi.numpy())
+    np.savez_compressed(os.path.join(GOLD, "semantic.npz"), **arrs)
+    print("semantic.npz: sizes", sizes, "S", spiral_sizes, "pair", arrs["pair_loss_relat"], arrs["pair_loss_abs"], "vol", float(vol))
+
+
 def gen_template():
     t0 = time.time()
     v, f = synthetic.box_sphere(42, 42, 20)

@@ -173,3 +173,120 @@ def train_step(model, optim, x, faces=None, edgereg_w=0.0):
     loss.backward()
     optim.step()
     return loss.detach()
+
+
+# =============================================================================================
+# Semantic model and its losses - restated in the reference's formulation
+# =============================================================================================
+class SemanticAEOracle(nn.Module):
+    """reference models.SpiralAutoencoder_multiz_partkps (models.py:166-310), same parameter names."""
+
+    def __init__(self, kps_index_list, vert_part_index_dict, filters_enc, filters_dec, latent_size, part_kps_latent_size,
+                 sizes, spiral_sizes, spirals, D, U, activation="elu"):
+        super().__init__()
+        self.sizes, self.spiral_sizes, self.spirals, self.D, self.U = sizes, spiral_sizes, spirals, D, U
+        self.kps_index_list = kps_index_list
+        self.parts = [torch.as_tensor(v, dtype=torch.long) for v in vert_part_index_dict.values()]
+        self.enc_plan, self.dec_plan = layer_plan(filters_enc, filters_dec, spiral_sizes, activation)
+        self.conv = nn.ModuleList([_Conv(c, S, o, a) for (c, S, o, a, _) in self.enc_plan])
+        feat = self.enc_plan[-1][2]
+        self.fc_latent_enc_list = nn.ModuleList([nn.Linear(len(v) * feat, latent_size) for v in self.parts])
+        self.fc_latent_dec_list = nn.ModuleList([nn.Linear(latent_size + part_kps_latent_size, len(v) * filters_dec[0][0])
+                                                 for v in self.parts])
+        self.kps_enc_list = nn.ModuleList([nn.Linear(len(k) * 3, part_kps_latent_size) for k in kps_index_list])
+        self.dconv = nn.ModuleList([_Conv(c, S, o, a) for (c, S, o, a, _) in self.dec_plan])
+
+    def encode(self, x, kps):
+        B, n_lvl, j = x.shape[0], len(self.spiral_sizes) - 1, 0
+        for lvl in range(n_lvl):
+            while j < len(self.enc_plan) and self.enc_plan[j][4] == lvl:
+                m = self.conv[j]
+                x = spiral_conv(x, self.spirals[lvl], m.conv.weight, m.conv.bias, m.act)
+                j += 1
+            x = torch.matmul(self.D[lvl], x)
+        z = torch.stack([fc(x[:, idx, :].reshape(B, -1)) for idx, fc in zip(self.parts, self.fc_latent_enc_list)], dim=1)
+        zk = torch.stack([fc(kps[:, idx, :].reshape(B, -1)) for idx, fc in zip(self.kps_index_list, self.kps_enc_list)], dim=1)
+        return z, zk, x[:, -1:, :]
+
+    def decode(self, z, zk, dummy):
+        B, n_lvl = z.shape[0], len(self.spiral_sizes) - 1
+        x = torch.cat([fc(torch.cat([z[:, k], zk[:, k]], dim=1)) for k, fc in enumerate(self.fc_latent_dec_list)], dim=1)
+        x = x.view(B, self.sizes[-1], -1)
+        order = torch.cat(self.parts)
+        y = x.clone()
+        y[:, order, :] = x[:, :order.shape[0], :]                       # models.py:270-272
+        x = torch.cat([y, dummy], dim=1)
+        j = 0
+        for lvl in range(n_lvl - 1, -1, -1):
+            x = torch.matmul(self.U[lvl], x)
+            while j < len(self.dec_plan) and self.dec_plan[j][4] == lvl:
+                m = self.dconv[j]
+                x = spiral_conv(x, self.spirals[lvl], m.conv.weight, m.conv.bias, m.act)
+                j += 1
+        return x
+
+    def forward(self, x, kps):
+        z, zk, dummy = self.encode(x, kps)
+        return self.decode(z, zk, dummy), z, zk
+
+
+def dist_matrix(x):
+    """utils_distance.py:366-376."""
+    r = torch.sum(x ** 2, dim=2).unsqueeze(2)
+    return F.relu(r - 2 * torch.bmm(x, x.transpose(2, 1)) + r.transpose(2, 1)) ** 0.5
+
+
+def angle_degrees(v, bone):
+    """utils_SH.py:442-478 for one part: v [B,n,3], bone [B,3] -> [B,n,n] degrees between
+    (v_i - v_j) and the bone; NaN (i == j) -> cos 1 -> 0 degrees."""
+    d = v[:, :, None, :] - v[:, None, :, :]
+    dm = torch.sqrt((d * d).sum(-1))
+    km = torch.sqrt((bone * bone).sum(-1))[:, None, None]
+    cos = torch.abs((d * bone[:, None, None, :]).sum(-1) / (dm * km))
+    cos = torch.where(torch.isnan(cos), torch.ones_like(cos), cos).clamp(0, 1)
+    return torch.arccos(cos) * 180 / torch.pi
+
+
+def bone_directions(kps, skl_list):
+    return torch.stack([kps[:, b[0]] - (kps[:, b[1]] if len(b) == 2 else (kps[:, b[1]] + kps[:, b[2]]) / 2) for b in skl_list], 1)
+
+
+def part_pairdist_loss(x_rec, x_gt, kps_gt, parts, skl_list, leaf=(0, 7, 10, 13, 16), scale=None, w_mode="threshold",
+                       thr=0.8, relat=True):
+    """train_funcs.py:243-284 (`interp`) / :353-389 (`exc`, scale=None), '1/K' part weights."""
+    bones = bone_directions(kps_gt, skl_list)
+    total = 0
+    for i, idx in enumerate(parts):
+        idx = torch.as_tensor(idx, dtype=torch.long)
+        De, De_r = dist_matrix(x_gt[:, idx, :]), dist_matrix(x_rec[:, idx, :])
+        if scale is not None:
+            De = De * scale[:, i][:, None, None]
+        if w_mode == "all_one" or i in leaf:
+            w = torch.ones_like(De)
+        else:
+            ang = angle_degrees(x_gt[:, idx, :], bones[:, i])
+            w = ang / 90 if w_mode in ("linear", "threshold") else torch.sin(ang / 180 * torch.pi)
+            if w_mode == "threshold":
+                w = torch.where(w < thr, torch.zeros_like(w), w)
+        w = w * (1 - torch.eye(w.shape[1], dtype=w.dtype))[None]
+        nz = torch.where((w * De) != 0)
+        if relat:
+            li = F.l1_loss(w[nz] * De_r[nz] / De[nz], w[nz])
+        else:
+            li = F.l1_loss(w[nz] * De_r[nz], w[nz] * De[nz])
+        total = total + li / len(parts)
+    return total
+
+
+def part_volume_loss(x_rec, x_gt, faces, face_part_index, parts):
+    """train_funcs.py:56-71 averaged over the batch (:323-329)."""
+    f = torch.as_tensor(faces, dtype=torch.long)
+    fpi = torch.as_tensor(face_part_index)
+    total = 0
+    for b in range(x_rec.shape[0]):
+        for k in parts:
+            tf = f[fpi == k]
+            rv = torch.sum(torch.linalg.cross(x_rec[b, tf[:, 0]], x_rec[b, tf[:, 1]]) * x_rec[b, tf[:, 2]])
+            gv = torch.sum(torch.linalg.cross(x_gt[b, tf[:, 0]], x_gt[b, tf[:, 1]]) * x_gt[b, tf[:, 2]])
+            total = total + (torch.abs(rv / gv) - torch.abs(gv / gv)).abs() / len(parts)
+    return total / x_rec.shape[0]

@@ -1,0 +1,236 @@
+// Part-wise pairwise-distance loss of the semantic training loop (reference
+// train_funcs.py:243-284 / :353-389 with utils_distance.calc_euclidean_dist_matrix (:366-376) and
+// utils_SH.angle_skl (:442-478)).
+//
+// For every body part p, batch entry b and ordered vertex pair (i, j), i != j, of the part:
+//     De   = |g_i - g_j| * scale[b,p]            ground-truth distance (scaled when the part is edited)
+//     De_r = |r_i - r_j|                         reconstructed distance
+//     w    = weight from the angle (degrees) between (g_i - g_j) and the part's bone direction:
+//            all_one | angle/90 | sin(angle) | angle/90 thresholded;  parts flagged "leaf" use w = 1
+//     pairs with w * De == 0 are dropped (reference `nozero_index`)
+//     term = |w * De_r / De - w|   (relative form)     or   |w * De_r - w * De|   (absolute form)
+//     loss = sum_p w_part[p] * mean_{kept pairs of p, all b} term
+// The reference materialises [B, n, n, 3] direction tensors and [B, n, n] distance / weight matrices
+// per part; here a workgroup stages the part's coordinates in LDS once and every thread sweeps one
+// row of pairs in registers.  Partial sums are reduced in a fixed order (no atomics).
+#include "sh_common.h"
+
+namespace {
+
+constexpr int PT = 128;     // rows (i) per workgroup
+
+struct PLParams {
+    const float* xr; const float* xg;        // [B][N1][3]
+    const float* bone;                       // [B][P][3]
+    const float* scale;                      // [B][P] or null
+    const int* part_ptr; const int* part_vert;
+    const int* tile_ptr;                     // [P+1] cumulative row tiles per part
+    const int* flags;                        // [P] bit0: weights are all one (leaf parts)
+    const float* w_part;                     // [P]
+    int B, N1, P, T;                         // T = tile_ptr[P]
+    int w_mode; float thr; int relat;
+};
+
+__device__ __forceinline__ float pair_weight(float vx, float vy, float vz, float d, float kx, float ky, float kz, float kn, int mode,
+                                             float thr, bool all_one) {
+    if (all_one || mode == 0) return 1.f;
+    float c = fabsf((vx * kx + vy * ky + vz * kz) / (d * kn));
+    c = (c != c) ? 1.f : c;                  // NaN -> 1   (utils_SH.py:459)
+    c = fminf(fmaxf(c, 0.f), 1.f);
+    const float ang = acosf(c) * 57.29577951308232f;
+    if (mode == 1) return ang / 90.f;                                   // 'linear'
+    if (mode == 2) return sinf(ang / 180.f * 3.14159265358979f);        // 'sin'
+    const float w = ang / 90.f;                                         // 'threshold'
+    return w < thr ? 0.f : w;
+}
+
+__device__ __forceinline__ int find_part(const int* tile_ptr, int P, int t) {
+    int p = 0;
+    while (p + 1 < P && tile_ptr[p + 1] <= t) ++p;
+    return p;
+}
+
+// forward: partial[(b*T + t)*2 + {0,1}] = (sum of terms, number of kept pairs) of the block's rows
+__global__ __launch_bounds__(PT) void pairdist_fwd_kernel(const PLParams q, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.x / q.T, t = blockIdx.x - b * q.T;
+    const int p = find_part(q.tile_ptr, q.P, t);
+    const int v0 = q.part_ptr[p], n = q.part_ptr[p + 1] - v0;
+    float* G = sm;            // [n][3]
+    float* R = sm + 3 * n;    // [n][3]
+    for (int i = threadIdx.x; i < n; i += PT) {
+        const long o = ((long)b * q.N1 + q.part_vert[v0 + i]) * 3;
+        G[3 * i] = q.xg[o]; G[3 * i + 1] = q.xg[o + 1]; G[3 * i + 2] = q.xg[o + 2];
+        R[3 * i] = q.xr[o]; R[3 * i + 1] = q.xr[o + 1]; R[3 * i + 2] = q.xr[o + 2];
+    }
+    __syncthreads();
+    const float kx = q.bone[((long)b * q.P + p) * 3], ky = q.bone[((long)b * q.P + p) * 3 + 1], kz = q.bone[((long)b * q.P + p) * 3 + 2];
+    const float kn = sqrtf(kx * kx + ky * ky + kz * kz);
+    const float sc = q.scale ? q.scale[(long)b * q.P + p] : 1.f;
+    const bool all_one = q.flags[p] & 1;
+    const int i = (t - q.tile_ptr[p]) * PT + threadIdx.x;
+    float s = 0.f, cnt = 0.f;
+    if (i < n) {
+        const float gx = G[3 * i], gy = G[3 * i + 1], gz = G[3 * i + 2];
+        const float rx = R[3 * i], ry = R[3 * i + 1], rz = R[3 * i + 2];
+        for (int j = 0; j < n; ++j) {
+            if (j == i) continue;
+            const float vx = gx - G[3 * j], vy = gy - G[3 * j + 1], vz = gz - G[3 * j + 2];
+            const float d = sqrtf(vx * vx + vy * vy + vz * vz);
+            const float w = pair_weight(vx, vy, vz, d, kx, ky, kz, kn, q.w_mode, q.thr, all_one);
+            const float De = d * sc;
+            if (w * De == 0.f) continue;
+            const float ux = rx - R[3 * j], uy = ry - R[3 * j + 1], uz = rz - R[3 * j + 2];
+            const float Dr = sqrtf(ux * ux + uy * uy + uz * uz);
+            s += q.relat ? fabsf(w * Dr / De - w) : fabsf(w * Dr - w * De);
+            cnt += 1.f;
+        }
+    }
+    __shared__ float red[2][PT / 64];
+    s = sh_wave_sum(s); cnt = sh_wave_sum(cnt);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f, c = 0.f;
+        for (int w = 0; w < PT / 64; ++w) { a += red[0][w]; c += red[1][w]; }
+        partial[((long)b * q.T + t) * 2] = a;
+        partial[((long)b * q.T + t) * 2 + 1] = c;
+    }
+}
+
+// part_sum[p], part_cnt[p] = fixed-order sums over the part's (b, tile) partials; loss = sum_p w_p * sum/cnt
+__global__ __launch_bounds__(64) void pairdist_final_kernel(const float* __restrict__ partial, const int* __restrict__ tile_ptr,
+                                                            const float* __restrict__ w_part, int B, int P, int T,
+                                                            float* __restrict__ part_sum, float* __restrict__ part_cnt,
+                                                            float* __restrict__ loss) {
+    __shared__ float ls[64];
+    const int p = threadIdx.x;
+    float contrib = 0.f;
+    if (p < P) {
+        double s = 0.0, c = 0.0;
+        for (int b = 0; b < B; ++b)
+            for (int t = tile_ptr[p]; t < tile_ptr[p + 1]; ++t) {
+                s += (double)partial[((long)b * T + t) * 2];
+                c += (double)partial[((long)b * T + t) * 2 + 1];
+            }
+        part_sum[p] = (float)s;
+        part_cnt[p] = (float)c;
+        contrib = c > 0.0 ? (float)(w_part[p] * s / c) : 0.f;
+    }
+    ls[threadIdx.x] = contrib;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = 0.f;
+        for (int k = 0; k < P; ++k) tot += ls[k];
+        loss[0] = tot;
+    }
+}
+
+// backward w.r.t. the reconstruction: both (i,j) and (j,i) are terms of the loss and are equal, so
+// d loss / d r_i = 2 * sum_j coef_ij * (r_i - r_j) / |r_i - r_j|
+__global__ __launch_bounds__(PT) void pairdist_bwd_kernel(const PLParams q, const float* __restrict__ part_cnt,
+                                                          const float* __restrict__ gscale, float* __restrict__ grad) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.x / q.T, t = blockIdx.x - b * q.T;
+    const int p = find_part(q.tile_ptr, q.P, t);
+    const int v0 = q.part_ptr[p], n = q.part_ptr[p + 1] - v0;
+    float* G = sm;
+    float* R = sm + 3 * n;
+    for (int i = threadIdx.x; i < n; i += PT) {
+        const long o = ((long)b * q.N1 + q.part_vert[v0 + i]) * 3;
+        G[3 * i] = q.xg[o]; G[3 * i + 1] = q.xg[o + 1]; G[3 * i + 2] = q.xg[o + 2];
+        R[3 * i] = q.xr[o]; R[3 * i + 1] = q.xr[o + 1]; R[3 * i + 2] = q.xr[o + 2];
+    }
+    __syncthreads();
+    const float kx = q.bone[((long)b * q.P + p) * 3], ky = q.bone[((long)b * q.P + p) * 3 + 1], kz = q.bone[((long)b * q.P + p) * 3 + 2];
+    const float kn = sqrtf(kx * kx + ky * ky + kz * kz);
+    const float sc = q.scale ? q.scale[(long)b * q.P + p] : 1.f;
+    const bool all_one = q.flags[p] & 1;
+    const float cnt = part_cnt[p];
+    const int i = (t - q.tile_ptr[p]) * PT + threadIdx.x;
+    if (i >= n) return;
+    const float norm = cnt > 0.f ? 2.f * gscale[0] * q.w_part[p] / cnt : 0.f;
+    const float gx = G[3 * i], gy = G[3 * i + 1], gz = G[3 * i + 2];
+    const float rx = R[3 * i], ry = R[3 * i + 1], rz = R[3 * i + 2];
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    for (int j = 0; j < n; ++j) {
+        if (j == i) continue;
+        const float vx = gx - G[3 * j], vy = gy - G[3 * j + 1], vz = gz - G[3 * j + 2];
+        const float d = sqrtf(vx * vx + vy * vy + vz * vz);
+        const float w = pair_weight(vx, vy, vz, d, kx, ky, kz, kn, q.w_mode, q.thr, all_one);
+        const float De = d * sc;
+        if (w * De == 0.f) continue;
+        const float ux = rx - R[3 * j], uy = ry - R[3 * j + 1], uz = rz - R[3 * j + 2];
+        const float Dr = sqrtf(ux * ux + uy * uy + uz * uz);
+        if (Dr == 0.f) continue;                                   // |.|' undefined at 0: no contribution
+        const float e = q.relat ? (w * Dr / De - w) : (w * Dr - w * De);
+        const float sg = e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f);
+        const float c = sg * (q.relat ? w / De : w) / Dr;
+        ax += c * ux; ay += c * uy; az += c * uz;
+    }
+    const long o = ((long)b * q.N1 + q.part_vert[v0 + i]) * 3;
+    grad[o] = norm * ax; grad[o + 1] = norm * ay; grad[o + 2] = norm * az;
+}
+
+int fill(PLParams& q, const float* x_rec, const float* x_gt, const float* bone, const float* scale, const int32_t* part_ptr,
+         const int32_t* part_vert, const int32_t* tile_ptr, const int32_t* flags, const float* w_part, int B, int N1, int P,
+         int T, int w_mode, float thr, int relat) {
+    SH_REQUIRE(x_rec && x_gt && bone && part_ptr && part_vert && tile_ptr && flags && w_part, SH_ERR_INVALID_ARG,
+               "sh_part_pairdist_loss: null pointer");
+    SH_REQUIRE(B > 0 && N1 > 0 && P > 0 && P <= 64 && T > 0, SH_ERR_INVALID_ARG, "sh_part_pairdist_loss: bad size (P must be <= 64)");
+    SH_REQUIRE(w_mode >= 0 && w_mode <= 3, SH_ERR_INVALID_ARG, "sh_part_pairdist_loss: unknown weight mode %d", w_mode);
+    q.xr = x_rec; q.xg = x_gt; q.bone = bone; q.scale = scale; q.part_ptr = part_ptr; q.part_vert = part_vert;
+    q.tile_ptr = tile_ptr; q.flags = flags; q.w_part = w_part; q.B = B; q.N1 = N1; q.P = P; q.T = T;
+    q.w_mode = w_mode; q.thr = thr; q.relat = relat;
+    return SH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sh_part_pairdist_tile_rows(void) { return PT; }
+
+int sh_part_pairdist_loss_fwd(const float* x_rec, const float* x_gt, const float* bone, const float* scale, const int32_t* part_ptr,
+                              const int32_t* part_vert, const int32_t* tile_ptr, const int32_t* flags, const float* w_part, int B,
+                              int N1, int P, int T, int max_part, int w_mode, float w_threshold, int relat, float* loss,
+                              float* part_sum, float* part_cnt, void* workspace, size_t workspace_bytes, sh_stream_t stream) {
+    PLParams q{};
+    const int rc = fill(q, x_rec, x_gt, bone, scale, part_ptr, part_vert, tile_ptr, flags, w_part, B, N1, P, T, w_mode, w_threshold, relat);
+    if (rc != SH_OK) return rc;
+    SH_REQUIRE(loss && part_sum && part_cnt && workspace, SH_ERR_INVALID_ARG, "sh_part_pairdist_loss_fwd: null output");
+    SH_REQUIRE(workspace_bytes >= (size_t)B * T * 2 * sizeof(float), SH_ERR_WORKSPACE, "sh_part_pairdist_loss_fwd: workspace too small");
+    SH_REQUIRE(max_part > 0 && (size_t)max_part * 24 <= 160 * 1024, SH_ERR_UNSUPPORTED, "sh_part_pairdist_loss: part of %d vertices exceeds LDS", max_part);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* partial = static_cast<float*>(workspace);
+    {
+        ShProfScope ps(st, "pairdist_fwd_kernel|B=%d T=%d", B, T);
+        hipLaunchKernelGGL(pairdist_fwd_kernel, dim3((unsigned)(B * T)), dim3(PT), (size_t)max_part * 24, st, q, partial);
+    }
+    hipLaunchKernelGGL(pairdist_final_kernel, dim3(1), dim3(64), 0, st, partial, tile_ptr, w_part, B, P, T, part_sum, part_cnt, loss);
+    SH_CHECK_LAUNCH("part_pairdist_loss_fwd");
+    return SH_OK;
+}
+
+int sh_part_pairdist_loss_bwd(const float* x_rec, const float* x_gt, const float* bone, const float* scale, const int32_t* part_ptr,
+                              const int32_t* part_vert, const int32_t* tile_ptr, const int32_t* flags, const float* w_part, int B,
+                              int N1, int P, int T, int max_part, int w_mode, float w_threshold, int relat, const float* part_cnt,
+                              const float* gscale, float* grad, sh_stream_t stream) {
+    PLParams q{};
+    const int rc = fill(q, x_rec, x_gt, bone, scale, part_ptr, part_vert, tile_ptr, flags, w_part, B, N1, P, T, w_mode, w_threshold, relat);
+    if (rc != SH_OK) return rc;
+    SH_REQUIRE(part_cnt && gscale && grad, SH_ERR_INVALID_ARG, "sh_part_pairdist_loss_bwd: null pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(grad, 0, (size_t)B * N1 * 3 * sizeof(float), st) != hipSuccess) {
+        sh_set_error("sh_part_pairdist_loss_bwd: memset failed");
+        return SH_ERR_LAUNCH;
+    }
+    {
+        ShProfScope ps(st, "pairdist_bwd_kernel|B=%d T=%d", B, T);
+        hipLaunchKernelGGL(pairdist_bwd_kernel, dim3((unsigned)(B * T)), dim3(PT), (size_t)max_part * 24, st, q, part_cnt, gscale, grad);
+    }
+    SH_CHECK_LAUNCH("part_pairdist_loss_bwd");
+    return SH_OK;
+}
+
+}  // extern "C"

@@ -271,8 +271,8 @@ int launch_gg(const GGParams& p, int nblocks, hipStream_t st) {
     const int TV = TM >> p.log2TB;
     const size_t smem = (size_t)(2 * TM * KC + 2 * NT * 16 * KC) * sizeof(float) + (size_t)(TV * p.S) * sizeof(int);
     {
-        ShProfScope ps(st, "gather_gemm_kernel<%d, %s, %s>|R=%d B=%d K=%d N=%d grid=%d", NT, VEC4 ? "true" : "false",
-                       BWD_EPI ? "true" : "false", p.R, p.B, p.K, p.Nout, nblocks);
+        ShProfScope ps(st, "gather_gemm_kernel<%d, %s, %s, %s>|R=%d B=%d K=%d N=%d grid=%d", NT, VEC4 ? "true" : "false",
+                       BWD_EPI ? "true" : "false", p.log2TB == 4 ? "true" : "false", p.R, p.B, p.K, p.Nout, nblocks);
         if (p.log2TB == 4)
             hipLaunchKernelGGL((gather_gemm_kernel<NT, VEC4, BWD_EPI, true>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
         else

@@ -178,3 +178,99 @@ class SpiralAutoencoder(nn.Module):
     def forward(self, x):
         z = self.encode(x, self.VAE_flag)
         return self.decode(z), z
+
+
+class SpiralAutoencoder_multiz_partkps(nn.Module):
+    """reference models.py:166-310 - the paper's semantic autoencoder.
+
+    Same SpiralConv encoder / decoder stacks as the plain model (one HIP autograd node each); the
+    latent is per body part: 17 `Linear(n_k*C -> latent)` on the coarsest-level vertices of each
+    part (`fc_latent_enc_list`), 17 `Linear(3*len(kps_idx) -> part_kps_latent)` on the part's
+    joints (`kps_enc_list`), and 17 `Linear(latent + part_kps_latent -> n_k*C)` back
+    (`fc_latent_dec_list`).  Parameter names / shapes match the reference.
+    `newskl_list` replaces the global `cfg.CONSTANTS.newskl_list` (models.py:169,285)."""
+
+    def __init__(self, kps_index_list, vert_part_index_dict, filters_enc, filters_dec, latent_size, part_kps_latent_size,
+                 sizes, spiral_sizes, spirals, D, U, device, VAE_flag=False, activation='elu', newskl_list=None):
+        super().__init__()
+        from . import constants
+        self.newskl_list = constants.NEWSKL_LIST if newskl_list is None else newskl_list
+        self.kps_keep = constants.kps_keep(self.newskl_list)
+        self.kps_index_list, self.vert_part_index_dict = kps_index_list, vert_part_index_dict
+        self.part_kps_latent_size, self.latent_size = part_kps_latent_size, latent_size
+        self.sizes, self.spirals, self.spiral_sizes = sizes, spirals, spiral_sizes
+        self.filters_enc, self.filters_dec = filters_enc, filters_dec
+        self.D, self.U, self.device, self.activation, self.VAE_flag = D, U, device, activation, VAE_flag
+        levels = len(spiral_sizes) - 1
+        enc_layout, dec_layout = conv_layout(filters_enc, filters_dec, spiral_sizes, activation)
+        self.conv = nn.ModuleList([SpiralConv(c, S, o, activation=a, device=device) for (c, S, o, a, _) in enc_layout])
+        feat = enc_layout[-1][2]
+        parts = [np.asarray(v) for v in vert_part_index_dict.values()]
+        self.fc_latent_enc_list = nn.ModuleList([nn.Linear(len(v) * feat, (2 if VAE_flag else 1) * latent_size) for v in parts])
+        self.fc_latent_dec_list = nn.ModuleList([nn.Linear(latent_size + part_kps_latent_size, len(v) * filters_dec[0][0])
+                                                 for v in parts])
+        self.kps_enc_list = nn.ModuleList([nn.Linear(len(k) * 3, part_kps_latent_size) for k in kps_index_list])
+        self.dconv = nn.ModuleList([SpiralConv(c, S, o, activation=a, device=device) for (c, S, o, a, _) in dec_layout])
+
+        tables = [_as_table(spirals[l]) for l in range(levels)]
+        self._enc_stack = build_encoder_stack(enc_layout, tables, [_as_csr(D[l]) for l in range(levels)], sizes)
+        # decode(z, z_part_kps, dummy): the dummy row comes from the caller (the encoder's masked row,
+        # or demo.py:74's tensor) - treat its gradient as live
+        self._dec_stack = build_decoder_stack(dec_layout, tables, [_as_csr(U[l]) for l in range(levels)], sizes)
+        self._part_index = [torch.from_numpy(v.astype(np.int64)) for v in parts]
+        self._re_index = torch.from_numpy(np.concatenate(parts).astype(np.int64))
+        if device is not None:
+            self.to(device)
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        dev = self.conv[0].conv.weight.device
+        if self._enc_stack.device != dev:
+            self._enc_stack.to(dev)
+            self._dec_stack.to(dev)
+            self._part_index = [p.to(dev) for p in self._part_index]
+            self._re_index = self._re_index.to(dev)
+            self.device = dev
+        return out
+
+    def kps_encode(self, kps):
+        B = kps.shape[0]
+        return torch.cat([latent_linear(kps[:, idx, :].reshape(B, -1).contiguous(), m.weight, m.bias)[:, None]
+                          for idx, m in zip(self.kps_index_list, self.kps_enc_list)], dim=1)
+
+    def encode(self, x, kps, VAE_flag=None):
+        bsize = x.size(0)
+        h = run_stack(self._enc_stack, x, "bm", "bm", self.conv)            # [B, N_last+1, C]
+        z = torch.cat([latent_linear(h[:, idx, :].reshape(bsize, -1), m.weight, m.bias)[:, None]
+                       for idx, m in zip(self._part_index, self.fc_latent_enc_list)], dim=1)
+        return z, self.kps_encode(kps), h[:, -1:, :]
+
+    def decode(self, z, z_part_kps, dummy):
+        bsize = z.size(0)
+        x = torch.cat([latent_linear(torch.cat([z[:, k, :], z_part_kps[:, k, :]], dim=1).contiguous(), m.weight, m.bias)
+                       for k, m in enumerate(self.fc_latent_dec_list)], dim=1).view(bsize, self.sizes[-1], -1)
+        # models.py:270-272: rows are produced part by part, scatter them back to vertex order
+        out = x.clone()
+        out[:, self._re_index, :] = x[:, :self._re_index.shape[0], :]
+        h = torch.cat([out, dummy], dim=1)
+        return run_stack(self._dec_stack, h, "bm", "bm", self.dconv)
+
+    def kps2skl(self, kps_tmp):
+        """models.py:284-304: joints -> (unit bone direction, bone length) per entry of newskl_list."""
+        skl_list = self.newskl_list
+        if kps_tmp.shape[1] == len(skl_list) + 4:
+            kps = kps_tmp.clone()
+        else:
+            kps = torch.zeros((kps_tmp.shape[0], len(skl_list) + 4, 3), device=kps_tmp.device)
+            kps[:, self.kps_keep, :] = kps_tmp
+        skl = torch.zeros((kps.shape[0], len(skl_list), 4), device=kps.device)
+        for i, b in enumerate(skl_list):
+            v = kps[:, b[0], :] - (kps[:, b[1], :] if len(b) == 2 else (kps[:, b[1], :] + kps[:, b[2], :]) / 2)
+            n = torch.sqrt(torch.sum(v ** 2, dim=1))
+            skl[:, i, :3] = v / n[:, None]
+            skl[:, i, -1] = n
+        return skl
+
+    def forward(self, x, kps):
+        z, z_part_kps, dummy = self.encode(x, kps, self.VAE_flag)
+        return self.decode(z, z_part_kps, dummy), z, z_part_kps
