@@ -1,0 +1,283 @@
+"""Semantic training loop - reference train_funcs.train_autoencoder_dataloader_nonormal (:73-472).
+
+The reference loop cannot run on torch >= 2 (`dataloader_interp_iter.next()`, :155,:158,:288,:291), so
+it is restated here: same order of operations, same loss terms and weights, same logging tags and
+checkpoint layout; the global yacs `cfg` becomes `SemanticTrainOptions` (defaults =
+configure/traincfg.yaml).  Every loss is either a HIP kernel (L1, edge ratio, part pairwise distance)
+or a handful of small torch ops (joint regression, latent-norm regulariser, part volumes).
+
+One iteration = three encode+decode passes (reference :134, :224-227, :319-321):
+  rec     x -> x_hat                                   L1 (+ edge ratio, + latent-norm vs girth)
+  interp  scale part latents by `a`, decode            joint L1 + part pair-distance vs scaled GT
+  exc     swap bone orientations or lengths in batch   joint L1 + part pair-distance (+ part volume)
+"""
+from __future__ import annotations
+
+import os
+import random
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import constants as C
+from . import losses, part_losses
+from .train_funcs import _as_loss, save_checkpoint
+
+
+@dataclass
+class SemanticTrainOptions:
+    """configure/traincfg.yaml:16-52 + cfgs.py defaults."""
+    edit_mode: str = "equal"          # equal | rand | exc
+    rand_mode: str = "rand"
+    exc_mode: str = "ori_or_m"        # ori_m | ori_or_m | ori
+    editskl_flag: bool = False
+    noleaf_flag: bool = True
+    kpskeep_flag: bool = True
+    sklkeep_flag: bool = True
+    leafkeep_flag: bool = True
+    relat_flag: bool = True
+    w_mode: str = "threshold"
+    w_threshold: float = 0.8
+    w_part_mode: str = "1/K"
+    factor: tuple = (0.4, 0.8)
+    edgereg_epoch: int = 0; edgereg_w: float = 1e-2
+    zpartreg_epoch: int = 0; zpartreg_w: float = 1e-2
+    vol_epoch: int = 0; vol_w: float = 1e-2
+    interp_epoch: int = 0; interp_kps_w: float = 1.0; interp_euc_w: float = 1e-2
+    exc_epoch: int = 0; exc_kps_w: float = 1.0; exc_euc_w: float = 1e-2
+    ck_frequency: int = 100
+    part_list: list = field(default_factory=lambda: list(C.PART_LIST))
+    noleaf_part_list: list = field(default_factory=lambda: list(C.NOLEAF_PART_LIST))
+    measure_part_list: list = field(default_factory=lambda: list(C.MEASURE_PART_LIST))
+    newskl_list: list = field(default_factory=lambda: list(C.NEWSKL_LIST))
+    skl_list: list = field(default_factory=lambda: list(C.SKL_LIST))
+
+
+class SemanticContext:
+    """Per-run constants the reference recomputes at the top of its loop (:79-113)."""
+
+    def __init__(self, opts, shapedata, J_regressor, vert_part_index_dict, partname_list, device):
+        self.opts, self.device = opts, device
+        f_np = np.asarray(shapedata.reference_mesh.f).astype(np.int32)
+        self.f_np = f_np
+        self.faces = torch.from_numpy(f_np.astype(np.int64)).to(device)
+        self.J = torch.from_numpy(np.asarray(J_regressor, dtype=np.float32)).to(device)
+        n_verts = self.J.shape[1]
+        self.partname_list = list(partname_list)
+        self.part_dict = vert_part_index_dict
+        self.fpi = torch.from_numpy(part_losses.face_part_index(f_np, vert_part_index_dict, n_verts)).to(device)
+        n_kps = len(opts.newskl_list) + 4
+        self.kps_keep = [i for i in range(n_kps) if not (opts.kpskeep_flag and i in C.KPS_DROPPED)]
+        self.skl_keep = [0, 1, 2, 3, 4, 6, 7, 8, 13, 14, 15, 16, 17] if opts.sklkeep_flag else list(range(len(opts.newskl_list)))
+        self.newskl_keep = [i for i in range(len(opts.newskl_list)) if i not in (5, 9, 10)]
+        self.leaf_list = [0, 7, 10, 13, 16] if opts.leafkeep_flag else []
+        self.part_index_in_allpart = [opts.part_list.index(p) for p in opts.noleaf_part_list]
+        self.part_index_in_measure = [opts.measure_part_list.index(p) for p in opts.noleaf_part_list]
+        K = len(self.partname_list)
+        if opts.w_part_mode == "n/N":
+            wp = [len(vert_part_index_dict[p]) / n_verts for p in self.partname_list]
+        else:                                   # '1/K' (and '1/rand_num' in the exc branch, :361-362)
+            wp = [1.0 / K] * K
+        self.tables = part_losses.PartTables({p: vert_part_index_dict[p] for p in self.partname_list}, device,
+                                             leaf_parts=self.leaf_list, w_part=wp)
+        self.face_tables = None
+
+    def joints(self, x):
+        return torch.matmul(self.J, x[:, :-1, :]).float()          # reference :131,:161,:296
+
+
+def _edit_scales(ctx, opts, B, epoch, measure=None, draw=None):
+    """reference :163-221 -> (part indices being edited, a [B, len(parts)])."""
+    dev = ctx.device
+    lo, hi = opts.factor
+    if opts.edit_mode == "rand":
+        if opts.rand_mode == "warm_up" and epoch < 100:
+            part_num = 1 if epoch < 20 else 2 if epoch < 50 else 4 if epoch < 75 else 8
+        else:
+            part_num = random.randint(1, len(ctx.partname_list))
+        part_index = random.sample(list(range(len(opts.part_list))), part_num)
+        if opts.noleaf_flag:
+            for leaf in (0, 7, 10, 13, 16):                         # the reference removes at most one (elif chain)
+                if leaf in part_index:
+                    part_index.remove(leaf)
+                    break
+        a = torch.rand(len(part_index), device=dev) * lo + hi
+        return part_index, a[None].repeat(B, 1)
+    if opts.edit_mode == "equal":
+        f = (torch.rand(1, device=dev) * lo + hi) if draw is None else torch.as_tensor([draw], device=dev, dtype=torch.float32)
+        return ctx.part_index_in_allpart, torch.ones((B, len(opts.noleaf_part_list)), device=dev) * f
+    if opts.edit_mode == "exc":
+        return ctx.part_index_in_allpart, torch.flip(measure, dims=[0]) / measure
+    raise NotImplementedError(opts.edit_mode)
+
+
+def _full_scale(ctx, part_index, a, B):
+    s = torch.ones((B, len(ctx.partname_list)), device=ctx.device)
+    for k, p in enumerate(part_index):
+        s[:, p] = a[:, k]
+    return s
+
+
+def semantic_losses(model, ctx, tx, tx_interp, tx_exc, epoch, measure=None, interp_measure=None, loss_fn=None,
+                    draw_factor=None, exc_choice=None):
+    """All loss terms of one iteration (reference :129-389).  Returns (total, dict of terms)."""
+    o = ctx.opts
+    loss_fn = _as_loss(loss_fn)
+    terms = {}
+    kps_GT = ctx.joints(tx)
+    tx_hat, tx_zpart, _ = model(tx, kps_GT[:, ctx.kps_keep])
+    terms["rec_loss"] = loss_fn(tx, tx_hat)
+    loss = terms["rec_loss"]
+    if epoch > o.edgereg_epoch and o.edgereg_w > 0:
+        if ctx.face_tables is None:
+            ctx.face_tables = losses.FaceTables(ctx.f_np, tx.shape[1], ctx.device)
+        terms["edgereg_loss"] = losses.edge_ratio_loss(tx_hat, tx, ctx.face_tables)
+        loss = loss + o.edgereg_w * terms["edgereg_loss"]
+    if epoch > o.zpartreg_epoch and o.zpartreg_w > 0 and measure is not None:
+        terms["zpartreg_loss"] = part_losses.zpart_regulariser(tx_zpart, measure, ctx.part_index_in_allpart,
+                                                               ctx.part_index_in_measure, o.relat_flag)
+        loss = loss + o.zpartreg_w * terms["zpartreg_loss"]
+
+    if epoch > o.interp_epoch and tx_interp is not None:
+        B = tx_interp.shape[0]
+        kps_i = ctx.joints(tx_interp)
+        if o.editskl_flag:
+            n = len(ctx.skl_keep) if o.edit_mode == "rand" else 1
+            f = torch.rand(n, device=ctx.device) * o.factor[0] + o.factor[1]
+            skl = part_losses.kps2skl(kps_i, "ori_m", o.newskl_list)
+            skl[:, ctx.skl_keep, 3] = skl[:, ctx.skl_keep, 3] * (f[None] if n > 1 else f)
+            new_kps = part_losses.skl2kps(skl, "ori_m", o.newskl_list)
+        else:
+            new_kps = kps_i[:, ctx.kps_keep]
+        part_index, a = _edit_scales(ctx, o, B, epoch, interp_measure, draw_factor)
+        latent, latent_kps, dummy = model.encode(tx_interp, new_kps)
+        scale = _full_scale(ctx, part_index, a, B)
+        rec_interp = model.decode(latent * scale[:, :, None], latent_kps, dummy)
+        if o.interp_kps_w > 0:
+            terms["interp_kps_loss"] = (ctx.joints(rec_interp)[:, ctx.kps_keep] - new_kps).abs().mean()
+            loss = loss + o.interp_kps_w * terms["interp_kps_loss"]
+        if o.interp_euc_w > 0:
+            terms["interp_euc_loss"] = part_losses.part_pairdist_loss(rec_interp, tx_interp, kps_i, ctx.tables, scale=scale,
+                                                                      w_mode=o.w_mode, w_threshold=o.w_threshold,
+                                                                      relat=o.relat_flag, skl_list=o.skl_list)
+            loss = loss + o.interp_euc_w * terms["interp_euc_loss"]
+
+    if epoch > o.exc_epoch and tx_exc is not None:
+        kps_e = ctx.joints(tx_exc)
+        mode = o.exc_mode
+        if mode == "ori_or_m":
+            pick = (np.random.rand(1) > 0.5) if exc_choice is None else (exc_choice == "ori")
+            mode = "ori" if pick else "m"
+        if mode == "ori_m":
+            new_kps = torch.flip(kps_e, dims=[0])[:, ctx.kps_keep]
+            exc_kind = "ori_m"
+        else:
+            skl = part_losses.kps2skl(kps_e, "ori_m", o.newskl_list)
+            if mode == "ori":
+                skl[:, ctx.newskl_keep, :3] = torch.flip(skl[:, ctx.newskl_keep, :3], dims=[0])
+            else:
+                skl[:, ctx.skl_keep, 3] = torch.flip(skl[:, ctx.skl_keep, 3], dims=[0])
+            new_kps = part_losses.skl2kps(skl, "ori_m", o.newskl_list)
+            exc_kind = mode
+        latent, latent_kps, dummy = model.encode(tx_exc, new_kps)
+        rec_exc = model.decode(latent, latent_kps, dummy)
+        if epoch > o.vol_epoch and o.vol_w > 0 and exc_kind == "ori":
+            terms["vol_loss"] = part_losses.part_volume_loss(rec_exc[:, :-1], tx_exc[:, :-1], ctx.faces, ctx.fpi,
+                                                             ctx.part_index_in_allpart)
+            loss = loss + o.vol_w * terms["vol_loss"]
+        if o.exc_kps_w > 0:
+            terms["exc_kps_loss"] = (ctx.joints(rec_exc)[:, ctx.kps_keep] - new_kps).abs().mean()
+            loss = loss + o.exc_kps_w * terms["exc_kps_loss"]
+        if o.exc_euc_w > 0:
+            terms["exc_euc_loss"] = part_losses.part_pairdist_loss(rec_exc, tx_exc, kps_e, ctx.tables, scale=None, w_mode=o.w_mode,
+                                                                   w_threshold=o.w_threshold, relat=o.relat_flag,
+                                                                   skl_list=o.skl_list)
+            loss = loss + o.exc_euc_w * terms["exc_euc_loss"]
+    return loss, terms
+
+
+class _Cycler:
+    """`dataloader_interp_iter.next()` with the reference's restart behaviour (:154-158): when the
+    loader is exhausted it is restarted and the FIRST batch of the new pass is skipped."""
+
+    def __init__(self, loader):
+        self.loader, self.it = loader, iter(loader)
+
+    def next(self):
+        try:
+            return next(self.it)
+        except StopIteration:
+            self.it = iter(self.loader)
+            next(self.it)
+            return next(self.it)
+
+
+TAGS = ["rec_loss", "edgereg_loss", "zpartreg_loss", "vol_loss", "interp_kps_loss", "interp_euc_loss", "exc_kps_loss",
+        "exc_euc_loss"]
+
+
+def train_autoencoder_dataloader_nonormal(dataloader_train, dataloader_val, device, model, optim, loss_fn,
+                                          start_epoch, n_epochs, eval_freq, dataloader_interp, scheduler,
+                                          writer, shapedata, metadata_dir, samples_dir, checkpoint_path,
+                                          J_regressor, vert_part_index_dict, partname_list, save_recons=False,
+                                          *, options: SemanticTrainOptions = None, reducer=None, verbose=True):
+    opts = options or SemanticTrainOptions()
+    ctx = SemanticContext(opts, shapedata, J_regressor, vert_part_index_dict, partname_list, device)
+    loss_fn = _as_loss(loss_fn)
+    total_steps = (start_epoch - 1) * len(dataloader_train)
+    eval_freq = len(dataloader_train)
+    cyc = None
+    history = []
+    for epoch in range(start_epoch, n_epochs + 1):
+        model.train()
+        if cyc is None:
+            cyc = _Cycler(dataloader_interp)
+        tloss = torch.zeros((), device=device)
+        for b, sample in enumerate(dataloader_train):
+            optim.zero_grad()
+            tx = sample["verts"].to(device)
+            measure = sample["measure"].to(device) if "measure" in sample else None
+            inp_i = cyc.next() if epoch > opts.interp_epoch else None
+            inp_e = cyc.next() if epoch > opts.exc_epoch else None
+            loss, terms = semantic_losses(model, ctx, tx,
+                                          None if inp_i is None else inp_i["verts"].to(device),
+                                          None if inp_e is None else inp_e["verts"].to(device), epoch, measure,
+                                          None if inp_i is None or "measure" not in inp_i else inp_i["measure"].to(device), loss_fn)
+            if reducer is not None:
+                reducer.prepare()
+            loss.backward()
+            if reducer is not None:
+                reducer.finish()
+            optim.step()
+            tloss += tx.shape[0] * loss.detach()
+            if writer and total_steps % eval_freq == 0:
+                writer.add_scalar("loss/loss/data_loss", loss.item(), total_steps)
+                for t in TAGS:
+                    writer.add_scalar("loss/loss/" + t, float(terms[t]) if t in terms else 0.0, total_steps)
+            total_steps += 1
+
+        model.eval()
+        vloss = torch.zeros((), device=device)
+        with torch.no_grad():
+            for sample in dataloader_val:
+                tx = sample["verts"].to(device)
+                kps = ctx.joints(tx)
+                tx_hat_val = model(tx, kps[:, ctx.kps_keep])[0]
+                vloss += tx.shape[0] * loss_fn(tx[:, :-1, :], tx_hat_val[:, :-1, :])
+        if scheduler:
+            scheduler.step()
+        epoch_tloss = float(tloss) / float(len(dataloader_train.dataset))
+        epoch_vloss = float(vloss) / float(len(dataloader_val.dataset)) if len(dataloader_val.dataset) > 0 else None
+        if writer:
+            writer.add_scalar("avg_epoch_train_loss", epoch_tloss, epoch)
+            if epoch_vloss is not None:
+                writer.add_scalar("avg_epoch_valid_loss", epoch_vloss, epoch)
+        if verbose:
+            print("epoch {0} | tr {1} | val {2}".format(epoch, epoch_tloss, epoch_vloss))
+        history.append((epoch, epoch_tloss, epoch_vloss))
+        if epoch % opts.ck_frequency == 0 and metadata_dir is not None:
+            save_checkpoint(os.path.join(metadata_dir, checkpoint_path + "%s.pth.tar" % epoch), epoch, model, optim, scheduler)
+    if verbose:
+        print("~FIN~")
+    return history

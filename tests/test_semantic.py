@@ -155,3 +155,97 @@ def test_hip_part_pairdist_loss_matches_reference(sem, relat):
                                         list(fine.values()), C.SKL_LIST, LEAF, None, mode, 0.8, relat)
         assert lm.item() == pytest.approx(float(lo), rel=1e-4), mode
     assert torch.equal(pl.part_pairdist_loss(rec.detach(), x, kf, tb, relat=relat), pl.part_pairdist_loss(rec.detach(), x, kf, tb, relat=relat))
+
+
+# ------------------------------------------------------------------------------------------ semantic loop
+def _oracle_terms(g, h, coarse, fine, draw, exc_kind):
+    """One iteration of the semantic loop (train_funcs.py:129-389) composed from the ORACLE pieces
+    (each pinned to the reference above): the expected value of every loss term."""
+    from semantichuman_amd import part_losses as pl           # only kps2skl/skl2kps (pure torch, pinned above)
+    S, D, U = h.dense_constants()
+    m = ref_cpu.SemanticAEOracle(C.KPS_INDEX_LIST, coarse, C.FILTER_SIZES_ENC, C.FILTER_SIZES_DEC, 8, 8, h.sizes, h.spiral_sizes, S, D, U)
+    m.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w0/")})
+    J = torch.from_numpy(g["J_regressor"])
+    joints = lambda x: torch.matmul(J, x[:, :-1, :]).float()
+    keep = C.kps_keep()
+    parts = list(fine.values())
+    tx = torch.from_numpy(g["x"])
+    tx_i, tx_e = torch.flip(tx, dims=[0]).contiguous(), (tx * 1.02).contiguous()
+    tx_e[:, -1] = 0
+    out = {}
+    kps = joints(tx)
+    x_hat, zpart, _ = m(tx, kps[:, keep])
+    out["rec_loss"] = torch.nn.functional.l1_loss(tx, x_hat)
+    out["edgereg_loss"] = ref_cpu.edge_ratio_loss(x_hat, tx, h.faces)
+    measure = torch.from_numpy(np.abs(g["edit_scale"][:, :16]).astype(np.float32)) + 0.5
+    pia = [C.PART_LIST.index(p) for p in C.NOLEAF_PART_LIST]
+    pim = [C.MEASURE_PART_LIST.index(p) for p in C.NOLEAF_PART_LIST]
+    zm = torch.sqrt((zpart ** 2).sum(2))
+    out["zpartreg_loss"] = (zm[:, pia] / measure[:, pim] - 1).abs().mean()
+    kps_i = joints(tx_i)
+    scale = torch.ones(tx.shape[0], 17)
+    scale[:, pia] = draw
+    lat, lk, dummy = m.encode(tx_i, kps_i[:, keep])
+    rec_i = m.decode(lat * scale[:, :, None], lk, dummy)
+    out["interp_kps_loss"] = (joints(rec_i)[:, keep] - kps_i[:, keep]).abs().mean()
+    out["interp_euc_loss"] = ref_cpu.part_pairdist_loss(rec_i, tx_i, kps_i, parts, C.SKL_LIST, LEAF, scale, "threshold", 0.8, True)
+    kps_e = joints(tx_e)
+    skl = pl.kps2skl(kps_e, "ori_m")
+    newskl_keep = [i for i in range(len(C.NEWSKL_LIST)) if i not in (5, 9, 10)]
+    skl[:, newskl_keep, :3] = torch.flip(skl[:, newskl_keep, :3], dims=[0])
+    new_kps = pl.skl2kps(skl, "ori_m")
+    lat, lk, dummy = m.encode(tx_e, new_kps)
+    rec_e = m.decode(lat, lk, dummy)
+    out["vol_loss"] = ref_cpu.part_volume_loss(rec_e[:, :-1], tx_e[:, :-1], h.faces, g["face_part_index"], pia)
+    out["exc_kps_loss"] = (joints(rec_e)[:, keep] - new_kps).abs().mean()
+    out["exc_euc_loss"] = ref_cpu.part_pairdist_loss(rec_e, tx_e, kps_e, parts, C.SKL_LIST, LEAF, None, "threshold", 0.8, True)
+    w = C.LOSS_WEIGHTS
+    total = (out["rec_loss"] + w["edgereg_w"] * out["edgereg_loss"] + w["zpartreg_w"] * out["zpartreg_loss"]
+             + w["interp_kps_w"] * out["interp_kps_loss"] + w["interp_euc_w"] * out["interp_euc_loss"] + w["vol_w"] * out["vol_loss"]
+             + w["exc_kps_w"] * out["exc_kps_loss"] + w["exc_euc_w"] * out["exc_euc_loss"])
+    return {k: float(v) for k, v in out.items()}, float(total), (tx, tx_i, tx_e, measure)
+
+
+@pytest.mark.gpu
+def test_hip_semantic_iteration_and_loop(sem, tmp_path):
+    import semantichuman_amd as sh
+    from semantichuman_amd import train_semantic as ts
+    from types import SimpleNamespace
+    g, h, coarse, fine = sem
+    dev = torch.device("cuda:0")
+    want, want_total, (tx, tx_i, tx_e, measure) = _oracle_terms(g, h, coarse, fine, draw=1.1, exc_kind="ori")
+    m = sh.SpiralAutoencoder_multiz_partkps(C.KPS_INDEX_LIST, coarse, C.FILTER_SIZES_ENC, C.FILTER_SIZES_DEC, 8, 8, h.sizes,
+                                            h.spiral_sizes, h.spirals, h.D, h.U, dev)
+    m.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w0/")})
+    shapedata = SimpleNamespace(reference_mesh=SimpleNamespace(f=h.faces))
+    ctx = ts.SemanticContext(ts.SemanticTrainOptions(), shapedata, g["J_regressor"], fine, C.PART_LIST, dev)
+    total, terms = ts.semantic_losses(m, ctx, tx.to(dev), tx_i.to(dev), tx_e.to(dev), epoch=1, measure=measure.to(dev),
+                                      draw_factor=1.1, exc_choice="ori")
+    assert set(terms) == set(want)
+    for k in want:
+        assert float(terms[k]) == pytest.approx(want[k], rel=2e-4), k
+    assert float(total) == pytest.approx(want_total, rel=2e-4)
+    total.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+    # the loop itself: tags, checkpoint, loss goes down over a few Adam steps
+    class DS(torch.utils.data.Dataset):
+        dummy_node = True
+        def __init__(self, x): self.x = x
+        def __len__(self): return self.x.shape[0]
+        def __getitem__(self, i): return {"verts": self.x[i], "idx": i, "measure": measure[i % measure.shape[0]]}
+    data = torch.cat([tx, tx_i * 0.99, tx_e], 0)
+    ld = torch.utils.data.DataLoader(DS(data), batch_size=3, shuffle=False)
+    tags = []
+    writer = SimpleNamespace(add_scalar=lambda t, v, s: tags.append((t, v, s)))
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-5)
+    sched = torch.optim.lr_scheduler.StepLR(opt, 1, gamma=0.99)
+    torch.manual_seed(0); np.random.seed(0)
+    hist = ts.train_autoencoder_dataloader_nonormal(ld, ld, dev, m, opt, torch.nn.functional.l1_loss, 1, 3, 10, ld, sched, writer,
+                                                    shapedata, str(tmp_path), str(tmp_path), "checkpoint", g["J_regressor"], fine,
+                                                    C.PART_LIST, False, options=ts.SemanticTrainOptions(ck_frequency=3), verbose=False)
+    assert len(hist) == 3 and hist[-1][1] < hist[0][1] and all(np.isfinite(x[1]) for x in hist)
+    assert {"loss/loss/data_loss", "loss/loss/interp_euc_loss", "loss/loss/exc_kps_loss", "avg_epoch_train_loss"} <= {t for t, _, _ in tags}
+    ck = torch.load(tmp_path / "checkpoint3.pth.tar", map_location="cpu", weights_only=False)
+    assert sorted(ck) == ["autoencoder_state_dict", "epoch", "optimizer_state_dict", "scheduler_state_dict"]
+    assert list(ck["autoencoder_state_dict"].keys()) == [str(k) for k in g["state_dict_keys"]]
