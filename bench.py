@@ -63,7 +63,9 @@ def conv_launch_table(model, B):
                 # backward-data = the same kernel over the transposed table; algorithmic FLOPs are
                 # those of the R*S real (row, position) pairs, not of the padded n_in*S table
                 add("gather_gemm_kernel<%d, %s, true, %s>" % (nt(st.cin), vecb, tb16), fl, byt)
-            ctw = 2 if K > 64 else 1
+            cp = nt(st.cout) * 16                      # same choice as plan_wgrad() in csrc/spiral_conv.hip
+            cost1, cost2 = -(-K // 64) * (64 + cp), -(-K // 128) * (128 + cp)
+            ctw = 1 if (nt(st.cout) == 8 or cost1 <= cost2) else 2
             add("wgrad_kernel<%d, %d, %s>" % (nt(st.cout), ctw, vec), fl, byt)
             first = False
     return out

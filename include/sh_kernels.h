@@ -121,6 +121,18 @@ SH_API int sh_spiral_conv_bwd_wgt(const float* dpre, int64_t dp_sv, int64_t dp_s
                            int B, int R, int S, int Cin, int Cout,
                            sh_stream_t stream);
 
+/* Batched forms for a whole stack of layers (one launch instead of one per layer; host arrays of
+ * n_layers entries, passed by value into the kernel arguments -> graph-capturable):
+ *  - sh_spiral_conv_bwd_wgt called with dW == NULL only writes its partial slabs into `workspace`;
+ *    sh_spiral_conv_bwd_wgt_reduce_multi then reduces the slabs of up to 16 layers (same B,R,S,Cin,Cout
+ *    as the producing calls; dbias[i] may be NULL);
+ *  - sh_weight_transpose_multi transposes up to 32 weights. */
+SH_API int sh_spiral_conv_bwd_wgt_reduce_multi(int n_layers, const void* const* workspaces, float* const* dW,
+                                        float* const* dbias, const int* B, const int* R, const int* S,
+                                        const int* Cin, const int* Cout, sh_stream_t stream);
+SH_API int sh_weight_transpose_multi(int n_layers, const float* const* weight, float* const* weight_t,
+                              const int* S, const int* Cin, const int* Cout, sh_stream_t stream);
+
 /* dpre = dy * act'(y) with row zero_row forced to 0 (aten::elu_backward + mask, models.py:46-51). */
 SH_API int sh_act_backward(const float* dy, int64_t dy_sv, int64_t dy_sb,
                     const float* y, int64_t y_sv, int64_t y_sb,

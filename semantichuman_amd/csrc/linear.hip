@@ -135,12 +135,15 @@ __global__ __launch_bounds__(LTHREADS) void skinny_gemm_kernel(const SGParams p)
         for (int ks = 0; ks < LK / 16; ++ks) {
             const int pq = ((lq + 4 * ks) ^ (lane & 7)) << 2;
             const f32x4 g = *reinterpret_cast<const f32x4*>(Ab + pq);
+            f32x4 wq[4];
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const f32x4 wq = *reinterpret_cast<const f32x4*>(Bb + n * 16 * LK + pq);
+            for (int n = 0; n < 4; ++n) wq[n] = *reinterpret_cast<const f32x4*>(Bb + n * 16 * LK + pq);
+            // t outer, n inner: consecutive MFMAs go to different accumulators (the 16x16x4 form has a
+            // 40-cycle dependent latency against a 32-cycle issue interval)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[t], g[t], acc[n], 0, 0, 0);
-            }
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[n][t], g[t], acc[n], 0, 0, 0);
         }
         sg_store(As[buf ^ 1], p.a_mode, tid, ra, ma);
         sg_store(Bs[buf ^ 1], p.b_mode, tid, rb, mb);

@@ -379,6 +379,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(const WGParams p) {
     // K read (s=0, c=0): they only feed weight columns that are never stored.
     const int gq = tid % GQ, grow0 = tid / GQ;
     const int k = cg * KCW + 4 * gq;
+    const bool k_in = k < p.K;
     int s4[4], c4[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -427,8 +428,9 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(const WGParams p) {
             const bool ok = vbase + vl < p.R && ((g_bok >> i) & 1u);
             mg |= (ok ? 1u : 0u) << i;
             if (VEC4) {
-                const int u = Tl[vl * S + s4[0]];
-                rg[i] = *reinterpret_cast<const f32x4*>(p.x + (long)u * p.x_sv + g_boff[i] + c4[0]);
+                // columns past K (padding of the last column group) all read ONE shared line
+                const long off = k_in ? (long)Tl[vl * S + s4[0]] * p.x_sv + g_boff[i] + c4[0] : 0;
+                rg[i] = *reinterpret_cast<const f32x4*>(p.x + off);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -577,6 +579,60 @@ __global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restri
     }
 }
 
+// Several layers' slab reductions / weight transposes in ONE launch (descriptors passed by value as
+// kernel arguments, so the launch is graph-capturable): the step has ~9 of each and each is far too
+// small to fill the chip, so what they cost separately is launch latency.
+constexpr int MR_MAX = 32;
+struct MultiReduce {
+    const float* slab[MR_MAX]; long stride[MR_MAX]; long n[MR_MAX]; float* out[MR_MAX];
+    int nslab[MR_MAX]; int block0[MR_MAX]; int nd;
+};
+__global__ __launch_bounds__(1024) void slab_reduce_multi_kernel(const MultiReduce m) {
+    __shared__ float red[16][64];
+    int d = 0;
+    while (d + 1 < m.nd && m.block0[d + 1] <= (int)blockIdx.x) ++d;
+    const float* __restrict__ slab = m.slab[d];
+    const long stride = m.stride[d], n = m.n[d];
+    const int nslab = m.nslab[d];
+    const int ox = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const long i = (long)(blockIdx.x - m.block0[d]) * 64 + ox;
+    float s = 0.f;
+    if (i < n) {
+        int r = ry;
+        for (; r + 48 < nslab; r += 64) {
+            const float a = slab[(long)r * stride + i], b = slab[(long)(r + 16) * stride + i];
+            const float c = slab[(long)(r + 32) * stride + i], e = slab[(long)(r + 48) * stride + i];
+            s += (a + b) + (c + e);
+        }
+        for (; r < nslab; r += 16) s += slab[(long)r * stride + i];
+    }
+    red[ry][ox] = s;
+    __syncthreads();
+    if (ry == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][ox];
+        m.out[d][i] = t;
+    }
+}
+
+struct MultiTranspose {
+    const float* w[MR_MAX]; float* wt[MR_MAX]; int S[MR_MAX]; int Cin[MR_MAX]; int Cout[MR_MAX]; int block0[MR_MAX]; int nd;
+};
+__global__ __launch_bounds__(256) void weight_transpose_multi_kernel(const MultiTranspose m) {
+    int d = 0;
+    while (d + 1 < m.nd && m.block0[d + 1] <= (int)blockIdx.x) ++d;
+    const int S = m.S[d], Cin = m.Cin[d], Cout = m.Cout[d];
+    const long n = (long)S * Cin * Cout;
+    const long i = (long)(blockIdx.x - m.block0[d]) * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int co = (int)(i % Cout);
+    const long t = i / Cout;
+    const int s = (int)(t % S);
+    const int ci = (int)(t / S);
+    m.wt[d][i] = m.w[d][(long)co * S * Cin + (long)s * Cin + ci];      // wt[ci][s*Cout + co] = w[co][s*Cin + ci]
+}
+
 struct WGPlan {
     int log2TB, n_btiles, n_vtiles, nvc, steps_per_block, nrc, ncg, ctw, cot;
 };
@@ -592,10 +648,18 @@ WGPlan plan_wgrad(int B, int R, int S, int Cin, int Cout) {
     const int tv = TMW >> w.log2TB;
     w.n_btiles = sh_cdiv(B, tb);
     w.n_vtiles = sh_cdiv(R, tv);
-    w.ctw = K > 64 ? 2 : 1;
-    w.ncg = sh_cdiv(K, 64 * w.ctw);
     const int cot = sh_cdiv(Cout, 16);
     w.cot = cot <= 1 ? 1 : cot <= 2 ? 2 : cot <= 4 ? 4 : 8;
+    // column-group width (64 or 128 weight columns): minimise the staged work per row, i.e. column
+    // groups x (gathered columns incl. the padding of the last group + the dpre channels re-read by
+    // every group); 128 channels x 128 columns would need 360 registers (1 wave/SIMD) -> 64 there.
+    {
+        const int cp = w.cot * 16;
+        const long cost1 = (long)sh_cdiv(K, 64) * (64 + cp), cost2 = (long)sh_cdiv(K, 128) * (128 + cp);
+        static const int force = sh_env_int("SH_WG_CTW", 0, 0, 2);
+        w.ctw = force ? force : ((w.cot == 8 || cost1 <= cost2) ? 1 : 2);
+    }
+    w.ncg = sh_cdiv(K, 64 * w.ctw);
     // vertex chunks per batch slice: enough blocks to fill the chip, few enough that the partial
     // slabs stay small, and a table slice that fits its LDS area
     int nvc = blocks_target / (w.ncg * w.n_btiles);
@@ -707,7 +771,7 @@ size_t sh_spiral_conv_bwd_wgt_workspace(int B, int R, int S, int Cin, int Cout) 
 int sh_spiral_conv_bwd_wgt(const float* dpre, int64_t dp_sv, int64_t dp_sb, const float* x, int64_t x_sv, int64_t x_sb,
                            const int32_t* table, float* dW, float* dbias, void* workspace, size_t workspace_bytes, int B,
                            int R, int S, int Cin, int Cout, sh_stream_t stream) {
-    SH_REQUIRE(dpre && x && table && dW && workspace, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_wgt: null pointer");
+    SH_REQUIRE(dpre && x && table && workspace, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_wgt: null pointer");
     SH_REQUIRE(B > 0 && R > 0 && S > 0 && Cin > 0 && Cout > 0, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_wgt: non-positive size");
     SH_REQUIRE(Cout <= 128, SH_ERR_UNSUPPORTED, "sh_spiral_conv_bwd_wgt: more than 128 output channels (%d) not built", Cout);
     SH_REQUIRE(workspace_bytes >= sh_spiral_conv_bwd_wgt_workspace(B, R, S, Cin, Cout), SH_ERR_WORKSPACE,
@@ -733,6 +797,7 @@ int sh_spiral_conv_bwd_wgt(const float* dpre, int64_t dp_sv, int64_t dp_sb, cons
     }
 #undef SH_WG_CASE
     if (rc != SH_OK) return rc;
+    if (!dW) return SH_OK;            // deferred: the caller reduces several layers at once (.._reduce_multi)
     const long n = p.slab_stride;
     ShProfScope ps(st, "slab_reduce_kernel");
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, st, p.slab, p.slab_stride, w.nrc, n, dW);
@@ -740,6 +805,52 @@ int sh_spiral_conv_bwd_wgt(const float* dpre, int64_t dp_sv, int64_t dp_sb, cons
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((Cout + 63) / 64)), dim3(1024), 0, st, p.slab + p.bias_off,
                            (long)Cout, w.nrc, (long)Cout, dbias);
     SH_CHECK_LAUNCH("slab_reduce");
+    return SH_OK;
+}
+
+int sh_spiral_conv_bwd_wgt_reduce_multi(int n_layers, const void* const* workspaces, float* const* dW, float* const* dbias,
+                                        const int* B, const int* R, const int* S, const int* Cin, const int* Cout,
+                                        sh_stream_t stream) {
+    SH_REQUIRE(n_layers > 0 && 2 * n_layers <= MR_MAX && workspaces && dW && dbias && B && R && S && Cin && Cout,
+               SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_wgt_reduce_multi: bad argument (at most %d layers)", MR_MAX / 2);
+    MultiReduce m{};
+    int nd = 0, blocks = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        SH_REQUIRE(workspaces[i] && dW[i], SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_wgt_reduce_multi: null pointer in layer %d", i);
+        const WGPlan w = plan_wgrad(B[i], R[i], S[i], Cin[i], Cout[i]);
+        const long stride = (long)Cout[i] * S[i] * Cin[i];
+        const float* slab = static_cast<const float*>(workspaces[i]);
+        m.slab[nd] = slab; m.stride[nd] = stride; m.nslab[nd] = w.nrc; m.n[nd] = stride; m.out[nd] = dW[i]; m.block0[nd] = blocks;
+        blocks += (int)((stride + 63) / 64); ++nd;
+        if (dbias[i]) {
+            m.slab[nd] = slab + (long)w.nrc * stride; m.stride[nd] = Cout[i]; m.nslab[nd] = w.nrc; m.n[nd] = Cout[i];
+            m.out[nd] = dbias[i]; m.block0[nd] = blocks;
+            blocks += (Cout[i] + 63) / 64; ++nd;
+        }
+    }
+    m.nd = nd;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ShProfScope ps(st, "slab_reduce_multi_kernel");
+    hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, m);
+    SH_CHECK_LAUNCH("slab_reduce_multi");
+    return SH_OK;
+}
+
+int sh_weight_transpose_multi(int n_layers, const float* const* weight, float* const* weight_t, const int* S, const int* Cin,
+                              const int* Cout, sh_stream_t stream) {
+    SH_REQUIRE(n_layers > 0 && n_layers <= MR_MAX && weight && weight_t && S && Cin && Cout, SH_ERR_INVALID_ARG,
+               "sh_weight_transpose_multi: bad argument (at most %d layers)", MR_MAX);
+    MultiTranspose m{};
+    int blocks = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        SH_REQUIRE(weight[i] && weight_t[i] && S[i] > 0 && Cin[i] > 0 && Cout[i] > 0, SH_ERR_INVALID_ARG,
+                   "sh_weight_transpose_multi: bad layer %d", i);
+        m.w[i] = weight[i]; m.wt[i] = weight_t[i]; m.S[i] = S[i]; m.Cin[i] = Cin[i]; m.Cout[i] = Cout[i]; m.block0[i] = blocks;
+        blocks += (int)(((long)S[i] * Cin[i] * Cout[i] + 255) / 256);
+    }
+    m.nd = n_layers;
+    hipLaunchKernelGGL(weight_transpose_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), m);
+    SH_CHECK_LAUNCH("weight_transpose_multi");
     return SH_OK;
 }
 

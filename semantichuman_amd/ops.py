@@ -95,6 +95,55 @@ def spiral_conv_bwd_wgt(dpre, dp_layout, x, x_layout, table, R, S, Cin, Cout, wa
     return dW, db
 
 
+def spiral_conv_bwd_wgt_deferred(dpre, dp_layout, x, x_layout, table, R, S, Cin, Cout, want_bias=True):
+    """Weight-gradient pass that only writes its partial slabs; returns a job for
+    `spiral_conv_bwd_wgt_reduce` (which reduces the slabs of a whole stack in one launch)."""
+    B, _, C1, dsv, dsb = _dims(dpre, dp_layout)
+    B2, _, C2, xsv, xsb = _dims(x, x_layout)
+    assert B == B2 and C1 == Cout and C2 == Cin
+    lib = _lib.load()
+    nbytes = lib.sh_spiral_conv_bwd_wgt_workspace(B, R, S, Cin, Cout)
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
+    check(lib.sh_spiral_conv_bwd_wgt(ptr(dpre), dsv, dsb, ptr(x), xsv, xsb, ptr(table), ptr(None), ptr(None), ptr(ws),
+                                     nbytes, B, R, S, Cin, Cout, stream_ptr()), "sh_spiral_conv_bwd_wgt")
+    dW = torch.empty((Cout, S * Cin), dtype=torch.float32, device=x.device)
+    db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
+    return dict(ws=ws, dW=dW, db=db, dims=(B, R, S, Cin, Cout))
+
+
+def _c_ptr_array(tensors):
+    import ctypes
+    return (ctypes.c_void_p * len(tensors))(*[0 if t is None else t.data_ptr() for t in tensors])
+
+
+def _c_int_array(vals):
+    import ctypes
+    return (ctypes.c_int * len(vals))(*vals)
+
+
+def spiral_conv_bwd_wgt_reduce(jobs):
+    """One launch: fixed-order reduction of the partial slabs of every job (<= 16)."""
+    if not jobs:
+        return
+    import ctypes
+    cols = list(zip(*[j["dims"] for j in jobs]))
+    args = [_c_ptr_array([j["ws"] for j in jobs]), _c_ptr_array([j["dW"] for j in jobs]), _c_ptr_array([j["db"] for j in jobs])]
+    args += [_c_int_array(c) for c in cols]
+    check(_lib.load().sh_spiral_conv_bwd_wgt_reduce_multi(len(jobs), *[ctypes.cast(a, ctypes.c_void_p) for a in args], stream_ptr()),
+          "sh_spiral_conv_bwd_wgt_reduce_multi")
+
+
+def weight_transpose_multi(weights, dims):
+    """dims: [(S, Cin, Cout)] -> list of weight_t tensors, one launch."""
+    import ctypes
+    outs = [torch.empty((ci, s * co), dtype=torch.float32, device=w.device) for w, (s, ci, co) in zip(weights, dims)]
+    cols = list(zip(*dims))
+    args = [_c_ptr_array(list(weights)), _c_ptr_array(outs)] + [_c_int_array(c) for c in cols]
+    check(_lib.load().sh_weight_transpose_multi(len(outs), *[ctypes.cast(a, ctypes.c_void_p) for a in args], stream_ptr()),
+          "sh_weight_transpose_multi")
+    return outs
+
+
 def act_backward(dy, dy_layout, y, y_layout, dpre, dp_layout, R, act, zero_row):
     B, _, C, asv, asb = _dims(dy, dy_layout)
     _, _, _, ysv, ysb = _dims(y, y_layout)

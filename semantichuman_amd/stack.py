@@ -188,6 +188,13 @@ class Stack:
         def in_of(i):
             return (x, in_layout) if i == 0 else (acts[i - 1], "vm")
 
+        # all weight transposes of the stack in one launch (weights are known up front)
+        conv_idx = [i for i, st in enumerate(steps) if st.kind == "conv" and (i > 0 or need_x_grad)]
+        wts = dict(zip(conv_idx, ops.weight_transpose_multi([weights[steps[i].param] for i in conv_idx],
+                                                            [(steps[i].S, steps[i].cin, steps[i].cout) for i in conv_idx]))) \
+            if conv_idx else {}
+        jobs = []                # deferred weight-gradient reductions (one launch at the end)
+
         # gradient entering the last step
         st = steps[last]
         if st.kind == "conv":
@@ -221,13 +228,11 @@ class Stack:
                 if side is not None:
                     side.wait_stream(main)                     # dpre_i (and input_i) are complete on main
                     keep_alive.append(cur)
-                    with torch.cuda.stream(side):
-                        dW, db = ops.spiral_conv_bwd_wgt(cur, cur_layout, inp, inp_layout, st.dev["table"], st.R, st.S,
-                                                         st.cin, st.cout, want_bias=need_bias[st.param])
-                else:
-                    dW, db = ops.spiral_conv_bwd_wgt(cur, cur_layout, inp, inp_layout, st.dev["table"], st.R, st.S,
-                                                     st.cin, st.cout, want_bias=need_bias[st.param])
-                grads[st.param] = (dW, db)
+                with torch.cuda.stream(side if side is not None else main):
+                    job = ops.spiral_conv_bwd_wgt_deferred(cur, cur_layout, inp, inp_layout, st.dev["table"], st.R, st.S,
+                                                           st.cin, st.cout, want_bias=need_bias[st.param])
+                jobs.append(job)
+                grads[st.param] = (job["dW"], job["db"])
                 if want_in:
                     # rows referenced more than once per (input row, position): sum them into the
                     # extra rows of the dpre buffer first (see mesh_ops.TransposedTable)
@@ -236,8 +241,7 @@ class Stack:
                         ops.spmm(st.dev["sum1"], cur, "vm", cur[st.R:], "vm", n1)
                     if n2:
                         ops.spmm(st.dev["sum2"], cur, "vm", cur[st.R + n1:], "vm", n2)
-                    wt = ops.weight_transpose(weights[st.param], st.S, st.cin, st.cout)
-                    ops.spiral_conv_bwd_data(cur, cur_layout, st.dev["table_t"], wt, g_in, g_layout,
+                    ops.spiral_conv_bwd_data(cur, cur_layout, st.dev["table_t"], wts[i], g_in, g_layout,
                                              ep["yprev"], ep["yp_layout"], ep["act_prev"], ep["zero_row"],
                                              st.n_in, st.S, st.cin, st.cout)
             elif want_in:
@@ -245,6 +249,9 @@ class Stack:
                          yp_layout=ep["yp_layout"], act_prev=ep["act_prev"], zero_row=ep["zero_row"])
             if want_in:
                 cur, cur_layout = g_in, g_layout
+        with torch.cuda.stream(side if side is not None else main):
+            for k in range(0, len(jobs), 16):
+                ops.spiral_conv_bwd_wgt_reduce(jobs[k:k + 16])
         if side is not None:
             main.wait_stream(side)                             # join: gradients are consumed on main
             for dW, db in grads.values():
