@@ -48,6 +48,14 @@ def conv_launch_table(model, B):
         return 1 if t <= 1 else 2 if t <= 2 else 4 if t <= 4 else 8
     first = True
     tb16 = "true" if B >= 16 else "false"          # batch-slice width of the tiles (SH_GG_TB default 16)
+    tb = 16 if B >= 16 else 1 << max(0, (B - 1).bit_length())
+
+    def nt_split(rows, nout):
+        """Output-channel tiles per workgroup after the few-tiles split of dispatch_gg() (csrc/spiral_conv.hip)."""
+        t, blocks, split = nt(nout), -(-rows // (128 // tb)) * -(-B // tb), 1
+        while t > 1 and blocks * split < 768:
+            t //= 2; split *= 2
+        return t
     for stack in (model._enc_stack, model._dec_stack):
         for st in stack.steps:
             if st.kind != "conv":
@@ -57,12 +65,12 @@ def conv_launch_table(model, B):
             vec = "true" if st.cin % 4 == 0 else "false"
             # fwd: read each needed input row once + weights, write output
             byt = 4.0 * (B * st.n_in * st.cin + B * st.R * st.cout + st.cout * K)
-            add("gather_gemm_kernel<%d, %s, false, %s>" % (nt(st.cout), vec, tb16), fl, byt)
+            add("gather_gemm_kernel<%d, %s, false, %s>" % (nt_split(st.R, st.cout), vec, tb16), fl, byt)
             vecb = "true" if st.cout % 4 == 0 else "false"
             if not (first and stack is model._enc_stack):
                 # backward-data = the same kernel over the transposed table; algorithmic FLOPs are
                 # those of the R*S real (row, position) pairs, not of the padded n_in*S table
-                add("gather_gemm_kernel<%d, %s, true, %s>" % (nt(st.cin), vecb, tb16), fl, byt)
+                add("gather_gemm_kernel<%d, %s, true, %s>" % (nt_split(st.n_in, st.cin), vecb, tb16), fl, byt)
             cp = nt(st.cout) * 16                      # same choice as plan_wgrad() in csrc/spiral_conv.hip
             cost1, cost2 = -(-K // 64) * (64 + cp), -(-K // 128) * (128 + cp)
             ctw = 1 if (nt(st.cout) == 8 or cost1 <= cost2) else 2

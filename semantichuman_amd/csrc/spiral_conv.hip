@@ -41,6 +41,7 @@ struct GGParams {
     int act;            // forward: activation of this layer; backward: activation that produced x
     int zero_row;
     int log2TB, n_btiles, n_vtiles, nchunks;
+    int nsplit;         // workgroups per row tile (each owns NT*16 output channels)
     int vec_out;        // Nout % 4 == 0 and output strides 16-B aligned
 };
 
@@ -53,7 +54,12 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_kernel(const GGParams p)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int TB = 1 << p.log2TB, TV = TM >> p.log2TB;
-    const int tile = sh_xcd_remap(blockIdx.x, gridDim.x);
+    // work item = (row tile, output-channel split).  Layers with few row tiles (coarse mesh levels)
+    // split their output channels over `nsplit` workgroups so that the launch still fills the chip;
+    // the splits of one tile are adjacent in the XCD-contiguous order (they gather the same rows).
+    const int item = sh_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = item / p.nsplit;
+    const int n_base = (item - tile * p.nsplit) * (NT * 16);
     const int bt = tile / p.n_vtiles, vt = tile - bt * p.n_vtiles;     // batch-slice-major order
     const int v0 = vt * TV, b0 = bt * TB;
     const int S = p.S;
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_kernel(const GGParams p)
     bool w_ok[WQ];
 #pragma unroll
     for (int i = 0; i < WQ; ++i) {
-        const int n = rbase + 32 * i;
+        const int n = n_base + rbase + 32 * i;
         w_ok[i] = n < p.Nout;
         w_off[i] = w_ok[i] ? (long)n * p.K : 0;
     }
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_kernel(const GGParams p)
         const bool zero = v == p.zero_row;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-            const int n0 = n * 16 + lq * 4;
+            const int n0 = n_base + n * 16 + lq * 4;
             if (n0 >= p.Nout) continue;
             f32x4 a = acc[m][n];
             if (p.vec_out) {
@@ -304,10 +310,16 @@ int dispatch_gg(GGParams& p, hipStream_t st) {
                 (reinterpret_cast<uintptr_t>(p.y) % 16 == 0) &&
                 (!p.bias || reinterpret_cast<uintptr_t>(p.bias) % 16 == 0) &&
                 (!p.yprev || ((p.yp_sv % 4 == 0) && (p.yp_sb % 4 == 0) && reinterpret_cast<uintptr_t>(p.yprev) % 16 == 0));
-    const int nt = sh_cdiv(p.Nout, 16);
+    int nt = sh_cdiv(p.Nout, 16);
+    nt = nt <= 1 ? 1 : nt <= 2 ? 2 : nt <= 4 ? 4 : 8;
+    // too few row tiles to fill 256 CUs x ~3 workgroups: split the output channels over workgroups
+    static const int fill_target = sh_env_int("SH_GG_FILL", 768, 1, 1 << 20);
+    p.nsplit = 1;
+    while (nt > 1 && nblocks * p.nsplit < fill_target) { nt >>= 1; p.nsplit <<= 1; }
+    const long nitems = nblocks * p.nsplit;
 #define SH_GG_CASE(NTV)                                                                  \
-    return vec4 ? launch_gg<NTV, true, BWD_EPI>(p, (int)nblocks, st)              \
-                : launch_gg<NTV, false, BWD_EPI>(p, (int)nblocks, st)
+    return vec4 ? launch_gg<NTV, true, BWD_EPI>(p, (int)nitems, st)              \
+                : launch_gg<NTV, false, BWD_EPI>(p, (int)nitems, st)
     if (nt <= 1) { SH_GG_CASE(1); }
     if (nt <= 2) { SH_GG_CASE(2); }
     if (nt <= 4) { SH_GG_CASE(4); }
