@@ -222,6 +222,43 @@ SH_API int sh_part_pairdist_loss_bwd(const float* x_rec, const float* x_gt, cons
                               int w_mode, float w_threshold, int relat, const float* part_cnt, const float* gscale,
                               float* grad, sh_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Body measurements (utils_SH.py:86-98 cal_length, :144-161 measure_body_quick; numpy twins
+ * obj2npy.py:61-79), batched over meshes.
+ * Girth of ring p = length of the CLOSED polyline through its n_p points
+ *   q_i = v[ring_a[i]] * (1 - ring_f[i]) + v[ring_b[i]] * ring_f[i],   i in [ring_ptr[p], ring_ptr[p+1])
+ * (utils_SH.py:155-158: closing segment q_0-q_last plus the n_p-1 consecutive ones).
+ * v: [B] meshes of [*][3] floats, batch stride v_sb floats; girth [B][P].
+ * Bone length p = | k[bones[3p]] - k[bones[3p+1]] |, or, when bones[3p+2] >= 0,
+ *   | k[bones[3p]] - (k[bones[3p+1]] + k[bones[3p+2]]) / 2 |   (utils_SH.py:94-97);
+ * kps contiguous [B][K][3]; bones int32 [P][3]; length [B][P].
+ */
+SH_API int sh_measure_girth(const float* v, int64_t v_sb, const int32_t* ring_ptr, const int32_t* ring_a,
+                     const int32_t* ring_b, const float* ring_f, int B, int P, float* girth, sh_stream_t stream);
+SH_API int sh_bone_length(const float* kps, const int32_t* bones, int B, int K, int P, float* length, sh_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * GPU-resident dataset (autoencoder_dataset.py:26-58; main.py:209-237).  The reference loads and
+ * normalises one .npy per sample in DataLoader worker processes; here the packed split is
+ * normalised once on device and every batch is a row gather from the resident tensor.
+ *
+ * sh_dataset_normalize: raw contiguous [n][N][3] -> out contiguous [n][N+dummy_rows][3] (dummy rows
+ * zero, :45-48), applying in the reference's order (:29-43) the steps selected by `flags`:
+ *   ZEROMEAN  v -= mean_v(v)                      ZEROROOT  v -= sum_v j_root[v] * v   (J_regressor row 0)
+ *   ONELENGTH v = v / (max_y - min_y) * 1.5       SMALL     v = v / 1.5
+ *   GASS      v = (v - mean[N][3]) / stdv[N][3]   NORMAL    v = (v - center[n][3]) * scale[n][3]
+ * then NaN -> 0.  Unused table pointers may be NULL.
+ * sh_gather_meshes: out[j][:] = src[idx[j]][:] for j < b, rows of row_elems floats, idx int64 on
+ * device (bit-exact copy; the caller guarantees 0 <= idx[j] < rows of src).
+ */
+enum sh_norm_flags {
+    SH_NORM_ZEROMEAN = 1, SH_NORM_ZEROROOT = 2, SH_NORM_ONELENGTH = 4, SH_NORM_SMALL = 8, SH_NORM_GASS = 16, SH_NORM_NORMAL = 32
+};
+SH_API int sh_dataset_normalize(const float* raw, float* out, int n, int N, int dummy_rows, unsigned flags,
+                         const float* j_root, const float* mean, const float* stdv, const float* center,
+                         const float* scale, sh_stream_t stream);
+SH_API int sh_gather_meshes(const float* src, int64_t row_elems, const int64_t* idx, int b, float* out, sh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -414,6 +414,86 @@ def gen_semantic():
     print("semantic.npz: sizes", sizes, "S", spiral_sizes, "pair", arrs["pair_loss_relat"], arrs["pair_loss_abs"], "vol", float(vol))
 
 
+def gen_measure():
+    """Body measurements: reference utils_SH.cal_girth on plane cuts of the 578-vertex
+    mesh (girth, intersection points X, ring order), then utils_SH.measure_body_quick / cal_length on a
+    batch of deformed meshes using the edge-point lists those cuts calibrate."""
+    import utils_SH as ref_sh
+    from semantichuman_amd import constants as C
+    v, f = synthetic.box_sphere(12, 12, 6)
+    edges = np.unique(np.sort(np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [0, 2]]]), axis=1), axis=0)
+    planes = [((0.0, 0.0, z), (0.0, 0.0, 1.0)) for z in (-0.61, -0.33, 0.02, 0.41, 0.7)]
+    planes += [((0.03, 0.0, 0.0), (1.0, 0.05, 0.02)), ((0.0, -0.02, 0.1), (0.1, 1.0, 0.3)), ((0.01, 0.02, -0.2), (0.3, 0.2, 1.0))]
+    arrs, factor_list, epi_list = {"verts": v.astype(np.float32), "n_planes": len(planes)}, [], []
+    for i, (p, n) in enumerate(planes):
+        p, n = np.asarray(p, dtype=np.float32), np.asarray(n, dtype=np.float32)
+        side = (v - p) @ n
+        e = edges[side[edges[:, 0]] * side[edges[:, 1]] < 0]
+        pts = torch.from_numpy(v[e].astype(np.float32))                                   # [n, 2, 3]
+        girth, X, order = ref_sh.cal_girth(torch.from_numpy(p), torch.from_numpy(n), pts)
+        a, b = v[e[:, 0]], v[e[:, 1]]
+        fac = (np.linalg.norm(X.numpy() - a, axis=1) / np.linalg.norm(b - a, axis=1)).astype(np.float32)
+        o = order.numpy()
+        factor_list.append(fac[o][:, None]); epi_list.append(e[o])
+        arrs.update({"plane_p_%d" % i: p, "plane_n_%d" % i: n, "cut_edges_%d" % i: e.astype(np.int32),
+                     "girth_%d" % i: np.float32(girth), "X_%d" % i: X.numpy(), "order_%d" % i: o.astype(np.int32),
+                     "factor_%d" % i: factor_list[-1], "epi_%d" % i: epi_list[-1].astype(np.int32)})
+    B = 4
+    x = torch.from_numpy(synthetic.synth_batch(v, B, seed=33))
+    J = np.abs(synthetic.closed_form_fill((35, v.shape[0]), 1.0, 0.618, 0.3)) ** 8
+    J = (J / J.sum(1, keepdims=True)).astype(np.float32)
+    kps = torch.matmul(torch.from_numpy(J), x[:, :-1, :]).float()
+    skl = C.SKL_LIST[1:]                                                                   # obj2npy.py:97
+    G, L = [], []
+    for bb in range(B):
+        g, l = ref_sh.measure_body_quick(x[bb], kps[bb], skl, [torch.from_numpy(t) for t in factor_list],
+                                         [torch.from_numpy(t) for t in epi_list])
+        G.append(g.numpy()); L.append(l.numpy())
+    arrs.update(x=x.numpy(), kps=kps.numpy(), girth_batch=np.stack(G), length_batch=np.stack(L),
+                length_newskl=np.stack([ref_sh.cal_length(kps[bb], C.NEWSKL_LIST).numpy() for bb in range(B)]))
+    np.savez_compressed(os.path.join(GOLD, "measure.npz"), **arrs)
+    print("measure.npz: rings", [int(t.shape[0]) for t in epi_list], "girths", [float(arrs["girth_%d" % i]) for i in range(len(planes))])
+
+
+NORMALIZATIONS = ["No", "zeromean", "zeroroot", "zeroroot_onelength_small", "gass", "normal", "zeromean_zeroroot_normal"]
+
+
+def gen_dataset():
+    """Data path: the reference's autoencoder_dataset.__getitem__ on a 12-mesh split written
+    in its on-disk layout, once per normalisation string; raw inputs + expected items are stored."""
+    import tempfile
+    import types
+    import autoencoder_dataset as ref_ds
+    from semantichuman_amd import dataset as my_ds
+    v, _ = synthetic.box_sphere(6, 6, 4)
+    n = 12
+    raw = synthetic.synth_batch(v, n, seed=41, dummy=False).astype(np.float32)
+    raw += np.float32(0.3) * synthetic.closed_form_fill((n, 1, 3), 1.0, 2.1, 0.4).astype(np.float32)   # off-centre meshes
+    raw[3, 17, 1] = np.nan                                                                          # :43 NaN -> 0
+    measure = synthetic.closed_form_fill((n, 32), 0.5, 0.77, 0.2).astype(np.float32) + 1
+    J = np.abs(synthetic.closed_form_fill((35, v.shape[0]), 1.0, 0.618, 0.3)) ** 8
+    J = (J / J.sum(1, keepdims=True)).astype(np.float32)
+    clean = np.nan_to_num(raw)
+    shapedata = types.SimpleNamespace(                                                                # shape_data.py:39-46
+        mean=np.mean(clean, axis=0), std=np.std(clean, axis=0),
+        center=(np.max(clean, axis=1) + np.min(clean, axis=1)) / 2, scale=1 / (np.max(clean, axis=1) - np.min(clean, axis=1)))
+    arrs = dict(raw=raw, measure=measure, J_regressor=J, mean=shapedata.mean, std=shapedata.std, center=shapedata.center,
+                scale=shapedata.scale, normalizations=np.asarray(NORMALIZATIONS))
+    with tempfile.TemporaryDirectory() as tmp:
+        my_ds.write_split(tmp, "train", raw, measure)
+        for k, norm in enumerate(NORMALIZATIONS):
+            ds = ref_ds.autoencoder_dataset(tmp, "train", shapedata, normalization=norm, dummy_node=True, measure_flag=True,
+                                            J_regressor=J)
+            items = [ds[i] for i in range(len(ds))]
+            arrs["verts_%d" % k] = np.stack([it["verts"].numpy() for it in items])
+            assert all(it["idx"] == i for i, it in enumerate(items))
+            arrs["measure_out_%d" % k] = np.stack([it["measure"].numpy() for it in items])
+        ds = ref_ds.autoencoder_dataset(tmp, "train", shapedata, normalization="zeroroot", dummy_node=False, J_regressor=J)
+        arrs["verts_nodummy"] = np.stack([ds[i]["verts"].numpy() for i in range(len(ds))])
+    np.savez_compressed(os.path.join(GOLD, "dataset.npz"), **arrs)
+    print("dataset.npz:", {k: a.shape for k, a in arrs.items() if k.startswith("verts")})
+
+
 def gen_template():
     t0 = time.time()
     v, f = synthetic.box_sphere(42, 42, 20)
@@ -452,7 +532,11 @@ def gen_template():
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-template", action="store_true")
+    ap.add_argument("--only", default=None, help="run a single generator, e.g. measure / semantic")
     a = ap.parse_args()
+    if a.only:
+        globals()["gen_" + a.only]()
+        sys.exit(0)
     os.makedirs(GOLD, exist_ok=True)
     gen_small()
     gen_conv_acts()

@@ -21,6 +21,8 @@ Reference lines followed:
   l1 loss                train_funcs.py:501  (F.l1_loss(tx, tx_hat), all N+1 rows)
   edge_ratio_loss        train_funcs.py:12-39, 503-508
   eval_metrics           test_funcs.py:41-49
+  bone_lengths, girths, plane_ring   utils_SH.py:86-161
+  dataset_item           autoencoder_dataset.py:26-50
 """
 from __future__ import annotations
 
@@ -290,3 +292,78 @@ def part_volume_loss(x_rec, x_gt, faces, face_part_index, parts):
             gv = torch.sum(torch.linalg.cross(x_gt[b, tf[:, 0]], x_gt[b, tf[:, 1]]) * x_gt[b, tf[:, 2]])
             total = total + (torch.abs(rv / gv) - torch.abs(gv / gv)).abs() / len(parts)
     return total / x_rec.shape[0]
+
+
+def bone_lengths(kps, skl_list):
+    """utils_SH.py:86-98 cal_length: kps [K, 3] -> [len(skl_list)]."""
+    out = torch.zeros(len(skl_list), dtype=kps.dtype)
+    for i, s in enumerate(skl_list):
+        tail = kps[s[1]] if len(s) == 2 else (kps[s[1]] + kps[s[2]]) / 2
+        out[i] = torch.sqrt(torch.sum((kps[s[0]] - tail) ** 2))
+    return out
+
+
+def girths(v, factor_list, edge_point_index_list):
+    """utils_SH.py:153-159 (measure_body_quick): sequential closed-polyline length of every ring of one mesh."""
+    out = []
+    for fac, epi in zip(factor_list, edge_point_index_list):
+        fac = torch.as_tensor(fac, dtype=v.dtype)
+        epi = torch.as_tensor(epi, dtype=torch.long)
+        q = v[epi[:, 0], :] * (1 - fac) + v[epi[:, 1], :] * fac
+        g = torch.sqrt(torch.sum((q[0] - q[-1]) ** 2))
+        for i in range(q.shape[0] - 1):
+            g = g + torch.sqrt(torch.sum((q[i] - q[i + 1]) ** 2))
+        out.append(g)
+    return torch.stack(out)
+
+
+def plane_ring(face_point, face_normal, points):
+    """utils_SH.py:100-142 cal_girth in the reference's formulation: one 3x3 solve per cut edge
+    (rows: plane equation; the two symmetric equations of the edge's line), then the signed-angle sort."""
+    n_pts = points.shape[0]
+    A = torch.zeros((n_pts, 3, 3), dtype=points.dtype)
+    Bv = torch.zeros((n_pts, 3), dtype=points.dtype)
+    lp = points[:, 0, :]
+    lo = points[:, 0, :] - points[:, 1, :]
+    lo = torch.where(lo == 0, torch.full_like(lo, 1e-6), lo)
+    A[:, 0, :] = face_normal[None]
+    A[:, 1, 0], A[:, 1, 1] = 1 / lo[:, 0], -1 / lo[:, 1]
+    A[:, 2, 0], A[:, 2, 2] = 1 / lo[:, 0], -1 / lo[:, 2]
+    Bv[:, 0] = torch.sum(face_point * face_normal)
+    Bv[:, 1] = lp[:, 0] / lo[:, 0] - lp[:, 1] / lo[:, 1]
+    Bv[:, 2] = lp[:, 0] / lo[:, 0] - lp[:, 2] / lo[:, 2]
+    X = torch.linalg.solve(A, Bv)
+    Xv = X - X.mean(dim=0)
+    m = torch.sqrt(torch.sum(Xv * Xv, dim=1))
+    cos = torch.sum(Xv[0:1] * Xv[1:], dim=1) / (m[1:] * m[0])
+    theta = torch.arccos(cos) / torch.pi * 180
+    cr = torch.linalg.cross(Xv[0:1].expand(n_pts - 1, 3), Xv[1:])
+    flag = torch.where(cr[:, 0] * cr[:, 1] * cr[:, 2] > 0, 1.0, -1.0).to(points.dtype)
+    order = torch.sort(torch.cat((torch.zeros(1, dtype=points.dtype), theta * flag)))[1]
+    g = torch.sqrt(torch.sum((X[order[0]] - X[order[-1]]) ** 2))
+    for i in range(n_pts - 1):
+        g = g + torch.sqrt(torch.sum((X[order[i]] - X[order[i + 1]]) ** 2))
+    return g, X, order
+
+
+def dataset_item(verts_init, normalization, J_regressor=None, shapedata=None, idx=0, dummy_node=True):
+    """autoencoder_dataset.py:26-50: normalise one loaded sample [N, 3] and append the dummy node (numpy)."""
+    import numpy as np
+    v = np.array(verts_init)
+    if "zeromean" in normalization:
+        v = v - np.mean(v, axis=0)
+    if "zeroroot" in normalization:
+        v = v - np.matmul(J_regressor, v)[0]
+    if "onelength" in normalization:
+        v = v / (np.max(v, axis=0) - np.min(v, axis=0))[1] * 1.5
+    if "small" in normalization:
+        v = v / 1.5
+    if "gass" in normalization:
+        v = (v - shapedata.mean) / shapedata.std
+    if "normal" in normalization:
+        v = (v - shapedata.center[idx, :]) * shapedata.scale[idx]
+    v[np.where(np.isnan(v))] = 0.0
+    v = v.astype("float32")
+    if dummy_node:
+        v = np.concatenate([v, np.zeros((1, v.shape[1]), dtype=np.float32)], axis=0)
+    return v

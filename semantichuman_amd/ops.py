@@ -251,3 +251,56 @@ def edge_ratio_loss_bwd(x_hat, x, faces, vptr, vcorner, gscale):
     check(_lib.load().sh_edge_ratio_loss_bwd(ptr(x_hat), ptr(x), ptr(faces), ptr(vptr), ptr(vcorner), x.shape[0], x.shape[1],
                                              faces.shape[0], ptr(gscale), ptr(g), stream_ptr()), "sh_edge_ratio_loss_bwd")
     return g
+
+
+def measure_girth(v, rings):
+    """v [B, rows, 3] fp32 (rows may include the dummy row); rings = (ptr, a, b, f) device tensors -> girth [B, P]."""
+    ptr_, a, b, f = rings
+    if not (v.is_cuda and v.dtype == torch.float32 and v.dim() == 3 and v.shape[2] == 3 and v.stride(2) == 1
+            and v.stride(1) == 3):
+        raise RuntimeError("semantichuman_amd.measure_girth needs fp32 HIP vertices [B, rows, 3] (got %s %s %s); there is "
+                           "no CPU path" % (v.device, v.dtype, tuple(v.shape)))
+    B, P = v.shape[0], ptr_.numel() - 1
+    out = torch.empty((B, P), dtype=torch.float32, device=v.device)
+    check(_lib.load().sh_measure_girth(ptr(v), v.stride(0) if B > 1 else v.shape[1] * 3, ptr(ptr_), ptr(a), ptr(b), ptr(f),
+                                       B, P, ptr(out), stream_ptr()), "sh_measure_girth")
+    return out
+
+
+def bone_length(kps, bones):
+    """kps [B, K, 3] fp32 contiguous; bones int32 [P, 3] (third id -1 for a two-joint bone) -> length [B, P]."""
+    if not (kps.is_cuda and kps.dtype == torch.float32 and kps.dim() == 3 and kps.shape[2] == 3 and kps.is_contiguous()):
+        raise RuntimeError("semantichuman_amd.bone_length needs contiguous fp32 HIP joints [B, K, 3]; there is no CPU path")
+    B, K, P = kps.shape[0], kps.shape[1], bones.shape[0]
+    out = torch.empty((B, P), dtype=torch.float32, device=kps.device)
+    check(_lib.load().sh_bone_length(ptr(kps), ptr(bones), B, K, P, ptr(out), stream_ptr()), "sh_bone_length")
+    return out
+
+
+NORM_FLAGS = {"zeromean": 1, "zeroroot": 2, "onelength": 4, "small": 8, "gass": 16, "normal": 32}
+
+
+def dataset_normalize(raw, flags, dummy_rows=1, j_root=None, mean=None, std=None, center=None, scale=None):
+    """raw [n, N, 3] fp32 HIP tensor -> normalised, dummy-padded [n, N + dummy_rows, 3]."""
+    if not (raw.is_cuda and raw.dtype == torch.float32 and raw.dim() == 3 and raw.shape[2] == 3 and raw.is_contiguous()):
+        raise RuntimeError("semantichuman_amd.dataset_normalize needs a contiguous fp32 HIP tensor [n, N, 3]; there is no CPU path")
+    n, N = raw.shape[0], raw.shape[1]
+    for t, shape in ((j_root, (N,)), (mean, (N, 3)), (std, (N, 3)), (center, (n, 3)), (scale, (n, 3))):
+        if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == shape):
+            raise RuntimeError("dataset_normalize: table must be a contiguous fp32 HIP tensor of shape %s, got %s" % (shape, tuple(t.shape)))
+    out = torch.empty((n, N + dummy_rows, 3), dtype=torch.float32, device=raw.device)
+    check(_lib.load().sh_dataset_normalize(ptr(raw), ptr(out), n, N, dummy_rows, flags, ptr(j_root), ptr(mean), ptr(std),
+                                           ptr(center), ptr(scale), stream_ptr()), "sh_dataset_normalize")
+    return out
+
+
+def gather_meshes(src, idx):
+    """src [n, ...] contiguous fp32 HIP tensor, idx int64 HIP tensor [b] -> src[idx] (bit-exact copy)."""
+    if not (src.is_cuda and src.dtype == torch.float32 and src.is_contiguous() and idx.is_cuda and idx.dtype == torch.int64
+            and idx.dim() == 1 and idx.is_contiguous()):
+        raise RuntimeError("semantichuman_amd.gather_meshes needs a contiguous fp32 HIP tensor and an int64 HIP index; no CPU path")
+    b = idx.numel()
+    out = torch.empty((b,) + tuple(src.shape[1:]), dtype=torch.float32, device=src.device)
+    if b:
+        check(_lib.load().sh_gather_meshes(ptr(src), src[0].numel(), ptr(idx), b, ptr(out), stream_ptr()), "sh_gather_meshes")
+    return out

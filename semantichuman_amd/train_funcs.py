@@ -95,7 +95,7 @@ def train_autoencoder_dataloader(dataloader_train, dataloader_val, device, model
             if writer and total_steps % eval_freq == 0:
                 writer.add_scalar("loss/loss/data_loss", loss.item(), total_steps)
                 writer.add_scalar("loss/loss/rec_loss", rec_loss.item(), total_steps)
-                writer.add_scalar("loss/loss/edgereg_loss", float(edgereg_loss), total_steps)
+                writer.add_scalar("loss/loss/edgereg_loss", float(edgereg_loss.detach()), total_steps)
             total_steps += 1
 
         model.eval()
