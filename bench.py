@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured hipGraph")
+    ap.add_argument("--adam", choices=["hip", "torch"], default="hip", help="library Adam kernel, or torch's fused capturable Adam")
+    ap.add_argument("--adam-overlap", action="store_true", help="update the big parameters on a side stream underneath backward (measured: no gain, the GPU is already saturated)")
     ap.add_argument("--cpu-iters", type=int, default=2)
     args = ap.parse_args()
 
@@ -115,7 +117,12 @@ def main():
     torch.manual_seed(2)                          # cfgs.py:46 seed; identical replicas on every rank
     model = sh.SpiralAutoencoder(FE, FD, 256, h.sizes, h.spiral_sizes, h.spirals, h.D, h.U, dev)
     init_state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    optim = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-5, capturable=True, fused=True)   # main.py:262
+    if args.adam == "hip":                        # main.py:262
+        optim = sh.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-5)
+        if world == 1 and args.adam_overlap:
+            optim.overlap_backward()              # the two latent FCs (99 % of the parameters) update underneath the encoder backward
+    else:
+        optim = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-5, capturable=True, fused=True)
     ft = sh.FaceTables(h.faces, h.sizes[0] + 1, dev)
     reducer = GradientAllReducer(model, bucket_cap_mb=64.0) if world > 1 else None
 
@@ -210,6 +217,8 @@ def main():
         nprof = 5
         from semantichuman_amd import stack as _stack
         overlap_was, _stack.OVERLAP_WGRAD = _stack.OVERLAP_WGRAD, False     # serial launches: clean per-kernel durations
+        if args.adam == "hip":
+            optim.remove_overlap()
         _lib.profile_enable(True)
         for i in range(nprof):
             o = (i * B) % n_data

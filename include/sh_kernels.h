@@ -259,6 +259,20 @@ SH_API int sh_dataset_normalize(const float* raw, float* out, int n, int N, int 
                          const float* scale, sh_stream_t stream);
 SH_API int sh_gather_meshes(const float* src, int64_t row_elems, const int64_t* idx, int b, float* out, sh_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Optimiser: torch.optim.Adam with coupled L2 weight decay (main.py:262; steps at
+ * train_funcs.py:391-392, 509-510), multi-tensor.  For every tensor i < n_tensors, with t = steps[i][0] + 1:
+ *   g' = g + weight_decay * p;  m = lerp(m, g', 1 - beta1);  v = beta2 * v + (1 - beta2) * g'^2;
+ *   p -= (lr / (1 - beta1^t)) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps);   then steps[i][0] += 1.
+ * params / grads / exp_avg / exp_avg_sq / steps / numel are HOST arrays of length n_tensors holding
+ * DEVICE pointers (steps[i]: one float, the number of updates applied so far) and element counts;
+ * `lr` is a DEVICE scalar, so a captured launch follows learning-rate schedules and step counts
+ * without re-capture.
+ */
+SH_API int sh_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                 float* const* exp_avg_sq, float* const* steps, const int64_t* numel, const float* lr,
+                 double beta1, double beta2, double eps, double weight_decay, sh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,3 +10,4 @@ from .losses import FaceTables, edge_ratio_loss, eval_l1, l1_loss, vertex_l2_mm 
 
 __version__ = "0.1.0"
 from .models import SpiralAutoencoder_multiz_partkps  # noqa: F401,E402
+from . import dataset, measure, optim  # noqa: F401,E402

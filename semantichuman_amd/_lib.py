@@ -49,6 +49,7 @@ SIGNATURES = {
     "sh_bone_length": (c_int, [_P, _P, _I, _I, _I, _P, _P]),
     "sh_dataset_normalize": (c_int, [_P, _P, _I, _I, _I, ctypes.c_uint, _P, _P, _P, _P, _P, _P]),
     "sh_gather_meshes": (c_int, [_P, _L, _P, _I, _P, _P]),
+    "sh_adam_step": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P] + [ctypes.c_double] * 4 + [_P]),
 }
 
 _lib = None

@@ -1,0 +1,124 @@
+"""Adam on the HIP kernel.
+
+`Adam` is a drop-in for `torch.optim.Adam(params, lr, betas, eps, weight_decay)` as the reference
+constructs it (main.py:262: coupled L2 weight decay, no amsgrad) - same constructor keywords, same
+`state_dict()` layout (`state[i] = {'step', 'exp_avg', 'exp_avg_sq'}` + `param_groups`), so the
+reference's checkpoints load into it and its checkpoints load into torch's Adam, and
+`torch.optim.lr_scheduler.StepLR` (main.py:263-264) drives it unchanged.
+
+All parameters of a group are updated by one multi-tensor launch (sh_adam_step).  Learning rate and
+step counts live in device memory, so a step captured in a hipGraph keeps following the schedule.
+
+`overlap_backward(min_numel)`: the update is HBM-bound (7 passes over every parameter-sized array)
+while the backward pass is MFMA-bound, so large parameters can be updated on a side stream as soon
+as autograd has produced their gradient, underneath the rest of backward; `step()` then joins the
+side stream and updates what is left.  The result is identical to updating everything in `step()`
+(Adam's update of a parameter depends only on that parameter's own gradient).  Do not enable it
+when gradients are modified between backward and step (clipping, all-reduce averaging).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+class Adam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
+        if amsgrad:
+            raise NotImplementedError("semantichuman_amd.optim.Adam: amsgrad is not used by the reference and not built")
+        if not 0.0 <= lr or not 0.0 <= eps or not 0.0 <= weight_decay or not all(0.0 <= b < 1.0 for b in betas):
+            raise ValueError("invalid Adam hyper-parameters lr=%r betas=%r eps=%r weight_decay=%r" % (lr, betas, eps, weight_decay))
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=False))
+        self._lr_dev = {}            # id(group) -> (device scalar, value it holds)
+        self._early = set()          # parameters already updated during this backward
+        self._hooks = []
+        self._side = None
+
+    # ---------------------------------------------------------------------------------- internals
+    def _state_of(self, p):
+        st = self.state[p]
+        if not st:
+            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                raise RuntimeError("semantichuman_amd.optim.Adam updates contiguous fp32 HIP parameters (got %s %s); there "
+                                   "is no CPU path" % (p.device, p.dtype))
+            st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        elif not (st["step"].is_cuda and st["step"].dtype == torch.float32):        # state loaded from a torch.optim.Adam checkpoint
+            st["step"] = torch.as_tensor(float(st["step"]), dtype=torch.float32, device=p.device)
+        return st
+
+    def _lr_tensor(self, group, device):
+        cur = self._lr_dev.get(id(group))
+        lr = float(group["lr"])
+        if cur is None or cur[0].device != device:
+            cur = (torch.full((), lr, dtype=torch.float32, device=device), lr)
+        elif cur[1] != lr:
+            cur[0].fill_(lr)                                   # scheduler changed it: refresh in stream order
+            cur = (cur[0], lr)
+        self._lr_dev[id(group)] = cur
+        return cur[0]
+
+    def _apply(self, group, params):
+        params = [p for p in params if p.grad is not None]
+        if not params:
+            return
+        n = len(params)
+        arr = lambda: (ctypes.c_void_p * n)()                      # noqa: E731
+        P, G, M, V, S, N = arr(), arr(), arr(), arr(), arr(), (ctypes.c_int64 * n)()
+        keep = []
+        for i, p in enumerate(params):
+            g = p.grad
+            if g.is_sparse or g.dtype != torch.float32 or g.device != p.device:
+                raise RuntimeError("semantichuman_amd.optim.Adam needs dense fp32 gradients on the parameter's device")
+            if not g.is_contiguous():
+                g = g.contiguous()
+                keep.append(g)
+            st = self._state_of(p)
+            P[i], G[i], M[i], V[i], S[i] = p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), \
+                st["step"].data_ptr()
+            N[i] = p.numel()
+        lr = self._lr_tensor(group, params[0].device)
+        b1, b2 = group["betas"]
+        _lib.check(_lib.load().sh_adam_step(n, P, G, M, V, S, N, _lib.ptr(lr), float(b1), float(b2), float(group["eps"]),
+                                            float(group["weight_decay"]), _lib.stream_ptr()), "sh_adam_step")
+
+    # ---------------------------------------------------------------------------------- overlap with backward
+    def overlap_backward(self, min_numel=1 << 20):
+        """Update parameters of at least `min_numel` elements as soon as their gradient exists (see module doc)."""
+        self.remove_overlap()
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.requires_grad and p.numel() >= min_numel:
+                    self._hooks.append(p.register_post_accumulate_grad_hook(lambda q, g=group: self._on_grad(g, q)))
+        return self
+
+    def remove_overlap(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+    def _on_grad(self, group, p):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=p.device)
+        self._side.wait_stream(torch.cuda.current_stream(p.device))      # the gradient was produced on the current stream
+        with torch.cuda.stream(self._side):
+            self._apply(group, [p])
+        self._early.add(id(p))
+
+    # ---------------------------------------------------------------------------------- torch.optim API
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if self._early:
+            torch.cuda.current_stream(self._side.device).wait_stream(self._side)   # join: early updates are part of this step
+        for group in self.param_groups:
+            self._apply(group, [p for p in group["params"] if id(p) not in self._early])
+        self._early.clear()
+        return loss

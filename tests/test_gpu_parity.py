@@ -249,14 +249,16 @@ def make_models(h, g, latent):
     return m, om
 
 
-def test_autoencoder_vs_reference_golden(golden_dir):
+@pytest.mark.parametrize("adam", ["torch", "hip"])
+def test_autoencoder_vs_reference_golden(golden_dir, adam):
     """models.SpiralAutoencoder of the REFERENCE (run in the build container, vectors committed):
-    outputs, latent, loss, every parameter gradient, weights after one Adam step, eval metric."""
+    outputs, latent, loss, every parameter gradient, weights after one Adam step (torch.optim.Adam and the
+    library's own Adam kernel), eval metric."""
     p = os.path.join(golden_dir, "small_ae.npz")
     g, h = np.load(p), load_hierarchy(p)
     m, om = make_models(h, g, 16)
     x = torch.from_numpy(g["x"]).to(dev())
-    opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-5)
+    opt = (torch.optim.Adam if adam == "torch" else sh.optim.Adam)(m.parameters(), lr=1e-3, weight_decay=5e-5)
     opt.zero_grad()
     x_hat, z = m(x)
     close(x_hat, g["x_hat"], FWD_TOL, "x_hat")
