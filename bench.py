@@ -71,10 +71,15 @@ def conv_launch_table(model, B):
                 # backward-data = the same kernel over the transposed table; algorithmic FLOPs are
                 # those of the R*S real (row, position) pairs, not of the padded n_in*S table
                 add("gather_gemm_kernel<%d, %s, true, %s>" % (nt_split(st.n_in, st.cin), vecb, tb16), fl, byt)
-            cp = nt(st.cout) * 16                      # same choice as plan_wgrad() in csrc/spiral_conv.hip
-            cost1, cost2 = -(-K // 64) * (64 + cp), -(-K // 128) * (128 + cp)
-            ctw = 1 if (nt(st.cout) == 8 or cost1 <= cost2) else 2
-            add("wgrad_kernel<%d, %d, %s>" % (nt(st.cout), ctw, vec), fl, byt)
+            if st.cin % 4 == 0:                        # same choices as plan_wgrad() in csrc/spiral_conv.hip
+                cot = nt(st.cout)
+                add("wgrad_stream_kernel<%d, %d, %d, %s>" % (cot, 1 if B <= 4 else 4, 3 if cot <= 2 else 2,
+                                                             "true" if B % (4 if B <= 4 else 16) == 0 else "false"), fl, byt)
+            else:
+                cp = nt(st.cout) * 16
+                cost1, cost2 = -(-K // 64) * (64 + cp), -(-K // 128) * (128 + cp)
+                ctw = 1 if (nt(st.cout) == 8 or cost1 <= cost2) else 2
+                add("wgrad_kernel<%d, %d, %s>" % (nt(st.cout), ctw, vec), fl, byt)
             first = False
     return out
 

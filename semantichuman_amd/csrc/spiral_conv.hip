@@ -335,6 +335,9 @@ int dispatch_gg(GGParams& p, hipStream_t st) {
 // dimension is the ROW index.  Each block ends by writing its partial to a slab; a second kernel
 // sums the slabs in a fixed order (no atomics -> bitwise reproducible).
 constexpr int TMW = 32;
+#ifndef SH_WG_ABLATE
+#define SH_WG_ABLATE 0      // diagnostic builds only (tools/ablate_wgrad.sh): 1 no global loads, 2 no MFMA, 4 no LDS stores, 8 no LDS reads
+#endif
 constexpr int WG_TABLE_CAP = 8192;      // ints of gather table a workgroup keeps in LDS (32 KiB)
 
 struct WGParams {
@@ -431,6 +434,12 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(const WGParams p) {
     // when the tile is written to LDS two steps later.  Invalid rows MUST be zeroed here because
     // rows are the reduction dimension.
     auto load_step = [&](int st, f32x4 (&rg)[GP], f32x4 (&rp)[PP], unsigned& mg, unsigned& mp) {
+        if (SH_WG_ABLATE & 1) {
+            mg = mp = ~0u;
+            for (int i = 0; i < GP; ++i) rg[i] = (f32x4){1.f, 2.f, 3.f, (float)st};
+            for (int i = 0; i < PP; ++i) rp[i] = (f32x4){1.f, 2.f, 3.f, (float)st};
+            return;
+        }
         st = st < nsteps ? st : nsteps - 1;
         const int vloc = st * TV;                       // local vertex index of the step's first vertex
         mg = 0; mp = 0;
@@ -469,6 +478,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(const WGParams p) {
         }
     };
     auto store_step = [&](int buf, const f32x4 (&rg)[GP], const f32x4 (&rp)[PP], unsigned mg, unsigned mp) {
+        if ((SH_WG_ABLATE & 4) && rg[0][0] != 12345.f) return;
         float* Gb = Gs + buf * TMW * LDG;
         float* Pb = Ps + buf * TMW * LDP;
 #pragma unroll
@@ -500,9 +510,9 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(const WGParams p) {
             for (int kk = 0; kk < 4; ++kk) {
                 const int row = 16 * half + 4 * kk + lk;
 #pragma unroll
-                for (int a = 0; a < CTW; ++a) gf[kk][a] = Gb[row * LDG + a * 16];
+                for (int a = 0; a < CTW; ++a) gf[kk][a] = (SH_WG_ABLATE & 8) ? (float)(row + a) : Gb[row * LDG + a * 16];
 #pragma unroll
-                for (int b = 0; b < COT; ++b) pf[kk][b] = Pb[row * LDP + b * 16];
+                for (int b = 0; b < COT; ++b) pf[kk][b] = (SH_WG_ABLATE & 8) ? (float)(row - b) : Pb[row * LDP + b * 16];
             }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
@@ -510,7 +520,8 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(const WGParams p) {
                 for (int a = 0; a < CTW; ++a)
 #pragma unroll
                     for (int b = 0; b < COT; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(gf[kk][a], pf[kk][b], acc[a][b], 0, 0, 0);
+                        if (SH_WG_ABLATE & 2) acc[a][b][0] += gf[kk][a] * pf[kk][b];
+                        else acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(gf[kk][a], pf[kk][b], acc[a][b], 0, 0, 0);
         }
         if (cg == 0 && tid < COT * 16) {
             const float* Pc = Ps + buf * TMW * LDP + tid;
@@ -645,8 +656,144 @@ __global__ __launch_bounds__(256) void weight_transpose_multi_kernel(const Multi
     m.wt[d][i] = m.w[d][(long)co * S * Cin + (long)s * Cin + ci];      // wt[ci][s*Cout + co] = w[co][s*Cin + ci]
 }
 
+// ------------------------------------------------------------------------------------------
+// weight gradient, streaming form (Cin % 4 == 0).  The staged kernel above moves the gathered
+// tile through LDS only to transpose it; measured on MI355X its global loads, LDS traffic and
+// MFMAs barely overlap (profiles/r01_ablation_wgrad.txt).  Here every WAVE owns 64 weight columns
+// and a row chunk, and feeds the matrix pipe straight from its 16-byte global loads - no LDS for
+// the operands, no barrier in the loop:
+//   lane (a = lane & 15, kq = lane >> 4) loads x[nbr(v, s_a)][b0 + 4g + kq][c_a .. c_a+3], the four
+//   gathered columns k_a .. k_a+3 (k_a = 64 cg + 4a) of row (v, b0 + 4g + kq).  MFMA t takes element t
+//   as its A operand: A_t[i = a][k = kq] = G[row kq][col 4a + t], so one load feeds 4 MFMAs whose
+//   outputs are the column sets {4i + t}.  The B operand is dpre[row kq][cout = a + 16 b], one
+//   4-byte load per output-channel tile.  acc[t][b][j] = dW[cout 16b + a][col 64cg + 16kq + 4j + t].
+// The loads of the next DEPTH-1 vertices are in flight while a vertex's MFMAs issue.
+struct WSParams {
+    const float* dpre; long dp_sv, dp_sb;
+    const float* x; long x_sv, x_sb;
+    const int* table;
+    float* slab; long slab_stride, bias_off;
+    int B, R, S, Cin, Cout, K;
+    int log2TB, n_btiles, nvc, vpc, ncg, n_items;     // vpc = vertices per chunk
+};
+
+template <int COT, int NG, int DEPTH, bool FULL>
+__global__ __launch_bounds__(NTHREADS) void wgrad_stream_kernel(const WSParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int* Tl = reinterpret_cast<int*>(smem) + wave * p.vpc * p.S;          // this wave's table lines
+    const int item_raw = sh_xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
+    const bool active = item_raw < p.n_items;
+    const int item = active ? item_raw : 0;
+    const int rc = item / p.ncg, cg = item - rc * p.ncg;
+    const int bt = rc / p.nvc, vc = rc - bt * p.nvc;
+    const int b0 = bt << p.log2TB;
+    const int v_begin = vc * p.vpc;
+    const int nv = active ? min(p.vpc, p.R - v_begin) : 0;
+    const int S = p.S;
+    for (int i = lane; i < nv * S; i += 64) Tl[i] = p.table[(long)v_begin * S + i];
+    __syncthreads();
+    if (nv <= 0) return;
+
+    const int la = lane & 15, kq = lane >> 4;
+    const int k0 = cg * 64 + 4 * la;
+    const bool k_in = k0 < p.K;                                  // columns past K: read column 0, never stored
+    const int s_l = k_in ? k0 / p.Cin : 0, c_l = k_in ? k0 - s_l * p.Cin : 0;
+    // batch entry of this lane in group g: b0 + 4g + kq
+    int bcl[NG];
+    unsigned bok = 0;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int b = b0 + 4 * g + kq;
+        bok |= (b < p.B ? 1u : 0u) << g;
+        bcl[g] = b < p.B ? b : p.B - 1;
+    }
+    const float* xb = p.x + c_l;
+    const float* pb = p.dpre + (long)v_begin * p.dp_sv;
+    int pco[COT];
+#pragma unroll
+    for (int b = 0; b < COT; ++b) pco[b] = min(16 * b + la, p.Cout - 1);      // channels past Cout: duplicate, never stored
+
+    f32x4 gr[DEPTH][NG];
+    float pr[DEPTH][NG][COT];
+    auto load_v = [&](int vl, f32x4 (&g4)[NG], float (&pp)[NG][COT]) {
+        vl = vl < nv ? vl : nv - 1;
+        const float* gsrc = xb + (long)Tl[vl * S + s_l] * p.x_sv;
+        const float* psrc = pb + (long)vl * p.dp_sv;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) g4[g] = *reinterpret_cast<const f32x4*>(gsrc + (long)bcl[g] * p.x_sb);
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int b = 0; b < COT; ++b) pp[g][b] = psrc[(long)bcl[g] * p.dp_sb + pco[b]];
+    };
+
+    f32x4 acc[4][COT];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int b = 0; b < COT; ++b) acc[t][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bs[COT];
+#pragma unroll
+    for (int b = 0; b < COT; ++b) bs[b] = 0.f;
+
+    auto mma_v = [&](const f32x4 (&g4)[NG], const float (&pp)[NG][COT]) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            float pv[COT];
+#pragma unroll
+            for (int b = 0; b < COT; ++b) pv[b] = (FULL || ((bok >> g) & 1u)) ? pp[g][b] : 0.f;   // rows are the reduction index
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int b = 0; b < COT; ++b) acc[t][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(g4[g][t], pv[b], acc[t][b], 0, 0, 0);
+            if (cg == 0) {
+#pragma unroll
+                for (int b = 0; b < COT; ++b) bs[b] += pv[b];
+            }
+        }
+    };
+
+#pragma unroll
+    for (int d = 0; d < DEPTH - 1; ++d) load_v(d, gr[d], pr[d]);
+    for (int vl = 0; vl < nv; vl += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            if (vl + d < nv) {                                   // wave-uniform
+                load_v(vl + d + DEPTH - 1, gr[(d + DEPTH - 1) % DEPTH], pr[(d + DEPTH - 1) % DEPTH]);
+                __builtin_amdgcn_sched_barrier(0);               // prefetch loads stay ahead of the MFMAs
+                mma_v(gr[d], pr[d]);
+            }
+        }
+    }
+
+    float* slab = p.slab + (long)rc * p.slab_stride;
+#pragma unroll
+    for (int b = 0; b < COT; ++b) {
+        const int co = 16 * b + la;
+        if (co >= p.Cout) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = cg * 64 + 16 * kq + 4 * j;
+            if (col < p.K)
+                *reinterpret_cast<f32x4*>(slab + (long)co * p.K + col) = (f32x4){acc[0][b][j], acc[1][b][j], acc[2][b][j], acc[3][b][j]};
+        }
+    }
+    if (cg == 0) {
+#pragma unroll
+        for (int b = 0; b < COT; ++b) {
+            float v = bs[b];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int co = 16 * b + la;
+            if (kq == 0 && co < p.Cout) p.slab[p.bias_off + (long)rc * p.Cout + co] = v;
+        }
+    }
+}
+
 struct WGPlan {
     int log2TB, n_btiles, n_vtiles, nvc, steps_per_block, nrc, ncg, ctw, cot;
+    int stream, vpc;    // streaming form: batch slice 1 << log2TB, nvc chunks of vpc vertices, ncg = ceil(K / 64)
 };
 
 WGPlan plan_wgrad(int B, int R, int S, int Cin, int Cout) {
@@ -682,7 +829,51 @@ WGPlan plan_wgrad(int B, int R, int S, int Cin, int Cout) {
     if (w.steps_per_block > max_steps) w.steps_per_block = max_steps;
     w.nvc = sh_cdiv(w.n_vtiles, w.steps_per_block);
     w.nrc = w.nvc * w.n_btiles;
+    // streaming form (wgrad_stream_kernel): work item = (64-column group, batch slice, vertex chunk), one per wave
+    static const int stream_on = sh_env_int("SH_WG_STREAM", 1, 0, 1);
+    w.stream = (stream_on && Cin % 4 == 0) ? 1 : 0;
+    w.vpc = 0;
+    if (w.stream) {
+        static const int items_target = sh_env_int("SH_WS_ITEMS", 1024, 64, 1 << 20);
+        static const int slab_mb = sh_env_int("SH_WS_SLAB_MB", 32, 1, 4096);
+        const int tbs = B <= 4 ? 4 : 16;                       // batch slice: 1 or 4 groups of 4 rows
+        w.log2TB = sh_ilog2_floor(tbs);
+        w.n_btiles = sh_cdiv(B, tbs);
+        w.ncg = sh_cdiv(K, 64);
+        long nrc_t = items_target / w.ncg;
+        const long cap = ((long)slab_mb << 20) / ((long)Cout * K * 4);     // partial slabs are written and re-read once
+        if (nrc_t > cap) nrc_t = cap;
+        if (nrc_t < 1) nrc_t = 1;
+        long nvc_t = nrc_t / w.n_btiles;
+        if (nvc_t < 1) nvc_t = 1;
+        if (nvc_t > R) nvc_t = R;
+        int vpc = sh_cdiv(R, (int)nvc_t);
+        const int vcap = 2048 / S > 0 ? 2048 / S : 1;          // table lines of a wave: <= 8 KiB of LDS
+        if (vpc > vcap) vpc = vcap;
+        w.vpc = vpc;
+        w.nvc = sh_cdiv(R, vpc);
+        w.nrc = w.nvc * w.n_btiles;
+    }
     return w;
+}
+
+template <int COT, int NG, bool FULL>
+int launch_ws(const WSParams& p, hipStream_t st) {
+    constexpr int DEPTH = COT <= 2 ? 3 : 2;       // vertices of loads in flight (deeper measured no faster)
+    const size_t smem = (size_t)4 * p.vpc * p.S * sizeof(int);
+    const int grid = sh_cdiv(p.n_items, 4);
+    ShProfScope ps(st, "wgrad_stream_kernel<%d, %d, %d, %s>|R=%d B=%d K=%d N=%d grid=%d", COT, NG, DEPTH, FULL ? "true" : "false", p.R,
+                   p.B, p.K, p.Cout, grid);
+    hipLaunchKernelGGL((wgrad_stream_kernel<COT, NG, DEPTH, FULL>), dim3(grid), dim3(NTHREADS), smem, st, p);
+    SH_CHECK_LAUNCH("wgrad_stream");
+    return SH_OK;
+}
+
+template <int COT>
+int dispatch_ws(const WSParams& p, hipStream_t st) {
+    const bool full = (p.B & ((1 << p.log2TB) - 1)) == 0;
+    if (p.log2TB == 2) return full ? launch_ws<COT, 1, true>(p, st) : launch_ws<COT, 1, false>(p, st);
+    return full ? launch_ws<COT, 4, true>(p, st) : launch_ws<COT, 4, false>(p, st);
 }
 
 template <int COT, int CTW>
@@ -801,6 +992,18 @@ int sh_spiral_conv_bwd_wgt(const float* dpre, int64_t dp_sv, int64_t dp_sb, cons
     const bool vec4 = (Cin % 4 == 0) && (x_sv % 4 == 0) && (x_sb % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) &&
                       (reinterpret_cast<uintptr_t>(dpre) % 16 == 0);
     int rc;
+    if (w.stream) {
+        SH_REQUIRE((x_sv % 4 == 0) && (x_sb % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0), SH_ERR_UNSUPPORTED,
+                   "sh_spiral_conv_bwd_wgt: x must be 16-byte aligned with strides that are multiples of 4 floats");
+        WSParams s{};
+        s.dpre = dpre; s.dp_sv = dp_sv; s.dp_sb = dp_sb; s.x = x; s.x_sv = x_sv; s.x_sb = x_sb; s.table = table;
+        s.slab = p.slab; s.slab_stride = p.slab_stride; s.bias_off = p.bias_off;
+        s.B = B; s.R = R; s.S = S; s.Cin = Cin; s.Cout = Cout; s.K = p.K;
+        s.log2TB = w.log2TB; s.n_btiles = w.n_btiles; s.nvc = w.nvc; s.vpc = w.vpc; s.ncg = w.ncg;
+        s.n_items = w.nrc * w.ncg;
+        rc = w.cot == 1 ? dispatch_ws<1>(s, st) : w.cot == 2 ? dispatch_ws<2>(s, st) : w.cot == 4 ? dispatch_ws<4>(s, st)
+                                                                                                  : dispatch_ws<8>(s, st);
+    } else
 #define SH_WG_CASE(C, T) rc = launch_wg<C, T>(p, w, vec4, st)
     if (w.ctw == 1) {
         if (w.cot == 1) SH_WG_CASE(1, 1); else if (w.cot == 2) SH_WG_CASE(2, 1); else if (w.cot == 4) SH_WG_CASE(4, 1); else SH_WG_CASE(8, 1);

@@ -31,7 +31,7 @@ from .mesh_ops import CSR, TransposedTable
 import os
 
 # run weight-gradient kernels on a side stream, concurrently with the backward-data chain
-OVERLAP_WGRAD = os.environ.get("SH_OVERLAP_WGRAD", "1") != "0"
+OVERLAP_WGRAD = os.environ.get("SH_OVERLAP_WGRAD", "0") != "0"
 
 
 def _dev(a: np.ndarray, device):
