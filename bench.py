@@ -56,6 +56,16 @@ def conv_launch_table(model, B):
         while t > 1 and blocks * split < 768:
             t //= 2; split *= 2
         return t
+    def gg_name(t, cg, bwd):
+        """dispatch_gg(): two channel tiles with 16-byte gathers run the direct (LDS-free gather) form; 3-channel
+        gathered rows with one channel tile run the padded-quad (dwordx3) mode of the staged kernel."""
+        if cg == 3 and t == 1:
+            return "gather_gemm_kernel<1, true, %s, %s, true>" % (bwd, tb16)
+        vec4 = "true" if cg % 4 == 0 else "false"
+        if t == 2 and vec4 == "true":
+            return "gather_gemm_direct_kernel<2, %s>" % bwd
+        return "gather_gemm_kernel<%d, %s, %s, %s, false>" % (t, vec4, bwd, tb16)
+
     for stack in (model._enc_stack, model._dec_stack):
         for st in stack.steps:
             if st.kind != "conv":
@@ -65,16 +75,16 @@ def conv_launch_table(model, B):
             vec = "true" if st.cin % 4 == 0 else "false"
             # fwd: read each needed input row once + weights, write output
             byt = 4.0 * (B * st.n_in * st.cin + B * st.R * st.cout + st.cout * K)
-            add("gather_gemm_kernel<%d, %s, false, %s>" % (nt_split(st.R, st.cout), vec, tb16), fl, byt)
-            vecb = "true" if st.cout % 4 == 0 else "false"
+            add(gg_name(nt_split(st.R, st.cout), st.cin, "false"), fl, byt)
             if not (first and stack is model._enc_stack):
                 # backward-data = the same kernel over the transposed table; algorithmic FLOPs are
                 # those of the R*S real (row, position) pairs, not of the padded n_in*S table
-                add("gather_gemm_kernel<%d, %s, true, %s>" % (nt_split(st.n_in, st.cin), vecb, tb16), fl, byt)
-            if st.cin % 4 == 0:                        # same choices as plan_wgrad() in csrc/spiral_conv.hip
+                add(gg_name(nt_split(st.n_in, st.cin), st.cout, "true"), fl, byt)
+            if st.cin % 4 == 0 or st.cin == 3:         # same choices as plan_wgrad() in csrc/spiral_conv.hip
                 cot = nt(st.cout)
-                add("wgrad_stream_kernel<%d, %d, %d, %s>" % (cot, 1 if B <= 4 else 4, 3 if cot <= 2 else 2,
-                                                             "true" if B % (4 if B <= 4 else 16) == 0 else "false"), fl, byt)
+                add("wgrad_stream_kernel<%d, %d, %d, %s, %s>" % (cot, 1 if B <= 4 else 4, 3 if cot <= 2 else 2,
+                                                                 "true" if B % (4 if B <= 4 else 16) == 0 else "false",
+                                                                 "true" if st.cin == 3 else "false"), fl, byt)
             else:
                 cp = nt(st.cout) * 16
                 cost1, cost2 = -(-K // 64) * (64 + cp), -(-K // 128) * (128 + cp)
@@ -247,11 +257,12 @@ def main():
             if name in table and table[name]["launches"] == cnt / nprof:
                 e["tflops"] = table[name]["flops"] / (tot / nprof * 1e-3) / 1e12
             kernels.append(e)
-        # The dominant kernel of the step is the fused gather+MFMA conv kernel: `gather_gemm_kernel`
-        # (forward and backward-data) takes the largest share of the step as a family; the roofline is
+        # The dominant kernel of the step is the fused gather+MFMA conv kernel: `gather_gemm_kernel` and its
+        # direct form `gather_gemm_direct_kernel` (forward and backward-data) take the largest share of the
+        # step as a family; the roofline is
         # quoted for its single most expensive instantiation, under the exact name rocprofv3 prints
         # (profiles/), achieved = algorithmic FLOPs of its launches / their measured duration.
-        conv = [k for k in kernels if "tflops" in k and k["kernel"].startswith("gather_gemm_kernel")]
+        conv = [k for k in kernels if "tflops" in k and k["kernel"].startswith("gather_gemm_")]
         dom = conv[0] if conv else kernels[0]
         fam = {}
         for k in kernels:

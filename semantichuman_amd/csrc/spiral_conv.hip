@@ -24,6 +24,8 @@
 // rounding (tolerance stated in tests/), and are bitwise reproducible run to run.
 #include "sh_common.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int TM = 128;
@@ -38,6 +40,7 @@ struct GGParams {
     float* y; long y_sv, y_sb;
     const float* yprev; long yp_sv, yp_sb;
     int B, R, S, Cg, Nout, K;
+    int Kw;             // row stride of w (== K except in the 3-channel mode, where K counts padded quads)
     int act;            // forward: activation of this layer; backward: activation that produced x
     int zero_row;
     int log2TB, n_btiles, n_vtiles, nchunks;
@@ -45,7 +48,16 @@ struct GGParams {
     int vec_out;        // Nout % 4 == 0 and output strides 16-B aligned
 };
 
-template <int NT, bool VEC4, bool BWD_EPI, bool TB16>
+// 3-channel rows (the xyz input of the first encoder layer, the xyz gradient entering the last decoder layer):
+// a 12-byte row is loaded as one 4-byte-aligned dwordx3 and treated as a 16-byte quad whose 4th channel is zero,
+// so these layers run the vector path over K' = 4 S columns instead of the scalar one over 3 S.
+struct __attribute__((packed, aligned(4))) sh_f3 { float a, b, c; };
+__device__ __forceinline__ f32x4 sh_ld3(const float* p) {
+    const sh_f3 v = *reinterpret_cast<const sh_f3*>(p);
+    return (f32x4){v.a, v.b, v.c, 0.f};
+}
+
+template <int NT, bool VEC4, bool BWD_EPI, bool TB16, bool C3 = false>
 __global__ __launch_bounds__(NTHREADS) void gather_gemm_kernel(const GGParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* As = reinterpret_cast<float*>(smem);            // [2][TM][KC]
@@ -108,7 +120,7 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_kernel(const GGParams p)
     for (int i = 0; i < WQ; ++i) {
         const int n = n_base + rbase + 32 * i;
         w_ok[i] = n < p.Nout;
-        w_off[i] = w_ok[i] ? (long)n * p.K : 0;
+        w_off[i] = w_ok[i] ? (long)n * p.Kw : 0;
     }
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
@@ -127,14 +139,17 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_kernel(const GGParams p)
             if (FAST) {
                 const float* src = p.x + (unsigned)Ts[a_ts[0] + s] + ch;      // Ts holds row * x_sv (element offsets)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const f32x4*>(src + a_boff[i]);
+                for (int i = 0; i < 4; ++i) ra[i] = C3 ? sh_ld3(src + a_boff[i]) : *reinterpret_cast<const f32x4*>(src + a_boff[i]);
             } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    ra[i] = *reinterpret_cast<const f32x4*>(p.x + (unsigned)Ts[a_ts[i] + s] + a_boff[i] + ch);
+                for (int i = 0; i < 4; ++i) {
+                    const float* src = p.x + (unsigned)Ts[a_ts[i] + s] + a_boff[i] + ch;
+                    ra[i] = C3 ? sh_ld3(src) : *reinterpret_cast<const f32x4*>(src);
+                }
             }
 #pragma unroll
-            for (int i = 0; i < WQ; ++i) rw[i] = *reinterpret_cast<const f32x4*>(p.w + w_off[i] + kc);
+            for (int i = 0; i < WQ; ++i)
+                rw[i] = C3 ? sh_ld3(p.w + w_off[i] + 3 * s) : *reinterpret_cast<const f32x4*>(p.w + w_off[i] + kc);
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) ra[i] = zero4;
@@ -272,17 +287,226 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_kernel(const GGParams p)
     }
 }
 
-template <int NT, bool VEC4, bool BWD_EPI>
+// ------------------------------------------------------------------------------------------
+// Direct form of the same kernel (Cg % 4 == 0): the gathered operand never touches LDS.  A wave's
+// 32 tile rows are private to it, so staging them through LDS only re-laid them out for the MFMA;
+// instead lane (r = lane & 15, kq = lane >> 4) loads the 16-byte quad x[row r][k0 + 16 ks + 4 kq ..+3]
+// it will feed to the matrix pipe itself (element t of the quad is the B operand of MFMA t, the
+// weight quad W[n][same k] from LDS the A operand).  Only the weight chunk, shared by the four
+// waves, goes through LDS (triple-buffered, one barrier per chunk); gathered chunks c+1 and c+2
+// are in flight in registers while chunk c multiplies.  Same tiling, K order and epilogue as
+// gather_gemm_kernel, hence bit-identical results.
+template <int NT, bool BWD_EPI>
+__global__ __launch_bounds__(NTHREADS) void gather_gemm_direct_kernel(const GGParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Ws = reinterpret_cast<float*>(smem);                 // [3][NT*16][KC]
+    int* Ts = reinterpret_cast<int*>(Ws + 3 * NT * 16 * KC);    // table tile (element offsets)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int TB = 1 << p.log2TB, TV = TM >> p.log2TB;
+    const int item = sh_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = item / p.nsplit;
+    const int n_base = (item - tile * p.nsplit) * (NT * 16);
+    const int bt = tile / p.n_vtiles, vt = tile - bt * p.n_vtiles;
+    const int v0 = vt * TV, b0 = bt * TB;
+    const int S = p.S;
+    {
+        const int nT = TV * S;
+        const long lim = (long)p.R * S;
+        for (int i = tid; i < nT; i += NTHREADS) {
+            const long g = (long)v0 * S + i;
+            Ts[i] = g < lim ? (int)(unsigned)((long)p.table[g] * p.x_sv) : 0;
+        }
+    }
+    __syncthreads();
+
+    const int lrow = lane & 15, lq = lane >> 4;
+    int a_ts[2];
+    long a_boff[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int row = 32 * wave + 16 * m + lrow;
+        const int vl = row >> p.log2TB, bl = row & (TB - 1);
+        a_ts[m] = vl * S;
+        a_boff[m] = (b0 + bl) < p.B ? (long)(b0 + bl) * p.x_sb : 0;      // rows past B read row 0 of the slice; never stored
+    }
+    // running (k, s, channel) of this lane's quads (ks = 0, 1) for the next chunk to load
+    int k_n[2], s_n[2], c_n[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        k_n[ks] = 16 * ks + 4 * lq;
+        s_n[ks] = k_n[ks] / p.Cg;
+        c_n[ks] = k_n[ks] - s_n[ks] * p.Cg;
+    }
+    const int adv_s = KC / p.Cg, adv_c = KC - adv_s * p.Cg;
+    auto load_a = [&](f32x4 (&ra)[2][2]) {
+        unsigned toff[2][2];
+        int ch[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {                        // all table lookups first: one LDS round trip per chunk
+            const bool kok = k_n[ks] < p.K;                     // K tail / prefetch past the end: any valid address
+            const int s = kok ? s_n[ks] : 0;
+            ch[ks] = kok ? c_n[ks] : 0;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) toff[m][ks] = (unsigned)Ts[a_ts[m] + s];
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) ra[m][ks] = *reinterpret_cast<const f32x4*>(p.x + toff[m][ks] + a_boff[m] + ch[ks]);
+            k_n[ks] += KC;
+            c_n[ks] += adv_c;
+            s_n[ks] += adv_s;
+            const bool wrap = c_n[ks] >= p.Cg;
+            c_n[ks] = wrap ? c_n[ks] - p.Cg : c_n[ks];
+            s_n[ks] = wrap ? s_n[ks] + 1 : s_n[ks];
+        }
+    };
+
+    // weight chunk staging: thread -> quad q of rows rbase + 32 i (as in gather_gemm_kernel)
+    const int q = tid & 7, rbase = tid >> 3;
+    constexpr int WQ = NT >= 2 ? NT / 2 : 1;
+    const bool w_thread = (NT >= 2) || tid < 128;
+    long w_off[WQ];
+#pragma unroll
+    for (int i = 0; i < WQ; ++i) {
+        const int n = n_base + rbase + 32 * i;
+        w_off[i] = n < p.Nout ? (long)n * p.Kw : 0;
+    }
+    int kw_n = 4 * q;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto load_w = [&](f32x4 (&rw)[WQ], unsigned& mask) {
+        const bool kok = kw_n < p.K;
+        mask = kok ? 1u : 0u;
+        const int kc = kok ? kw_n : 0;
+#pragma unroll
+        for (int i = 0; i < WQ; ++i) rw[i] = *reinterpret_cast<const f32x4*>(p.w + w_off[i] + kc);
+        kw_n += KC;
+    };
+    auto store_w = [&](int buf, const f32x4 (&rw)[WQ], unsigned mask) {
+        if (w_thread) {
+            float* Wb = Ws + buf * NT * 16 * KC;
+            const int pq = (q ^ (rbase & 7)) << 2;
+#pragma unroll
+            for (int i = 0; i < WQ; ++i) *reinterpret_cast<f32x4*>(Wb + (rbase + 32 * i) * KC + pq) = mask ? rw[i] : zero4;
+        }
+    };
+
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = zero4;
+    auto compute = [&](int buf, const f32x4 (&ra)[2][2]) {
+        const float* Wb = Ws + buf * NT * 16 * KC + lrow * KC;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int pq = ((lq + 4 * ks) ^ (lane & 7)) << 2;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const f32x4 wq = *reinterpret_cast<const f32x4*>(Wb + n * 16 * KC + pq);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[t], ra[0][ks][t], acc[0][n], 0, 0, 0);
+                    acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[t], ra[1][ks][t], acc[1][n], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    f32x4 ra[3][2][2], rw[3][WQ];
+    unsigned mw[3];
+    load_a(ra[0]); load_w(rw[0], mw[0]);                 // chunk 0
+    store_w(0, rw[0], mw[0]);
+    __syncthreads();
+    load_a(ra[1]); load_w(rw[1], mw[1]);                 // chunk 1
+    // one chunk: J = c mod 3 names the register sets / LDS buffers statically
+    auto step = [&](auto J) {
+        constexpr int j = decltype(J)::value;
+        load_a(ra[(j + 2) % 3]); load_w(rw[(j + 2) % 3], mw[(j + 2) % 3]);               // chunk c+2
+        __builtin_amdgcn_sched_barrier(0);               // keep the prefetch loads AHEAD of the MFMA phase
+        compute(j, ra[j]);
+        store_w((j + 1) % 3, rw[(j + 1) % 3], mw[(j + 1) % 3]);                           // chunk c+1
+        __syncthreads();
+    };
+    // explicit early exits (not three independent `if`s): the compiler must see that a skipped step ends
+    // the loop, or it drains every outstanding load (vmcnt(0)) where the paths merge
+    for (int c = 0; c < p.nchunks; c += 3) {
+        step(std::integral_constant<int, 0>{});
+        if (c + 1 >= p.nchunks) break;
+        step(std::integral_constant<int, 1>{});
+        if (c + 2 >= p.nchunks) break;
+        step(std::integral_constant<int, 2>{});
+    }
+
+    // ---- epilogue (identical to gather_gemm_kernel): lane holds channels n0..n0+3 of tile row 32*wave + 16*m + lrow
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int row = 32 * wave + 16 * m + lrow;
+        const int vl = row >> p.log2TB, bl = row & (TB - 1);
+        const int v = v0 + vl, b = b0 + bl;
+        if (v >= p.R || b >= p.B) continue;
+        float* yrow = p.y + (long)v * p.y_sv + (long)b * p.y_sb;
+        const float* yp = (BWD_EPI && p.yprev) ? p.yprev + (long)v * p.yp_sv + (long)b * p.yp_sb : nullptr;
+        const bool zero = v == p.zero_row;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int n0 = n_base + n * 16 + lq * 4;
+            if (n0 >= p.Nout) continue;
+            f32x4 a = acc[m][n];
+            if (p.vec_out) {
+                if (!BWD_EPI) {
+                    if (p.bias) a += *reinterpret_cast<const f32x4*>(p.bias + n0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[j] = sh_act_fwd(a[j], p.act);
+                } else if (yp) {
+                    const f32x4 yv = *reinterpret_cast<const f32x4*>(yp + n0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[j] *= sh_act_grad_from_out(yv[j], p.act);
+                }
+                if (zero) a = (f32x4){0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(yrow + n0) = a;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (n0 + j >= p.Nout) continue;
+                    float vv = a[j];
+                    if (!BWD_EPI) {
+                        if (p.bias) vv += p.bias[n0 + j];
+                        vv = sh_act_fwd(vv, p.act);
+                    } else if (yp) {
+                        vv *= sh_act_grad_from_out(yp[n0 + j], p.act);
+                    }
+                    yrow[n0 + j] = zero ? 0.f : vv;
+                }
+            }
+        }
+    }
+}
+
+template <int NT, bool BWD_EPI>
+int launch_ggd(const GGParams& p, int nblocks, hipStream_t st) {
+    const int TV = TM >> p.log2TB;
+    const size_t smem = (size_t)(3 * NT * 16 * KC) * sizeof(float) + (size_t)(TV * p.S) * sizeof(int);
+    ShProfScope ps(st, "gather_gemm_direct_kernel<%d, %s>|R=%d B=%d K=%d N=%d grid=%d", NT, BWD_EPI ? "true" : "false", p.R, p.B,
+                   p.K, p.Nout, nblocks);
+    hipLaunchKernelGGL((gather_gemm_direct_kernel<NT, BWD_EPI>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
+    SH_CHECK_LAUNCH("gather_gemm_direct");
+    return SH_OK;
+}
+
+template <int NT, bool VEC4, bool BWD_EPI, bool C3 = false>
 int launch_gg(const GGParams& p, int nblocks, hipStream_t st) {
     const int TV = TM >> p.log2TB;
     const size_t smem = (size_t)(2 * TM * KC + 2 * NT * 16 * KC) * sizeof(float) + (size_t)(TV * p.S) * sizeof(int);
     {
-        ShProfScope ps(st, "gather_gemm_kernel<%d, %s, %s, %s>|R=%d B=%d K=%d N=%d grid=%d", NT, VEC4 ? "true" : "false",
-                       BWD_EPI ? "true" : "false", p.log2TB == 4 ? "true" : "false", p.R, p.B, p.K, p.Nout, nblocks);
+        ShProfScope ps(st, "gather_gemm_kernel<%d, %s, %s, %s, %s>|R=%d B=%d K=%d N=%d grid=%d", NT, VEC4 ? "true" : "false",
+                       BWD_EPI ? "true" : "false", p.log2TB == 4 ? "true" : "false", C3 ? "true" : "false", p.R, p.B, p.K, p.Nout,
+                       nblocks);
         if (p.log2TB == 4)
-            hipLaunchKernelGGL((gather_gemm_kernel<NT, VEC4, BWD_EPI, true>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
+            hipLaunchKernelGGL((gather_gemm_kernel<NT, VEC4, BWD_EPI, true, C3>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
         else
-            hipLaunchKernelGGL((gather_gemm_kernel<NT, VEC4, BWD_EPI, false>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
+            hipLaunchKernelGGL((gather_gemm_kernel<NT, VEC4, BWD_EPI, false, C3>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
     }
     SH_CHECK_LAUNCH("gather_gemm");
     return SH_OK;
@@ -299,6 +523,13 @@ int dispatch_gg(GGParams& p, hipStream_t st) {
     const int TV = TM >> p.log2TB;
     p.n_btiles = sh_cdiv(p.B, tb);
     p.n_vtiles = sh_cdiv(p.R, TV);
+    p.Kw = p.K;
+    int nt = sh_cdiv(p.Nout, 16);
+    nt = nt <= 1 ? 1 : nt <= 2 ? 2 : nt <= 4 ? 4 : 8;
+    // 3-channel gathered rows (built for one channel tile): dwordx3 loads, K counted in zero-padded quads
+    static const int c3_on = sh_env_int("SH_GG_C3", 1, 0, 1);
+    const bool c3 = c3_on && p.Cg == 3 && nt == 1 && reinterpret_cast<uintptr_t>(p.w) % 4 == 0;
+    if (c3) { p.Cg = 4; p.K = 4 * p.S; }
     p.nchunks = sh_cdiv(p.K, KC);
     const long nblocks = (long)p.n_vtiles * p.n_btiles;
     SH_REQUIRE(nblocks > 0 && nblocks < (1L << 31), SH_ERR_UNSUPPORTED, "gather_gemm: grid %ld out of range", nblocks);
@@ -310,17 +541,20 @@ int dispatch_gg(GGParams& p, hipStream_t st) {
                 (reinterpret_cast<uintptr_t>(p.y) % 16 == 0) &&
                 (!p.bias || reinterpret_cast<uintptr_t>(p.bias) % 16 == 0) &&
                 (!p.yprev || ((p.yp_sv % 4 == 0) && (p.yp_sb % 4 == 0) && reinterpret_cast<uintptr_t>(p.yprev) % 16 == 0));
-    int nt = sh_cdiv(p.Nout, 16);
-    nt = nt <= 1 ? 1 : nt <= 2 ? 2 : nt <= 4 ? 4 : 8;
     // too few row tiles to fill 256 CUs x ~3 workgroups: split the output channels over workgroups
     static const int fill_target = sh_env_int("SH_GG_FILL", 768, 1, 1 << 20);
     p.nsplit = 1;
     while (nt > 1 && nblocks * p.nsplit < fill_target) { nt >>= 1; p.nsplit <<= 1; }
     const long nitems = nblocks * p.nsplit;
+    static const int direct_on = sh_env_int("SH_GG_DIRECT", 1, 0, 1);
 #define SH_GG_CASE(NTV)                                                                  \
     return vec4 ? launch_gg<NTV, true, BWD_EPI>(p, (int)nitems, st)              \
                 : launch_gg<NTV, false, BWD_EPI>(p, (int)nitems, st)
+    if (c3) return launch_gg<1, true, BWD_EPI, true>(p, (int)nitems, st);
     if (nt <= 1) { SH_GG_CASE(1); }
+    // the direct form wins for two channel tiles (2-8 us per launch on MI355X) and loses for 1 and 4: a chunk of a
+    // one-tile layer has too few MFMAs between the weight-chunk barriers, four tiles are bound elsewhere
+    if (nt <= 2 && vec4 && direct_on) return launch_ggd<2, BWD_EPI>(p, (int)nitems, st);
     if (nt <= 2) { SH_GG_CASE(2); }
     if (nt <= 4) { SH_GG_CASE(4); }
     SH_GG_CASE(8);
@@ -677,7 +911,8 @@ struct WSParams {
     int log2TB, n_btiles, nvc, vpc, ncg, n_items;     // vpc = vertices per chunk
 };
 
-template <int COT, int NG, int DEPTH, bool FULL>
+// C3: Cin == 3, columns counted in zero-padded quads (k' = 4 s + c), dwordx3 gathers, scalar slab stores.
+template <int COT, int NG, int DEPTH, bool FULL, bool C3 = false>
 __global__ __launch_bounds__(NTHREADS) void wgrad_stream_kernel(const WSParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -697,8 +932,8 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_stream_kernel(const WSParams p
 
     const int la = lane & 15, kq = lane >> 4;
     const int k0 = cg * 64 + 4 * la;
-    const bool k_in = k0 < p.K;                                  // columns past K: read column 0, never stored
-    const int s_l = k_in ? k0 / p.Cin : 0, c_l = k_in ? k0 - s_l * p.Cin : 0;
+    const bool k_in = C3 ? k0 < 4 * p.S : k0 < p.K;              // columns past K: read column 0, never stored
+    const int s_l = k_in ? (C3 ? k0 >> 2 : k0 / p.Cin) : 0, c_l = (k_in && !C3) ? k0 - s_l * p.Cin : 0;
     // batch entry of this lane in group g: b0 + 4g + kq
     int bcl[NG];
     unsigned bok = 0;
@@ -721,7 +956,8 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_stream_kernel(const WSParams p
         const float* gsrc = xb + (long)Tl[vl * S + s_l] * p.x_sv;
         const float* psrc = pb + (long)vl * p.dp_sv;
 #pragma unroll
-        for (int g = 0; g < NG; ++g) g4[g] = *reinterpret_cast<const f32x4*>(gsrc + (long)bcl[g] * p.x_sb);
+        for (int g = 0; g < NG; ++g)
+            g4[g] = C3 ? sh_ld3(gsrc + (long)bcl[g] * p.x_sb) : *reinterpret_cast<const f32x4*>(gsrc + (long)bcl[g] * p.x_sb);
 #pragma unroll
         for (int g = 0; g < NG; ++g)
 #pragma unroll
@@ -775,8 +1011,15 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_stream_kernel(const WSParams p
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int col = cg * 64 + 16 * kq + 4 * j;
-            if (col < p.K)
+            if (C3) {                                            // quad col/4 = spiral position; element 3 is the zero padding
+                const int sp = col >> 2;
+                if (sp < p.S) {
+                    float* dst = slab + (long)co * p.K + 3 * sp;
+                    dst[0] = acc[0][b][j]; dst[1] = acc[1][b][j]; dst[2] = acc[2][b][j];
+                }
+            } else if (col < p.K) {
                 *reinterpret_cast<f32x4*>(slab + (long)co * p.K + col) = (f32x4){acc[0][b][j], acc[1][b][j], acc[2][b][j], acc[3][b][j]};
+            }
         }
     }
     if (cg == 0) {
@@ -831,7 +1074,7 @@ WGPlan plan_wgrad(int B, int R, int S, int Cin, int Cout) {
     w.nrc = w.nvc * w.n_btiles;
     // streaming form (wgrad_stream_kernel): work item = (64-column group, batch slice, vertex chunk), one per wave
     static const int stream_on = sh_env_int("SH_WG_STREAM", 1, 0, 1);
-    w.stream = (stream_on && Cin % 4 == 0) ? 1 : 0;
+    w.stream = (stream_on && (Cin % 4 == 0 || Cin == 3)) ? 1 : 0;
     w.vpc = 0;
     if (w.stream) {
         static const int items_target = sh_env_int("SH_WS_ITEMS", 1024, 64, 1 << 20);
@@ -839,7 +1082,7 @@ WGPlan plan_wgrad(int B, int R, int S, int Cin, int Cout) {
         const int tbs = B <= 4 ? 4 : 16;                       // batch slice: 1 or 4 groups of 4 rows
         w.log2TB = sh_ilog2_floor(tbs);
         w.n_btiles = sh_cdiv(B, tbs);
-        w.ncg = sh_cdiv(K, 64);
+        w.ncg = sh_cdiv(Cin == 3 ? 4 * S : K, 64);            // 3-channel inputs: columns counted in padded quads
         long nrc_t = items_target / w.ncg;
         const long cap = ((long)slab_mb << 20) / ((long)Cout * K * 4);     // partial slabs are written and re-read once
         if (nrc_t > cap) nrc_t = cap;
@@ -862,9 +1105,11 @@ int launch_ws(const WSParams& p, hipStream_t st) {
     constexpr int DEPTH = COT <= 2 ? 3 : 2;       // vertices of loads in flight (deeper measured no faster)
     const size_t smem = (size_t)4 * p.vpc * p.S * sizeof(int);
     const int grid = sh_cdiv(p.n_items, 4);
-    ShProfScope ps(st, "wgrad_stream_kernel<%d, %d, %d, %s>|R=%d B=%d K=%d N=%d grid=%d", COT, NG, DEPTH, FULL ? "true" : "false", p.R,
-                   p.B, p.K, p.Cout, grid);
-    hipLaunchKernelGGL((wgrad_stream_kernel<COT, NG, DEPTH, FULL>), dim3(grid), dim3(NTHREADS), smem, st, p);
+    const bool c3 = p.Cin == 3;
+    ShProfScope ps(st, "wgrad_stream_kernel<%d, %d, %d, %s, %s>|R=%d B=%d K=%d N=%d grid=%d", COT, NG, DEPTH, FULL ? "true" : "false",
+                   c3 ? "true" : "false", p.R, p.B, p.K, p.Cout, grid);
+    if (c3) hipLaunchKernelGGL((wgrad_stream_kernel<COT, NG, DEPTH, FULL, true>), dim3(grid), dim3(NTHREADS), smem, st, p);
+    else hipLaunchKernelGGL((wgrad_stream_kernel<COT, NG, DEPTH, FULL, false>), dim3(grid), dim3(NTHREADS), smem, st, p);
     SH_CHECK_LAUNCH("wgrad_stream");
     return SH_OK;
 }
@@ -993,7 +1238,7 @@ int sh_spiral_conv_bwd_wgt(const float* dpre, int64_t dp_sv, int64_t dp_sb, cons
                       (reinterpret_cast<uintptr_t>(dpre) % 16 == 0);
     int rc;
     if (w.stream) {
-        SH_REQUIRE((x_sv % 4 == 0) && (x_sb % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0), SH_ERR_UNSUPPORTED,
+        SH_REQUIRE(Cin == 3 || ((x_sv % 4 == 0) && (x_sb % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0)), SH_ERR_UNSUPPORTED,
                    "sh_spiral_conv_bwd_wgt: x must be 16-byte aligned with strides that are multiples of 4 floats");
         WSParams s{};
         s.dpre = dpre; s.dp_sv = dp_sv; s.dp_sb = dp_sb; s.x = x; s.x_sv = x_sv; s.x_sb = x_sb; s.table = table;
