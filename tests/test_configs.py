@@ -1,0 +1,92 @@
+"""BASELINE.json configs 4 and 5 as parity cases: too large for the CPU oracle end to end, so they are
+checked through size-independent properties plus oracle comparisons on slices the oracle finishes in seconds.
+
+  config 4  ~27k-vertex mesh (box_sphere(84,84,40) = 27 554 V), spiral length 18, batch 32: gather-bound stress case
+  config 5  decode of random latents at batch 1024 on the 6890-vertex template
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu
+from semantichuman_amd.hierarchy import load_hierarchy
+
+FE = [[3, 16, 32, 64, 128], [[], [], [], [], []]]
+FD = [[128, 64, 32, 32, 16], [[], [], [], [], 3]]
+
+
+def test_27k_template_fixture(golden_dir):
+    h = load_hierarchy(os.path.join(golden_dir, "template27554.npz"))
+    assert h.sizes == [27554, 13777, 6889, 3445, 1723] and h.spiral_sizes == [18] * 5
+    for lvl, sp in enumerate(h.spirals):
+        assert sp.shape == (h.sizes[lvl] + 1, 18) and sp.min() >= -1 and sp.max() < h.sizes[lvl]
+        assert np.all(sp[:-1, 0] == np.arange(h.sizes[lvl])) and np.all(sp[-1] == -1)      # column 0 = the vertex itself; dummy row
+    for lvl, u in enumerate(h.U):
+        np.testing.assert_allclose(np.asarray(u.todense()).sum(1)[:-1], 1.0, atol=1e-5)   # barycentric rows
+
+
+# ------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_config4_27k_vertices_spiral18_batch32(golden_dir):
+    import semantichuman_amd as sh
+    from semantichuman_amd import synthetic
+    h = load_hierarchy(os.path.join(golden_dir, "template27554.npz"))
+    dev = torch.device("cuda:0")
+    torch.manual_seed(4)
+    m = sh.SpiralAutoencoder(FE, FD, 256, h.sizes, h.spiral_sizes, h.spirals, h.D, h.U, dev)
+    B = 32
+    x = torch.from_numpy(synthetic.synth_batch(h.verts, B, seed=5)).to(dev)
+
+    def grads(xb):
+        m.zero_grad(set_to_none=True)
+        xh, z = m(xb)
+        loss = sh.l1_loss(xb, xh) * xb.shape[0]                       # sum over the batch (up to the constant 1/(rows*3))
+        loss.backward()
+        return xh.detach(), z.detach(), [p.grad.detach().clone() for p in m.parameters()]
+    xh, z, g_full = grads(x)
+    assert torch.isfinite(xh).all() and torch.isfinite(z).all() and float(xh[:, -1].abs().max()) == 0.0
+    # batch independence: any slice of the batch gives the same meshes (tile shapes differ -> fp32 tolerance, not bits)
+    xh4, z4, _ = grads(x[:4])
+    tol = 1e-5 * float(xh.abs().max())
+    assert float((xh[:4] - xh4).abs().max()) <= tol and float((z[:4] - z4).abs().max()) <= 1e-5 * float(z.abs().max())
+    # linearity of the weight gradient in the batch: dW(all 32) = dW(first 16) + dW(last 16)
+    _, _, g_a = grads(x[:16])
+    _, _, g_b = grads(x[16:])
+    for (name, _), gf, ga, gb in zip(m.named_parameters(), g_full, g_a, g_b):
+        scale = float(gf.abs().max()) + 1e-30
+        assert float((gf - (ga + gb)).abs().max()) <= 1e-4 * scale, name
+    # one 27k-vertex layer against the oracle's gather + linear (B = 2, the reference's formulation)
+    S, _, _ = h.dense_constants()
+    conv = m.dconv[3]                                                  # level 0, 32 -> 16 channels, S = 18
+    xin = torch.from_numpy(synthetic.closed_form_fill((2, h.sizes[0] + 1, 32), 0.5, 0.71, 0.3).astype(np.float32))
+    xin[:, -1] = 0
+    want = ref_cpu.spiral_conv(xin, S[0], conv.conv.weight.detach().cpu(), conv.conv.bias.detach().cpu(), "elu")
+    got = conv(xin.to(dev), torch.from_numpy(h.spirals[0].astype(np.int64))[None].to(dev))
+    assert float((got.cpu() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+@pytest.mark.gpu
+def test_config5_decode_batch1024(golden_dir):
+    import semantichuman_amd as sh
+    h = load_hierarchy(os.path.join(golden_dir, "template6890.npz"))
+    dev = torch.device("cuda:0")
+    torch.manual_seed(2)
+    m = sh.SpiralAutoencoder(FE, FD, 256, h.sizes, h.spiral_sizes, h.spirals, h.D, h.U, dev)
+    z = torch.randn(1024, 256, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        out = m.decode(z.to(dev))
+        assert out.shape == (1024, 6891, 3) and torch.isfinite(out).all() and float(out[:, -1].abs().max()) == 0.0
+        ragged = m.decode(z[:672].to(dev))                              # the last batch of 100 000 latents
+        sl = m.decode(z[500:508].to(dev))
+    tol = 1e-5 * float(out.abs().max())
+    assert float((ragged - out[:672]).abs().max()) <= tol
+    assert float((sl - out[500:508]).abs().max()) <= tol
+    # two latents through the oracle (dense U matmuls, index gathers) with the same weights
+    S, D, U = h.dense_constants()
+    om = ref_cpu.SpiralAEOracle(FE, FD, 256, h.sizes, h.spiral_sizes, S, D, U)
+    om.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    with torch.no_grad():
+        want = om.decode(z[[3, 1000]])
+    assert float((out[[3, 1000]].cpu() - want).abs().max()) <= 1e-5 * float(want.abs().max())
