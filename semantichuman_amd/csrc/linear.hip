@@ -15,6 +15,8 @@
 // summed in a fixed order by a second kernel (deterministic, no atomics).
 #include "sh_common.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int LT = 64;      // tile rows (both operands)
@@ -225,6 +227,240 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     out[n] = s;
 }
 
+// ------------------------------------------------------------------------------------------
+// Streaming forms for M <= 64 (the batch): wave-autonomous, no LDS, no barrier - the scheme of
+// wgrad_stream_kernel (spiral_conv.hip).  Every wave owns an output tile and feeds the matrix pipe
+// straight from 16-byte global loads; a few steps of loads are in flight while one multiplies.
+// MFMA t of a step takes element t of each loaded quad, so one 16-byte load feeds four MFMAs.
+#ifndef SH_LS_DEPTH
+#define SH_LS_DEPTH 2      // steps of loads in flight besides the one multiplying; measured 2 <= 3 < 5 (register pressure)
+#endif
+constexpr int LS_DEPTH = SH_LS_DEPTH;
+
+// runs f(s + J, J) for J = 0 .. D-1, stopping after the last valid step; the early exits are explicit branches so the
+// compiler sees that a skipped step ends the loop (independent `if`s make it drain all loads where the paths merge)
+template <int J, int D, class F>
+__device__ __forceinline__ bool ls_run_steps(int s, int n, F&& f) {
+    f(s + J, std::integral_constant<int, J>{});
+    if constexpr (J + 1 < D) {
+        if (s + J + 1 >= n) return true;
+        return ls_run_steps<J + 1, D>(s, n, f);
+    }
+    return false;
+}
+
+struct LSParams {
+    const float* a;      // small operand (x or dy), row-major [M][*]
+    const float* w;      // weight-shaped operand
+    const float* bias;
+    float* out;          // result (nsplit == 1) ...
+    float* slab;         // ... or [nsplit][M][cols] partials
+    int M, N, K;
+    int range, nsplit, groups;     // reduction range per split (multiple of 16), #splits, #64-wide output groups
+};
+
+// forward: y[m][n] = sum_k x[m][k] W[n][k].  Item = (64 output columns, k range); both operands contiguous in k.
+template <int MT>
+__global__ __launch_bounds__(LTHREADS) void linear_fwd_stream_kernel(const LSParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int item = sh_xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
+    if (item >= p.groups * p.nsplit) return;
+    const int ng = item % p.groups, sp = item / p.groups;
+    const int n0 = ng * 64, k_begin = sp * p.range;
+    const int nsteps = (min(p.K, k_begin + p.range) - k_begin) >> 4;
+    const int lr = lane & 15, kq = lane >> 4;
+    const float* xrow[MT];
+    const float* wrow[4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) xrow[mt] = p.a + (long)min(16 * mt + lr, p.M - 1) * p.K + k_begin + 4 * kq;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) wrow[nt] = p.w + (long)(n0 + 16 * nt + lr) * p.K + k_begin + 4 * kq;
+    f32x4 xa[LS_DEPTH][MT], wb[LS_DEPTH][4], acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto load = [&](int s, f32x4 (&x4)[MT], f32x4 (&w4)[4]) {
+        const int off = 16 * (s < nsteps ? s : nsteps - 1);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) x4[mt] = *reinterpret_cast<const f32x4*>(xrow[mt] + off);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) w4[nt] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wrow[nt] + off));
+    };
+    auto mma = [&](const f32x4 (&x4)[MT], const f32x4 (&w4)[4]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[nt][t], x4[mt][t], acc[mt][nt], 0, 0, 0);
+    };
+    auto step = [&](int s, auto J) {
+        constexpr int j = decltype(J)::value;
+        load(s + LS_DEPTH - 1, xa[(j + LS_DEPTH - 1) % LS_DEPTH], wb[(j + LS_DEPTH - 1) % LS_DEPTH]);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(xa[j], wb[j]);
+    };
+    if (nsteps > 0) {
+#pragma unroll
+        for (int d = 0; d < LS_DEPTH - 1; ++d) load(d, xa[d], wb[d]);
+        for (int s = 0; s < nsteps; s += LS_DEPTH)
+            if (ls_run_steps<0, LS_DEPTH>(s, nsteps, step)) break;
+    }
+    // lane holds y[m = 16 mt + lr][n0 + 16 nt + 4 kq .. +3]
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = 16 * mt + lr;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n = n0 + 16 * nt + 4 * kq;
+            f32x4 v = acc[mt][nt];
+            if (p.nsplit > 1) {
+                *reinterpret_cast<f32x4*>(p.slab + ((long)sp * p.M + m) * p.N + n) = v;
+            } else {
+                if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                *reinterpret_cast<f32x4*>(p.out + (long)m * p.N + n) = v;
+            }
+        }
+    }
+}
+
+// backward-data: dx[m][k] = sum_n dy[m][n] W[n][k].  Item = (64 output columns k, n range).  The weight quad runs along
+// the OUTPUT index: lane (a, rr) loads W[nb + 4 rr + e][k0 + 4 a ..+3] for e = 0..3; MFMA (e, t) reduces over the four rows
+// {nb + 4 rr' + e} and produces the columns {k0 + 4 a' + t}.  dy quads run along n: element e pairs with weight row e.
+template <int MT>
+__global__ __launch_bounds__(LTHREADS) void linear_bwd_data_stream_kernel(const LSParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int item = sh_xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
+    if (item >= p.groups * p.nsplit) return;
+    const int kg = item % p.groups, sp = item / p.groups;
+    const int k0 = kg * 64, n_begin = sp * p.range;
+    const int nsteps = (min(p.N, n_begin + p.range) - n_begin) >> 4;
+    const int la = lane & 15, rr = lane >> 4;
+    const float* drow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) drow[mt] = p.a + (long)min(16 * mt + la, p.M - 1) * p.N + n_begin + 4 * rr;
+    const float* wbase = p.w + (long)(n_begin + 4 * rr) * p.K + k0 + 4 * la;
+    f32x4 dq[LS_DEPTH][MT], wq[LS_DEPTH][4], acc[4][MT];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[t][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto load = [&](int s, f32x4 (&d4)[MT], f32x4 (&w4)[4]) {
+        const int nb = 16 * (s < nsteps ? s : nsteps - 1);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) d4[mt] = *reinterpret_cast<const f32x4*>(drow[mt] + nb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w4[e] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wbase + (long)(nb + e) * p.K));
+    };
+    auto mma = [&](const f32x4 (&d4)[MT], const f32x4 (&w4)[4]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[e][t], d4[mt][e], acc[t][mt], 0, 0, 0);
+    };
+    auto step = [&](int s, auto J) {
+        constexpr int j = decltype(J)::value;
+        load(s + LS_DEPTH - 1, dq[(j + LS_DEPTH - 1) % LS_DEPTH], wq[(j + LS_DEPTH - 1) % LS_DEPTH]);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(dq[j], wq[j]);
+    };
+    if (nsteps > 0) {
+#pragma unroll
+        for (int d = 0; d < LS_DEPTH - 1; ++d) load(d, dq[d], wq[d]);
+        for (int s = 0; s < nsteps; s += LS_DEPTH)
+            if (ls_run_steps<0, LS_DEPTH>(s, nsteps, step)) break;
+    }
+    // acc[t][mt][jj] = dx[m = 16 mt + la][k0 + 16 rr + 4 jj + t]
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = 16 * mt + la;
+        if (m >= p.M) continue;
+        float* dst = (p.nsplit > 1 ? p.slab + ((long)sp * p.M + m) * p.K : p.out + (long)m * p.K) + k0 + 16 * rr;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+            *reinterpret_cast<f32x4*>(dst + 4 * jj) = (f32x4){acc[0][mt][jj], acc[1][mt][jj], acc[2][mt][jj], acc[3][mt][jj]};
+    }
+}
+
+// weight gradient: dW[n][k] = sum_m dy[m][n] x[m][k].  Item = 64 x 64 output tile; the reduction index m (<= 64) is the
+// MFMA K dimension, both operands are loaded as quads along their OUTPUT index: lane (a, rr) holds dy[m0+rr][n0+4a..] and
+// x[m0+rr][k0+4a..]; MFMA (t', t) produces dW[n0 + 4 i + t'][k0 + 4 j + t] - one pair of loads feeds 16 MFMAs.
+// (A 16 x 256 tile with 1 KiB-contiguous writes was measured slower: 39 / 48 us against 38 / 40 us.)
+__global__ __launch_bounds__(LTHREADS) void linear_bwd_wgt_stream_kernel(const LSParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int item = sh_xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
+    const int ktiles = p.K >> 6;
+    if (item >= (p.N >> 6) * ktiles) return;
+    const int kt = item % ktiles, ntile = item / ktiles;
+    const int n0 = ntile * 64, k0 = kt * 64;
+    const int la = lane & 15, rr = lane >> 4;
+    const int nsteps = (p.M + 3) >> 2;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 dq[4], xq[4];
+    auto load = [&](int s, f32x4& d4, f32x4& x4) {
+        s = s < nsteps ? s : nsteps - 1;
+        const int m = 4 * s + rr;
+        const int mc = m < p.M ? m : p.M - 1;
+        d4 = *reinterpret_cast<const f32x4*>(p.a + (long)mc * p.N + n0 + 4 * la);
+        x4 = *reinterpret_cast<const f32x4*>(p.w + (long)mc * p.K + k0 + 4 * la);
+        if (m >= p.M) d4 = (f32x4){0.f, 0.f, 0.f, 0.f};            // rows are the reduction index
+    };
+    auto mma = [&](const f32x4& d4, const f32x4& x4) {
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int tk = 0; tk < 4; ++tk) acc[tn][tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(d4[tn], x4[tk], acc[tn][tk], 0, 0, 0);
+    };
+    // M <= 64 -> at most 16 steps: four register sets rotate
+    load(0, dq[0], xq[0]); load(1, dq[1], xq[1]); load(2, dq[2], xq[2]);
+    for (int s = 0; s < nsteps; s += 4) {
+        load(s + 3, dq[3], xq[3]); __builtin_amdgcn_sched_barrier(0); mma(dq[0], xq[0]);
+        if (s + 1 >= nsteps) break;
+        load(s + 4, dq[0], xq[0]); __builtin_amdgcn_sched_barrier(0); mma(dq[1], xq[1]);
+        if (s + 2 >= nsteps) break;
+        load(s + 5, dq[1], xq[1]); __builtin_amdgcn_sched_barrier(0); mma(dq[2], xq[2]);
+        if (s + 3 >= nsteps) break;
+        load(s + 6, dq[2], xq[2]); __builtin_amdgcn_sched_barrier(0); mma(dq[3], xq[3]);
+    }
+    // acc[tn][tk][jj] = dW[n0 + 16 rr + 4 jj + tn][k0 + 4 la + tk]
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            float* dst = p.out + (long)(n0 + 16 * rr + 4 * jj + tn) * p.K + k0 + 4 * la;
+            __builtin_nontemporal_store((f32x4){acc[tn][0][jj], acc[tn][1][jj], acc[tn][2][jj], acc[tn][3][jj]}, reinterpret_cast<f32x4*>(dst));
+        }
+}
+
+// plan of the streaming forms: enough items for one wave per SIMD (1024), reduction ranges multiples of 16
+struct LSPlan { bool ok; int range, nsplit, groups; };
+LSPlan plan_stream(int M, int out_cols, int red_len) {
+    LSPlan pl{false, red_len, 1, out_cols / 64};
+    static const int on = sh_env_int("SH_LIN_STREAM", 1, 0, 1);
+    if (!on || M > 64 || out_cols % 64 != 0 || red_len % 16 != 0) return pl;
+    pl.ok = true;
+    static const int items = sh_env_int("SH_LIN_ITEMS", 1024, 64, 1 << 20);
+    if (pl.groups < items / 2 && red_len >= 1024) {
+        int ns = items / pl.groups;
+        int rg = sh_cdiv(sh_cdiv(red_len, ns), 16) * 16;
+        if (rg < 64) rg = 64;
+        pl.range = rg;
+        pl.nsplit = sh_cdiv(red_len, rg);
+    }
+    return pl;
+}
+bool aligned16(const void* a, const void* b, const void* c) {
+    return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
+}
+
 int mode_of(const float* base, long s_row, long s_r, int rows, int R) {
     const bool aligned = (reinterpret_cast<uintptr_t>(base) & 15) == 0;
     if (s_r == 1 && (s_row & 3) == 0 && (R & 3) == 0 && aligned) return 0;
@@ -274,6 +510,35 @@ int run_gemm(SGParams& p, void* ws, size_t ws_bytes, hipStream_t st, const char*
     return SH_OK;
 }
 
+// launches the forward / backward-data streaming kernel (+ the split reduction); `cols` = output columns
+template <bool FWD>
+int run_stream(LSParams& p, const LSPlan& pl, int cols, void* ws, size_t ws_bytes, hipStream_t st, const char* what) {
+    p.range = pl.range; p.nsplit = pl.nsplit; p.groups = pl.groups;
+    const float* bias = p.bias;
+    if (p.nsplit > 1) {
+        SH_REQUIRE(ws && ws_bytes >= (size_t)p.nsplit * p.M * cols * sizeof(float), SH_ERR_WORKSPACE, "%s: workspace too small", what);
+        p.slab = static_cast<float*>(ws);
+    }
+    const int items = p.groups * p.nsplit, grid = sh_cdiv(items, 4), mt = sh_cdiv(p.M, 16);
+    {
+        ShProfScope ps(st, "%s<%d>|M=%d N=%d K=%d split=%d", FWD ? "linear_fwd_stream_kernel" : "linear_bwd_data_stream_kernel", mt, p.M,
+                       p.N, p.K, p.nsplit);
+#define SH_LS_CASE(MTV)                                                                                                   \
+    if (FWD) hipLaunchKernelGGL(linear_fwd_stream_kernel<MTV>, dim3(grid), dim3(LTHREADS), 0, st, p);                     \
+    else hipLaunchKernelGGL(linear_bwd_data_stream_kernel<MTV>, dim3(grid), dim3(LTHREADS), 0, st, p)
+        if (mt == 1) { SH_LS_CASE(1); } else if (mt == 2) { SH_LS_CASE(2); } else if (mt == 3) { SH_LS_CASE(3); } else { SH_LS_CASE(4); }
+#undef SH_LS_CASE
+    }
+    if (p.nsplit > 1) {
+        const long mn = (long)p.M * cols;
+        ShProfScope ps(st, "split_reduce_kernel");
+        hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)((mn + 63) / 64)), dim3(1024), 0, st, p.slab, p.nsplit, mn, cols, bias,
+                           p.out);
+    }
+    SH_CHECK_LAUNCH(what);
+    return SH_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -281,6 +546,11 @@ extern "C" {
 size_t sh_linear_workspace(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     size_t need = 0;
+    {   // streaming forms: forward splits K (output [M][N]), backward-data splits N (output [M][K])
+        const LSPlan f = plan_stream(M, N, K), d = plan_stream(M, K, N);
+        if (f.ok && f.nsplit > 1) need = (size_t)f.nsplit * M * N * sizeof(float);
+        if (d.ok && d.nsplit > 1 && (size_t)d.nsplit * M * K * sizeof(float) > need) need = (size_t)d.nsplit * M * K * sizeof(float);
+    }
     const int dims[3][3] = {{M, N, K}, {M, K, N}, {N, K, M}};      // fwd, bwd_data, bwd_wgt as (rows, cols, reduction)
     for (auto& d : dims) {
         const SGPlan pl = plan_split(d[0], d[1], d[2]);
@@ -295,6 +565,14 @@ size_t sh_linear_workspace(int M, int N, int K) {
 int sh_linear_fwd(const float* x, const float* weight, const float* bias, float* y, int M, int N, int K, void* workspace,
                   size_t workspace_bytes, sh_stream_t stream) {
     SH_REQUIRE(x && weight && y && M > 0 && N > 0 && K > 0, SH_ERR_INVALID_ARG, "sh_linear_fwd: bad argument");
+    {
+        const LSPlan pl = plan_stream(M, N, K);
+        if (pl.ok && aligned16(x, weight, y) && (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0)) {
+            LSParams s{};
+            s.a = x; s.w = weight; s.bias = bias; s.out = y; s.M = M; s.N = N; s.K = K;
+            return run_stream<true>(s, pl, N, workspace, workspace_bytes, static_cast<hipStream_t>(stream), "linear_fwd");
+        }
+    }
     SGParams p{};
     p.a = x; p.a_sm = K; p.a_sr = 1;
     p.b = weight; p.b_sn = K; p.b_sr = 1;
@@ -306,6 +584,14 @@ int sh_linear_fwd(const float* x, const float* weight, const float* bias, float*
 int sh_linear_bwd_data(const float* dy, const float* weight, float* dx, int M, int N, int K, void* workspace,
                        size_t workspace_bytes, sh_stream_t stream) {
     SH_REQUIRE(dy && weight && dx && M > 0 && N > 0 && K > 0, SH_ERR_INVALID_ARG, "sh_linear_bwd_data: bad argument");
+    {
+        const LSPlan pl = plan_stream(M, K, N);
+        if (pl.ok && aligned16(dy, weight, dx)) {
+            LSParams s{};
+            s.a = dy; s.w = weight; s.bias = nullptr; s.out = dx; s.M = M; s.N = N; s.K = K;
+            return run_stream<false>(s, pl, K, workspace, workspace_bytes, static_cast<hipStream_t>(stream), "linear_bwd_data");
+        }
+    }
     SGParams p{};                                   // dx(m,k) = sum_n dy(m,n) W(n,k)
     p.a = dy; p.a_sm = N; p.a_sr = 1;
     p.b = weight; p.b_sn = 1; p.b_sr = K;           // B(k, n) = W[n*K + k]
@@ -318,6 +604,19 @@ int sh_linear_bwd_wgt(const float* dy, const float* x, float* dW, float* dbias, 
                       size_t workspace_bytes, sh_stream_t stream) {
     SH_REQUIRE(dy && x && dW && M > 0 && N > 0 && K > 0, SH_ERR_INVALID_ARG, "sh_linear_bwd_wgt: bad argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    static const int stream_on = sh_env_int("SH_LIN_STREAM", 1, 0, 1);
+    if (stream_on && M <= 64 && N % 64 == 0 && K % 64 == 0 && aligned16(dy, x, dW)) {
+        LSParams s{};
+        s.a = dy; s.w = x; s.out = dW; s.M = M; s.N = N; s.K = K;
+        const int items = (N / 64) * (K / 64);
+        {
+            ShProfScope ps(st, "linear_bwd_wgt_stream_kernel|M=%d N=%d K=%d", M, N, K);
+            hipLaunchKernelGGL(linear_bwd_wgt_stream_kernel, dim3(sh_cdiv(items, 4)), dim3(LTHREADS), 0, st, s);
+        }
+        if (dbias) hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)sh_cdiv(N, 256)), dim3(256), 0, st, dy, M, N, dbias);
+        SH_CHECK_LAUNCH("linear_bwd_wgt");
+        return SH_OK;
+    }
     SGParams p{};                                   // dW(n,k) = sum_m dy(m,n) x(m,k)
     p.a = dy; p.a_sm = 1; p.a_sr = N;               // A(n, m) = dy[m*N + n]
     p.b = x; p.b_sn = 1; p.b_sr = K;                // B(k, m) = x[m*K + k]
