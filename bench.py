@@ -270,11 +270,21 @@ def main():
             f[0] += k["ms_per_step"]
             if k["kernel"] in table:
                 f[1] += table[k["kernel"]]["flops"]
+        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+        # collected separately; tools/pmc_traffic.py) - measured on the same workload, not in this run
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            traffic = pmc[dom["kernel"]]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         if "tflops" in dom:
             result["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
-                                  "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                                  "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                                  "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)",
                                   "avg_launch_ms": dom["avg_ms"], "launches_per_step": dom["launches_per_step"],
-                                  "flops_per_launch": table[dom["kernel"]]["flops"] / table[dom["kernel"]]["launches"]}
+                                  "flops_per_launch": table[dom["kernel"]]["flops"] / table[dom["kernel"]]["launches"],
+                                  "algorithmic_bytes_per_launch": table[dom["kernel"]]["bytes"] / table[dom["kernel"]]["launches"]}
         else:
             result["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                   "frac": None, "traffic": None, "avg_launch_ms": dom["avg_ms"]}

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""HBM traffic per kernel launch from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected SEPARATELY, as
+MI355X_MICROARCH.md 'HBM / rocprofv3 PMC slots' prescribes) of `python3 tools/layer_report.py`:
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/pmc_fetch -o fetch --output-format csv -- python3 tools/layer_report.py
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/pmc_write -o write --output-format csv -- python3 tools/layer_report.py
+    python3 tools/pmc_traffic.py gpurun_out/pmc_fetch/fetch_counter_collection.csv gpurun_out/pmc_write/write_counter_collection.csv profiles/r01_pmc_traffic
+
+Units / corrections (same guide): both counters are in KiB; on gfx950 FETCH_SIZE tallies the 128-byte requests of wide
+coalesced reads at 64 bytes, so it is doubled; WRITE_SIZE is exact.  Writes <out>.json (kernel name -> mean bytes per
+launch, keyed like rocprofv3 --stats prints the name minus the 'void (anonymous namespace)::' prefix and the
+argument list) and <out>.txt (one line per launch of one training step)."""
+import csv
+import json
+import re
+import sys
+from collections import OrderedDict, defaultdict
+
+
+def short(name):
+    n = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "")
+    return re.sub(r"\(.*$", "", n)
+
+
+def read(path, counter):
+    rows = []
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] == counter:
+                rows.append((int(r["Dispatch_Id"]), short(r["Kernel_Name"]), int(r["Grid_Size"]), float(r["Counter_Value"])))
+    rows.sort()
+    return rows
+
+
+def main():
+    fetch, write, out = read(sys.argv[1], "FETCH_SIZE"), read(sys.argv[2], "WRITE_SIZE"), sys.argv[3]
+    ours = lambda n: any(k in n for k in ("gather_gemm", "wgrad", "spmm", "skinny", "linear_", "adam", "slab_reduce", "split_reduce"))  # noqa: E731
+    agg = defaultdict(lambda: [0, 0.0, 0.0])
+    for (_, n, _, v) in fetch:
+        if ours(n):
+            agg[n][0] += 1; agg[n][1] += 2.0 * v * 1024.0
+    cnt_w = defaultdict(int)
+    for (_, n, _, v) in write:
+        if ours(n):
+            cnt_w[n] += 1; agg[n][2] += v * 1024.0
+    res = OrderedDict()
+    for n, (c, fb, wb) in sorted(agg.items(), key=lambda kv: -(kv[1][1] + kv[1][2])):
+        res[n] = {"launches_profiled": c, "fetch_bytes_per_launch": fb / c, "write_bytes_per_launch": wb / max(1, cnt_w[n]),
+                  "hbm_bytes_per_launch": fb / c + wb / max(1, cnt_w[n])}
+    json.dump(res, open(out + ".json", "w"), indent=1)
+    with open(out + ".txt", "w") as f:
+        f.write("# HBM bytes per launch, mean over the profiled launches (FETCH_SIZE x2 correction applied; see tools/pmc_traffic.py)\n")
+        f.write("%-60s %8s %12s %12s\n" % ("kernel", "launches", "fetch MB", "write MB"))
+        for n, r in res.items():
+            f.write("%-60s %8d %12.1f %12.1f\n" % (n, r["launches_profiled"], r["fetch_bytes_per_launch"] / 1e6, r["write_bytes_per_launch"] / 1e6))
+    print(open(out + ".txt").read())
+
+
+if __name__ == "__main__":
+    main()
