@@ -138,7 +138,7 @@ int sh_adam_step(int n_tensors, float* const* params, const float* const* grads,
         a.w1 = (float)(1.0 - beta1); a.b2 = (float)beta2; a.w2 = (float)(1.0 - beta2); a.eps = (float)eps; a.wd = (float)weight_decay;
         {
             ShProfScope ps(st, "adam_kernel|tensors=%d blocks=%ld", a.nt, blocks);
-            hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(ANT), 0, st, a);
+            SH_LAUNCH_PS(ps, adam_kernel, dim3((unsigned)blocks), dim3(ANT), 0, st, a);
         }
         hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(64), 0, st, a);
         SH_CHECK_LAUNCH("adam_step");

@@ -498,12 +498,12 @@ int run_gemm(SGParams& p, void* ws, size_t ws_bytes, hipStream_t st, const char*
     const long grid = (long)p.n_mtiles * p.n_ntiles * p.nsplit;
     {
         ShProfScope ps(st, "skinny_gemm_kernel|%s M=%d N=%d R=%d split=%d modes=%d%d", what, p.M, p.N, p.R, p.nsplit, p.a_mode, p.b_mode);
-        hipLaunchKernelGGL(skinny_gemm_kernel, dim3((unsigned)grid), dim3(LTHREADS), 0, st, p);
+        SH_LAUNCH_PS(ps, skinny_gemm_kernel, dim3((unsigned)grid), dim3(LTHREADS), 0, st, p);
     }
     if (p.nsplit > 1) {
         const long mn = (long)p.M * p.N;
         ShProfScope ps(st, "split_reduce_kernel");
-        hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)((mn + 63) / 64)), dim3(1024), 0, st, p.slab, p.nsplit, mn, p.N,
+        SH_LAUNCH_PS(ps, split_reduce_kernel, dim3((unsigned)((mn + 63) / 64)), dim3(1024), 0, st, p.slab, p.nsplit, mn, p.N,
                            bias, p.c);
     }
     SH_CHECK_LAUNCH(what);
@@ -524,15 +524,15 @@ int run_stream(LSParams& p, const LSPlan& pl, int cols, void* ws, size_t ws_byte
         ShProfScope ps(st, "%s<%d>|M=%d N=%d K=%d split=%d", FWD ? "linear_fwd_stream_kernel" : "linear_bwd_data_stream_kernel", mt, p.M,
                        p.N, p.K, p.nsplit);
 #define SH_LS_CASE(MTV)                                                                                                   \
-    if (FWD) hipLaunchKernelGGL(linear_fwd_stream_kernel<MTV>, dim3(grid), dim3(LTHREADS), 0, st, p);                     \
-    else hipLaunchKernelGGL(linear_bwd_data_stream_kernel<MTV>, dim3(grid), dim3(LTHREADS), 0, st, p)
+    if (FWD) SH_LAUNCH_PS(ps, linear_fwd_stream_kernel<MTV>, dim3(grid), dim3(LTHREADS), 0, st, p);                     \
+    else SH_LAUNCH_PS(ps, linear_bwd_data_stream_kernel<MTV>, dim3(grid), dim3(LTHREADS), 0, st, p)
         if (mt == 1) { SH_LS_CASE(1); } else if (mt == 2) { SH_LS_CASE(2); } else if (mt == 3) { SH_LS_CASE(3); } else { SH_LS_CASE(4); }
 #undef SH_LS_CASE
     }
     if (p.nsplit > 1) {
         const long mn = (long)p.M * cols;
         ShProfScope ps(st, "split_reduce_kernel");
-        hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)((mn + 63) / 64)), dim3(1024), 0, st, p.slab, p.nsplit, mn, cols, bias,
+        SH_LAUNCH_PS(ps, split_reduce_kernel, dim3((unsigned)((mn + 63) / 64)), dim3(1024), 0, st, p.slab, p.nsplit, mn, cols, bias,
                            p.out);
     }
     SH_CHECK_LAUNCH(what);
@@ -611,7 +611,7 @@ int sh_linear_bwd_wgt(const float* dy, const float* x, float* dW, float* dbias, 
         const int items = (N / 64) * (K / 64);
         {
             ShProfScope ps(st, "linear_bwd_wgt_stream_kernel|M=%d N=%d K=%d", M, N, K);
-            hipLaunchKernelGGL(linear_bwd_wgt_stream_kernel, dim3(sh_cdiv(items, 4)), dim3(LTHREADS), 0, st, s);
+            SH_LAUNCH_PS(ps, linear_bwd_wgt_stream_kernel, dim3(sh_cdiv(items, 4)), dim3(LTHREADS), 0, st, s);
         }
         if (dbias) hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)sh_cdiv(N, 256)), dim3(256), 0, st, dy, M, N, dbias);
         SH_CHECK_LAUNCH("linear_bwd_wgt");

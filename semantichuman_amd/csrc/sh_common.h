@@ -1,6 +1,7 @@
 // Shared device helpers for the gfx950 kernels of libsh_kernels.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include "../../include/sh_kernels.h"
@@ -33,10 +34,20 @@ void sh_set_error(const char* fmt, ...);
 bool sh_profile_on();
 void sh_profile_push(const char* name, hipEvent_t a, hipEvent_t b);
 struct ShProfScope {
-    hipStream_t st; hipEvent_t a, b; bool on; char name[96];
+    hipStream_t st; hipEvent_t a, b; bool on; bool ext; char name[96];
     ShProfScope(hipStream_t s, const char* fmt, ...);
     ~ShProfScope();
+    // first launch of the scope takes the start event; every launch re-targets the stop event (the last one wins)
+    hipEvent_t take_start() { hipEvent_t e = ext ? nullptr : a; ext = true; return e; }
 };
+// Launch inside a ShProfScope.  When profiling is on, the events are attached to the kernel dispatch itself
+// (hipExtLaunchKernelGGL: begin / end of the kernel's execution, what rocprofv3 --kernel-trace reports) instead of
+// bracketing it with event records on the stream, which would add the dispatch latency to every measurement.
+#define SH_LAUNCH_PS(ps, kernel, grid, block, smem, st, ...)                                                          \
+    do {                                                                                                              \
+        if ((ps).on) hipExtLaunchKernelGGL(kernel, grid, block, smem, st, (ps).take_start(), (ps).b, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel, grid, block, smem, st, __VA_ARGS__);                                          \
+    } while (0)
 
 // ---------------------------------------------------------------------------- activations
 // Forward activation (reference models.py:19-32) ...

@@ -36,7 +36,7 @@ void sh_profile_push(const char* name, hipEvent_t a, hipEvent_t b) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof.push_back({name, a, b});
 }
-ShProfScope::ShProfScope(hipStream_t s, const char* fmt, ...) : st(s), a(nullptr), b(nullptr), on(g_prof_on) {
+ShProfScope::ShProfScope(hipStream_t s, const char* fmt, ...) : st(s), a(nullptr), b(nullptr), on(g_prof_on), ext(false) {
     if (!on) return;
     va_list ap;
     va_start(ap, fmt);
@@ -48,7 +48,7 @@ ShProfScope::ShProfScope(hipStream_t s, const char* fmt, ...) : st(s), a(nullptr
 }
 ShProfScope::~ShProfScope() {
     if (!on) return;
-    (void)hipEventRecord(b, st);
+    if (!ext) (void)hipEventRecord(b, st);        // scopes whose launches carry the events themselves need no record
     sh_profile_push(name, a, b);
 }
 

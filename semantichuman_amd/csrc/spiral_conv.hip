@@ -490,7 +490,7 @@ int launch_ggd(const GGParams& p, int nblocks, hipStream_t st) {
     const size_t smem = (size_t)(3 * NT * 16 * KC) * sizeof(float) + (size_t)(TV * p.S) * sizeof(int);
     ShProfScope ps(st, "gather_gemm_direct_kernel<%d, %s>|R=%d B=%d K=%d N=%d grid=%d", NT, BWD_EPI ? "true" : "false", p.R, p.B,
                    p.K, p.Nout, nblocks);
-    hipLaunchKernelGGL((gather_gemm_direct_kernel<NT, BWD_EPI>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
+    SH_LAUNCH_PS(ps, (gather_gemm_direct_kernel<NT, BWD_EPI>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
     SH_CHECK_LAUNCH("gather_gemm_direct");
     return SH_OK;
 }
@@ -504,9 +504,9 @@ int launch_gg(const GGParams& p, int nblocks, hipStream_t st) {
                        BWD_EPI ? "true" : "false", p.log2TB == 4 ? "true" : "false", C3 ? "true" : "false", p.R, p.B, p.K, p.Nout,
                        nblocks);
         if (p.log2TB == 4)
-            hipLaunchKernelGGL((gather_gemm_kernel<NT, VEC4, BWD_EPI, true, C3>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
+            SH_LAUNCH_PS(ps, (gather_gemm_kernel<NT, VEC4, BWD_EPI, true, C3>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
         else
-            hipLaunchKernelGGL((gather_gemm_kernel<NT, VEC4, BWD_EPI, false, C3>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
+            SH_LAUNCH_PS(ps, (gather_gemm_kernel<NT, VEC4, BWD_EPI, false, C3>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
     }
     SH_CHECK_LAUNCH("gather_gemm");
     return SH_OK;
@@ -1108,8 +1108,8 @@ int launch_ws(const WSParams& p, hipStream_t st) {
     const bool c3 = p.Cin == 3;
     ShProfScope ps(st, "wgrad_stream_kernel<%d, %d, %d, %s, %s>|R=%d B=%d K=%d N=%d grid=%d", COT, NG, DEPTH, FULL ? "true" : "false",
                    c3 ? "true" : "false", p.R, p.B, p.K, p.Cout, grid);
-    if (c3) hipLaunchKernelGGL((wgrad_stream_kernel<COT, NG, DEPTH, FULL, true>), dim3(grid), dim3(NTHREADS), smem, st, p);
-    else hipLaunchKernelGGL((wgrad_stream_kernel<COT, NG, DEPTH, FULL, false>), dim3(grid), dim3(NTHREADS), smem, st, p);
+    if (c3) SH_LAUNCH_PS(ps, (wgrad_stream_kernel<COT, NG, DEPTH, FULL, true>), dim3(grid), dim3(NTHREADS), smem, st, p);
+    else SH_LAUNCH_PS(ps, (wgrad_stream_kernel<COT, NG, DEPTH, FULL, false>), dim3(grid), dim3(NTHREADS), smem, st, p);
     SH_CHECK_LAUNCH("wgrad_stream");
     return SH_OK;
 }
@@ -1131,8 +1131,8 @@ int launch_wg(const WGParams& p, const WGPlan& w, bool vec4, hipStream_t st) {
     dim3 grid(w.ncg * w.nrc);
     ShProfScope ps(st, "wgrad_kernel<%d, %d, %s>|R=%d B=%d K=%d N=%d grid=%d", COT, CTW, vec4 ? "true" : "false", p.R, p.B, p.K,
                    p.Cout, w.ncg * w.nrc);
-    if (vec4) hipLaunchKernelGGL((wgrad_kernel<COT, CTW, true>), grid, dim3(NTHREADS), smem, st, p);
-    else hipLaunchKernelGGL((wgrad_kernel<COT, CTW, false>), grid, dim3(NTHREADS), smem, st, p);
+    if (vec4) SH_LAUNCH_PS(ps, (wgrad_kernel<COT, CTW, true>), grid, dim3(NTHREADS), smem, st, p);
+    else SH_LAUNCH_PS(ps, (wgrad_kernel<COT, CTW, false>), grid, dim3(NTHREADS), smem, st, p);
     SH_CHECK_LAUNCH("wgrad");
     return SH_OK;
 }
@@ -1260,7 +1260,7 @@ int sh_spiral_conv_bwd_wgt(const float* dpre, int64_t dp_sv, int64_t dp_sb, cons
     if (!dW) return SH_OK;            // deferred: the caller reduces several layers at once (.._reduce_multi)
     const long n = p.slab_stride;
     ShProfScope ps(st, "slab_reduce_kernel");
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, st, p.slab, p.slab_stride, w.nrc, n, dW);
+    SH_LAUNCH_PS(ps, slab_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, st, p.slab, p.slab_stride, w.nrc, n, dW);
     if (dbias)
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((Cout + 63) / 64)), dim3(1024), 0, st, p.slab + p.bias_off,
                            (long)Cout, w.nrc, (long)Cout, dbias);
@@ -1291,7 +1291,7 @@ int sh_spiral_conv_bwd_wgt_reduce_multi(int n_layers, const void* const* workspa
     m.nd = nd;
     hipStream_t st = static_cast<hipStream_t>(stream);
     ShProfScope ps(st, "slab_reduce_multi_kernel");
-    hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, m);
+    SH_LAUNCH_PS(ps, slab_reduce_multi_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, m);
     SH_CHECK_LAUNCH("slab_reduce_multi");
     return SH_OK;
 }

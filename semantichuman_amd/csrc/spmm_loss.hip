@@ -208,10 +208,10 @@ int sh_spmm(const int32_t* rowptr, const int32_t* col, const float* val, const f
     hipStream_t st = static_cast<hipStream_t>(stream);
     ShProfScope ps(st, "spmm_kernel<%s>|rows=%d B=%d C=%d", vec ? "true" : "false", rows, B, C);
     if (vec)
-        hipLaunchKernelGGL(spmm_kernel<true>, dim3(grid), dim3(256), 0, st, rowptr, col, val, x, x_sv, x_sb, y, y_sv, y_sb,
+        SH_LAUNCH_PS(ps, spmm_kernel<true>, dim3(grid), dim3(256), 0, st, rowptr, col, val, x, x_sv, x_sb, y, y_sv, y_sb,
                            yprev, yp_sv, yp_sb, act_prev, zero_row, B, rows, C);
     else
-        hipLaunchKernelGGL(spmm_kernel<false>, dim3(grid), dim3(256), 0, st, rowptr, col, val, x, x_sv, x_sb, y, y_sv, y_sb,
+        SH_LAUNCH_PS(ps, spmm_kernel<false>, dim3(grid), dim3(256), 0, st, rowptr, col, val, x, x_sv, x_sb, y, y_sv, y_sb,
                            yprev, yp_sv, yp_sb, act_prev, zero_row, B, rows, C);
     SH_CHECK_LAUNCH("spmm");
     return SH_OK;
