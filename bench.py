@@ -151,7 +151,7 @@ def main():
     def fwd_bwd():
         optim.zero_grad(set_to_none=True)
         x_hat, _ = model(xin)
-        loss = sh.l1_loss(xin, x_hat) + 1e-2 * sh.edge_ratio_loss(x_hat, xin, ft)     # traincfg.yaml:41
+        loss, _ = sh.recon_loss(x_hat, xin, ft, 1e-2)     # l1 + 1e-2 * edge (train_funcs.py:501-508, traincfg.yaml:41), fused
         if reducer:
             reducer.prepare()
         loss.backward()

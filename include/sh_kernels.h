@@ -196,6 +196,17 @@ SH_API int sh_edge_ratio_loss_bwd(const float* x_hat, const float* x, const int3
                            const int32_t* vptr, const int32_t* vcorner, int B, int N1, int F,
                            const float* gscale, float* grad, sh_stream_t stream);
 
+/* The reconstruction loss of the plain training loop in one piece (train_funcs.py:501-508):
+ *   out3[0] = out3[1] + edge_w * out3[2],  out3[1] = mean |x - x_hat| (all N1 rows),  out3[2] = the edge-ratio term above;
+ * bwd writes grad = gscale[0] * d out3[0] / d x_hat.  Three launches instead of eleven; same arithmetic as the separate
+ * kernels.  workspace: sh_recon_loss_workspace() bytes. */
+SH_API size_t sh_recon_loss_workspace(void);
+SH_API int sh_recon_loss_fwd(const float* x_hat, const float* x, const int32_t* faces, int B, int N1, int F, float edge_w,
+                      float* out3, void* workspace, sh_stream_t stream);
+SH_API int sh_recon_loss_bwd(const float* x_hat, const float* x, const int32_t* faces, const int32_t* vptr,
+                      const int32_t* vcorner, int B, int N1, int F, float edge_w, const float* gscale, float* grad,
+                      sh_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Part-wise pairwise-distance loss of the semantic training loop (train_funcs.py:243-284 and
  * :353-389; utils_distance.calc_euclidean_dist_matrix :366-376; utils_SH.angle_skl :442-478).

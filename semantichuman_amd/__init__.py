@@ -6,7 +6,7 @@ reference's own nn.Module interface.  Importing the package works without a GPU;
 model does not (no CPU fallback).
 """
 from .models import SpiralAutoencoder, SpiralConv  # noqa: F401
-from .losses import FaceTables, edge_ratio_loss, eval_l1, l1_loss, vertex_l2_mm  # noqa: F401
+from .losses import FaceTables, edge_ratio_loss, eval_l1, l1_loss, recon_loss, vertex_l2_mm  # noqa: F401
 
 __version__ = "0.1.0"
 from .models import SpiralAutoencoder_multiz_partkps  # noqa: F401,E402

@@ -255,6 +255,7 @@ struct LSParams {
     const float* bias;
     float* out;          // result (nsplit == 1) ...
     float* slab;         // ... or [nsplit][M][cols] partials
+    float* dbias;        // weight-gradient kernel: column sums of dy (bias gradient) or null
     int M, N, K;
     int range, nsplit, groups;     // reduction range per split (multiple of 16), #splits, #64-wide output groups
 };
@@ -413,11 +414,15 @@ __global__ __launch_bounds__(LTHREADS) void linear_bwd_wgt_stream_kernel(const L
         x4 = *reinterpret_cast<const f32x4*>(p.w + (long)mc * p.K + k0 + 4 * la);
         if (m >= p.M) d4 = (f32x4){0.f, 0.f, 0.f, 0.f};            // rows are the reduction index
     };
+    // the tiles of the first column block also own the bias gradient of their 64 rows: db[n] = sum_m dy[m][n]
+    const bool own_bias = kt == 0 && p.dbias != nullptr;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     auto mma = [&](const f32x4& d4, const f32x4& x4) {
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
             for (int tk = 0; tk < 4; ++tk) acc[tn][tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(d4[tn], x4[tk], acc[tn][tk], 0, 0, 0);
+        if (own_bias) bsum += d4;
     };
     // M <= 64 -> at most 16 steps: four register sets rotate
     load(0, dq[0], xq[0]); load(1, dq[1], xq[1]); load(2, dq[2], xq[2]);
@@ -429,6 +434,16 @@ __global__ __launch_bounds__(LTHREADS) void linear_bwd_wgt_stream_kernel(const L
         load(s + 5, dq[1], xq[1]); __builtin_amdgcn_sched_barrier(0); mma(dq[2], xq[2]);
         if (s + 3 >= nsteps) break;
         load(s + 6, dq[2], xq[2]); __builtin_amdgcn_sched_barrier(0); mma(dq[3], xq[3]);
+    }
+    if (own_bias) {                                                   // fixed order: steps in sequence, then the four row groups
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = bsum[j];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            bsum[j] = v;
+        }
+        if (rr == 0) *reinterpret_cast<f32x4*>(p.dbias + n0 + 4 * la) = bsum;
     }
     // acc[tn][tk][jj] = dW[n0 + 16 rr + 4 jj + tn][k0 + 4 la + tk]
 #pragma unroll
@@ -608,12 +623,13 @@ int sh_linear_bwd_wgt(const float* dy, const float* x, float* dW, float* dbias, 
     if (stream_on && M <= 64 && N % 64 == 0 && K % 64 == 0 && aligned16(dy, x, dW)) {
         LSParams s{};
         s.a = dy; s.w = x; s.out = dW; s.M = M; s.N = N; s.K = K;
+        s.dbias = (dbias && (reinterpret_cast<uintptr_t>(dbias) & 15) == 0) ? dbias : nullptr;      // fused into the tile kernel
         const int items = (N / 64) * (K / 64);
         {
             ShProfScope ps(st, "linear_bwd_wgt_stream_kernel|M=%d N=%d K=%d", M, N, K);
             SH_LAUNCH_PS(ps, linear_bwd_wgt_stream_kernel, dim3(sh_cdiv(items, 4)), dim3(LTHREADS), 0, st, s);
         }
-        if (dbias) hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)sh_cdiv(N, 256)), dim3(256), 0, st, dy, M, N, dbias);
+        if (dbias && !s.dbias) hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)sh_cdiv(N, 256)), dim3(256), 0, st, dy, M, N, dbias);
         SH_CHECK_LAUNCH("linear_bwd_wgt");
         return SH_OK;
     }

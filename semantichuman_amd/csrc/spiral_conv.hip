@@ -1149,18 +1149,33 @@ __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __re
     wt[i] = w[(long)co * S * Cin + (long)s * Cin + ci];
 }
 
+// one workgroup per row (vertex), 32-bit index arithmetic, 16-byte accesses when the channel count allows
+template <bool VEC4>
 __global__ void act_backward_kernel(const float* __restrict__ dy, long dy_sv, long dy_sb,
                                     const float* __restrict__ y, long y_sv, long y_sb,
                                     float* __restrict__ dp, long dp_sv, long dp_sb,
                                     int B, int R, int C, int act, int zero_row) {
-    const long n = (long)R * B * C;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        const long t = i / C;
-        const int b = (int)(t % B);
-        const int r = (int)(t / B);
-        const float g = dy[r * dy_sv + b * dy_sb + c] * sh_act_grad_from_out(y[r * y_sv + b * y_sb + c], act);
-        dp[r * dp_sv + b * dp_sb + c] = r == zero_row ? 0.f : g;
+    const int cq = VEC4 ? C >> 2 : C;                 // elements (or quads) per (row, batch) entry
+    const int per_row = B * cq;
+    for (int r = blockIdx.x; r < R; r += gridDim.x) {
+        const bool zero = r == zero_row;
+        const float* dyr = dy + (long)r * dy_sv;
+        const float* yr = y + (long)r * y_sv;
+        float* dpr = dp + (long)r * dp_sv;
+        for (int i = threadIdx.x; i < per_row; i += blockDim.x) {
+            const int b = i / cq, c = i - b * cq;
+            if (VEC4) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(dyr + (long)b * dy_sb + 4 * c);
+                const f32x4 yv = *reinterpret_cast<const f32x4*>(yr + (long)b * y_sb + 4 * c);
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = zero ? 0.f : g[j] * sh_act_grad_from_out(yv[j], act);
+                *reinterpret_cast<f32x4*>(dpr + (long)b * dp_sb + 4 * c) = o;
+            } else {
+                const float g = dyr[(long)b * dy_sb + c] * sh_act_grad_from_out(yr[(long)b * y_sb + c], act);
+                dpr[(long)b * dp_sb + c] = zero ? 0.f : g;
+            }
+        }
     }
 }
 
@@ -1318,10 +1333,16 @@ int sh_act_backward(const float* dy, int64_t dy_sv, int64_t dy_sb, const float* 
                     int64_t dp_sv, int64_t dp_sb, int B, int R, int C, int act, int zero_row, sh_stream_t stream) {
     SH_REQUIRE(dy && y && dpre && B > 0 && R > 0 && C > 0, SH_ERR_INVALID_ARG, "sh_act_backward: bad argument");
     SH_REQUIRE(act >= SH_ACT_IDENTITY && act <= SH_ACT_TANH, SH_ERR_INVALID_ARG, "sh_act_backward: unknown activation %d", act);
-    const long n = (long)R * B * C;
-    const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
-    hipLaunchKernelGGL(act_backward_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), dy, dy_sv, dy_sb, y,
-                       y_sv, y_sb, dpre, dp_sv, dp_sb, B, R, C, act, zero_row);
+    const bool vec = (C % 4 == 0) && ((dy_sv | dy_sb | y_sv | y_sb | dp_sv | dp_sb) % 4 == 0) &&
+                     ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dpre)) % 16 == 0);
+    const int blocks = R < 16384 ? R : 16384;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (vec)
+        hipLaunchKernelGGL(act_backward_kernel<true>, dim3(blocks), dim3(256), 0, st, dy, dy_sv, dy_sb, y, y_sv, y_sb, dpre, dp_sv, dp_sb,
+                           B, R, C, act, zero_row);
+    else
+        hipLaunchKernelGGL(act_backward_kernel<false>, dim3(blocks), dim3(256), 0, st, dy, dy_sv, dy_sb, y, y_sv, y_sb, dpre, dp_sv, dp_sb,
+                           B, R, C, act, zero_row);
     SH_CHECK_LAUNCH("act_backward");
     return SH_OK;
 }

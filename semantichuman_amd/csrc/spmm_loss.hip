@@ -185,6 +185,78 @@ __global__ void edge_loss_bwd_kernel(const float* __restrict__ xh, const float* 
     }
 }
 
+// ---- fused training loss: total = mean|x - x_hat| + w * edge_ratio(x_hat, x) in three launches instead of eleven
+// (each small launch costs a ~5 us slot of a replayed graph, whatever it computes).
+// One grid computes the partial sums of BOTH terms; part[0..nb) = L1 partials, part[RED_BLOCKS..+nb) = edge partials.
+__global__ void recon_partial_kernel(const float* __restrict__ xh, const float* __restrict__ x, const int* __restrict__ faces,
+                                     int B, int N1, int F, float* __restrict__ part) {
+    __shared__ float red[16];
+    float s = 0.f;
+    const long n = (long)B * N1 * 3;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s += fabsf(x[i] - xh[i]);
+    const float t1 = block_sum(s, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = t1;
+    __syncthreads();
+    s = 0.f;
+    const long nf = (long)B * F;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nf; i += (long)gridDim.x * blockDim.x) {
+        const long bb = i / F;
+        const int f = (int)(i - bb * F);
+        const int ia = faces[3 * f], ib = faces[3 * f + 1], ic = faces[3 * f + 2];
+        const float* ph = xh + bb * N1 * 3;
+        const float* pg = x + bb * N1 * 3;
+        s += fabsf(edge_len(ph, ia, ib) / (edge_len(pg, ia, ib) + 0.00001f) - 1.f);
+        s += fabsf(edge_len(ph, ib, ic) / (edge_len(pg, ib, ic) + 0.00001f) - 1.f);
+        s += fabsf(edge_len(ph, ia, ic) / (edge_len(pg, ia, ic) + 0.00001f) - 1.f);
+    }
+    const float t2 = block_sum(s, red);
+    if (threadIdx.x == 0) part[RED_BLOCKS + blockIdx.x] = t2;
+}
+
+// out[0] = rec + w * edge, out[1] = rec, out[2] = edge (fixed-order double sums)
+__global__ void recon_final_kernel(const float* __restrict__ part, int np, double scale1, double scale2, float w, float* __restrict__ out) {
+    __shared__ double red[2][256];
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = threadIdx.x; i < np; i += 256) { s1 += (double)part[i]; s2 += (double)part[RED_BLOCKS + i]; }
+    red[0][threadIdx.x] = s1; red[1][threadIdx.x] = s2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float rec = (float)(red[0][0] * scale1), edge = (float)(red[1][0] * scale2);
+        out[0] = rec + w * edge; out[1] = rec; out[2] = edge;
+    }
+}
+
+// grad[b,v,:] = g * ( sign(x_hat - x) / n  +  w / (B F) * d edge / d x_hat[b,v,:] )
+__global__ void recon_bwd_kernel(const float* __restrict__ xh, const float* __restrict__ x, const int* __restrict__ faces,
+                                 const int* __restrict__ vptr, const int* __restrict__ vcorner, int B, int N1, int F, float w,
+                                 const float* __restrict__ gscale, float* __restrict__ grad) {
+    const float g0 = gscale[0];
+    const float s1 = g0 / ((float)B * (float)N1 * 3.f), s2 = g0 * w / ((float)B * (float)F);
+    const long n = (long)B * N1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long bb = i / N1;
+        const int v = (int)(i - bb * N1);
+        const float* ph = xh + bb * N1 * 3;
+        const float* pg = x + bb * N1 * 3;
+        float g[3] = {0.f, 0.f, 0.f};
+        for (int e = vptr[v]; e < vptr[v + 1]; ++e) {
+            const int c = vcorner[e], f = c / 3, kx = c - 3 * f;
+            const int o1 = faces[3 * f + (kx + 1) % 3], o2 = faces[3 * f + (kx + 2) % 3];
+            edge_grad(ph, pg, v, o1, g);
+            edge_grad(ph, pg, v, o2, g);
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float df = ph[3 * v + d] - pg[3 * v + d];
+            grad[i * 3 + d] = s2 * g[d] + (df > 0.f ? s1 : (df < 0.f ? -s1 : 0.f));
+        }
+    }
+}
+
 inline int grid_for(long n, int per_block) {
     long g = (n + per_block - 1) / per_block;
     if (g < 1) g = 1;
@@ -264,6 +336,32 @@ int sh_edge_ratio_loss_fwd(const float* x_hat, const float* x, const int32_t* fa
     hipLaunchKernelGGL(edge_loss_partial_kernel, dim3(nb), dim3(256), 0, st, x_hat, x, faces, B, N1, F, part);
     hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, st, part, nb, 1.0 / (double)n, loss);
     SH_CHECK_LAUNCH("edge_ratio_loss_fwd");
+    return SH_OK;
+}
+
+size_t sh_recon_loss_workspace(void) { return (size_t)2 * RED_BLOCKS * sizeof(float); }
+
+int sh_recon_loss_fwd(const float* x_hat, const float* x, const int32_t* faces, int B, int N1, int F, float edge_w, float* out3,
+                      void* workspace, sh_stream_t stream) {
+    SH_REQUIRE(x_hat && x && faces && out3 && workspace && B > 0 && N1 > 0 && F > 0, SH_ERR_INVALID_ARG, "sh_recon_loss_fwd: bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* part = static_cast<float*>(workspace);
+    const long n = (long)B * N1 * 3;
+    const int nb = grid_for(n, 2048) < RED_BLOCKS ? grid_for(n, 2048) : RED_BLOCKS;
+    hipLaunchKernelGGL(recon_partial_kernel, dim3(nb), dim3(256), 0, st, x_hat, x, faces, B, N1, F, part);
+    hipLaunchKernelGGL(recon_final_kernel, dim3(1), dim3(256), 0, st, part, nb, 1.0 / (double)n, 1.0 / ((double)B * F), edge_w, out3);
+    SH_CHECK_LAUNCH("recon_loss_fwd");
+    return SH_OK;
+}
+
+int sh_recon_loss_bwd(const float* x_hat, const float* x, const int32_t* faces, const int32_t* vptr, const int32_t* vcorner, int B,
+                      int N1, int F, float edge_w, const float* gscale, float* grad, sh_stream_t stream) {
+    SH_REQUIRE(x_hat && x && faces && vptr && vcorner && gscale && grad && B > 0 && N1 > 0 && F > 0, SH_ERR_INVALID_ARG,
+               "sh_recon_loss_bwd: bad argument");
+    const long n = (long)B * N1;
+    hipLaunchKernelGGL(recon_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x_hat, x, faces, vptr,
+                       vcorner, B, N1, F, edge_w, gscale, grad);
+    SH_CHECK_LAUNCH("recon_loss_bwd");
     return SH_OK;
 }
 

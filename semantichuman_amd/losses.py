@@ -73,6 +73,30 @@ def edge_ratio_loss(x_hat, x, ft: FaceTables):
     return _EdgeRatioLoss.apply(x_hat, x.detach(), ft)
 
 
+class _ReconLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_hat, x, ft: FaceTables, edge_w: float):
+        x_hat, x = x_hat.contiguous(), x.contiguous()
+        ctx.save_for_backward(x_hat, x)
+        ctx.ft, ctx.edge_w = ft, float(edge_w)
+        out = ops.recon_loss_fwd(x_hat, x, ft.faces, edge_w)
+        ctx.mark_non_differentiable(out[1:])
+        return out[0], out[1:]
+
+    @staticmethod
+    def backward(ctx, g, _unused):
+        x_hat, x = ctx.saved_tensors
+        ft = ctx.ft
+        return ops.recon_loss_bwd(x_hat, x, ft.faces, ft.vptr, ft.vcorner, ctx.edge_w, g.contiguous()), None, None, None
+
+
+def recon_loss(x_hat, x, ft: FaceTables, edge_w: float):
+    """The loss of the plain training loop in one piece: `l1_loss(x, x_hat) + edge_w * edge_ratio_loss(x_hat, x, ft)`
+    (train_funcs.py:501-508) with the same arithmetic, but three kernel launches instead of eleven.
+    Returns (total, parts) where parts = float32 [2] = (l1, edge), detached, for logging."""
+    return _ReconLoss.apply(x_hat, x.detach(), ft, edge_w)
+
+
 def vertex_l2_mm(x_hat, x, dummy_node: bool = True, mm_constant: float = 1000.0):
     """mean per-vertex Euclidean error in mm, dummy row dropped (test_funcs.py:42-49)."""
     n_real = x.shape[1] - 1 if dummy_node else x.shape[1]

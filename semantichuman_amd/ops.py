@@ -246,6 +246,23 @@ def edge_ratio_loss_fwd(x_hat, x, faces):
     return out
 
 
+def recon_loss_fwd(x_hat, x, faces, edge_w):
+    """-> float32 [3] = (l1 + edge_w * edge, l1, edge) for contiguous [B, N1, 3] tensors."""
+    assert x_hat.shape == x.shape and x.shape[2] == 3 and x_hat.is_contiguous() and x.is_contiguous() and x.is_cuda
+    out = torch.empty((3,), dtype=torch.float32, device=x.device)
+    ws = torch.empty(_lib.load().sh_recon_loss_workspace() // 4, dtype=torch.float32, device=x.device)
+    check(_lib.load().sh_recon_loss_fwd(ptr(x_hat), ptr(x), ptr(faces), x.shape[0], x.shape[1], faces.shape[0], float(edge_w),
+                                        ptr(out), ptr(ws), stream_ptr()), "sh_recon_loss_fwd")
+    return out
+
+
+def recon_loss_bwd(x_hat, x, faces, vptr, vcorner, edge_w, gscale):
+    g = torch.empty_like(x_hat)
+    check(_lib.load().sh_recon_loss_bwd(ptr(x_hat), ptr(x), ptr(faces), ptr(vptr), ptr(vcorner), x.shape[0], x.shape[1],
+                                        faces.shape[0], float(edge_w), ptr(gscale), ptr(g), stream_ptr()), "sh_recon_loss_bwd")
+    return g
+
+
 def edge_ratio_loss_bwd(x_hat, x, faces, vptr, vcorner, gscale):
     g = torch.empty_like(x_hat)
     check(_lib.load().sh_edge_ratio_loss_bwd(ptr(x_hat), ptr(x), ptr(faces), ptr(vptr), ptr(vcorner), x.shape[0], x.shape[1],

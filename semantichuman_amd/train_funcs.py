@@ -77,14 +77,20 @@ def train_autoencoder_dataloader(dataloader_train, dataloader_val, device, model
             tx = sample_dict["verts"].to(device)
             cur_bsize = tx.shape[0]
             tx_hat = model(tx)[0]
-            rec_loss = loss_fn(tx, tx_hat)
-            loss = rec_loss
             if epoch > edgereg_epoch and edgereg_w > 0:
                 if face_tables is None or n_rows != tx.shape[1]:
                     n_rows = tx.shape[1]
                     face_tables = losses.FaceTables(f_np, n_rows, device)
-                edgereg_loss = losses.edge_ratio_loss(tx_hat, tx, face_tables)
-                loss = loss + edgereg_w * edgereg_loss
+                if loss_fn is losses.l1_loss:                 # the reference's loss: both terms in one fused op
+                    loss, parts = losses.recon_loss(tx_hat, tx, face_tables, edgereg_w)
+                    rec_loss, edgereg_loss = parts[0], parts[1]
+                else:
+                    rec_loss = loss_fn(tx, tx_hat)
+                    edgereg_loss = losses.edge_ratio_loss(tx_hat, tx, face_tables)
+                    loss = rec_loss + edgereg_w * edgereg_loss
+            else:
+                rec_loss = loss_fn(tx, tx_hat)
+                loss = rec_loss
             if reducer is not None:
                 reducer.prepare()
             loss.backward()

@@ -355,3 +355,22 @@ def test_batch64_properties(golden_dir):
             assert torch.allclose(a, prm.grad, rtol=1e-5, atol=1e-9), name
         else:
             assert torch.equal(a, prm.grad), name     # our kernels: fixed-order slab reduction, no atomics
+
+
+def test_fused_recon_loss_equals_separate_terms(golden_dir):
+    """recon_loss = l1_loss + w * edge_ratio_loss: same values (fixed-order sums) and the same gradient."""
+    p = os.path.join(golden_dir, "small_ae.npz")
+    g, h = np.load(p), load_hierarchy(p)
+    x = torch.from_numpy(g["x"]).to(dev())
+    xh0 = torch.from_numpy(g["x_hat"]).to(dev())
+    ft = sh.FaceTables(h.faces, h.sizes[0] + 1, dev())
+    a = xh0.clone().requires_grad_(True)
+    total, parts = sh.recon_loss(a, x, ft, 1e-2)
+    (total * 3.0).backward()
+    b = xh0.clone().requires_grad_(True)
+    rec, edge = sh.l1_loss(x, b), sh.edge_ratio_loss(b, x, ft)
+    ((rec + 1e-2 * edge) * 3.0).backward()
+    assert parts[0].item() == pytest.approx(rec.item(), rel=1e-6) and parts[1].item() == pytest.approx(edge.item(), rel=1e-6)
+    assert total.item() == pytest.approx((rec + 1e-2 * edge).item(), rel=1e-6)
+    assert parts[0].item() == pytest.approx(float(g["loss_rec"]), rel=1e-5) and parts[1].item() == pytest.approx(float(g["loss_edge"]), rel=1e-5)
+    close(a.grad, b.grad.cpu().numpy(), 1e-6, "fused loss gradient")
