@@ -185,10 +185,11 @@ def test_spmm_vs_dense(golden_dir):
 
 
 @pytest.mark.parametrize("mnk", [(64, 256, 55296), (64, 55296, 256), (4, 16, 1536), (3, 1536, 16), (5, 7, 13), (130, 70, 4100),
-                                 (1, 8, 136), (64, 8, 2176)])
+                                 (1, 8, 136), (64, 8, 2176), (20, 128, 2048), (3, 64, 4096), (33, 320, 256), (48, 192, 1088)])
 def test_latent_linear_vs_torch(mnk):
     """y = x W^T + b and its gradients (the latent FCs, models.py:130,144) - ragged sizes, the
-    split-reduction path (K = 55296, 4100) and the wide-output path (N = 55296)."""
+    split-reduction path (K = 55296, 4100), the wide-output path (N = 55296), and batches of 3 / 20 / 33 / 48 rows through
+    the streaming kernels (masked 16-row tiles)."""
     from semantichuman_amd.linear import latent_linear
     M, N, K = mnk
     rs = np.random.RandomState(M + N + K)
