@@ -25,33 +25,56 @@ import torch.distributed as dist
 
 
 class GradBucket:
-    def __init__(self, params: List[torch.nn.Parameter]):
+    """Either a packed bucket of small gradients (copied into `flat`), or - `inplace` - ONE large gradient that is
+    all-reduced where autograd left it: the two 56.6 MB FC gradients would otherwise cost a 227 MB copy pass per step."""
+
+    def __init__(self, params: List[torch.nn.Parameter], inplace: bool = False):
         self.params = params
+        self.inplace = inplace
         self.numel = sum(p.numel() for p in params)
         p0 = params[0]
-        self.flat = torch.zeros(self.numel, dtype=p0.dtype, device=p0.device)
+        self.flat = None if inplace else torch.zeros(self.numel, dtype=p0.dtype, device=p0.device)
         self.views, o = [], 0
-        for p in params:
-            self.views.append(self.flat[o:o + p.numel()].view_as(p))
-            o += p.numel()
+        if not inplace:
+            for p in params:
+                self.views.append(self.flat[o:o + p.numel()].view_as(p))
+                o += p.numel()
         self.pending = 0
         self.work = None
+        self.buf = None          # the tensor in flight
 
 
 class GradientAllReducer:
     """Bucketed, overlapped gradient averaging for a replicated nn.Module."""
 
-    def __init__(self, module: torch.nn.Module, process_group=None, bucket_cap_mb: float = 64.0, overlap: bool = True):
+    def __init__(self, module: torch.nn.Module, process_group=None, bucket_cap_mb: float = 64.0, overlap: bool = True,
+                 inplace_min_mb: float = 16.0):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.overlap = overlap
+        # RCCL averages in the collective (ncclAvg): no pre-scaling pass.  gloo (CPU tests) only sums.
+        self.avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         params = [p for p in module.parameters() if p.requires_grad]
+        if self.avg and self.world > 1 and params:
+            try:                                               # every rank builds its reducer: a collective probe is safe
+                probe = torch.ones(1, dtype=params[0].dtype, device=params[0].device)
+                dist.all_reduce(probe, op=dist.ReduceOp.AVG, group=process_group)
+                self.avg = bool(probe.item() == 1.0)
+            except (RuntimeError, ValueError):
+                self.avg = False                               # older collectives library: sum of pre-scaled gradients
         # backward produces gradients roughly in reverse registration order
         cap = int(bucket_cap_mb * 1024 * 1024)
+        big = int(inplace_min_mb * 1024 * 1024)
         self.buckets: List[GradBucket] = []
         cur, cur_bytes = [], 0
         for p in reversed(params):
             nbytes = p.numel() * p.element_size()
+            if nbytes >= big:                                  # large gradient: reduced in place, its own message
+                if cur:
+                    self.buckets.append(GradBucket(cur))
+                    cur, cur_bytes = [], 0
+                self.buckets.append(GradBucket([p], inplace=True))
+                continue
             if cur and cur_bytes + nbytes > cap:
                 self.buckets.append(GradBucket(cur))
                 cur, cur_bytes = [], 0
@@ -71,7 +94,7 @@ class GradientAllReducer:
 
     @property
     def message_bytes(self) -> int:
-        return sum(b.numel * b.flat.element_size() for b in self.buckets)
+        return sum(b.numel * b.params[0].element_size() for b in self.buckets)
 
     def prepare(self):
         """Call before backward (after zero_grad)."""
@@ -81,15 +104,25 @@ class GradientAllReducer:
         self._armed = True
 
     def _launch(self, b: GradBucket):
-        scale = 1.0 / self.world
-        for p, v in zip(b.params, b.views):
+        scale = 1.0 if self.avg else 1.0 / self.world
+        if b.inplace:
+            p = b.params[0]
             if p.grad is None:
-                v.zero_()
-            elif p.grad.data_ptr() != v.data_ptr():
-                torch.mul(p.grad, scale, out=v)
-            else:
-                v.mul_(scale)
-        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                p.grad = torch.zeros_like(p)
+            b.buf = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+            if scale != 1.0:
+                b.buf.mul_(scale)
+        else:
+            for p, v in zip(b.params, b.views):
+                if p.grad is None:
+                    v.zero_()
+                elif p.grad.data_ptr() != v.data_ptr():
+                    torch.mul(p.grad, scale, out=v) if scale != 1.0 else v.copy_(p.grad)
+                elif scale != 1.0:
+                    v.mul_(scale)
+            b.buf = b.flat
+        op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM
+        b.work = dist.all_reduce(b.buf, op=op, group=self.group, async_op=True)
 
     def _on_grad(self, p):
         if not self._armed:
@@ -109,8 +142,12 @@ class GradientAllReducer:
                 self._launch(b)
         for b in self.buckets:
             b.work.wait()
-            for p, v in zip(b.params, b.views):
-                p.grad = v
+            if b.inplace:
+                b.params[0].grad = b.buf
+            else:
+                for p, v in zip(b.params, b.views):
+                    p.grad = v
+            b.buf = None
         self._armed = False
 
     def remove_hooks(self):

@@ -41,8 +41,10 @@ def _worker(rank, world, port, golden_dir, overlap, out_dir):
     from semantichuman_amd import synthetic
     from semantichuman_amd.parallel import GradientAllReducer, all_reduce_mean_scalar, shard_batch
     m, h = _build(golden_dir)
-    red = GradientAllReducer(m, bucket_cap_mb=0.05, overlap=overlap)          # small cap -> several buckets
+    # small cap -> several packed buckets; gradients >= 50 KB (the two latent FCs here) are reduced in place
+    red = GradientAllReducer(m, bucket_cap_mb=0.05, overlap=overlap, inplace_min_mb=0.05)
     assert len(red.buckets) > 3 and red.message_bytes == sum(p.numel() * 4 for p in m.parameters())
+    assert sum(b.inplace for b in red.buckets) >= 2 and any(not b.inplace for b in red.buckets)
     x = torch.from_numpy(synthetic.synth_batch(h.verts, 4, seed=5))
     xs = x[shard_batch(4, rank, world)]
     opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-5)
