@@ -30,6 +30,7 @@ struct AdamArgs {
 
 __device__ __forceinline__ void adam_update(float& p, float g, float& m, float& v, float w, float beta2, float w2, float eps, float wd,
                                             float step_size, float bc2_sqrt) {
+#pragma clang fp contract(off)      // same rounding on the 16-byte and the scalar path (no call-site dependent FMA fusion)
     if (wd != 0.f) g += wd * p;                                   // coupled L2 (torch.optim.Adam, not AdamW)
     const float d = g - m;
     m = w < 0.5f ? m + w * d : g - d * (1.f - w);                 // lerp(m, g, 1 - beta1)

@@ -48,14 +48,16 @@ class GradientAllReducer:
     """Bucketed, overlapped gradient averaging for a replicated nn.Module."""
 
     def __init__(self, module: torch.nn.Module, process_group=None, bucket_cap_mb: float = 64.0, overlap: bool = True,
-                 inplace_min_mb: float = 16.0):
+                 inplace_min_mb: float = 16.0, force_collectives: bool = False):
+        """force_collectives: issue the collectives even in a world of one rank (exercises the RCCL path on a 1-GPU box)."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force_collectives and dist.is_initialized())
         self.overlap = overlap
         # RCCL averages in the collective (ncclAvg): no pre-scaling pass.  gloo (CPU tests) only sums.
         self.avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         params = [p for p in module.parameters() if p.requires_grad]
-        if self.avg and self.world > 1 and params:
+        if self.avg and self.active and params:
             try:                                               # every rank builds its reducer: a collective probe is safe
                 probe = torch.ones(1, dtype=params[0].dtype, device=params[0].device)
                 dist.all_reduce(probe, op=dist.ReduceOp.AVG, group=process_group)
@@ -87,7 +89,7 @@ class GradientAllReducer:
             for i, p in enumerate(b.params):
                 self._where[p] = (b, i)
         self._hooks = []
-        if self.world > 1 and overlap:
+        if self.active and overlap:
             for p in params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self._armed = False
@@ -135,7 +137,7 @@ class GradientAllReducer:
     def finish(self):
         """Call after backward, before optimizer.step(): waits for the collectives and makes
         every .grad the averaged gradient."""
-        if self.world == 1:
+        if not self.active:
             return
         for b in self.buckets:
             if b.work is None:           # not launched by a hook (overlap off, or unused params)

@@ -51,7 +51,8 @@ def test_hip_adam_matches_torch_adam(wd):
     assert o1.param_groups[0]["lr"] == o2.param_groups[0]["lr"]
     for a, b in zip(mine, ref):
         assert float(o1.state[a]["step"]) == float(o2.state[b]["step"]) == 6
-        np.testing.assert_allclose(o1.state[a]["exp_avg"].cpu().numpy(), o2.state[b]["exp_avg"].numpy(), atol=1e-9, rtol=2e-6)
+        # exp_avg = lerp(exp_avg, g, 0.1) of O(1) gradients: agreement to an ulp of the terms, not of a cancelled result
+        np.testing.assert_allclose(o1.state[a]["exp_avg"].cpu().numpy(), o2.state[b]["exp_avg"].numpy(), atol=1e-7, rtol=2e-6)
         np.testing.assert_allclose(o1.state[a]["exp_avg_sq"].cpu().numpy(), o2.state[b]["exp_avg_sq"].numpy(), atol=1e-12, rtol=2e-6)
 
 

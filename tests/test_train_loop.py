@@ -120,3 +120,43 @@ def test_hip_loop_matches_reference_loop(golden_dir, tmp_path):
     assert opt2.param_groups[0]["lr"] == pytest.approx(opt.param_groups[0]["lr"])
     x = torch.from_numpy(g["x_val"]).to(dev)
     assert torch.equal(m2(x)[0], m(x)[0])
+
+
+@pytest.mark.gpu
+def test_hip_step_through_rccl_reducer_matches_plain_step(golden_dir):
+    """One rank, backend "nccl" (= RCCL): the bucketed / in-place gradient all-reduce with the collectives forced on must
+    leave a training step unchanged (average over one rank), with the library's Adam reading the reduced gradients."""
+    import torch.distributed as dist
+    import semantichuman_amd as sh
+    from semantichuman_amd.parallel import GradientAllReducer
+    g, g0, h, _ = golden(golden_dir)
+    dev = torch.device("cuda:0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        x = torch.from_numpy(g["x_train"][:2]).to(dev)
+        ft = sh.FaceTables(h.faces, h.sizes[0] + 1, dev)
+        ends = []
+        for use_reducer in (False, True):
+            m = sh.SpiralAutoencoder(FE, FD, 16, h.sizes, h.spiral_sizes, h.spirals, h.D, h.U, dev)
+            m.load_state_dict({k[3:]: torch.from_numpy(g0[k]) for k in g0.files if k.startswith("w0/")})
+            opt = sh.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-5)
+            red = GradientAllReducer(m, bucket_cap_mb=0.05, inplace_min_mb=0.05, force_collectives=True) if use_reducer else None
+            if red is not None:
+                assert red.active and any(b.inplace for b in red.buckets) and any(not b.inplace for b in red.buckets)
+            for _ in range(2):
+                opt.zero_grad(set_to_none=True)
+                loss, _ = sh.recon_loss(m(x)[0], x, ft, 1e-2)
+                if red is not None:
+                    red.prepare()
+                loss.backward()
+                if red is not None:
+                    red.finish()
+                opt.step()
+            torch.cuda.synchronize()
+            ends.append([p.detach().clone() for p in m.parameters()])
+        for a, b in zip(*ends):
+            assert torch.equal(a, b)
+    finally:
+        dist.destroy_process_group()
