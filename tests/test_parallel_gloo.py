@@ -78,7 +78,9 @@ def test_two_rank_data_parallel_equals_single_process(golden_dir, tmp_path, over
         loss = torch.nn.functional.l1_loss(x, m(x)[0])
         loss.backward()
         opt.step()
-    assert r0["loss"] == pytest.approx(float(loss), rel=1e-5)
+    # the second step's loss already carries the first Adam update, whose +-lr moves on ~zero gradients depend on fp32
+    # summation order (shard means vs one global mean): agreement to 1e-4, not to rounding
+    assert r0["loss"] == pytest.approx(float(loss), rel=1e-4)
     for k, v in m.state_dict().items():
         d = (r0["w"][k] - v).abs()
         # Adam turns fp32 sum-order noise on ~zero gradients into +-lr steps for a few elements:
