@@ -58,9 +58,10 @@ enum sh_act {
 SH_API int sh_version(void);
 SH_API const char* sh_last_error(void);
 
-/* Optional per-kernel timing with HIP events recorded on the launch stream, immediately before
- * and after each kernel launch (used by bench.py for the roofline figures; off by default, must
- * be off while a hipGraph is being captured).  sh_profile_get synchronises on the events. */
+/* Optional per-kernel timing with HIP events attached to the kernel dispatch itself (begin / end of
+ * the kernel's execution, what rocprofv3 --kernel-trace reports; minor helper kernels are bracketed
+ * by event records on the stream instead).  Used by bench.py for the roofline figures; off by
+ * default, must be off while a hipGraph is being captured.  sh_profile_get synchronises on the events. */
 SH_API int sh_profile_enable(int on);                 /* on=1 start recording (clears), on=0 stop */
 SH_API int sh_profile_count(void);
 SH_API int sh_profile_get(int i, char* name, int name_len, float* ms);
