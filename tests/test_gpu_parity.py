@@ -375,3 +375,37 @@ def test_fused_recon_loss_equals_separate_terms(golden_dir):
     assert total.item() == pytest.approx((rec + 1e-2 * edge).item(), rel=1e-6)
     assert parts[0].item() == pytest.approx(float(g["loss_rec"]), rel=1e-5) and parts[1].item() == pytest.approx(float(g["loss_edge"]), rel=1e-5)
     close(a.grad, b.grad.cpu().numpy(), 1e-6, "fused loss gradient")
+
+
+def test_c_abi_error_contract():
+    """Bad calls return a negative status and leave a message in sh_last_error(); the Python wrappers turn that into
+    RuntimeError - nothing fails silently and nothing falls back."""
+    import ctypes
+    from semantichuman_amd import _lib
+    lib = _lib.load()
+    d = dev()
+    x = torch.zeros((2, 9, 4), device=d)
+    table = torch.zeros((9, 3), dtype=torch.int32, device=d)
+    w = torch.zeros((4, 12), device=d)
+    y = torch.zeros((2, 9, 4), device=d)
+    st = _lib.stream_ptr()
+    # null pointer -> SH_ERR_INVALID_ARG
+    assert lib.sh_spiral_conv_fwd(None, 4, 36, _lib.ptr(table), _lib.ptr(w), None, _lib.ptr(y), 4, 36, 2, 9, 3, 4, 4, 2, 8, st) == -1
+    assert b"null" in lib.sh_last_error()
+    # unknown activation id
+    assert lib.sh_spiral_conv_fwd(_lib.ptr(x), 4, 36, _lib.ptr(table), _lib.ptr(w), None, _lib.ptr(y), 4, 36, 2, 9, 3, 4, 4, 17, 8, st) == -1
+    # more output channels than the kernels are built for -> SH_ERR_UNSUPPORTED, message names the limit
+    assert lib.sh_spiral_conv_fwd(_lib.ptr(x), 4, 36, _lib.ptr(table), _lib.ptr(w), None, _lib.ptr(y), 4, 36, 2, 9, 3, 4, 200, 2, 8, st) == -2
+    assert b"128" in lib.sh_last_error()
+    # workspace too small -> SH_ERR_WORKSPACE
+    need = lib.sh_spiral_conv_bwd_wgt_workspace(2, 9, 3, 4, 4)
+    assert need > 0
+    ws = torch.zeros(4, device=d)
+    dW = torch.zeros((4, 12), device=d)
+    rc = lib.sh_spiral_conv_bwd_wgt(_lib.ptr(y), 4, 36, _lib.ptr(x), 4, 36, _lib.ptr(table), _lib.ptr(dW), None, _lib.ptr(ws),
+                                    ctypes.c_size_t(16), 2, 9, 3, 4, 4, st)
+    assert rc == -3 and b"workspace" in lib.sh_last_error()
+    # the typed wrappers raise
+    with pytest.raises(RuntimeError, match="status -2"):
+        ops.spiral_conv_fwd(x, "bm", table, torch.zeros((200, 12), device=d), None, torch.zeros((2, 9, 200), device=d), "bm", 9, 3, 2, 8)
+    torch.cuda.synchronize()
