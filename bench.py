@@ -111,15 +111,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # SH_BENCH_BACKEND=gloo lets the multi-rank control flow be exercised on a box with ONE GPU (all ranks share it,
+    # collectives go through the host); the measured configuration is always nccl = RCCL, one rank per GPU
+    backend = os.environ.get("SH_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world:
         if rank == 0:
             print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     import semantichuman_amd as sh
     from semantichuman_amd import _lib, synthetic
@@ -228,13 +235,15 @@ def main():
     }
 
     # ---- roofline of the dominant kernel: HIP events recorded by the library around every launch
-    if rank == 0 and not args.no_roofline:
+    if not args.no_roofline:
+        # EVERY rank runs these steps (the gradient all-reduce inside them is a collective); only rank 0 records
         nprof = 5
         from semantichuman_amd import stack as _stack
         overlap_was, _stack.OVERLAP_WGRAD = _stack.OVERLAP_WGRAD, False     # serial launches: clean per-kernel durations
         if args.adam == "hip":
             optim.remove_overlap()
-        _lib.profile_enable(True)
+        if rank == 0:
+            _lib.profile_enable(True)
         for i in range(nprof):
             o = (i * B) % n_data
             xin.copy_(data[o:o + B])
@@ -243,9 +252,10 @@ def main():
                 reducer.finish()
             optim.step()
         torch.cuda.synchronize()
+        _stack.OVERLAP_WGRAD = overlap_was
+    if rank == 0 and not args.no_roofline:
         recs = _lib.profile_records_by_kernel()
         _lib.profile_enable(False)
-        _stack.OVERLAP_WGRAD = overlap_was
         agg = {}
         for name, _shape, ms in recs:
             a = agg.setdefault(name, [0, 0.0])
