@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--adam", choices=["hip", "torch"], default="hip", help="library Adam kernel, or torch's fused capturable Adam")
     ap.add_argument("--adam-overlap", action="store_true", help="update the big parameters on a side stream underneath backward (measured: no gain, the GPU is already saturated)")
     ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--template", default=os.path.join("tests", "golden", "template6890.npz"),
+                    help="mesh hierarchy fixture; tests/golden/template27554.npz + --batch 32 is BASELINE config 4")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -134,7 +136,7 @@ def main():
     from semantichuman_amd.parallel import GradientAllReducer
     _lib.load()                                   # fail loudly if the HIP library is missing
 
-    h = load_hierarchy(os.path.join(ROOT, "tests", "golden", "template6890.npz"))
+    h = load_hierarchy(args.template if os.path.isabs(args.template) else os.path.join(ROOT, args.template))
     B = args.batch
     torch.manual_seed(2)                          # cfgs.py:46 seed; identical replicas on every rank
     model = sh.SpiralAutoencoder(FE, FD, 256, h.sizes, h.spiral_sizes, h.spirals, h.D, h.U, dev)
@@ -219,15 +221,17 @@ def main():
         l2mm = float(sh.vertex_l2_mm(xh, test).item())
 
     result = {
-        "metric": "training meshes/sec at 6890 verts, batch=64",
+        "metric": "training meshes/sec at %d verts, batch=%d" % (h.sizes[0], B),
         "value": world * B * args.steps / elapsed,
         "unit": "meshes/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "plain spiral AE training step (fwd + L1 + 1e-2*edge loss + bwd + Adam), box_sphere(42,42,20) "
-                               "6890-vertex template, levels %s, spiral sizes %s, nz 256, 28.55M params" % (h.sizes, h.spiral_sizes[:-1]),
+        "config": {"workload": "plain spiral AE training step (fwd + L1 + 1e-2*edge loss + bwd + Adam), %s, levels %s, "
+                               "spiral sizes %s, nz 256, %.2fM params"
+                               % ("box_sphere(42,42,20) 6890-vertex template" if h.sizes[0] == 6890 else "%d-vertex template" % h.sizes[0],
+                                  h.sizes, h.spiral_sizes[:-1], sum(p.numel() for p in model.parameters()) / 1e6),
                    "global_batch": world * B, "per_gpu_batch": B, "parallelism": "dp%d" % world,
                    "launch": "hipGraph replay" if graph is not None else "eager"},
         "train_loss_last": final_loss,
