@@ -55,15 +55,15 @@ def conv_launch_table(model, B):
         t, blocks, split = nt(nout), -(-rows // (128 // tb)) * -(-B // tb), 1
         while t > 1 and blocks * split < 768:
             t //= 2; split *= 2
-        return t
-    def gg_name(t, cg, bwd):
+        return t, blocks * split
+    def gg_name(t, cg, bwd, blocks128=0):
         """dispatch_gg(): two channel tiles with 16-byte gathers run the direct (LDS-free gather) form; 3-channel
         gathered rows with one channel tile run the padded-quad (dwordx3) mode of the staged kernel."""
         if cg == 3 and t == 1:
             return "gather_gemm_kernel<1, true, %s, %s, true>" % (bwd, tb16)
         vec4 = "true" if cg % 4 == 0 else "false"
         if t == 2 and vec4 == "true":
-            return "gather_gemm_direct_kernel<2, %s>" % bwd
+            return "gather_gemm_direct_kernel<2, %s, %d>" % (bwd, 1 if blocks128 <= 1024 else 2)
         return "gather_gemm_kernel<%d, %s, %s, %s, false>" % (t, vec4, bwd, tb16)
 
     for stack in (model._enc_stack, model._dec_stack):
@@ -75,11 +75,11 @@ def conv_launch_table(model, B):
             vec = "true" if st.cin % 4 == 0 else "false"
             # fwd: read each needed input row once + weights, write output
             byt = 4.0 * (B * st.n_in * st.cin + B * st.R * st.cout + st.cout * K)
-            add(gg_name(nt_split(st.R, st.cout), st.cin, "false"), fl, byt)
+            add(gg_name(nt_split(st.R, st.cout)[0], st.cin, "false", nt_split(st.R, st.cout)[1]), fl, byt)
             if not (first and stack is model._enc_stack):
                 # backward-data = the same kernel over the transposed table; algorithmic FLOPs are
                 # those of the R*S real (row, position) pairs, not of the padded n_in*S table
-                add(gg_name(nt_split(st.n_in, st.cin), st.cout, "true"), fl, byt)
+                add(gg_name(nt_split(st.n_in, st.cin)[0], st.cout, "true", nt_split(st.n_in, st.cin)[1]), fl, byt)
             if st.cin % 4 == 0 or st.cin == 3:         # same choices as plan_wgrad() in csrc/spiral_conv.hip
                 cot = nt(st.cout)
                 add("wgrad_stream_kernel<%d, %d, %d, %s, %s>" % (cot, 1 if B <= 4 else 4, 3 if cot <= 2 else 2,

@@ -296,14 +296,14 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_kernel(const GGParams p)
 // waves, goes through LDS (triple-buffered, one barrier per chunk); gathered chunks c+1 and c+2
 // are in flight in registers while chunk c multiplies.  Same tiling, K order and epilogue as
 // gather_gemm_kernel, hence bit-identical results.
-template <int NT, bool BWD_EPI>
+template <int NT, bool BWD_EPI, int RT>      // RT = 16-row tiles per wave: the workgroup covers 64*RT rows
 __global__ __launch_bounds__(NTHREADS) void gather_gemm_direct_kernel(const GGParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Ws = reinterpret_cast<float*>(smem);                 // [3][NT*16][KC]
     int* Ts = reinterpret_cast<int*>(Ws + 3 * NT * 16 * KC);    // table tile (element offsets)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int TB = 1 << p.log2TB, TV = TM >> p.log2TB;
+    const int TB = 1 << p.log2TB, TV = (64 * RT) >> p.log2TB;
     const int item = sh_xcd_remap(blockIdx.x, gridDim.x);
     const int tile = item / p.nsplit;
     const int n_base = (item - tile * p.nsplit) * (NT * 16);
@@ -321,11 +321,11 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_direct_kernel(const GGPa
     __syncthreads();
 
     const int lrow = lane & 15, lq = lane >> 4;
-    int a_ts[2];
-    long a_boff[2];
+    int a_ts[RT];
+    long a_boff[RT];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int row = 32 * wave + 16 * m + lrow;
+    for (int m = 0; m < RT; ++m) {
+        const int row = 16 * RT * wave + 16 * m + lrow;
         const int vl = row >> p.log2TB, bl = row & (TB - 1);
         a_ts[m] = vl * S;
         a_boff[m] = (b0 + bl) < p.B ? (long)(b0 + bl) * p.x_sb : 0;      // rows past B read row 0 of the slice; never stored
@@ -339,8 +339,8 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_direct_kernel(const GGPa
         c_n[ks] = k_n[ks] - s_n[ks] * p.Cg;
     }
     const int adv_s = KC / p.Cg, adv_c = KC - adv_s * p.Cg;
-    auto load_a = [&](f32x4 (&ra)[2][2]) {
-        unsigned toff[2][2];
+    auto load_a = [&](f32x4 (&ra)[RT][2]) {
+        unsigned toff[RT][2];
         int ch[2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {                        // all table lookups first: one LDS round trip per chunk
@@ -348,12 +348,12 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_direct_kernel(const GGPa
             const int s = kok ? s_n[ks] : 0;
             ch[ks] = kok ? c_n[ks] : 0;
 #pragma unroll
-            for (int m = 0; m < 2; ++m) toff[m][ks] = (unsigned)Ts[a_ts[m] + s];
+            for (int m = 0; m < RT; ++m) toff[m][ks] = (unsigned)Ts[a_ts[m] + s];
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-            for (int m = 0; m < 2; ++m) ra[m][ks] = *reinterpret_cast<const f32x4*>(p.x + toff[m][ks] + a_boff[m] + ch[ks]);
+            for (int m = 0; m < RT; ++m) ra[m][ks] = *reinterpret_cast<const f32x4*>(p.x + toff[m][ks] + a_boff[m] + ch[ks]);
             k_n[ks] += KC;
             c_n[ks] += adv_c;
             s_n[ks] += adv_s;
@@ -392,12 +392,12 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_direct_kernel(const GGPa
         }
     };
 
-    f32x4 acc[2][NT];
+    f32x4 acc[RT][NT];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < RT; ++m)
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[m][n] = zero4;
-    auto compute = [&](int buf, const f32x4 (&ra)[2][2]) {
+    auto compute = [&](int buf, const f32x4 (&ra)[RT][2]) {
         const float* Wb = Ws + buf * NT * 16 * KC + lrow * KC;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -406,15 +406,14 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_direct_kernel(const GGPa
             for (int n = 0; n < NT; ++n) {
                 const f32x4 wq = *reinterpret_cast<const f32x4*>(Wb + n * 16 * KC + pq);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[t], ra[0][ks][t], acc[0][n], 0, 0, 0);
-                    acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[t], ra[1][ks][t], acc[1][n], 0, 0, 0);
-                }
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int m = 0; m < RT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[t], ra[m][ks][t], acc[m][n], 0, 0, 0);
             }
         }
     };
 
-    f32x4 ra[3][2][2], rw[3][WQ];
+    f32x4 ra[3][RT][2], rw[3][WQ];
     unsigned mw[3];
     load_a(ra[0]); load_w(rw[0], mw[0]);                 // chunk 0
     store_w(0, rw[0], mw[0]);
@@ -439,10 +438,10 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_direct_kernel(const GGPa
         step(std::integral_constant<int, 2>{});
     }
 
-    // ---- epilogue (identical to gather_gemm_kernel): lane holds channels n0..n0+3 of tile row 32*wave + 16*m + lrow
+    // ---- epilogue (identical to gather_gemm_kernel): lane holds channels n0..n0+3 of tile row 16*RT*wave + 16*m + lrow
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int row = 32 * wave + 16 * m + lrow;
+    for (int m = 0; m < RT; ++m) {
+        const int row = 16 * RT * wave + 16 * m + lrow;
         const int vl = row >> p.log2TB, bl = row & (TB - 1);
         const int v = v0 + vl, b = b0 + bl;
         if (v >= p.R || b >= p.B) continue;
@@ -485,12 +484,24 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_direct_kernel(const GGPa
 }
 
 template <int NT, bool BWD_EPI>
-int launch_ggd(const GGParams& p, int nblocks, hipStream_t st) {
-    const int TV = TM >> p.log2TB;
+int launch_ggd(const GGParams& p_in, int nblocks128 /* workgroups if the tiles had 128 rows */, hipStream_t st) {
+    // 16-row tiles per wave.  Measured on MI355X (B = 64): one tile per wave (64-row workgroups, twice as many of them)
+    // is 3-8 % faster while the launch has <= 1024 workgroups of 128 rows, two tiles are level above that, four are
+    // 10-30 % slower (registers: fewer waves per SIMD to hide the LDS and global latencies).
+    static const int rt_pref = sh_env_int("SH_GG_RT", 0, 0, 4);
+    GGParams p = p_in;
+    const int tb = 1 << p.log2TB;
+    int rt = rt_pref == 0 ? (nblocks128 <= 1024 ? 1 : 2) : (rt_pref == 3 ? 2 : rt_pref);
+    if (tb > 64 * rt) rt = 2;
+    const int TV = (64 * rt) >> p.log2TB;
+    p.n_vtiles = sh_cdiv(p.R, TV);
+    const int nblocks = p.n_vtiles * p.n_btiles * p.nsplit;
     const size_t smem = (size_t)(3 * NT * 16 * KC) * sizeof(float) + (size_t)(TV * p.S) * sizeof(int);
-    ShProfScope ps(st, "gather_gemm_direct_kernel<%d, %s>|R=%d B=%d K=%d N=%d grid=%d", NT, BWD_EPI ? "true" : "false", p.R, p.B,
-                   p.K, p.Nout, nblocks);
-    SH_LAUNCH_PS(ps, (gather_gemm_direct_kernel<NT, BWD_EPI>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
+    ShProfScope ps(st, "gather_gemm_direct_kernel<%d, %s, %d>|R=%d B=%d K=%d N=%d grid=%d", NT, BWD_EPI ? "true" : "false", rt, p.R,
+                   p.B, p.K, p.Nout, nblocks);
+    if (rt == 4) SH_LAUNCH_PS(ps, (gather_gemm_direct_kernel<NT, BWD_EPI, 4>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
+    else if (rt == 1) SH_LAUNCH_PS(ps, (gather_gemm_direct_kernel<NT, BWD_EPI, 1>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
+    else SH_LAUNCH_PS(ps, (gather_gemm_direct_kernel<NT, BWD_EPI, 2>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
     SH_CHECK_LAUNCH("gather_gemm_direct");
     return SH_OK;
 }
