@@ -62,8 +62,8 @@ def conv_launch_table(model, B):
         if cg == 3 and t == 1:
             return "gather_gemm_kernel<1, true, %s, %s, true>" % (bwd, tb16)
         vec4 = "true" if cg % 4 == 0 else "false"
-        if t == 2 and vec4 == "true":
-            return "gather_gemm_direct_kernel<2, %s, %d>" % (bwd, 1 if blocks128 <= 1024 else 2)
+        if t in (2, 4) and vec4 == "true":
+            return "gather_gemm_direct_kernel<%d, %s, %d>" % (t, bwd, 1 if blocks128 <= 1024 else 2)
         return "gather_gemm_kernel<%d, %s, %s, %s, false>" % (t, vec4, bwd, tb16)
 
     for stack in (model._enc_stack, model._dec_stack):

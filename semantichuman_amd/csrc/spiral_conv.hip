@@ -562,6 +562,9 @@ int dispatch_gg(GGParams& p, hipStream_t st) {
     return vec4 ? launch_gg<NTV, true, BWD_EPI>(p, (int)nitems, st)              \
                 : launch_gg<NTV, false, BWD_EPI>(p, (int)nitems, st)
     if (c3) return launch_gg<1, true, BWD_EPI, true>(p, (int)nitems, st);
+    static const int direct_mask = sh_env_int("SH_GG_DIRECT_NT", 6, 0, 15);      // bit set: that channel-tile count runs the direct form (1: measured slower)
+    if (nt <= 1 && vec4 && direct_on && (direct_mask & 1)) return launch_ggd<1, BWD_EPI>(p, (int)nitems, st);
+    if (nt == 4 && vec4 && direct_on && (direct_mask & 4)) return launch_ggd<4, BWD_EPI>(p, (int)nitems, st);
     if (nt <= 1) { SH_GG_CASE(1); }
     // the direct form wins for two channel tiles (2-8 us per launch on MI355X) and loses for 1 and 4: a chunk of a
     // one-tile layer has too few MFMAs between the weight-chunk barriers, four tiles are bound elsewhere
