@@ -19,10 +19,15 @@ __global__ __launch_bounds__(256) void spmm_kernel(const int* __restrict__ rowpt
                                                    long yp_sv, long yp_sb, int act, int zero_row, int B, int rows, int C) {
     const int CW = VEC ? C >> 2 : C;
     const int per_row = B * CW;
-    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    // work item = (row, 256-element part of the row): coarse levels have few, long rows (432 x 32 KB) and would not
+    // fill the chip with one workgroup per row
+    const int parts = (per_row + 255) >> 8;
+    const long items = (long)rows * parts;
+    for (long it = blockIdx.x; it < items; it += gridDim.x) {
+        const int r = (int)(it / parts), part = (int)(it - (long)r * parts);
         const int e0 = rowptr[r], e1 = rowptr[r + 1];
         const bool zero = r == zero_row;
-        for (int j = threadIdx.x; j < per_row; j += 256) {
+        for (int j = part * 256 + threadIdx.x; j < per_row && j < (part + 1) * 256; j += 256) {
             const int b = j / CW, cw = j - b * CW;
             const int co = VEC ? 4 * cw : cw;
             const long xo = (long)b * x_sb + co;
@@ -276,7 +281,9 @@ int sh_spmm(const int32_t* rowptr, const int32_t* col, const float* val, const f
     const bool vec = (C % 4 == 0) && (x_sv % 4 == 0) && (x_sb % 4 == 0) && (y_sv % 4 == 0) && (y_sb % 4 == 0) &&
                      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) % 16 == 0) &&
                      (!yprev || (yp_sv % 4 == 0 && yp_sb % 4 == 0 && reinterpret_cast<uintptr_t>(yprev) % 16 == 0));
-    const int grid = rows < 8192 ? rows : 8192;
+    static const int grid_cap = sh_env_int("SH_SPMM_GRID", 4096, 64, 1 << 20);
+    const long items = (long)rows * (((long)B * (vec ? C / 4 : C) + 255) / 256);
+    const int grid = (int)(items < grid_cap ? items : grid_cap);
     hipStream_t st = static_cast<hipStream_t>(stream);
     ShProfScope ps(st, "spmm_kernel<%s>|rows=%d B=%d C=%d", vec ? "true" : "false", rows, B, C);
     if (vec)
