@@ -1171,12 +1171,15 @@ __global__ void act_backward_kernel(const float* __restrict__ dy, long dy_sv, lo
                                     int B, int R, int C, int act, int zero_row) {
     const int cq = VEC4 ? C >> 2 : C;                 // elements (or quads) per (row, batch) entry
     const int per_row = B * cq;
-    for (int r = blockIdx.x; r < R; r += gridDim.x) {
+    const int parts = (per_row + 255) >> 8;           // work item = 256-element part of a row (coarse levels: few long rows)
+    const long items = (long)R * parts;
+    for (long it = blockIdx.x; it < items; it += gridDim.x) {
+        const int r = (int)(it / parts), part = (int)(it - (long)r * parts);
         const bool zero = r == zero_row;
         const float* dyr = dy + (long)r * dy_sv;
         const float* yr = y + (long)r * y_sv;
         float* dpr = dp + (long)r * dp_sv;
-        for (int i = threadIdx.x; i < per_row; i += blockDim.x) {
+        for (int i = part * 256 + threadIdx.x; i < per_row && i < (part + 1) * 256; i += 256) {
             const int b = i / cq, c = i - b * cq;
             if (VEC4) {
                 const f32x4 g = *reinterpret_cast<const f32x4*>(dyr + (long)b * dy_sb + 4 * c);
@@ -1349,7 +1352,8 @@ int sh_act_backward(const float* dy, int64_t dy_sv, int64_t dy_sb, const float* 
     SH_REQUIRE(act >= SH_ACT_IDENTITY && act <= SH_ACT_TANH, SH_ERR_INVALID_ARG, "sh_act_backward: unknown activation %d", act);
     const bool vec = (C % 4 == 0) && ((dy_sv | dy_sb | y_sv | y_sb | dp_sv | dp_sb) % 4 == 0) &&
                      ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dpre)) % 16 == 0);
-    const int blocks = R < 16384 ? R : 16384;
+    const long items = (long)R * (((long)B * (vec ? C / 4 : C) + 255) / 256);
+    const int blocks = (int)(items < 8192 ? items : 8192);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (vec)
         hipLaunchKernelGGL(act_backward_kernel<true>, dim3(blocks), dim3(256), 0, st, dy, dy_sv, dy_sb, y, y_sv, y_sb, dpre, dp_sv, dp_sb,
