@@ -488,10 +488,10 @@ int launch_ggd(const GGParams& p_in, int nblocks128 /* workgroups if the tiles h
     // 16-row tiles per wave.  Measured on MI355X (B = 64): one tile per wave (64-row workgroups, twice as many of them)
     // is 3-8 % faster while the launch has <= 1024 workgroups of 128 rows, two tiles are level above that, four are
     // 10-30 % slower (registers: fewer waves per SIMD to hide the LDS and global latencies).
-    static const int rt_pref = sh_env_int("SH_GG_RT", 0, 0, 4);
+    static const int rt_pref = sh_env_int("SH_GG_RT", 0, 0, 2);
     GGParams p = p_in;
     const int tb = 1 << p.log2TB;
-    int rt = rt_pref == 0 ? (nblocks128 <= 1024 ? 1 : 2) : (rt_pref == 3 ? 2 : rt_pref);
+    int rt = rt_pref == 0 ? (nblocks128 <= 1024 ? 1 : 2) : rt_pref;
     if (tb > 64 * rt) rt = 2;
     const int TV = (64 * rt) >> p.log2TB;
     p.n_vtiles = sh_cdiv(p.R, TV);
@@ -499,8 +499,7 @@ int launch_ggd(const GGParams& p_in, int nblocks128 /* workgroups if the tiles h
     const size_t smem = (size_t)(3 * NT * 16 * KC) * sizeof(float) + (size_t)(TV * p.S) * sizeof(int);
     ShProfScope ps(st, "gather_gemm_direct_kernel<%d, %s, %d>|R=%d B=%d K=%d N=%d grid=%d", NT, BWD_EPI ? "true" : "false", rt, p.R,
                    p.B, p.K, p.Nout, nblocks);
-    if (rt == 4) SH_LAUNCH_PS(ps, (gather_gemm_direct_kernel<NT, BWD_EPI, 4>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
-    else if (rt == 1) SH_LAUNCH_PS(ps, (gather_gemm_direct_kernel<NT, BWD_EPI, 1>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
+    if (rt == 1) SH_LAUNCH_PS(ps, (gather_gemm_direct_kernel<NT, BWD_EPI, 1>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
     else SH_LAUNCH_PS(ps, (gather_gemm_direct_kernel<NT, BWD_EPI, 2>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
     SH_CHECK_LAUNCH("gather_gemm_direct");
     return SH_OK;
@@ -562,9 +561,8 @@ int dispatch_gg(GGParams& p, hipStream_t st) {
     return vec4 ? launch_gg<NTV, true, BWD_EPI>(p, (int)nitems, st)              \
                 : launch_gg<NTV, false, BWD_EPI>(p, (int)nitems, st)
     if (c3) return launch_gg<1, true, BWD_EPI, true>(p, (int)nitems, st);
-    static const int direct_mask = sh_env_int("SH_GG_DIRECT_NT", 6, 0, 15);      // bit set: that channel-tile count runs the direct form (1: measured slower)
-    if (nt <= 1 && vec4 && direct_on && (direct_mask & 1)) return launch_ggd<1, BWD_EPI>(p, (int)nitems, st);
-    if (nt == 4 && vec4 && direct_on && (direct_mask & 4)) return launch_ggd<4, BWD_EPI>(p, (int)nitems, st);
+    // the direct form serves 2 and 4 channel tiles; one tile (16 channels) measured 25-30 % slower in it than staged
+    if (nt == 4 && vec4 && direct_on) return launch_ggd<4, BWD_EPI>(p, (int)nitems, st);
     if (nt <= 1) { SH_GG_CASE(1); }
     // the direct form wins for two channel tiles (2-8 us per launch on MI355X) and loses for 1 and 4: a chunk of a
     // one-tile layer has too few MFMAs between the weight-chunk barriers, four tiles are bound elsewhere
