@@ -155,7 +155,7 @@ def main():
     test = torch.from_numpy(synthetic.synth_batch(h.verts, B, seed=7)).to(dev)
 
     xin = torch.empty((B, h.sizes[0] + 1, 3), dtype=torch.float32, device=dev)
-    loss_out = torch.zeros((), device=dev)
+    last = {}                                     # the step's loss tensor (a fixed address inside the graph's pool when captured)
 
     def fwd_bwd():
         optim.zero_grad(set_to_none=True)
@@ -164,7 +164,7 @@ def main():
         if reducer:
             reducer.prepare()
         loss.backward()
-        loss_out.copy_(loss.detach())
+        last["loss"] = loss.detach()
 
     use_graph = (not args.no_graph) and world == 1
     graph = None
@@ -214,7 +214,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    final_loss = float(loss_out.item())
+    final_loss = float(last["loss"].item())
 
     with torch.no_grad():
         xh, _ = model(test)
