@@ -18,6 +18,7 @@ Plan construction is pure numpy (testable without a GPU); `to(device)` uploads t
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from typing import Optional
 
@@ -27,10 +28,9 @@ import torch
 from . import mesh_ops, ops
 from .mesh_ops import CSR, TransposedTable
 
-
-import os
-
-# run weight-gradient kernels on a side stream, concurrently with the backward-data chain
+# Side-stream options, both OFF: measured on MI355X, concurrency between these kernels only re-orders MFMA/HBM-saturated
+# work and pays for the fork/join.
+# run weight-gradient kernels on a side stream, concurrently with the backward-data chain (1.97 vs 1.93 ms/step)
 OVERLAP_WGRAD = os.environ.get("SH_OVERLAP_WGRAD", "0") != "0"
 # run the small list pre-sum kernels of backward-data on a side stream, underneath the weight-gradient kernel of the
 # same layer (both only read dpre_i; the pre-sums are memory-bound and tiny, the weight gradient is MFMA-bound)
