@@ -48,6 +48,7 @@ def _worker(rank, world, port, golden_dir, overlap, out_dir):
     x = torch.from_numpy(synthetic.synth_batch(h.verts, 4, seed=5))
     xs = x[shard_batch(4, rank, world)]
     opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-5)
+    losses = []
     for _ in range(2):                                                          # two steps: hooks must re-arm
         opt.zero_grad()
         x_hat, _ = m(xs)
@@ -56,8 +57,8 @@ def _worker(rank, world, port, golden_dir, overlap, out_dir):
         loss.backward()
         red.finish()
         opt.step()
-    mean_loss = all_reduce_mean_scalar(loss.detach())
-    torch.save({"w": {k: v.clone() for k, v in m.state_dict().items()}, "loss": float(mean_loss)}, os.path.join(out_dir, "r%d.pt" % rank))
+        losses.append(float(all_reduce_mean_scalar(loss.detach())))
+    torch.save({"w": {k: v.clone() for k, v in m.state_dict().items()}, "loss": losses}, os.path.join(out_dir, "r%d.pt" % rank))
     dist.destroy_process_group()
 
 
@@ -73,14 +74,18 @@ def test_two_rank_data_parallel_equals_single_process(golden_dir, tmp_path, over
     m, h = _build(golden_dir)
     x = torch.from_numpy(synthetic.synth_batch(h.verts, 4, seed=5))
     opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-5)
+    ref_losses = []
     for _ in range(2):
         opt.zero_grad()
         loss = torch.nn.functional.l1_loss(x, m(x)[0])
         loss.backward()
         opt.step()
-    # the second step's loss already carries the first Adam update, whose +-lr moves on ~zero gradients depend on fp32
-    # summation order (shard means vs one global mean): agreement to 1e-4, not to rounding
-    assert r0["loss"] == pytest.approx(float(loss), rel=1e-4)
+        ref_losses.append(float(loss))
+    # step 1: mean of shard means == mean over the global batch, to rounding.  Step 2 already carries the first Adam
+    # update, whose +-lr moves on ~zero gradients depend on fp32 summation order (and on the thread count of the CPU
+    # reductions): a looser bound
+    assert r0["loss"][0] == pytest.approx(ref_losses[0], rel=1e-5)
+    assert r0["loss"][1] == pytest.approx(ref_losses[1], rel=2e-3)
     for k, v in m.state_dict().items():
         d = (r0["w"][k] - v).abs()
         # Adam turns fp32 sum-order noise on ~zero gradients into +-lr steps for a few elements:
