@@ -171,6 +171,27 @@ SH_API int sh_linear_bwd_wgt(const float* dy, const float* x, float* dW, float* 
                       void* workspace, size_t workspace_bytes, sh_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Grouped (ragged) dense layers: the 3 x 17 per-part nn.Linear layers of SpiralAutoencoder_multiz_partkps
+ * (models.py:200-204, applied one at a time at :236, :252, :269) in ONE launch per direction.  All groups read their
+ * inputs from, and write their outputs to, column ranges of two row-major matrices:
+ *   fwd       y[m][y_off[g] + n]  = sum_k x[m][x_off[g] + k] * W_g[n][k] + bias_g[n]            n < N[g], k < K[g]
+ *   bwd_data  dx[m][x_off[g] + k] = sum_n dy[m][y_off[g] + n] * W_g[n][k]
+ *   bwd_wgt   dW_g[n][k] = sum_m dy[m][y_off[g] + n] * x[m][x_off[g] + k];   dbias_g[n] = sum_m dy[m][y_off[g] + n]
+ * x / dx have row stride x_rs, y / dy row stride y_rs (elements).  w, bias, dW, dbias, x_off, y_off, N, K are HOST
+ * arrays of G entries (device pointers / element offsets / sizes); bias, dbias and their entries may be NULL.
+ * W_g is [N[g]][K[g]] row-major (nn.Linear.weight).  Deterministic; results overwrite their outputs.
+ */
+SH_API int sh_grouped_linear_fwd(int G, const float* x, int64_t x_rs, const int64_t* x_off, const float* const* w,
+                          const float* const* bias, float* y, int64_t y_rs, const int64_t* y_off, int M,
+                          const int* N, const int* K, sh_stream_t stream);
+SH_API int sh_grouped_linear_bwd_data(int G, const float* dy, int64_t y_rs, const int64_t* y_off, const float* const* w,
+                               float* dx, int64_t x_rs, const int64_t* x_off, int M, const int* N, const int* K,
+                               sh_stream_t stream);
+SH_API int sh_grouped_linear_bwd_wgt(int G, const float* dy, int64_t y_rs, const int64_t* y_off, const float* x,
+                              int64_t x_rs, const int64_t* x_off, float* const* dW, float* const* dbias, int M,
+                              const int* N, const int* K, sh_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Losses / metric.  All reductions are two-stage with a fixed order (no atomics).
  * workspace: at least sh_reduce_workspace() bytes.
  */

@@ -36,6 +36,9 @@ SIGNATURES = {
     "sh_linear_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, c_size_t, _P]),
     "sh_linear_bwd_data": (c_int, [_P, _P, _P, _I, _I, _I, _P, c_size_t, _P]),
     "sh_linear_bwd_wgt": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, c_size_t, _P]),
+    "sh_grouped_linear_fwd": (c_int, [_I, _P, _L, _P, _P, _P, _P, _L, _P, _I, _P, _P, _P]),
+    "sh_grouped_linear_bwd_data": (c_int, [_I, _P, _L, _P, _P, _P, _L, _P, _I, _P, _P, _P]),
+    "sh_grouped_linear_bwd_wgt": (c_int, [_I, _P, _L, _P, _P, _L, _P, _P, _P, _I, _P, _P, _P]),
     "sh_reduce_workspace": (c_size_t, []),
     "sh_l1_loss_fwd": (c_int, [_P, _P, _L, _P, _P, _P]),
     "sh_l1_loss_bwd": (c_int, [_P, _P, _L, _P, _P, _P]),

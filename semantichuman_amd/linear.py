@@ -34,3 +34,46 @@ def latent_linear(x: torch.Tensor, weight: torch.Tensor, bias) -> torch.Tensor:
     if x.dim() != 2:
         raise RuntimeError("latent_linear expects a 2-D input, got %s" % (tuple(x.shape),))
     return _LatentLinear.apply(x, weight, bias)
+
+
+class _GroupedLinear(torch.autograd.Function):
+    """All groups of one family of per-part layers in one launch per direction (csrc/grouped_linear.hip).
+    forward(x, x_off, y_cols, y_off, n_groups, w_0..w_{G-1}, b_0..b_{G-1})"""
+
+    @staticmethod
+    def forward(ctx, x, x_off, y_cols, y_off, G, *params):
+        weights, biases = list(params[:G]), list(params[G:])
+        x = x.contiguous()
+        weights_c = [w.contiguous() for w in weights]
+        ctx.save_for_backward(x, *weights_c)
+        ctx.meta = (tuple(x_off), y_cols, tuple(y_off), G, [b is not None for b in biases])
+        return ops.grouped_linear_fwd(x, x_off, weights_c, biases if any(b is not None for b in biases) else None, y_cols, y_off)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, *weights = ctx.saved_tensors
+        x_off, y_cols, y_off, G, has_bias = ctx.meta
+        dy = dy.contiguous()
+        dx = ops.grouped_linear_bwd_data(dy, y_off, weights, x.shape[1], x_off) if ctx.needs_input_grad[0] else None
+        need_w = [ctx.needs_input_grad[5 + g] for g in range(G)]
+        need_b = [has_bias[g] and ctx.needs_input_grad[5 + G + g] for g in range(G)]
+        dWs, dbs = [None] * G, [None] * G
+        if any(need_w) or any(need_b):
+            dWs, dbs = ops.grouped_linear_bwd_wgt(dy, y_off, x, x_off, weights, need_b)
+        return (dx, None, None, None, None) + tuple(dWs) + tuple(dbs)
+
+
+def grouped_linear(x: torch.Tensor, x_off, modules, y_off=None):
+    """Apply `modules[g]` (nn.Linear) to the column block x[:, x_off[g] : x_off[g] + in_features_g] for every g and
+    return the outputs side by side ([M, sum out_features], or at the given column offsets `y_off`).  What the
+    reference does with one `Linear` call per part (models.py:236,252,269)."""
+    if x.dim() != 2:
+        raise RuntimeError("grouped_linear expects a 2-D input, got %s" % (tuple(x.shape),))
+    outs = [m.out_features for m in modules]
+    if y_off is None:
+        y_off, o = [], 0
+        for n in outs:
+            y_off.append(o); o += n
+    y_cols = max(o + n for o, n in zip(y_off, outs))
+    G = len(modules)
+    return _GroupedLinear.apply(x, list(x_off), y_cols, list(y_off), G, *[m.weight for m in modules], *[m.bias for m in modules])

@@ -22,7 +22,7 @@ import torch.nn as nn
 
 from . import mesh_ops, ops
 from .mesh_ops import CSR
-from .linear import latent_linear
+from .linear import grouped_linear, latent_linear
 from .stack import ConvStep, SpmmStep, Stack, StackFunction, run_stack
 
 
@@ -219,6 +219,9 @@ class SpiralAutoencoder_multiz_partkps(nn.Module):
         self._dec_stack = build_decoder_stack(dec_layout, tables, [_as_csr(U[l]) for l in range(levels)], sizes)
         self._part_index = [torch.from_numpy(v.astype(np.int64)) for v in parts]
         self._re_index = torch.from_numpy(np.concatenate(parts).astype(np.int64))
+        self._part_off = [int(o) for o in np.cumsum([0] + [len(v) for v in parts[:-1]])]        # first row of each part
+        self._kps_cat = torch.from_numpy(np.concatenate([np.asarray(k, dtype=np.int64) for k in kps_index_list]))
+        self._kps_off = [int(3 * o) for o in np.cumsum([0] + [len(k) for k in kps_index_list[:-1]])]
         if device is not None:
             self.to(device)
 
@@ -230,25 +233,34 @@ class SpiralAutoencoder_multiz_partkps(nn.Module):
             self._dec_stack.to(dev)
             self._part_index = [p.to(dev) for p in self._part_index]
             self._re_index = self._re_index.to(dev)
+            self._kps_cat = self._kps_cat.to(dev)
             self.device = dev
         return out
 
+    # The reference applies the 3 x 17 per-part layers one `Linear` call at a time (models.py:236,252,269); here each
+    # family is ONE grouped launch per direction (linear.grouped_linear): the parts' inputs are gathered side by side
+    # with a single index op, the outputs come back side by side.
     def kps_encode(self, kps):
         B = kps.shape[0]
-        return torch.cat([latent_linear(kps[:, idx, :].reshape(B, -1).contiguous(), m.weight, m.bias)[:, None]
-                          for idx, m in zip(self.kps_index_list, self.kps_enc_list)], dim=1)
+        if self._kps_cat.device != kps.device:
+            self._kps_cat = self._kps_cat.to(kps.device)
+        x = kps[:, self._kps_cat, :].reshape(B, -1)                         # joints of part 0 | part 1 | ...
+        return grouped_linear(x, self._kps_off, self.kps_enc_list).view(B, len(self.kps_enc_list), -1)
 
     def encode(self, x, kps, VAE_flag=None):
         bsize = x.size(0)
         h = run_stack(self._enc_stack, x, "bm", "bm", self.conv)            # [B, N_last+1, C]
-        z = torch.cat([latent_linear(h[:, idx, :].reshape(bsize, -1), m.weight, m.bias)[:, None]
-                       for idx, m in zip(self._part_index, self.fc_latent_enc_list)], dim=1)
-        return z, self.kps_encode(kps), h[:, -1:, :]
+        feat = h.shape[2]
+        hp = h[:, self._re_index, :].reshape(bsize, -1)                     # vertices of part 0 | part 1 | ...
+        z = grouped_linear(hp, [o * feat for o in self._part_off], self.fc_latent_enc_list)
+        return z.view(bsize, len(self.fc_latent_enc_list), -1), self.kps_encode(kps), h[:, -1:, :]
 
     def decode(self, z, z_part_kps, dummy):
         bsize = z.size(0)
-        x = torch.cat([latent_linear(torch.cat([z[:, k, :], z_part_kps[:, k, :]], dim=1).contiguous(), m.weight, m.bias)
-                       for k, m in enumerate(self.fc_latent_dec_list)], dim=1).view(bsize, self.sizes[-1], -1)
+        zin = torch.cat([z, z_part_kps], dim=2)                             # [B, parts, latent + kps latent]
+        width = zin.shape[2]
+        x = grouped_linear(zin.reshape(bsize, -1), [k * width for k in range(zin.shape[1])], self.fc_latent_dec_list)
+        x = x.view(bsize, self.sizes[-1], -1)
         # models.py:270-272: rows are produced part by part, scatter them back to vertex order
         out = x.clone()
         out[:, self._re_index, :] = x[:, :self._re_index.shape[0], :]

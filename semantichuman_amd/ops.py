@@ -213,6 +213,53 @@ def linear_bwd_wgt(dy, x, want_bias=True):
     return dW, db
 
 
+def _glin_args(x_off, y_off, N, K):
+    import ctypes
+    G = len(N)
+    arr64 = lambda v: (ctypes.c_int64 * G)(*[int(t) for t in v])          # noqa: E731
+    arr32 = lambda v: (ctypes.c_int * G)(*[int(t) for t in v])            # noqa: E731
+    return G, arr64(x_off), arr64(y_off), arr32(N), arr32(K)
+
+
+def _ptr_array(tensors):
+    import ctypes
+    return (ctypes.c_void_p * len(tensors))(*[0 if t is None else t.data_ptr() for t in tensors])
+
+
+def grouped_linear_fwd(x, x_off, weights, biases, y_cols, y_off):
+    """y[:, y_off[g]:y_off[g]+N_g] = x[:, x_off[g]:x_off[g]+K_g] @ W_g.T + b_g for every group, one launch.
+    x [M, Kx] contiguous fp32; weights: list of [N_g, K_g]; biases: list (entries may be None) or None."""
+    _check2d(x, *weights)
+    M = x.shape[0]
+    y = torch.empty((M, y_cols), dtype=torch.float32, device=x.device)
+    G, xo, yo, N, K = _glin_args(x_off, y_off, [w.shape[0] for w in weights], [w.shape[1] for w in weights])
+    check(_lib.load().sh_grouped_linear_fwd(G, ptr(x), x.shape[1], xo, _ptr_array(weights),
+                                            _ptr_array(biases) if biases is not None else None, ptr(y), y_cols, yo, M, N, K,
+                                            stream_ptr()), "sh_grouped_linear_fwd")
+    return y
+
+
+def grouped_linear_bwd_data(dy, y_off, weights, x_cols, x_off):
+    _check2d(dy, *weights)
+    M = dy.shape[0]
+    dx = torch.zeros((M, x_cols), dtype=torch.float32, device=dy.device)      # columns no group covers stay zero
+    G, xo, yo, N, K = _glin_args(x_off, y_off, [w.shape[0] for w in weights], [w.shape[1] for w in weights])
+    check(_lib.load().sh_grouped_linear_bwd_data(G, ptr(dy), dy.shape[1], yo, _ptr_array(weights), ptr(dx), x_cols, xo, M, N, K,
+                                                 stream_ptr()), "sh_grouped_linear_bwd_data")
+    return dx
+
+
+def grouped_linear_bwd_wgt(dy, y_off, x, x_off, weights, want_bias):
+    _check2d(dy, x)
+    M = dy.shape[0]
+    dWs = [torch.empty_like(w) for w in weights]
+    dbs = [torch.empty((w.shape[0],), dtype=torch.float32, device=w.device) if wb else None for w, wb in zip(weights, want_bias)]
+    G, xo, yo, N, K = _glin_args(x_off, y_off, [w.shape[0] for w in weights], [w.shape[1] for w in weights])
+    check(_lib.load().sh_grouped_linear_bwd_wgt(G, ptr(dy), dy.shape[1], yo, ptr(x), x.shape[1], xo, _ptr_array(dWs),
+                                                _ptr_array(dbs), M, N, K, stream_ptr()), "sh_grouped_linear_bwd_wgt")
+    return dWs, dbs
+
+
 def _ws(device):
     return torch.empty(_lib.load().sh_reduce_workspace() // 4, dtype=torch.float32, device=device)
 

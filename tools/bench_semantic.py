@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Time one iteration of the SEMANTIC training loop (reference train_funcs.py:73-472) on the 6890-vertex
+template: SpiralAutoencoder_multiz_partkps, three passes (reconstruction, interpolation, exchange) with the part
+pairwise-distance, key-point, part-volume and latent-norm losses, backward, Adam.  The 17 body parts are synthetic
+(farthest-point Voronoi patches on the template, like the 578-vertex fixture), the joint regressor is a fixed positive
+sparse-ish matrix; batch 16 per pass (traincfg.yaml:21-23).  One JSON line.
+    python tools/bench_semantic.py [--batch 16] [--steps 20]"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import semantichuman_amd as sh                                   # noqa: E402
+from semantichuman_amd import constants as C, synthetic           # noqa: E402
+from semantichuman_amd import train_semantic as ts                # noqa: E402
+from semantichuman_amd.hierarchy import load_hierarchy            # noqa: E402
+
+
+def voronoi_parts(v, k):
+    seeds = [0]
+    dmin = np.linalg.norm(v - v[0], axis=1)
+    for _ in range(k - 1):
+        seeds.append(int(np.argmax(dmin)))
+        dmin = np.minimum(dmin, np.linalg.norm(v - v[seeds[-1]], axis=1))
+    owner = np.argmin(np.linalg.norm(v[:, None, :] - v[None, seeds, :], axis=2), axis=1)
+    return [np.sort(np.nonzero(owner == j)[0]) for j in range(k)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=20)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    h = load_hierarchy(os.path.join(ROOT, "tests", "golden", "template6890.npz"))
+    vi = h.verts / np.asarray((0.25, 0.15, 0.9))
+    fine = dict(zip(C.PART_LIST, voronoi_parts(vi, 17)))
+    # coarsest level: vertices of level 4 are a subset of level 0 (row selects): compose the selects
+    idx = np.arange(h.sizes[0])
+    for d in h.D:                                   # CSR row selects incl. the dummy row: col[:-1] = kept vertices
+        idx = idx[np.asarray(d.col[:-1])]
+    coarse = dict(zip(C.PART_LIST, voronoi_parts(vi[idx], 17)))
+    J = np.abs(synthetic.closed_form_fill((35, h.sizes[0]), 1.0, 0.618, 0.3)) ** 8
+    J = (J / J.sum(1, keepdims=True)).astype(np.float32)
+    torch.manual_seed(2)
+    m = sh.SpiralAutoencoder_multiz_partkps(C.KPS_INDEX_LIST, coarse, C.FILTER_SIZES_ENC, C.FILTER_SIZES_DEC, 8, 8, h.sizes,
+                                            h.spiral_sizes, h.spirals, h.D, h.U, dev)
+    opt = sh.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-5)
+    ctx = ts.SemanticContext(ts.SemanticTrainOptions(), SimpleNamespace(reference_mesh=SimpleNamespace(f=h.faces)), J, fine,
+                             C.PART_LIST, dev)
+    B = a.batch
+    tx, txi, txe = (torch.from_numpy(synthetic.synth_batch(h.verts, B, seed=s)).to(dev) for s in (1, 2, 3))
+    measure = torch.ones((B, 32), device=dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        total, _ = ts.semantic_losses(m, ctx, tx, txi, txe, epoch=1, measure=measure, draw_factor=1.1, exc_choice="ori")
+        total.backward()
+        opt.step()
+        return total
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    print(json.dumps({"metric": "semantic training iteration (3 passes), 6890 vertices", "batch_per_pass": B, "steps": a.steps,
+                      "ms_per_iteration": 1e3 * dt, "meshes_per_s": 3 * B / dt, "loss": float(loss.detach()), "dtype": "f32",
+                      "data": "synthetic (Voronoi parts, synthetic joint regressor)",
+                      "parts": {n: int(len(p)) for n, p in list(fine.items())[:4]}}))
+
+
+if __name__ == "__main__":
+    main()
