@@ -79,14 +79,27 @@ class _PairDist(torch.autograd.Function):
         return grad, None, None, None, None, None, None, None
 
 
+_BONE_INDEX_CACHE = {}
+
+
+def _bone_index(skl_list, device):
+    """Index tensors (head, tail, second tail or tail again) of a bone list - one gather instead of a Python loop."""
+    key = (id(skl_list), len(skl_list), str(device))
+    hit = _BONE_INDEX_CACHE.get(key)
+    if hit is None or hit[0] is not skl_list:
+        idx = [torch.tensor([b[0] for b in skl_list], device=device), torch.tensor([b[1] for b in skl_list], device=device),
+               torch.tensor([b[2] if len(b) == 3 else b[1] for b in skl_list], device=device)]
+        hit = (skl_list, idx)
+        _BONE_INDEX_CACHE[key] = hit
+    return hit[1]
+
+
 def bone_directions(kps, skl_list=None):
     """[B, P, 3] bone vector of each part from the FULL joint set (utils_SH.py:449-452):
     joint a - joint b, or joint a - mean(joint b, joint c)."""
     skl_list = constants.SKL_LIST if skl_list is None else skl_list
-    out = []
-    for b in skl_list:
-        out.append(kps[:, b[0], :] - (kps[:, b[1], :] if len(b) == 2 else (kps[:, b[1], :] + kps[:, b[2], :]) / 2))
-    return torch.stack(out, dim=1)
+    i0, i1, i2 = _bone_index(skl_list, kps.device)
+    return kps[:, i0, :] - (kps[:, i1, :] + kps[:, i2, :]) / 2          # two-joint bones have i2 == i1: (a + a) / 2 == a exactly
 
 
 def part_pairdist_loss(x_rec, x_gt, kps_gt, tables: PartTables, scale=None, w_mode="threshold", w_threshold=0.8, relat=True,
@@ -119,12 +132,10 @@ def part_volume_loss(x_rec, x_gt, faces, fpi, parts):
         a, b, c = x[:, faces[:, 0]], x[:, faces[:, 1]], x[:, faces[:, 2]]
         return (torch.cross(a, b, dim=2) * c).sum(2)                       # [B, F]
     vr, vg = signed(x_rec), signed(x_gt)
-    total = 0
-    for k in parts:
-        m = (fpi == k).to(vr.dtype)
-        rk, gk = (vr * m).sum(1), (vg * m).sum(1)
-        total = total + (torch.abs(rk / gk) - torch.abs(gk / gk)).abs().mean()
-    return total / len(parts)
+    # per-part sums of the face volumes as one product with the [F, parts] membership matrix
+    member = (fpi[:, None] == torch.as_tensor(list(parts), device=fpi.device)[None, :]).to(vr.dtype)
+    rk, gk = vr @ member, vg @ member                                       # [B, parts]
+    return (torch.abs(rk / gk) - torch.abs(gk / gk)).abs().mean(0).sum() / len(parts)
 
 
 def zpart_regulariser(z_part, measure, part_idx, measure_idx, relat=True):
@@ -143,8 +154,8 @@ def kps2skl(kps_tmp, skl_mode="ori_m", newskl_list=None):
     else:
         kps = torch.zeros((kps_tmp.shape[0], len(skl_list) + 4, 3), device=kps_tmp.device)
         kps[:, constants.kps_keep(skl_list), :] = kps_tmp
-    vec = torch.stack([kps[:, b[0], :] - (kps[:, b[1], :] if len(b) == 2 else (kps[:, b[1], :] + kps[:, b[2], :]) / 2)
-                       for b in skl_list], dim=1)                        # [B, n_bones, 3]
+    i0, i1, i2 = _bone_index(skl_list, kps.device)
+    vec = kps[:, i0, :] - (kps[:, i1, :] + kps[:, i2, :]) / 2            # [B, n_bones, 3]; i2 == i1 for two-joint bones
     n = torch.sqrt(torch.sum(vec ** 2, dim=2, keepdim=True))
     if skl_mode in ("ori_m", "kps_ori_m"):
         return torch.cat([vec / n, n], dim=2)
@@ -157,21 +168,44 @@ def kps2skl(kps_tmp, skl_mode="ori_m", newskl_list=None):
     raise NotImplementedError(skl_mode)
 
 
+_SKL_LEVELS_CACHE = {}
+
+
+def _skl_levels(skl_list, device):
+    """Bones grouped by depth in the kinematic tree, in the order the reference's loop resolves them
+    (utils_SH.py:77-83: joint b[1] = joint b[0] - bone, joints not yet assigned count as the origin)."""
+    key = (id(skl_list), len(skl_list), str(device))
+    hit = _SKL_LEVELS_CACHE.get(key)
+    if hit is None or hit[0] is not skl_list:
+        n_j = len(skl_list) + 4
+        depth_of_joint, levels = {}, {}
+        for k, b in enumerate(skl_list):
+            d = depth_of_joint[b[0]] + 1 if b[0] in depth_of_joint else 0
+            depth_of_joint[b[1]] = d
+            levels.setdefault(d, []).append((b[1], b[0] if b[0] in depth_of_joint and depth_of_joint[b[0]] < d else n_j, k))
+        out = []
+        for d in sorted(levels):
+            c, p, k = zip(*levels[d])
+            out.append(tuple(torch.tensor(t, device=device) for t in (c, p, k)))
+        hit = (skl_list, out)
+        _SKL_LEVELS_CACHE[key] = hit
+    return hit[1]
+
+
 def skl2kps(skl, skl_mode="ori_m", newskl_list=None):
-    """utils_SH.py:71-84: rebuild joints from the root outwards (joint b[1] = joint b[0] - bone)."""
+    """utils_SH.py:71-84: rebuild joints from the root outwards (joint b[1] = joint b[0] - bone), one tree level at a
+    time - the same subtraction per joint as the reference's bone-by-bone loop."""
     skl_list = constants.NEWSKL_LIST if newskl_list is None else newskl_list
-    kps = [None] * (len(skl_list) + 4)
-    zero = torch.zeros((skl.shape[0], 3), device=skl.device, dtype=skl.dtype)
-    for k, b in enumerate(skl_list):
-        if skl_mode == "vec":
-            bone = skl[:, k, :]
-        elif skl_mode == "vec_m":
-            bone = skl[:, k, :3]
-        elif skl_mode in ("ori_m", "kps_ori_m"):
-            bone = skl[:, k, :3] * skl[:, k, 3:]
-        else:
-            raise NotImplementedError(skl_mode)
-        parent = kps[b[0]] if kps[b[0]] is not None else zero
-        kps[b[1]] = parent - bone
-    out = torch.stack([k if k is not None else zero for k in kps], dim=1)
-    return out[:, constants.kps_keep(skl_list), :]
+    if skl_mode == "vec":
+        bone = skl
+    elif skl_mode == "vec_m":
+        bone = skl[:, :, :3]
+    elif skl_mode in ("ori_m", "kps_ori_m"):
+        bone = skl[:, :, :3] * skl[:, :, 3:]
+    else:
+        raise NotImplementedError(skl_mode)
+    n_j = len(skl_list) + 4
+    kps = torch.zeros((skl.shape[0], n_j + 1, 3), device=skl.device, dtype=skl.dtype)      # slot n_j: the origin
+    for child, parent, k in _skl_levels(skl_list, skl.device):
+        kps = kps.index_copy(1, child, kps[:, parent, :] - bone[:, k, :])
+    return kps[:, constants.kps_keep(skl_list), :]

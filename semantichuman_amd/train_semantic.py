@@ -114,8 +114,7 @@ def _edit_scales(ctx, opts, B, epoch, measure=None, draw=None):
 
 def _full_scale(ctx, part_index, a, B):
     s = torch.ones((B, len(ctx.partname_list)), device=ctx.device)
-    for k, p in enumerate(part_index):
-        s[:, p] = a[:, k]
+    s[:, list(part_index)] = a
     return s
 
 
