@@ -120,12 +120,73 @@ def _full_scale(ctx, part_index, a, B):
 
 def semantic_losses(model, ctx, tx, tx_interp, tx_exc, epoch, measure=None, interp_measure=None, loss_fn=None,
                     draw_factor=None, exc_choice=None):
-    """All loss terms of one iteration (reference :129-389).  Returns (total, dict of terms)."""
+    """All loss terms of one iteration (reference :129-389).  Returns (total, dict of terms).
+
+    The reference runs the network three times per iteration (reconstruction :131-133, interpolation :221-227,
+    exchange :320-321).  The three passes are the same encode -> (scale some part latents) -> decode with different
+    inputs, so they run here as ONE pass over the concatenated batch: a third of the launches, three times the rows per
+    launch, and every parameter gradient is produced once instead of accumulated three times."""
     o = ctx.opts
     loss_fn = _as_loss(loss_fn)
     terms = {}
+    do_interp = epoch > o.interp_epoch and tx_interp is not None
+    do_exc = epoch > o.exc_epoch and tx_exc is not None
+    B0 = tx.shape[0]
     kps_GT = ctx.joints(tx)
-    tx_hat, tx_zpart, _ = model(tx, kps_GT[:, ctx.kps_keep])
+    xs, ks = [tx], [kps_GT[:, ctx.kps_keep]]
+
+    if do_interp:
+        Bi = tx_interp.shape[0]
+        kps_i = ctx.joints(tx_interp)
+        if o.editskl_flag:
+            n = len(ctx.skl_keep) if o.edit_mode == "rand" else 1
+            f = torch.rand(n, device=ctx.device) * o.factor[0] + o.factor[1]
+            skl = part_losses.kps2skl(kps_i, "ori_m", o.newskl_list)
+            skl[:, ctx.skl_keep, 3] = skl[:, ctx.skl_keep, 3] * (f[None] if n > 1 else f)
+            new_kps_i = part_losses.skl2kps(skl, "ori_m", o.newskl_list)
+        else:
+            new_kps_i = kps_i[:, ctx.kps_keep]
+        part_index, a = _edit_scales(ctx, o, Bi, epoch, interp_measure, draw_factor)
+        scale = _full_scale(ctx, part_index, a, Bi)
+        xs.append(tx_interp); ks.append(new_kps_i)
+
+    if do_exc:
+        Be = tx_exc.shape[0]
+        kps_e = ctx.joints(tx_exc)
+        mode = o.exc_mode
+        if mode == "ori_or_m":
+            pick = (np.random.rand(1) > 0.5) if exc_choice is None else (exc_choice == "ori")
+            mode = "ori" if pick else "m"
+        if mode == "ori_m":
+            new_kps_e = torch.flip(kps_e, dims=[0])[:, ctx.kps_keep]
+            exc_kind = "ori_m"
+        else:
+            skl = part_losses.kps2skl(kps_e, "ori_m", o.newskl_list)
+            if mode == "ori":
+                skl[:, ctx.newskl_keep, :3] = torch.flip(skl[:, ctx.newskl_keep, :3], dims=[0])
+            else:
+                skl[:, ctx.skl_keep, 3] = torch.flip(skl[:, ctx.skl_keep, 3], dims=[0])
+            new_kps_e = part_losses.skl2kps(skl, "ori_m", o.newskl_list)
+            exc_kind = mode
+        xs.append(tx_exc); ks.append(new_kps_e)
+
+    # one pass of the network over [reconstruction | interpolation | exchange]
+    X = torch.cat(xs, dim=0) if len(xs) > 1 else tx
+    K = torch.cat(ks, dim=0) if len(ks) > 1 else ks[0]
+    latent, latent_kps, dummy = model.encode(X, K)
+    lat_in = latent
+    if do_interp:                                              # scale the edited parts' latents of the interpolation rows
+        full = torch.ones((X.shape[0], latent.shape[1]), device=ctx.device, dtype=latent.dtype)
+        full[B0:B0 + Bi] = scale
+        lat_in = latent * full[:, :, None]
+    rec = model.decode(lat_in, latent_kps, dummy)
+    tx_hat, tx_zpart = rec[:B0], latent[:B0]
+    o0 = B0
+    if do_interp:
+        rec_interp, o0 = rec[o0:o0 + Bi], o0 + Bi
+    if do_exc:
+        rec_exc = rec[o0:o0 + Be]
+
     terms["rec_loss"] = loss_fn(tx, tx_hat)
     loss = terms["rec_loss"]
     if epoch > o.edgereg_epoch and o.edgereg_w > 0:
@@ -138,23 +199,9 @@ def semantic_losses(model, ctx, tx, tx_interp, tx_exc, epoch, measure=None, inte
                                                                ctx.part_index_in_measure, o.relat_flag)
         loss = loss + o.zpartreg_w * terms["zpartreg_loss"]
 
-    if epoch > o.interp_epoch and tx_interp is not None:
-        B = tx_interp.shape[0]
-        kps_i = ctx.joints(tx_interp)
-        if o.editskl_flag:
-            n = len(ctx.skl_keep) if o.edit_mode == "rand" else 1
-            f = torch.rand(n, device=ctx.device) * o.factor[0] + o.factor[1]
-            skl = part_losses.kps2skl(kps_i, "ori_m", o.newskl_list)
-            skl[:, ctx.skl_keep, 3] = skl[:, ctx.skl_keep, 3] * (f[None] if n > 1 else f)
-            new_kps = part_losses.skl2kps(skl, "ori_m", o.newskl_list)
-        else:
-            new_kps = kps_i[:, ctx.kps_keep]
-        part_index, a = _edit_scales(ctx, o, B, epoch, interp_measure, draw_factor)
-        latent, latent_kps, dummy = model.encode(tx_interp, new_kps)
-        scale = _full_scale(ctx, part_index, a, B)
-        rec_interp = model.decode(latent * scale[:, :, None], latent_kps, dummy)
+    if do_interp:
         if o.interp_kps_w > 0:
-            terms["interp_kps_loss"] = (ctx.joints(rec_interp)[:, ctx.kps_keep] - new_kps).abs().mean()
+            terms["interp_kps_loss"] = (ctx.joints(rec_interp)[:, ctx.kps_keep] - new_kps_i).abs().mean()
             loss = loss + o.interp_kps_w * terms["interp_kps_loss"]
         if o.interp_euc_w > 0:
             terms["interp_euc_loss"] = part_losses.part_pairdist_loss(rec_interp, tx_interp, kps_i, ctx.tables, scale=scale,
@@ -162,31 +209,13 @@ def semantic_losses(model, ctx, tx, tx_interp, tx_exc, epoch, measure=None, inte
                                                                       relat=o.relat_flag, skl_list=o.skl_list)
             loss = loss + o.interp_euc_w * terms["interp_euc_loss"]
 
-    if epoch > o.exc_epoch and tx_exc is not None:
-        kps_e = ctx.joints(tx_exc)
-        mode = o.exc_mode
-        if mode == "ori_or_m":
-            pick = (np.random.rand(1) > 0.5) if exc_choice is None else (exc_choice == "ori")
-            mode = "ori" if pick else "m"
-        if mode == "ori_m":
-            new_kps = torch.flip(kps_e, dims=[0])[:, ctx.kps_keep]
-            exc_kind = "ori_m"
-        else:
-            skl = part_losses.kps2skl(kps_e, "ori_m", o.newskl_list)
-            if mode == "ori":
-                skl[:, ctx.newskl_keep, :3] = torch.flip(skl[:, ctx.newskl_keep, :3], dims=[0])
-            else:
-                skl[:, ctx.skl_keep, 3] = torch.flip(skl[:, ctx.skl_keep, 3], dims=[0])
-            new_kps = part_losses.skl2kps(skl, "ori_m", o.newskl_list)
-            exc_kind = mode
-        latent, latent_kps, dummy = model.encode(tx_exc, new_kps)
-        rec_exc = model.decode(latent, latent_kps, dummy)
+    if do_exc:
         if epoch > o.vol_epoch and o.vol_w > 0 and exc_kind == "ori":
             terms["vol_loss"] = part_losses.part_volume_loss(rec_exc[:, :-1], tx_exc[:, :-1], ctx.faces, ctx.fpi,
                                                              ctx.part_index_in_allpart)
             loss = loss + o.vol_w * terms["vol_loss"]
         if o.exc_kps_w > 0:
-            terms["exc_kps_loss"] = (ctx.joints(rec_exc)[:, ctx.kps_keep] - new_kps).abs().mean()
+            terms["exc_kps_loss"] = (ctx.joints(rec_exc)[:, ctx.kps_keep] - new_kps_e).abs().mean()
             loss = loss + o.exc_kps_w * terms["exc_kps_loss"]
         if o.exc_euc_w > 0:
             terms["exc_euc_loss"] = part_losses.part_pairdist_loss(rec_exc, tx_exc, kps_e, ctx.tables, scale=None, w_mode=o.w_mode,
