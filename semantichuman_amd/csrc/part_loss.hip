@@ -17,7 +17,10 @@
 
 namespace {
 
-constexpr int PT = 128;     // rows (i) per workgroup
+constexpr int PT = 32;      // rows (i) per workgroup
+constexpr int JS = 4;       // threads per row: each sweeps every JS-th partner j (a part has ~400 vertices and a batch only
+                            // ~2000 row tiles of 128: one thread per row left the chip at < 2 waves per SIMD)
+constexpr int PNT = PT * JS;   // threads per workgroup
 
 struct PLParams {
     const float* xr; const float* xg;        // [B][N1][3]
@@ -51,14 +54,14 @@ __device__ __forceinline__ int find_part(const int* tile_ptr, int P, int t) {
 }
 
 // forward: partial[(b*T + t)*2 + {0,1}] = (sum of terms, number of kept pairs) of the block's rows
-__global__ __launch_bounds__(PT) void pairdist_fwd_kernel(const PLParams q, float* __restrict__ partial) {
+__global__ __launch_bounds__(PNT) void pairdist_fwd_kernel(const PLParams q, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.x / q.T, t = blockIdx.x - b * q.T;
     const int p = find_part(q.tile_ptr, q.P, t);
     const int v0 = q.part_ptr[p], n = q.part_ptr[p + 1] - v0;
     float* G = sm;            // [n][3]
     float* R = sm + 3 * n;    // [n][3]
-    for (int i = threadIdx.x; i < n; i += PT) {
+    for (int i = threadIdx.x; i < n; i += PNT) {
         const long o = ((long)b * q.N1 + q.part_vert[v0 + i]) * 3;
         G[3 * i] = q.xg[o]; G[3 * i + 1] = q.xg[o + 1]; G[3 * i + 2] = q.xg[o + 2];
         R[3 * i] = q.xr[o]; R[3 * i + 1] = q.xr[o + 1]; R[3 * i + 2] = q.xr[o + 2];
@@ -68,12 +71,12 @@ __global__ __launch_bounds__(PT) void pairdist_fwd_kernel(const PLParams q, floa
     const float kn = sqrtf(kx * kx + ky * ky + kz * kz);
     const float sc = q.scale ? q.scale[(long)b * q.P + p] : 1.f;
     const bool all_one = q.flags[p] & 1;
-    const int i = (t - q.tile_ptr[p]) * PT + threadIdx.x;
+    const int i = (t - q.tile_ptr[p]) * PT + (threadIdx.x / JS), seg = threadIdx.x % JS;
     float s = 0.f, cnt = 0.f;
     if (i < n) {
         const float gx = G[3 * i], gy = G[3 * i + 1], gz = G[3 * i + 2];
         const float rx = R[3 * i], ry = R[3 * i + 1], rz = R[3 * i + 2];
-        for (int j = 0; j < n; ++j) {
+        for (int j = seg; j < n; j += JS) {
             if (j == i) continue;
             const float vx = gx - G[3 * j], vy = gy - G[3 * j + 1], vz = gz - G[3 * j + 2];
             const float d = sqrtf(vx * vx + vy * vy + vz * vz);
@@ -86,13 +89,13 @@ __global__ __launch_bounds__(PT) void pairdist_fwd_kernel(const PLParams q, floa
             cnt += 1.f;
         }
     }
-    __shared__ float red[2][PT / 64];
+    __shared__ float red[2][PNT / 64];
     s = sh_wave_sum(s); cnt = sh_wave_sum(cnt);
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = cnt; }
     __syncthreads();
     if (threadIdx.x == 0) {
         float a = 0.f, c = 0.f;
-        for (int w = 0; w < PT / 64; ++w) { a += red[0][w]; c += red[1][w]; }
+        for (int w = 0; w < PNT / 64; ++w) { a += red[0][w]; c += red[1][w]; }
         partial[((long)b * q.T + t) * 2] = a;
         partial[((long)b * q.T + t) * 2 + 1] = c;
     }
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(64) void pairdist_final_kernel(const float* __restr
 
 // backward w.r.t. the reconstruction: both (i,j) and (j,i) are terms of the loss and are equal, so
 // d loss / d r_i = 2 * sum_j coef_ij * (r_i - r_j) / |r_i - r_j|
-__global__ __launch_bounds__(PT) void pairdist_bwd_kernel(const PLParams q, const float* __restrict__ part_cnt,
+__global__ __launch_bounds__(PNT) void pairdist_bwd_kernel(const PLParams q, const float* __restrict__ part_cnt,
                                                           const float* __restrict__ gscale, float* __restrict__ grad) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.x / q.T, t = blockIdx.x - b * q.T;
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(PT) void pairdist_bwd_kernel(const PLParams q, cons
     const int v0 = q.part_ptr[p], n = q.part_ptr[p + 1] - v0;
     float* G = sm;
     float* R = sm + 3 * n;
-    for (int i = threadIdx.x; i < n; i += PT) {
+    for (int i = threadIdx.x; i < n; i += PNT) {
         const long o = ((long)b * q.N1 + q.part_vert[v0 + i]) * 3;
         G[3 * i] = q.xg[o]; G[3 * i + 1] = q.xg[o + 1]; G[3 * i + 2] = q.xg[o + 2];
         R[3 * i] = q.xr[o]; R[3 * i + 1] = q.xr[o + 1]; R[3 * i + 2] = q.xr[o + 2];
@@ -147,13 +150,13 @@ __global__ __launch_bounds__(PT) void pairdist_bwd_kernel(const PLParams q, cons
     const float sc = q.scale ? q.scale[(long)b * q.P + p] : 1.f;
     const bool all_one = q.flags[p] & 1;
     const float cnt = part_cnt[p];
-    const int i = (t - q.tile_ptr[p]) * PT + threadIdx.x;
-    if (i >= n) return;
+    const int i = (t - q.tile_ptr[p]) * PT + (threadIdx.x / JS), seg = threadIdx.x % JS;
+    if (i >= n) return;                                             // the JS threads of a row leave together
     const float norm = cnt > 0.f ? 2.f * gscale[0] * q.w_part[p] / cnt : 0.f;
     const float gx = G[3 * i], gy = G[3 * i + 1], gz = G[3 * i + 2];
     const float rx = R[3 * i], ry = R[3 * i + 1], rz = R[3 * i + 2];
     float ax = 0.f, ay = 0.f, az = 0.f;
-    for (int j = 0; j < n; ++j) {
+    for (int j = seg; j < n; j += JS) {
         if (j == i) continue;
         const float vx = gx - G[3 * j], vy = gy - G[3 * j + 1], vz = gz - G[3 * j + 2];
         const float d = sqrtf(vx * vx + vy * vy + vz * vz);
@@ -168,6 +171,11 @@ __global__ __launch_bounds__(PT) void pairdist_bwd_kernel(const PLParams q, cons
         const float c = sg * (q.relat ? w / De : w) / Dr;
         ax += c * ux; ay += c * uy; az += c * uz;
     }
+#pragma unroll
+    for (int m = 1; m < JS; m <<= 1) {                               // the row's JS partial sums (adjacent lanes), fixed order
+        ax += __shfl_xor(ax, m, 64); ay += __shfl_xor(ay, m, 64); az += __shfl_xor(az, m, 64);
+    }
+    if (seg != 0) return;
     const long o = ((long)b * q.N1 + q.part_vert[v0 + i]) * 3;
     grad[o] = norm * ax; grad[o + 1] = norm * ay; grad[o + 2] = norm * az;
 }
@@ -205,7 +213,7 @@ int sh_part_pairdist_loss_fwd(const float* x_rec, const float* x_gt, const float
     float* partial = static_cast<float*>(workspace);
     {
         ShProfScope ps(st, "pairdist_fwd_kernel|B=%d T=%d", B, T);
-        hipLaunchKernelGGL(pairdist_fwd_kernel, dim3((unsigned)(B * T)), dim3(PT), (size_t)max_part * 24, st, q, partial);
+        hipLaunchKernelGGL(pairdist_fwd_kernel, dim3((unsigned)(B * T)), dim3(PNT), (size_t)max_part * 24, st, q, partial);
     }
     hipLaunchKernelGGL(pairdist_final_kernel, dim3(1), dim3(64), 0, st, partial, tile_ptr, w_part, B, P, T, part_sum, part_cnt, loss);
     SH_CHECK_LAUNCH("part_pairdist_loss_fwd");
@@ -227,7 +235,7 @@ int sh_part_pairdist_loss_bwd(const float* x_rec, const float* x_gt, const float
     }
     {
         ShProfScope ps(st, "pairdist_bwd_kernel|B=%d T=%d", B, T);
-        hipLaunchKernelGGL(pairdist_bwd_kernel, dim3((unsigned)(B * T)), dim3(PT), (size_t)max_part * 24, st, q, part_cnt, gscale, grad);
+        hipLaunchKernelGGL(pairdist_bwd_kernel, dim3((unsigned)(B * T)), dim3(PNT), (size_t)max_part * 24, st, q, part_cnt, gscale, grad);
     }
     SH_CHECK_LAUNCH("part_pairdist_loss_bwd");
     return SH_OK;
