@@ -79,6 +79,22 @@ class _PairDist(torch.autograd.Function):
         return grad, None, None, None, None, None, None, None
 
 
+_INDEX_CACHE = {}
+
+
+def index_tensor(values, device):
+    """Device-resident int64 index tensor of a Python index list, cached: indexing a device tensor with a list uploads
+    the list on every call (a synchronous host-to-device copy, and illegal inside a hipGraph capture)."""
+    if torch.is_tensor(values):
+        return values
+    key = (tuple(int(v) for v in values), str(device))
+    t = _INDEX_CACHE.get(key)
+    if t is None:
+        t = torch.tensor(key[0], dtype=torch.int64, device=device)
+        _INDEX_CACHE[key] = t
+    return t
+
+
 _BONE_INDEX_CACHE = {}
 
 
@@ -133,7 +149,7 @@ def part_volume_loss(x_rec, x_gt, faces, fpi, parts):
         return (torch.cross(a, b, dim=2) * c).sum(2)                       # [B, F]
     vr, vg = signed(x_rec), signed(x_gt)
     # per-part sums of the face volumes as one product with the [F, parts] membership matrix
-    member = (fpi[:, None] == torch.as_tensor(list(parts), device=fpi.device)[None, :]).to(vr.dtype)
+    member = (fpi[:, None] == index_tensor(parts, fpi.device)[None, :]).to(vr.dtype)
     rk, gk = vr @ member, vg @ member                                       # [B, parts]
     return (torch.abs(rk / gk) - torch.abs(gk / gk)).abs().mean(0).sum() / len(parts)
 
@@ -141,6 +157,7 @@ def part_volume_loss(x_rec, x_gt, faces, fpi, parts):
 def zpart_regulariser(z_part, measure, part_idx, measure_idx, relat=True):
     """train_funcs.py:145-152: L1 between the norm of each part latent and the part's girth."""
     zm = torch.sqrt(torch.sum(z_part ** 2, dim=2))
+    part_idx, measure_idx = index_tensor(part_idx, zm.device), index_tensor(measure_idx, zm.device)
     if relat:
         return (zm[:, part_idx] / measure[:, measure_idx] - 1).abs().mean()
     return (zm[:, part_idx] - measure[:, measure_idx]).abs().mean()
@@ -153,7 +170,7 @@ def kps2skl(kps_tmp, skl_mode="ori_m", newskl_list=None):
         kps = kps_tmp.clone()
     else:
         kps = torch.zeros((kps_tmp.shape[0], len(skl_list) + 4, 3), device=kps_tmp.device)
-        kps[:, constants.kps_keep(skl_list), :] = kps_tmp
+        kps[:, index_tensor(constants.kps_keep(skl_list), kps_tmp.device), :] = kps_tmp
     i0, i1, i2 = _bone_index(skl_list, kps.device)
     vec = kps[:, i0, :] - (kps[:, i1, :] + kps[:, i2, :]) / 2            # [B, n_bones, 3]; i2 == i1 for two-joint bones
     n = torch.sqrt(torch.sum(vec ** 2, dim=2, keepdim=True))
@@ -208,4 +225,4 @@ def skl2kps(skl, skl_mode="ori_m", newskl_list=None):
     kps = torch.zeros((skl.shape[0], n_j + 1, 3), device=skl.device, dtype=skl.dtype)      # slot n_j: the origin
     for child, parent, k in _skl_levels(skl_list, skl.device):
         kps = kps.index_copy(1, child, kps[:, parent, :] - bone[:, k, :])
-    return kps[:, constants.kps_keep(skl_list), :]
+    return kps[:, index_tensor(constants.kps_keep(skl_list), kps.device), :]

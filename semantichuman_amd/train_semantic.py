@@ -82,6 +82,9 @@ class SemanticContext:
         self.tables = part_losses.PartTables({p: vert_part_index_dict[p] for p in self.partname_list}, device,
                                              leaf_parts=self.leaf_list, w_part=wp)
         self.face_tables = None
+        # device-resident copies of the index lists used on device tensors every iteration
+        it = part_losses.index_tensor
+        self.kps_keep_t, self.skl_keep_t, self.newskl_keep_t = it(self.kps_keep, device), it(self.skl_keep, device), it(self.newskl_keep, device)
 
     def joints(self, x):
         return torch.matmul(self.J, x[:, :-1, :]).float()          # reference :131,:161,:296
@@ -105,8 +108,9 @@ def _edit_scales(ctx, opts, B, epoch, measure=None, draw=None):
         a = torch.rand(len(part_index), device=dev) * lo + hi
         return part_index, a[None].repeat(B, 1)
     if opts.edit_mode == "equal":
-        f = (torch.rand(1, device=dev) * lo + hi) if draw is None else torch.as_tensor([draw], device=dev, dtype=torch.float32)
-        return ctx.part_index_in_allpart, torch.ones((B, len(opts.noleaf_part_list)), device=dev) * f
+        if draw is None:
+            return ctx.part_index_in_allpart, torch.ones((B, len(opts.noleaf_part_list)), device=dev) * (torch.rand(1, device=dev) * lo + hi)
+        return ctx.part_index_in_allpart, torch.full((B, len(opts.noleaf_part_list)), float(draw), device=dev)
     if opts.edit_mode == "exc":
         return ctx.part_index_in_allpart, torch.flip(measure, dims=[0]) / measure
     raise NotImplementedError(opts.edit_mode)
@@ -114,7 +118,7 @@ def _edit_scales(ctx, opts, B, epoch, measure=None, draw=None):
 
 def _full_scale(ctx, part_index, a, B):
     s = torch.ones((B, len(ctx.partname_list)), device=ctx.device)
-    s[:, list(part_index)] = a
+    s[:, part_losses.index_tensor(part_index, ctx.device)] = a
     return s
 
 
@@ -133,7 +137,7 @@ def semantic_losses(model, ctx, tx, tx_interp, tx_exc, epoch, measure=None, inte
     do_exc = epoch > o.exc_epoch and tx_exc is not None
     B0 = tx.shape[0]
     kps_GT = ctx.joints(tx)
-    xs, ks = [tx], [kps_GT[:, ctx.kps_keep]]
+    xs, ks = [tx], [kps_GT[:, ctx.kps_keep_t]]
 
     if do_interp:
         Bi = tx_interp.shape[0]
@@ -142,10 +146,10 @@ def semantic_losses(model, ctx, tx, tx_interp, tx_exc, epoch, measure=None, inte
             n = len(ctx.skl_keep) if o.edit_mode == "rand" else 1
             f = torch.rand(n, device=ctx.device) * o.factor[0] + o.factor[1]
             skl = part_losses.kps2skl(kps_i, "ori_m", o.newskl_list)
-            skl[:, ctx.skl_keep, 3] = skl[:, ctx.skl_keep, 3] * (f[None] if n > 1 else f)
+            skl[:, ctx.skl_keep_t, 3] = skl[:, ctx.skl_keep_t, 3] * (f[None] if n > 1 else f)
             new_kps_i = part_losses.skl2kps(skl, "ori_m", o.newskl_list)
         else:
-            new_kps_i = kps_i[:, ctx.kps_keep]
+            new_kps_i = kps_i[:, ctx.kps_keep_t]
         part_index, a = _edit_scales(ctx, o, Bi, epoch, interp_measure, draw_factor)
         scale = _full_scale(ctx, part_index, a, Bi)
         xs.append(tx_interp); ks.append(new_kps_i)
@@ -158,14 +162,14 @@ def semantic_losses(model, ctx, tx, tx_interp, tx_exc, epoch, measure=None, inte
             pick = (np.random.rand(1) > 0.5) if exc_choice is None else (exc_choice == "ori")
             mode = "ori" if pick else "m"
         if mode == "ori_m":
-            new_kps_e = torch.flip(kps_e, dims=[0])[:, ctx.kps_keep]
+            new_kps_e = torch.flip(kps_e, dims=[0])[:, ctx.kps_keep_t]
             exc_kind = "ori_m"
         else:
             skl = part_losses.kps2skl(kps_e, "ori_m", o.newskl_list)
             if mode == "ori":
-                skl[:, ctx.newskl_keep, :3] = torch.flip(skl[:, ctx.newskl_keep, :3], dims=[0])
+                skl[:, ctx.newskl_keep_t, :3] = torch.flip(skl[:, ctx.newskl_keep_t, :3], dims=[0])
             else:
-                skl[:, ctx.skl_keep, 3] = torch.flip(skl[:, ctx.skl_keep, 3], dims=[0])
+                skl[:, ctx.skl_keep_t, 3] = torch.flip(skl[:, ctx.skl_keep_t, 3], dims=[0])
             new_kps_e = part_losses.skl2kps(skl, "ori_m", o.newskl_list)
             exc_kind = mode
         xs.append(tx_exc); ks.append(new_kps_e)
@@ -201,7 +205,7 @@ def semantic_losses(model, ctx, tx, tx_interp, tx_exc, epoch, measure=None, inte
 
     if do_interp:
         if o.interp_kps_w > 0:
-            terms["interp_kps_loss"] = (ctx.joints(rec_interp)[:, ctx.kps_keep] - new_kps_i).abs().mean()
+            terms["interp_kps_loss"] = (ctx.joints(rec_interp)[:, ctx.kps_keep_t] - new_kps_i).abs().mean()
             loss = loss + o.interp_kps_w * terms["interp_kps_loss"]
         if o.interp_euc_w > 0:
             terms["interp_euc_loss"] = part_losses.part_pairdist_loss(rec_interp, tx_interp, kps_i, ctx.tables, scale=scale,
@@ -215,7 +219,7 @@ def semantic_losses(model, ctx, tx, tx_interp, tx_exc, epoch, measure=None, inte
                                                              ctx.part_index_in_allpart)
             loss = loss + o.vol_w * terms["vol_loss"]
         if o.exc_kps_w > 0:
-            terms["exc_kps_loss"] = (ctx.joints(rec_exc)[:, ctx.kps_keep] - new_kps_e).abs().mean()
+            terms["exc_kps_loss"] = (ctx.joints(rec_exc)[:, ctx.kps_keep_t] - new_kps_e).abs().mean()
             loss = loss + o.exc_kps_w * terms["exc_kps_loss"]
         if o.exc_euc_w > 0:
             terms["exc_euc_loss"] = part_losses.part_pairdist_loss(rec_exc, tx_exc, kps_e, ctx.tables, scale=None, w_mode=o.w_mode,
@@ -291,7 +295,7 @@ def train_autoencoder_dataloader_nonormal(dataloader_train, dataloader_val, devi
             for sample in dataloader_val:
                 tx = sample["verts"].to(device)
                 kps = ctx.joints(tx)
-                tx_hat_val = model(tx, kps[:, ctx.kps_keep])[0]
+                tx_hat_val = model(tx, kps[:, ctx.kps_keep_t])[0]
                 vloss += tx.shape[0] * loss_fn(tx[:, :-1, :], tx_hat_val[:, :-1, :])
         if scheduler:
             scheduler.step()
