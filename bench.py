@@ -50,13 +50,18 @@ def conv_launch_table(model, B):
     tb16 = "true" if B >= 16 else "false"          # batch-slice width of the tiles (SH_GG_TB default 16)
     tb = 16 if B >= 16 else 1 << max(0, (B - 1).bit_length())
 
-    def nt_split(rows, nout):
+    def nt_split(rows, nout, cg):
         """Output-channel tiles per workgroup after the few-tiles split of dispatch_gg() (csrc/spiral_conv.hip)."""
         t, blocks, split = nt(nout), -(-rows // (128 // tb)) * -(-B // tb), 1
-        while t > 1 and blocks * split < 768:
+        direct = cg % 4 == 0
+        while t > 2 and blocks * split < 768:
             t //= 2; split *= 2
+        if t == 2 and blocks * split * (2 if direct else 1) < 768:
+            t, split = 1, split * 2
+        if t == 8 and direct:
+            t, split = 4, split * 2
         return t, blocks * split
-    def gg_name(t, cg, bwd, blocks128=0):
+    def gg_name(t, blocks128, cg, bwd):
         """dispatch_gg(): two channel tiles with 16-byte gathers run the direct (LDS-free gather) form; 3-channel
         gathered rows with one channel tile run the padded-quad (dwordx3) mode of the staged kernel."""
         if cg == 3 and t == 1:
@@ -75,11 +80,11 @@ def conv_launch_table(model, B):
             vec = "true" if st.cin % 4 == 0 else "false"
             # fwd: read each needed input row once + weights, write output
             byt = 4.0 * (B * st.n_in * st.cin + B * st.R * st.cout + st.cout * K)
-            add(gg_name(nt_split(st.R, st.cout)[0], st.cin, "false", nt_split(st.R, st.cout)[1]), fl, byt)
+            add(gg_name(*nt_split(st.R, st.cout, st.cin), cg=st.cin, bwd="false"), fl, byt)
             if not (first and stack is model._enc_stack):
                 # backward-data = the same kernel over the transposed table; algorithmic FLOPs are
                 # those of the R*S real (row, position) pairs, not of the padded n_in*S table
-                add(gg_name(nt_split(st.n_in, st.cin)[0], st.cout, "true", nt_split(st.n_in, st.cin)[1]), fl, byt)
+                add(gg_name(*nt_split(st.n_in, st.cin, st.cout), cg=st.cout, bwd="true"), fl, byt)
             if st.cin % 4 == 0 or st.cin == 3:         # same choices as plan_wgrad() in csrc/spiral_conv.hip
                 cot = nt(st.cout)
                 add("wgrad_stream_kernel<%d, %d, %d, %s, %s>" % (cot, 1 if B <= 4 else 4, 3 if cot <= 2 else 2,

@@ -553,10 +553,16 @@ int dispatch_gg(GGParams& p, hipStream_t st) {
                 (!p.yprev || ((p.yp_sv % 4 == 0) && (p.yp_sb % 4 == 0) && reinterpret_cast<uintptr_t>(p.yprev) % 16 == 0));
     // too few row tiles to fill 256 CUs x ~3 workgroups: split the output channels over workgroups
     static const int fill_target = sh_env_int("SH_GG_FILL", 768, 1, 1 << 20);
-    p.nsplit = 1;
-    while (nt > 1 && nblocks * p.nsplit < fill_target) { nt >>= 1; p.nsplit <<= 1; }
-    const long nitems = nblocks * p.nsplit;
     static const int direct_on = sh_env_int("SH_GG_DIRECT", 1, 0, 1);
+    p.nsplit = 1;
+    while (nt > 2 && nblocks * p.nsplit < fill_target) { nt >>= 1; p.nsplit <<= 1; }
+    // two channel tiles run in the direct form with 64-row workgroups (twice the count): only split them further if even
+    // that does not fill the chip - one tile per workgroup is the slower staged form
+    if (nt == 2 && nblocks * p.nsplit * ((vec4 && direct_on) ? 2 : 1) < fill_target) { nt = 1; p.nsplit <<= 1; }
+    // eight channel tiles only exist staged; two workgroups of four tiles in the direct form are faster although each
+    // gathers the rows again (27 554-vertex template, 128 channels: 88 -> ~105 TFLOP/s)
+    if (nt == 8 && vec4 && direct_on) { nt = 4; p.nsplit <<= 1; }
+    const long nitems = nblocks * p.nsplit;
 #define SH_GG_CASE(NTV)                                                                  \
     return vec4 ? launch_gg<NTV, true, BWD_EPI>(p, (int)nitems, st)              \
                 : launch_gg<NTV, false, BWD_EPI>(p, (int)nitems, st)
@@ -1105,6 +1111,20 @@ WGPlan plan_wgrad(int B, int R, int S, int Cin, int Cout) {
         int vpc = sh_cdiv(R, (int)nvc_t);
         const int vcap = 2048 / S > 0 ? 2048 / S : 1;          // table lines of a wave: <= 8 KiB of LDS
         if (vpc > vcap) vpc = vcap;
+        // The table cap can force more items than the target (long spirals on fine levels).  All of them are resident at
+        // once, so what matters is that every CU gets the same number: round the item count up to a whole multiple of
+        // the target (measured at 27 554 vertices, spiral 18: 2.1 "rounds" ran at 67 TFLOP/s, 3.0 at ~95).
+        {
+            const long per_chunk = (long)w.ncg * w.n_btiles;
+            const long items = per_chunk * sh_cdiv(R, vpc);
+            if (items > items_target) {
+                const long rounds = (items + items_target - 1) / items_target;
+                long nvc_goal = rounds * items_target / per_chunk;
+                const long cap2 = 2 * (((long)slab_mb << 20) / ((long)Cout * K * 4)) / w.n_btiles;
+                if (nvc_goal > cap2) nvc_goal = cap2;
+                if (nvc_goal > sh_cdiv(R, vpc)) vpc = sh_cdiv(R, (int)nvc_goal);
+            }
+        }
         w.vpc = vpc;
         w.nvc = sh_cdiv(R, vpc);
         w.nrc = w.nvc * w.n_btiles;

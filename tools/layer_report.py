@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-launch timing of one training step (library HIP events), with shapes and achieved TFLOP/s.
-Run on the GPU box:  python tools/layer_report.py [batch]"""
+Run on the GPU box:  python tools/layer_report.py [batch] [template.npz]"""
 import os
 import re
 import sys
@@ -17,7 +17,8 @@ FE = [[3, 16, 32, 64, 128], [[], [], [], [], []]]
 FD = [[128, 64, 32, 32, 16], [[], [], [], [], 3]]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 dev = torch.device("cuda:0")
-h = load_hierarchy(os.path.join(ROOT, "tests", "golden", "template6890.npz"))
+TEMPLATE = sys.argv[2] if len(sys.argv) > 2 else os.path.join("tests", "golden", "template6890.npz")
+h = load_hierarchy(TEMPLATE if os.path.isabs(TEMPLATE) else os.path.join(ROOT, TEMPLATE))
 torch.manual_seed(2)
 model = sh.SpiralAutoencoder(FE, FD, 256, h.sizes, h.spiral_sizes, h.spirals, h.D, h.U, dev)
 ft = sh.FaceTables(h.faces, h.sizes[0] + 1, dev)
