@@ -122,7 +122,13 @@ def main():
     # collectives go through the host); the measured configuration is always nccl = RCCL, one rank per GPU
     backend = os.environ.get("SH_BENCH_BACKEND", "nccl")
     dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
-    if world > 1:
+    # SH_BENCH_FORCE_REDUCER=1: run the data-parallel control flow (hooks, buckets, RCCL calls, eager launches) in a world
+    # of ONE rank - what the multi-GPU path costs on the host side, measurable on a 1-GPU box
+    force_reducer = os.environ.get("SH_BENCH_FORCE_REDUCER", "0") != "0"
+    if force_reducer and world == 1:
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_reducer:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
@@ -153,7 +159,7 @@ def main():
     else:
         optim = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-5, capturable=True, fused=True)
     ft = sh.FaceTables(h.faces, h.sizes[0] + 1, dev)
-    reducer = GradientAllReducer(model, bucket_cap_mb=64.0) if world > 1 else None
+    reducer = GradientAllReducer(model, bucket_cap_mb=64.0, force_collectives=force_reducer) if (world > 1 or force_reducer) else None
 
     n_data = 16 * B                               # resident synthetic set, disjoint per rank
     data = torch.from_numpy(synthetic.synth_batch(h.verts, n_data, seed=100 + rank)).to(dev)
@@ -171,7 +177,7 @@ def main():
         loss.backward()
         last["loss"] = loss.detach()
 
-    use_graph = (not args.no_graph) and world == 1
+    use_graph = (not args.no_graph) and world == 1 and not force_reducer
     graph = None
     if use_graph:
         # capture forward+backward+Adam once, replay per step: removes ~100 host launches/step
@@ -347,7 +353,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -10,9 +10,10 @@ Design for xGMI (point-to-point links, no switch): few, large messages.
   * gradients are packed into contiguous buckets in BACKWARD order; the plain autoencoder's
     114 MB of gradients are 99 % two latent FC matrices (2 x 56.6 MB), which become ready in
     the middle of backward (decoder stack -> fc_latent_dec -> fc_latent_enc -> encoder stack);
-  * a bucket's all-reduce is launched asynchronously the moment its last gradient has been
-    produced (post-accumulate-grad hooks), so the FC buckets travel while the encoder-stack
-    backward kernels run; `finish()` waits and re-points .grad at the reduced bucket views.
+  * the all-reduce of a large gradient is launched asynchronously the moment it has been produced
+    (post-accumulate-grad hook), so the FC messages travel while the encoder-stack backward kernels
+    run; the packed small gradients (1 % of the bytes) follow in `finish()`, which waits and re-points
+    .grad at the reduced bucket views.
 
 Backend "nccl" is RCCL on ROCm; on CPU (tests) the same code runs over gloo.
 """
@@ -39,7 +40,6 @@ class GradBucket:
             for p in params:
                 self.views.append(self.flat[o:o + p.numel()].view_as(p))
                 o += p.numel()
-        self.pending = 0
         self.work = None
         self.buf = None          # the tensor in flight
 
@@ -69,28 +69,28 @@ class GradientAllReducer:
         big = int(inplace_min_mb * 1024 * 1024)
         self.buckets: List[GradBucket] = []
         cur, cur_bytes = [], 0
+        small: List[GradBucket] = []
         for p in reversed(params):
             nbytes = p.numel() * p.element_size()
             if nbytes >= big:                                  # large gradient: reduced in place, its own message
-                if cur:
-                    self.buckets.append(GradBucket(cur))
-                    cur, cur_bytes = [], 0
                 self.buckets.append(GradBucket([p], inplace=True))
                 continue
             if cur and cur_bytes + nbytes > cap:
-                self.buckets.append(GradBucket(cur))
+                small.append(GradBucket(cur))
                 cur, cur_bytes = [], 0
             cur.append(p)
             cur_bytes += nbytes
         if cur:
-            self.buckets.append(GradBucket(cur))
-        self._where = {}
-        for b in self.buckets:
-            for i, p in enumerate(b.params):
-                self._where[p] = (b, i)
+            small.append(GradBucket(cur))
+        self.buckets += small                                  # all small gradients together (one message for this net)
+        # Only the large in-place messages are launched from hooks (they are what there is to overlap: 99 % of the
+        # bytes, ready in the middle of backward).  The small gradients are packed by ONE multi-tensor copy and go out as
+        # ONE message in finish(): packed per parameter they were 20 copy launches (a ~5 us slot each on the compute
+        # stream, profiles/r01_reducer_timeline.txt) and three messages for 1 % of the bytes.
+        self._where = {b.params[0]: b for b in self.buckets if b.inplace}
         self._hooks = []
         if self.active and overlap:
-            for p in params:
+            for p in self._where:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self._armed = False
 
@@ -101,7 +101,6 @@ class GradientAllReducer:
     def prepare(self):
         """Call before backward (after zero_grad)."""
         for b in self.buckets:
-            b.pending = len(b.params)
             b.work = None
         self._armed = True
 
@@ -112,27 +111,25 @@ class GradientAllReducer:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
             b.buf = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-            if scale != 1.0:
-                b.buf.mul_(scale)
         else:
+            src, dst = [], []
             for p, v in zip(b.params, b.views):
                 if p.grad is None:
                     v.zero_()
                 elif p.grad.data_ptr() != v.data_ptr():
-                    torch.mul(p.grad, scale, out=v) if scale != 1.0 else v.copy_(p.grad)
-                elif scale != 1.0:
-                    v.mul_(scale)
+                    src.append(p.grad)
+                    dst.append(v)
+            if dst:
+                torch._foreach_copy_(dst, src)                 # one multi-tensor launch, not one copy per parameter
             b.buf = b.flat
+        if scale != 1.0:
+            b.buf.mul_(scale)
         op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM
         b.work = dist.all_reduce(b.buf, op=op, group=self.group, async_op=True)
 
     def _on_grad(self, p):
-        if not self._armed:
-            return
-        b, _ = self._where[p]
-        b.pending -= 1
-        if b.pending == 0:
-            self._launch(b)
+        if self._armed:
+            self._launch(self._where[p])
 
     def finish(self):
         """Call after backward, before optimizer.step(): waits for the collectives and makes
@@ -140,7 +137,7 @@ class GradientAllReducer:
         if not self.active:
             return
         for b in self.buckets:
-            if b.work is None:           # not launched by a hook (overlap off, or unused params)
+            if b.work is None:           # the packed small gradients; or overlap off / a parameter backward did not reach
                 self._launch(b)
         for b in self.buckets:
             b.work.wait()
