@@ -153,6 +153,53 @@ SH_API int sh_spmm(const int32_t* rowptr, const int32_t* col, const float* val,
             int B, int rows, int C, sh_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Whole-stack execution.  The reference runs encode / decode as Python loops over layers
+ * (models.py:119-128 conv + D per level, :146-153 U + conv per level) and leaves the backward chain to
+ * autograd; issued call by call from Python that is ~25 us of host time per launch (measured), i.e. the
+ * host, not the GPU, paces an eagerly launched step.  These two entry points issue the launches of a
+ * whole stack - forward, or the hand-scheduled backward chain - from one call.  They only sequence the
+ * entry points above (same kernels, same results, same launch order as calling them one by one), never
+ * allocate and never synchronise: every buffer is the caller's.
+ *
+ * A step is a SpiralConv (kind 0; a row-select D is already folded into `table`) or a sparse
+ * re-sampling (kind 1).  Layouts: 0 = vertex-major [rows][B][C] (all internal tensors), 1 = batch-major
+ * [B][rows][C] (allowed for the stack input and the stack output only).
+ */
+typedef struct sh_csr_ref { const int32_t* rowptr; const int32_t* col; const float* val; } sh_csr_ref;
+typedef struct sh_stack_step {
+    int kind;                         /* 0 conv, 1 spmm */
+    int param;                        /* conv: index into the weights / biases / dW / dbias arrays */
+    /* conv */
+    const int32_t* table;             /* [R][S] */
+    const int32_t* table_t;           /* [n_in][S] transposed table (see sh_spiral_conv_bwd_data) */
+    int R, S, n_in, cin, cout, act, zero_row;
+    int n1, n2;                       /* extra rows of the pre-activation gradient buffer: list pre-sums, levels 1 and 2 */
+    sh_csr_ref sum1, sum2;            /* their unit-valued CSR (n1 / n2 rows) */
+    /* spmm */
+    sh_csr_ref m, mt;                 /* y = M x and its transpose */
+    int m_rows, m_cols;
+} sh_stack_step;
+
+/* outs[i]: output of step i, vertex-major, except outs[n_steps-1] which has layout out_layout.
+ * x: [rows0] rows of c0 channels in layout x_layout. */
+SH_API int sh_stack_forward(int n_steps, const sh_stack_step* steps, const float* x, int x_layout, int rows0, int c0, int B,
+                            const float* const* weights, const float* const* biases, float* const* outs, int out_layout,
+                            sh_stream_t stream);
+
+/* acts[i]: what sh_stack_forward wrote to outs[i].  g: gradient w.r.t. the stack output (out_layout).
+ * gin[i]: gradient w.r.t. the INPUT of step i - for i >= 1 vertex-major with (n1 + n2 of step i-1, if that is a
+ * conv) extra rows behind the real ones, for i == 0 layout x_layout, NULL when need_x_grad == 0; buffers of
+ * non-adjacent steps may alias (gin[i] is dead once gin[i-1] has been produced).  dpre_last: as gin[] for the
+ * output of the last step when that is a conv ([R + n1 + n2][B][cout]), else unused.  Per conv step i:
+ * weight_t[i] ([cin][S*cout], needed when i > 0 or need_x_grad), workspace[i] / workspace_bytes[i]
+ * (>= sh_spiral_conv_bwd_wgt_workspace); per parameter index: dW[p], dbias[p] (may be NULL). */
+SH_API int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, int x_layout, int rows0, int c0, int B,
+                             const float* const* acts, const float* g, int out_layout, const float* const* weights,
+                             float* const* gin, float* dpre_last, float* const* weight_t, void* const* workspace,
+                             const size_t* workspace_bytes, float* const* dW, float* const* dbias, int need_x_grad,
+                             sh_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Dense layers with one tiny and one huge dimension: the latent nn.Linear pair fc_latent_enc /
  * fc_latent_dec (models.py:85-86, applied at :130 and :144) and their autograd.  Contiguous
  * row-major tensors; weight is nn.Linear.weight [N][K].  All three stream the weight-shaped matrix

@@ -32,6 +32,8 @@ SIGNATURES = {
     "sh_weight_transpose_multi": (c_int, [_I, _P, _P, _P, _P, _P, _P]),
     "sh_act_backward": (c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _P]),
     "sh_spmm": (c_int, [_P, _P, _P, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _P]),
+    "sh_stack_forward": (c_int, [_I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
+    "sh_stack_backward": (c_int, [_I, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "sh_linear_workspace": (c_size_t, [_I, _I, _I]),
     "sh_linear_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, c_size_t, _P]),
     "sh_linear_bwd_data": (c_int, [_P, _P, _P, _I, _I, _I, _P, c_size_t, _P]),
@@ -57,6 +59,19 @@ SIGNATURES = {
     "sh_gather_meshes": (c_int, [_P, _L, _P, _I, _P, _P]),
     "sh_adam_step": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P] + [ctypes.c_double] * 4 + [_P]),
 }
+
+
+
+class CsrRef(ctypes.Structure):                        # sh_csr_ref
+    _fields_ = [("rowptr", c_void_p), ("col", c_void_p), ("val", c_void_p)]
+
+
+class StackStep(ctypes.Structure):                     # sh_stack_step (include/sh_kernels.h) - field order is the ABI
+    _fields_ = [("kind", c_int), ("param", c_int), ("table", c_void_p), ("table_t", c_void_p),
+                ("R", c_int), ("S", c_int), ("n_in", c_int), ("cin", c_int), ("cout", c_int), ("act", c_int), ("zero_row", c_int),
+                ("n1", c_int), ("n2", c_int), ("sum1", CsrRef), ("sum2", CsrRef), ("m", CsrRef), ("mt", CsrRef),
+                ("m_rows", c_int), ("m_cols", c_int)]
+
 
 _lib = None
 

@@ -1,0 +1,166 @@
+// Whole-stack execution (sh_stack_forward / sh_stack_backward): host-side sequencing of the conv / spmm /
+// activation-backward / weight-gradient entry points for one encoder or decoder stack.  It mirrors, launch for
+// launch, what semantichuman_amd/stack.py does call by call from Python (reference: the layer loops of
+// models.py:119-128 and :146-153 plus autograd's backward chain) - the point is host time: one call instead of
+// ~25 us of interpreter and ctypes work per launch.  No kernels here.
+#include "sh_common.h"
+
+namespace {
+
+struct Lay { long sv, sb; };                                   // element strides of (row, batch)
+inline Lay lay(int layout, int rows, int B, int C) {
+    return layout == 0 ? Lay{(long)B * C, (long)C} : Lay{(long)C, (long)rows * C};
+}
+inline int out_rows(const sh_stack_step& s) { return s.kind == 0 ? s.R : s.m_rows; }
+inline int in_rows(const sh_stack_step& s) { return s.kind == 0 ? s.n_in : s.m_cols; }
+
+int check_steps(int n, const sh_stack_step* st, int c0, const char* what) {
+    SH_REQUIRE(n > 0 && st, SH_ERR_INVALID_ARG, "%s: no steps", what);
+    int c = c0;
+    for (int i = 0; i < n; ++i) {
+        SH_REQUIRE(st[i].kind == 0 || st[i].kind == 1, SH_ERR_INVALID_ARG, "%s: step %d has kind %d", what, i, st[i].kind);
+        if (st[i].kind == 0) {
+            SH_REQUIRE(st[i].cin == c, SH_ERR_INVALID_ARG, "%s: step %d takes %d channels, its input has %d", what, i, st[i].cin, c);
+            SH_REQUIRE(st[i].table && st[i].param >= 0, SH_ERR_INVALID_ARG, "%s: step %d incomplete", what, i);
+            c = st[i].cout;
+        } else {
+            SH_REQUIRE(st[i].m.rowptr && st[i].m.col && st[i].m.val, SH_ERR_INVALID_ARG, "%s: step %d has no matrix", what, i);
+        }
+    }
+    return SH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sh_stack_forward(int n_steps, const sh_stack_step* steps, const float* x, int x_layout, int rows0, int c0, int B,
+                     const float* const* weights, const float* const* biases, float* const* outs, int out_layout,
+                     sh_stream_t stream) {
+    int rc = check_steps(n_steps, steps, c0, "sh_stack_forward");
+    if (rc != SH_OK) return rc;
+    SH_REQUIRE(x && weights && outs && B > 0, SH_ERR_INVALID_ARG, "sh_stack_forward: null pointer or empty batch");
+    const float* cur = x;
+    Lay cl = lay(x_layout, rows0, B, c0);
+    int c = c0;
+    for (int i = 0; i < n_steps; ++i) {
+        const sh_stack_step& s = steps[i];
+        const int co = s.kind == 0 ? s.cout : c;
+        const Lay ol = lay(i == n_steps - 1 ? out_layout : 0, out_rows(s), B, co);
+        SH_REQUIRE(outs[i], SH_ERR_INVALID_ARG, "sh_stack_forward: no output buffer for step %d", i);
+        if (s.kind == 0)
+            rc = sh_spiral_conv_fwd(cur, cl.sv, cl.sb, s.table, weights[s.param], biases ? biases[s.param] : nullptr, outs[i],
+                                    ol.sv, ol.sb, B, s.R, s.S, s.cin, s.cout, s.act, s.zero_row, stream);
+        else
+            rc = sh_spmm(s.m.rowptr, s.m.col, s.m.val, cur, cl.sv, cl.sb, outs[i], ol.sv, ol.sb, nullptr, 0, 0, 0, -1, B,
+                         s.m_rows, c, stream);
+        if (rc != SH_OK) return rc;
+        cur = outs[i]; cl = ol; c = co;
+    }
+    return SH_OK;
+}
+
+int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, int x_layout, int rows0, int c0, int B,
+                      const float* const* acts, const float* g, int out_layout, const float* const* weights,
+                      float* const* gin, float* dpre_last, float* const* weight_t, void* const* workspace,
+                      const size_t* workspace_bytes, float* const* dW, float* const* dbias, int need_x_grad,
+                      sh_stream_t stream) {
+    int rc = check_steps(n_steps, steps, c0, "sh_stack_backward");
+    if (rc != SH_OK) return rc;
+    SH_REQUIRE(x && acts && g && weights && gin && dW && B > 0, SH_ERR_INVALID_ARG, "sh_stack_backward: null pointer or empty batch");
+    SH_REQUIRE(n_steps <= 64, SH_ERR_UNSUPPORTED, "sh_stack_backward: more than 64 steps");
+    const int last = n_steps - 1;
+    int cin_of[64];                                            // channels entering step i
+    {
+        int c = c0;
+        for (int i = 0; i < n_steps; ++i) { cin_of[i] = c; if (steps[i].kind == 0) c = steps[i].cout; }
+    }
+    // all weight transposes of the stack in one launch
+    {
+        const float* w[32]; float* wt[32]; int S[32], Ci[32], Co[32];
+        int n = 0;
+        for (int i = 0; i < n_steps; ++i) {
+            if (steps[i].kind != 0 || !(i > 0 || need_x_grad)) continue;
+            SH_REQUIRE(weight_t && weight_t[i], SH_ERR_INVALID_ARG, "sh_stack_backward: no weight_t buffer for step %d", i);
+            SH_REQUIRE(n < 32, SH_ERR_UNSUPPORTED, "sh_stack_backward: more than 32 conv steps");
+            w[n] = weights[steps[i].param]; wt[n] = weight_t[i]; S[n] = steps[i].S; Ci[n] = steps[i].cin; Co[n] = steps[i].cout;
+            ++n;
+        }
+        if (n) {
+            rc = sh_weight_transpose_multi(n, w, wt, S, Ci, Co, stream);
+            if (rc != SH_OK) return rc;
+        }
+    }
+    // gradient entering the last step
+    const float* cur; Lay cl;
+    {
+        const sh_stack_step& s = steps[last];
+        if (s.kind == 0) {
+            SH_REQUIRE(dpre_last, SH_ERR_INVALID_ARG, "sh_stack_backward: no dpre_last buffer");
+            const Lay ol = lay(out_layout, s.R, B, s.cout), dl = lay(0, 0, B, s.cout);
+            rc = sh_act_backward(g, ol.sv, ol.sb, acts[last], ol.sv, ol.sb, dpre_last, dl.sv, dl.sb, B, s.R, s.cout, s.act,
+                                 s.zero_row, stream);
+            if (rc != SH_OK) return rc;
+            cur = dpre_last; cl = dl;
+        } else {
+            cur = g; cl = lay(out_layout, s.m_rows, B, cin_of[last]);
+        }
+    }
+    const void* job_ws[64]; float* job_dW[64]; float* job_db[64]; int jB[64], jR[64], jS[64], jCi[64], jCo[64];
+    int njobs = 0;
+    for (int i = last; i >= 0; --i) {
+        const sh_stack_step& s = steps[i];
+        const bool want_in = i > 0 || need_x_grad;
+        const float* inp = i == 0 ? x : acts[i - 1];
+        const Lay il = i == 0 ? lay(x_layout, rows0, B, c0) : lay(0, 0, B, cin_of[i]);
+        float* gi = want_in ? gin[i] : nullptr;
+        SH_REQUIRE(!want_in || gi, SH_ERR_INVALID_ARG, "sh_stack_backward: no gradient buffer for the input of step %d", i);
+        const Lay gl = i == 0 ? lay(x_layout, rows0, B, c0) : lay(0, 0, B, cin_of[i]);
+        // the activation derivative of the layer that produced this step's input is applied by whoever writes gin[i]
+        const float* yprev = nullptr; Lay yl{0, 0}; int act_prev = 0, zero_prev = -1;
+        if (i > 0 && steps[i - 1].kind == 0) {
+            yprev = acts[i - 1]; yl = lay(0, 0, B, steps[i - 1].cout); act_prev = steps[i - 1].act; zero_prev = steps[i - 1].zero_row;
+        }
+        if (s.kind == 0) {
+            SH_REQUIRE(workspace && workspace[i], SH_ERR_INVALID_ARG, "sh_stack_backward: no workspace for step %d", i);
+            rc = sh_spiral_conv_bwd_wgt(cur, cl.sv, cl.sb, inp, il.sv, il.sb, s.table, nullptr, nullptr, workspace[i],
+                                        workspace_bytes[i], B, s.R, s.S, s.cin, s.cout, stream);
+            if (rc != SH_OK) return rc;
+            job_ws[njobs] = workspace[i]; job_dW[njobs] = dW[s.param]; job_db[njobs] = dbias ? dbias[s.param] : nullptr;
+            jB[njobs] = B; jR[njobs] = s.R; jS[njobs] = s.S; jCi[njobs] = s.cin; jCo[njobs] = s.cout;
+            SH_REQUIRE(job_dW[njobs], SH_ERR_INVALID_ARG, "sh_stack_backward: no dW buffer for parameter %d", s.param);
+            ++njobs;
+            if (want_in) {
+                SH_REQUIRE(s.table_t, SH_ERR_INVALID_ARG, "sh_stack_backward: step %d has no transposed table", i);
+                float* mut = const_cast<float*>(cur);          // the extra rows behind the R real ones of this step's own buffer
+                if (s.n1) {
+                    rc = sh_spmm(s.sum1.rowptr, s.sum1.col, s.sum1.val, cur, cl.sv, cl.sb, mut + (long)s.R * cl.sv, cl.sv, cl.sb,
+                                 nullptr, 0, 0, 0, -1, B, s.n1, s.cout, stream);
+                    if (rc != SH_OK) return rc;
+                }
+                if (s.n2) {
+                    rc = sh_spmm(s.sum2.rowptr, s.sum2.col, s.sum2.val, cur, cl.sv, cl.sb, mut + (long)(s.R + s.n1) * cl.sv,
+                                 cl.sv, cl.sb, nullptr, 0, 0, 0, -1, B, s.n2, s.cout, stream);
+                    if (rc != SH_OK) return rc;
+                }
+                rc = sh_spiral_conv_bwd_data(cur, cl.sv, cl.sb, s.table_t, weight_t[i], gi, gl.sv, gl.sb, yprev, yl.sv, yl.sb,
+                                             act_prev, zero_prev, B, s.n_in, s.S, s.cin, s.cout, stream);
+                if (rc != SH_OK) return rc;
+            }
+        } else if (want_in) {
+            SH_REQUIRE(s.mt.rowptr && s.mt.col && s.mt.val, SH_ERR_INVALID_ARG, "sh_stack_backward: step %d has no transposed matrix", i);
+            rc = sh_spmm(s.mt.rowptr, s.mt.col, s.mt.val, cur, cl.sv, cl.sb, gi, gl.sv, gl.sb, yprev, yl.sv, yl.sb, act_prev,
+                         zero_prev, B, s.m_cols, cin_of[i], stream);
+            if (rc != SH_OK) return rc;
+        }
+        if (want_in) { cur = gi; cl = gl; }
+    }
+    for (int k = 0; k < njobs; k += 16) {
+        const int n = njobs - k < 16 ? njobs - k : 16;
+        rc = sh_spiral_conv_bwd_wgt_reduce_multi(n, job_ws + k, job_dW + k, job_db + k, jB + k, jR + k, jS + k, jCi + k, jCo + k, stream);
+        if (rc != SH_OK) return rc;
+    }
+    return SH_OK;
+}
+
+}  // extern "C"

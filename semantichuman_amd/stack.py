@@ -15,9 +15,17 @@ The reference runs encode/decode as a Python loop of small autograd ops
             elementwise pass and no saved pre-activation.  No atomics anywhere.
 
 Plan construction is pure numpy (testable without a GPU); `to(device)` uploads the tables.
+
+The launches of a stack are issued by ONE library call each way (`sh_stack_forward` / `sh_stack_backward`,
+csrc/stack_exec.hip) into buffers carved out of one arena per pass: issued call by call from Python
+(`run_forward` / `run_backward` below, kept for the side-stream experiments and as the cross-check of the native
+sequencing, SH_STACK_NATIVE=0) a launch costs ~25 us of host time, which made the host pace an eagerly
+launched step (1.2 ms of host time per step against 1.85 ms of GPU time, and more than that with gradient
+collectives in the loop).
 """
 from __future__ import annotations
 
+import ctypes
 import os
 from dataclasses import dataclass, field
 from typing import Optional
@@ -25,8 +33,17 @@ from typing import Optional
 import numpy as np
 import torch
 
-from . import mesh_ops, ops
+from . import _lib, mesh_ops, ops
 from .mesh_ops import CSR, TransposedTable
+
+# one library call per stack and direction (csrc/stack_exec.hip); 0 = the call-by-call Python sequencing below
+NATIVE = os.environ.get("SH_STACK_NATIVE", "1") != "0"
+_LAYOUT_ID = {"vm": 0, "bm": 1}
+_ALIGN = 64                       # floats: every carved buffer starts 256-byte aligned (16-byte vector accesses)
+
+
+def _round(n: int) -> int:
+    return (n + _ALIGN - 1) // _ALIGN * _ALIGN
 
 # Side-stream options, both OFF: measured on MI355X, concurrency between these kernels only re-orders MFMA/HBM-saturated
 # work and pays for the fork/join.
@@ -137,10 +154,164 @@ class Stack:
         for s in self.steps:
             s.to(device)
         self.device = torch.empty(0, device=device).device      # normalised ('cuda' -> 'cuda:0')
+        self._nsteps = None                                      # the step table holds device pointers of the old upload
         return self
 
     def conv_steps(self):
         return [s for s in self.steps if s.kind == "conv"]
+
+    # ------------------------------------------------------------------ native sequencing
+    def _native_steps(self):
+        """The sh_stack_step table (host memory; device pointers of the uploaded tables)."""
+        arr = getattr(self, "_nsteps", None)
+        if arr is not None:
+            return arr
+        P = lambda t: t.data_ptr()                                    # noqa: E731
+        arr = (_lib.StackStep * len(self.steps))()
+        for e, st in zip(arr, self.steps):
+            if st.kind == "conv":
+                e.kind, e.param = 0, st.param
+                e.table, e.table_t = P(st.dev["table"]), P(st.dev["table_t"])
+                e.R, e.S, e.n_in, e.cin, e.cout, e.act, e.zero_row = st.R, st.S, st.n_in, st.cin, st.cout, st.act, st.zero_row
+                e.n1, e.n2 = st.tt.n1, st.tt.n2
+                for name, ref in (("sum1", e.sum1), ("sum2", e.sum2)):
+                    if name in st.dev:
+                        ref.rowptr, ref.col, ref.val = (P(t) for t in st.dev[name])
+            else:
+                e.kind, e.param = 1, -1
+                e.m.rowptr, e.m.col, e.m.val = (P(t) for t in st.dev["m"])
+                e.mt.rowptr, e.mt.col, e.mt.val = (P(t) for t in st.dev["mt"])
+                e.m_rows, e.m_cols = st.csr.rows, st.csr.cols
+        self._nsteps = arr
+        return arr
+
+    def _plan(self, B: int, c0: int):
+        """Buffer sizes / arena offsets (in floats) for batch B; cached."""
+        key = (B, c0)
+        plans = self.__dict__.setdefault("_plans", {})
+        if key in plans:
+            return plans[key]
+        lib = _lib.load()
+        n = len(self.steps)
+        cin_of, c = [], c0
+        for st in self.steps:
+            cin_of.append(c)
+            c = st.cout if st.kind == "conv" else c
+        out_rows = [st.R if st.kind == "conv" else st.csr.rows for st in self.steps]
+        out_ch = [st.cout if st.kind == "conv" else cin_of[i] for i, st in enumerate(self.steps)]
+        # forward arena: outputs of all steps but the last
+        f_off, o = np.zeros(n, dtype=np.uint64), 0
+        for i in range(n - 1):
+            f_off[i] = o
+            o += _round(out_rows[i] * B * out_ch[i])
+        f_total = o
+        # backward arena: dpre of the last step | two alternating regions for the input-gradient chain | weight_t | slabs
+        last = self.steps[-1]
+        o = 0
+        dpre_last_off = 0
+        if last.kind == "conv":
+            o += _round((last.R + last.n_extra) * B * last.cout)
+        gin_size = [0] * n
+        for i in range(1, n):
+            st, prev = self.steps[i], self.steps[i - 1]
+            rows_in = st.n_in if st.kind == "conv" else st.csr.cols
+            gin_size[i] = (rows_in + (prev.n_extra if prev.kind == "conv" else 0)) * B * cin_of[i]
+        region = [_round(max([gin_size[i] for i in range(1, n) if i % 2 == par] + [0])) for par in (0, 1)]
+        region_off = [o, o + region[0]]
+        o += region[0] + region[1]
+        g_off = np.zeros(n, dtype=np.uint64)
+        g_mask = np.zeros(n, dtype=np.uint64)
+        for i in range(1, n):
+            g_off[i], g_mask[i] = region_off[i % 2], 1
+        wt_off, wt_mask = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+        ws_off, ws_mask, ws_bytes = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+        for i, st in enumerate(self.steps):
+            if st.kind != "conv":
+                continue
+            wt_off[i], wt_mask[i] = o, 1
+            o += _round(st.cin * st.S * st.cout)
+            nb = int(lib.sh_spiral_conv_bwd_wgt_workspace(B, st.R, st.S, st.cin, st.cout))
+            ws_off[i], ws_mask[i], ws_bytes[i] = o, 1, nb
+            o += _round((nb + 3) // 4)
+        b_total = o
+        # gradients of the parameters: one flat tensor, dW then dbias per parameter index
+        npar = 1 + max(st.param for st in self.steps if st.kind == "conv")
+        dW_off, db_off, shapes, o = np.zeros(npar, dtype=np.uint64), np.zeros(npar, dtype=np.uint64), [None] * npar, 0
+        for st in self.steps:
+            if st.kind != "conv":
+                continue
+            dW_off[st.param] = o
+            o += _round(st.cout * st.S * st.cin)
+            db_off[st.param] = o
+            o += _round(st.cout)
+            shapes[st.param] = (st.cout, st.S * st.cin)
+        plan = dict(f_off=f_off * 4, f_total=f_total, dpre_last_off=dpre_last_off, g_off=g_off * 4, g_mask=g_mask,
+                    wt_off=wt_off * 4, wt_mask=wt_mask, ws_off=ws_off * 4, ws_mask=ws_mask, ws_bytes=ws_bytes, b_total=b_total,
+                    dW_off=dW_off * 4, db_off=db_off * 4, dW_off_f=dW_off, db_off_f=db_off, shapes=shapes, p_total=o, npar=npar,
+                    out_rows=out_rows, out_ch=out_ch)
+        plans[key] = plan
+        return plan
+
+    @staticmethod
+    def _ptr_array(tensors):
+        return (ctypes.c_void_p * len(tensors))(*[0 if t is None else t.data_ptr() for t in tensors])
+
+    def native_forward(self, x, in_layout, out_layout, weights, biases):
+        """-> (output, arena holding the outputs of the inner steps)."""
+        B = x.shape[0] if in_layout == "bm" else x.shape[1]
+        rows0 = x.shape[1] if in_layout == "bm" else x.shape[0]
+        c0 = x.shape[2]
+        if not (x.is_contiguous() and x.dtype == torch.float32):
+            raise ValueError("expected a contiguous fp32 3-D tensor, got %s %s" % (tuple(x.shape), x.dtype))
+        if x.numel() >= 2 ** 32:
+            raise RuntimeError("semantichuman_amd: gathered tensors are addressed with 32-bit element offsets; "
+                               "%d elements is too large - split the batch" % x.numel())
+        plan = self._plan(B, c0)
+        n = len(self.steps)
+        arena = torch.empty(max(1, plan["f_total"]), dtype=torch.float32, device=x.device)
+        out = ops.alloc(B, plan["out_rows"][-1], plan["out_ch"][-1], out_layout, x.device)
+        outs = plan["f_off"] + np.uint64(arena.data_ptr())
+        outs[n - 1] = out.data_ptr()
+        _lib.check(_lib.load().sh_stack_forward(n, self._native_steps(), _lib.ptr(x), _LAYOUT_ID[in_layout], rows0, c0, B,
+                                                self._ptr_array(weights), self._ptr_array(biases), outs.ctypes.data,
+                                                _LAYOUT_ID[out_layout], _lib.stream_ptr()), "sh_stack_forward")
+        return out, arena
+
+    def native_backward(self, x, in_layout, out_layout, arena, out, g, weights, need_x_grad, need_bias):
+        """-> (grad_x or None, {param: (dW, db)})"""
+        B = x.shape[0] if in_layout == "bm" else x.shape[1]
+        rows0 = x.shape[1] if in_layout == "bm" else x.shape[0]
+        c0 = x.shape[2]
+        plan = self._plan(B, c0)
+        n = len(self.steps)
+        dev = x.device
+        work = torch.empty(max(1, plan["b_total"]), dtype=torch.float32, device=dev)
+        flat = torch.empty(max(1, plan["p_total"]), dtype=torch.float32, device=dev)
+        gx = ops.alloc(B, rows0, c0, in_layout, dev) if need_x_grad else None
+        acts = plan["f_off"] + np.uint64(arena.data_ptr())
+        acts[n - 1] = out.data_ptr()
+        wbase, fbase = np.uint64(work.data_ptr()), np.uint64(flat.data_ptr())
+        gin = (plan["g_off"] + wbase) * plan["g_mask"]
+        gin[0] = gx.data_ptr() if need_x_grad else 0
+        wt = (plan["wt_off"] + wbase) * plan["wt_mask"]
+        ws = (plan["ws_off"] + wbase) * plan["ws_mask"]
+        dW = plan["dW_off"] + fbase
+        assert len(need_bias) == plan["npar"] == len(weights)
+        db = (plan["db_off"] + fbase) * np.array([1 if nb else 0 for nb in need_bias], dtype=np.uint64)
+        _lib.check(_lib.load().sh_stack_backward(
+            n, self._native_steps(), _lib.ptr(x), _LAYOUT_ID[in_layout], rows0, c0, B, acts.ctypes.data, _lib.ptr(g),
+            _LAYOUT_ID[out_layout], self._ptr_array(weights), gin.ctypes.data, ctypes.c_void_p(int(wbase) + 4 * plan["dpre_last_off"]),
+            wt.ctypes.data, ws.ctypes.data, plan["ws_bytes"].ctypes.data, dW.ctypes.data, db.ctypes.data, 1 if need_x_grad else 0,
+            _lib.stream_ptr()), "sh_stack_backward")
+        grads = {}
+        for j, shp in enumerate(plan["shapes"]):
+            if shp is None:
+                continue
+            o = int(plan["dW_off_f"][j])
+            dWj = flat[o:o + shp[0] * shp[1]].view(shp)
+            o = int(plan["db_off_f"][j])
+            grads[j] = (dWj, flat[o:o + shp[0]] if need_bias[j] else None)
+        return gx, grads
 
     def _side_stream(self, dev):
         s = getattr(self, "_side", None)
@@ -286,24 +457,33 @@ class StackFunction(torch.autograd.Function):
         weights, biases = list(params[0::2]), list(params[1::2])
         x = x.contiguous()
         need = any(ctx.needs_input_grad[3:])
-        out, acts = stack.run_forward(x, in_layout, out_layout, weights, biases, keep=need)
         ctx.stack, ctx.layouts = stack, (in_layout, out_layout)
+        ctx.has_bias = [b is not None for b in biases]
+        ctx.native = NATIVE and not (OVERLAP_WGRAD or OVERLAP_PRESUM)
+        if ctx.native:
+            out, arena = stack.native_forward(x, in_layout, out_layout, weights, biases)
+            ctx.save_for_backward(x, out, arena, *weights)
+            return out
+        out, acts = stack.run_forward(x, in_layout, out_layout, weights, biases, keep=need)
         ctx.acts = acts[:-1]                 # internal activations; the output itself goes through
         ctx.save_for_backward(x, out, *weights)   # save_for_backward (no ctx <-> output cycle)
-        ctx.has_bias = [b is not None for b in biases]
         return out
 
     @staticmethod
     def backward(ctx, g):
         stack = ctx.stack
         in_layout, out_layout = ctx.layouts
-        x, out, *weights = ctx.saved_tensors
         g = g.contiguous()
         # forward args: (stack, in_layout, out_layout, x, w_0, b_0, w_1, b_1, ...)
         need_bias = [hb and ctx.needs_input_grad[5 + 2 * j] for j, hb in enumerate(ctx.has_bias)]
-        gx, grads = stack.run_backward(x, in_layout, out_layout, ctx.acts + [out], g, weights,
-                                       ctx.needs_input_grad[3], need_bias)
-        ctx.acts = None
+        if ctx.native:
+            x, out, arena, *weights = ctx.saved_tensors
+            gx, grads = stack.native_backward(x, in_layout, out_layout, arena, out, g, weights, ctx.needs_input_grad[3], need_bias)
+        else:
+            x, out, *weights = ctx.saved_tensors
+            gx, grads = stack.run_backward(x, in_layout, out_layout, ctx.acts + [out], g, weights,
+                                           ctx.needs_input_grad[3], need_bias)
+            ctx.acts = None
         res = [None, None, None, gx]
         for j in range(len(weights)):
             dW, db = grads.get(j, (None, None))
@@ -324,5 +504,7 @@ def run_stack(stack: Stack, x, in_layout, out_layout, convs):
         params += [m.conv.weight, m.conv.bias]
     if torch.is_grad_enabled() and (x.requires_grad or any(p is not None and p.requires_grad for p in params)):
         return StackFunction.apply(stack, in_layout, out_layout, x, *params)
+    if NATIVE:
+        return stack.native_forward(x.contiguous(), in_layout, out_layout, params[0::2], params[1::2])[0]
     out, _ = stack.run_forward(x.contiguous(), in_layout, out_layout, params[0::2], params[1::2], keep=False)
     return out

@@ -358,6 +358,36 @@ def test_batch64_properties(golden_dir):
             assert torch.equal(a, prm.grad), name     # our kernels: fixed-order slab reduction, no atomics
 
 
+@pytest.mark.parametrize("batch", [3, 64])
+def test_native_stack_sequencing_equals_call_by_call(golden_dir, batch, monkeypatch):
+    """sh_stack_forward / sh_stack_backward (one library call per stack and direction) issue the same launches as
+    the call-by-call Python sequencing: outputs, input gradient and every parameter gradient bitwise equal."""
+    from semantichuman_amd import stack as stack_mod, synthetic
+    p = os.path.join(golden_dir, "template6890.npz")
+    h = load_hierarchy(p)
+    torch.manual_seed(3)
+    m, _ = make_models(h, None, 256)
+    x = torch.from_numpy(synthetic.synth_batch(h.verts, batch, seed=2)).to(dev())
+
+    def run(native):
+        monkeypatch.setattr(stack_mod, "NATIVE", native)
+        m.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        x_hat, z = m(xi)
+        (sh.l1_loss(x, x_hat) + 0.1 * z.square().mean()).backward()
+        with torch.no_grad():
+            x_eval = m(x)[0]
+        return [x_hat.detach().clone(), z.detach().clone(), xi.grad.clone(), x_eval] + [q.grad.clone() for q in m.parameters()]
+
+    a, b = run(True), run(False)
+    names = ["x_hat", "z", "dx", "x_hat (no grad)"] + [n for n, _ in m.named_parameters()]
+    for name, u, v in zip(names, a, b):
+        if name.startswith("fc_") and name.endswith("weight"):
+            assert torch.allclose(u, v, rtol=1e-5, atol=1e-9), name      # split-K FC gradient (see test_batch64_properties)
+        else:
+            assert torch.equal(u, v), name
+
+
 def test_fused_recon_loss_equals_separate_terms(golden_dir):
     """recon_loss = l1_loss + w * edge_ratio_loss: same values (fixed-order sums) and the same gradient."""
     p = os.path.join(golden_dir, "small_ae.npz")
