@@ -130,6 +130,9 @@ def main():
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
     if world > 1 or force_reducer:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # the all-reduce kernels share the chip with backward kernels that are sized to fill every CU: give the
+        # collectives' stream dispatch priority so their few workgroups are placed as soon as a slot frees
+        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
