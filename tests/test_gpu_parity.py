@@ -388,6 +388,38 @@ def test_native_stack_sequencing_equals_call_by_call(golden_dir, batch, monkeypa
             assert torch.equal(u, v), name
 
 
+def test_vae_branch(golden_dir):
+    """VAE_flag=True (reference models.py:82-83, 131-136; off in every shipped config): fc_latent_enc has 2 * nz
+    outputs, z = z_mu + eps * exp(z_var / 2).  Checked in the deterministic limit (log-variance forced to -200:
+    z == z_mu, which must equal the plain model with the first nz rows of the weight) and statistically
+    (z_var == 0: z - z_mu is unit normal)."""
+    p = os.path.join(golden_dir, "small_ae.npz")
+    g, h = np.load(p), load_hierarchy(p)
+    m, om = make_models(h, g, 16)
+    torch.manual_seed(5)
+    mv = sh.SpiralAutoencoder(FE, FD, 16, h.sizes, h.spiral_sizes, h.spirals, h.D, h.U, dev(), VAE_flag=True)
+    assert mv.fc_latent_enc.weight.shape[0] == 32
+    sd = m.state_dict()
+    with torch.no_grad():
+        for k, v in mv.state_dict().items():
+            if not k.startswith("fc_latent_enc"):
+                v.copy_(sd[k])
+        mv.fc_latent_enc.weight[:16].copy_(sd["fc_latent_enc.weight"])
+        mv.fc_latent_enc.bias[:16].copy_(sd["fc_latent_enc.bias"])
+        mv.fc_latent_enc.weight[16:].zero_()
+        mv.fc_latent_enc.bias[16:].fill_(-200.0)
+    x = torch.from_numpy(g["x"]).to(dev())
+    x_hat, z = mv(x)
+    close(z, g["z"], FWD_TOL, "z (zero variance) vs reference")
+    close(x_hat, g["x_hat"], FWD_TOL, "x_hat (zero variance) vs reference")
+    assert torch.equal(mv.z_mu, z) and float(mv.z_var.max()) == -200.0
+    with torch.no_grad():
+        mv.fc_latent_enc.bias[16:].zero_()                     # unit variance
+    zs = torch.stack([mv.encode(x, True) - mv.z_mu for _ in range(200)])
+    assert abs(float(zs.mean())) < 0.05 and abs(float(zs.std()) - 1.0) < 0.05
+    assert mv.encode(x, False).shape[1] == 32                  # the flag argument overrides the attribute (models.py:115)
+
+
 def test_fused_recon_loss_equals_separate_terms(golden_dir):
     """recon_loss = l1_loss + w * edge_ratio_loss: same values (fixed-order sums) and the same gradient."""
     p = os.path.join(golden_dir, "small_ae.npz")
@@ -435,6 +467,17 @@ def test_c_abi_error_contract():
     rc = lib.sh_spiral_conv_bwd_wgt(_lib.ptr(y), 4, 36, _lib.ptr(x), 4, 36, _lib.ptr(table), _lib.ptr(dW), None, _lib.ptr(ws),
                                     ctypes.c_size_t(16), 2, 9, 3, 4, 4, st)
     assert rc == -3 and b"workspace" in lib.sh_last_error()
+    # whole-stack entry points: empty step table, channel mismatch between consecutive steps, missing output buffer
+    assert lib.sh_stack_forward(0, None, _lib.ptr(x), 1, 9, 4, 2, None, None, None, 1, st) == -1
+    steps = (_lib.StackStep * 1)()
+    steps[0].kind, steps[0].param, steps[0].table = 0, 0, table.data_ptr()
+    steps[0].R, steps[0].S, steps[0].n_in, steps[0].cin, steps[0].cout, steps[0].act, steps[0].zero_row = 9, 3, 9, 8, 4, 2, 8
+    wp, outs = (ctypes.c_void_p * 1)(w.data_ptr()), (ctypes.c_void_p * 1)(0)
+    assert lib.sh_stack_forward(1, steps, _lib.ptr(x), 1, 9, 4, 2, wp, None, outs, 1, st) == -1
+    assert b"channels" in lib.sh_last_error()
+    steps[0].cin = 4
+    assert lib.sh_stack_forward(1, steps, _lib.ptr(x), 1, 9, 4, 2, wp, None, outs, 1, st) == -1
+    assert b"output buffer" in lib.sh_last_error()
     # the typed wrappers raise
     with pytest.raises(RuntimeError, match="status -2"):
         ops.spiral_conv_fwd(x, "bm", table, torch.zeros((200, 12), device=d), None, torch.zeros((2, 9, 200), device=d), "bm", 9, 3, 2, 8)
