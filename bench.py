@@ -110,7 +110,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured hipGraph")
     ap.add_argument("--adam", choices=["hip", "torch"], default="hip", help="library Adam kernel, or torch's fused capturable Adam")
     ap.add_argument("--adam-overlap", action="store_true", help="update the big parameters on a side stream underneath backward (measured: no gain, the GPU is already saturated)")
-    ap.add_argument("--cpu-iters", type=int, default=4)
+    ap.add_argument("--cpu-iters", type=int, default=8, help="timed CPU-baseline steps (8 steps at batch 64 = ~13 s of host work)")
     ap.add_argument("--template", default=os.path.join("tests", "golden", "template6890.npz"),
                     help="mesh hierarchy fixture; tests/golden/template27554.npz + --batch 32 is BASELINE config 4")
     args = ap.parse_args()
