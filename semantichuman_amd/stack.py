@@ -235,7 +235,7 @@ class Stack:
             o += _round((nb + 3) // 4)
         b_total = o
         # gradients of the parameters: one flat tensor, dW then dbias per parameter index
-        npar = 1 + max(st.param for st in self.steps if st.kind == "conv")
+        npar = 1 + max([st.param for st in self.steps if st.kind == "conv"], default=-1)
         dW_off, db_off, shapes, o = np.zeros(npar, dtype=np.uint64), np.zeros(npar, dtype=np.uint64), [None] * npar, 0
         for st in self.steps:
             if st.kind != "conv":
