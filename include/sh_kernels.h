@@ -62,6 +62,10 @@ SH_API const char* sh_last_error(void);
  * the kernel's execution, what rocprofv3 --kernel-trace reports; minor helper kernels are bracketed
  * by event records on the stream instead).  Used by bench.py for the roofline figures; off by
  * default, must be off while a hipGraph is being captured.  sh_profile_get synchronises on the events. */
+/* Diagnostic: shader clock currently granted.  n_workgroups single-wave workgroups each time `iters` dependent fp32
+ * MFMAs with the shader-cycle counter and the 100 MHz counter: out[2*i] = shader cycles, out[2*i+1] = 100 MHz ticks
+ * (device memory, 2*n_workgroups entries).  tools/clock_probe.py launches it between training steps. */
+SH_API int sh_clock_probe(unsigned long long* out, int n_workgroups, int iters, sh_stream_t stream);
 SH_API int sh_profile_enable(int on);                 /* on=1 start recording (clears), on=0 stop */
 SH_API int sh_profile_count(void);
 SH_API int sh_profile_get(int i, char* name, int name_len, float* ms);

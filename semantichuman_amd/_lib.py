@@ -20,6 +20,7 @@ _P, _I, _L = c_void_p, c_int, c_int64
 SIGNATURES = {
     "sh_version": (c_int, []),
     "sh_last_error": (c_char_p, []),
+    "sh_clock_probe": (c_int, [_P, _I, _I, _P]),
     "sh_profile_enable": (c_int, [_I]),
     "sh_profile_count": (c_int, []),
     "sh_profile_get": (c_int, [_I, c_char_p, _I, ctypes.POINTER(c_float)]),

@@ -74,6 +74,30 @@ int sh_profile_get(int i, char* name, int name_len, float* ms) {
     if (hipEventElapsedTime(ms, g_prof[i].a, g_prof[i].b) != hipSuccess) return SH_ERR_LAUNCH;
     return SH_OK;
 }
+// ---- shader-clock probe (diagnostic) ------------------------------------------------------
+// One wavefront per workgroup stamps the shader-cycle counter and the 100 MHz wall counter around a fixed loop of
+// dependent fp32 MFMAs; out[2*wg] = shader cycles, out[2*wg+1] = 100 MHz ticks.  clock = cycles / ticks * 100 MHz.
+// Launched between the steps of a running workload it reads the clock the chip currently grants that workload.
+}  // extern "C"
+namespace {
+typedef float sh_probe_f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* out, int iters) {
+    sh_probe_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float a = 1.0f + threadIdx.x * 1e-3f, b = 0.5f;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    if (acc[0] == 12345.678f) out[0] = 0;                        // keep the loop
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { out[2 * blockIdx.x] = c1 - c0; out[2 * blockIdx.x + 1] = r1 - r0; }
+}
+}  // namespace
+extern "C" {
+int sh_clock_probe(unsigned long long* out, int n_workgroups, int iters, sh_stream_t stream) {
+    SH_REQUIRE(out && n_workgroups > 0 && iters > 0, SH_ERR_INVALID_ARG, "sh_clock_probe: bad argument");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(n_workgroups), dim3(64), 0, static_cast<hipStream_t>(stream), out, iters);
+    SH_CHECK_LAUNCH("sh_clock_probe");
+    return SH_OK;
+}
 int sh_version(void) { return 100; }   // major*10000 + minor*100 + patch
 const char* sh_last_error(void) { return g_err; }
 }
