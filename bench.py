@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured hipGraph")
     ap.add_argument("--adam", choices=["hip", "torch"], default="hip", help="library Adam kernel, or torch's fused capturable Adam")
     ap.add_argument("--adam-overlap", action="store_true", help="update the big parameters on a side stream underneath backward (measured: no gain, the GPU is already saturated)")
+    ap.add_argument("--grad-comm", choices=["fp32", "bf16"], default="fp32",
+                    help="N > 1: type of the two large gradient messages (bf16 halves the xGMI bytes; fp32 is the measured default)")
     ap.add_argument("--cpu-iters", type=int, default=8, help="timed CPU-baseline steps (8 steps at batch 64 = ~13 s of host work)")
     ap.add_argument("--template", default=os.path.join("tests", "golden", "template6890.npz"),
                     help="mesh hierarchy fixture; tests/golden/template27554.npz + --batch 32 is BASELINE config 4")
@@ -162,7 +164,9 @@ def main():
     else:
         optim = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-5, capturable=True, fused=True)
     ft = sh.FaceTables(h.faces, h.sizes[0] + 1, dev)
-    reducer = GradientAllReducer(model, bucket_cap_mb=64.0, force_collectives=force_reducer) if (world > 1 or force_reducer) else None
+    reducer = GradientAllReducer(model, bucket_cap_mb=64.0, force_collectives=force_reducer,
+                                 large_message_dtype=torch.bfloat16 if args.grad_comm == "bf16" else None) \
+        if (world > 1 or force_reducer) else None
 
     n_data = 16 * B                               # resident synthetic set, disjoint per rank
     data = torch.from_numpy(synthetic.synth_batch(h.verts, n_data, seed=100 + rank)).to(dev)
@@ -247,7 +251,10 @@ def main():
                                % ("box_sphere(42,42,20) 6890-vertex template" if h.sizes[0] == 6890 else "%d-vertex template" % h.sizes[0],
                                   h.sizes, h.spiral_sizes[:-1], sum(p.numel() for p in model.parameters()) / 1e6),
                    "global_batch": world * B, "per_gpu_batch": B, "parallelism": "dp%d" % world,
-                   "launch": "hipGraph replay" if graph is not None else "eager"},
+                   "launch": "hipGraph replay" if graph is not None else "eager",
+                   **({"gradient_messages": "%.1f MB %s all-reduce per step" % (
+                       sum(b.numel * (2 if (b.inplace and args.grad_comm == "bf16") else 4) for b in reducer.buckets) / 1e6,
+                       "bf16 (large) + fp32" if args.grad_comm == "bf16" else "fp32")} if reducer else {})},
         "train_loss_last": final_loss,
         "recon_l2_mm_after_run": l2mm,
     }

@@ -42,14 +42,19 @@ class GradBucket:
                 o += p.numel()
         self.work = None
         self.buf = None          # the tensor in flight
+        self.full = None         # the fp32 gradient while a reduced-precision copy of it is in flight
 
 
 class GradientAllReducer:
     """Bucketed, overlapped gradient averaging for a replicated nn.Module."""
 
     def __init__(self, module: torch.nn.Module, process_group=None, bucket_cap_mb: float = 64.0, overlap: bool = True,
-                 inplace_min_mb: float = 16.0, force_collectives: bool = False):
-        """force_collectives: issue the collectives even in a world of one rank (exercises the RCCL path on a 1-GPU box)."""
+                 inplace_min_mb: float = 16.0, force_collectives: bool = False, large_message_dtype=None):
+        """force_collectives: issue the collectives even in a world of one rank (exercises the RCCL path on a 1-GPU box).
+        large_message_dtype: e.g. torch.bfloat16 - the large in-place gradients travel in that type (half the xGMI
+        bytes: 57 MB instead of 114 MB for the plain autoencoder) and are converted back into the
+        fp32 gradient after the collective.  Off by default: fp32 training exchanges fp32 gradients."""
+        self.large_dtype = large_message_dtype
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (force_collectives and dist.is_initialized())
@@ -111,6 +116,8 @@ class GradientAllReducer:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
             b.buf = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+            if self.large_dtype is not None and self.large_dtype != b.buf.dtype:
+                b.full, b.buf = b.buf, b.buf.to(self.large_dtype)        # one conversion pass each way, half the message
         else:
             src, dst = [], []
             for p, v in zip(b.params, b.views):
@@ -142,6 +149,9 @@ class GradientAllReducer:
         for b in self.buckets:
             b.work.wait()
             if b.inplace:
+                if b.full is not None:
+                    b.full.copy_(b.buf)
+                    b.buf, b.full = b.full, None
                 b.params[0].grad = b.buf
             else:
                 for p, v in zip(b.params, b.views):

@@ -93,6 +93,40 @@ def test_two_rank_data_parallel_equals_single_process(golden_dir, tmp_path, over
         assert float(d.mean()) <= 1e-7 and float(d.max()) <= 2.1e-3, k
 
 
+def _worker_bf16(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from semantichuman_amd.parallel import GradientAllReducer
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(64, 512), torch.nn.Linear(512, 8))      # one "large" weight, three small tensors
+    red = GradientAllReducer(m, inplace_min_mb=0.1, large_message_dtype=torch.bfloat16)
+    assert [b.inplace for b in red.buckets] == [True, False]
+    torch.manual_seed(10 + rank)
+    x = torch.randn(16, 64)
+    red.prepare()
+    m(x).square().mean().backward()
+    local = [p.grad.clone() for p in m.parameters()]
+    red.finish()
+    torch.save({"local": local, "reduced": [p.grad.clone() for p in m.parameters()]}, os.path.join(out_dir, "b%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_bf16_large_messages(tmp_path):
+    """large_message_dtype=bfloat16: the large gradient is averaged through a bf16 message (relative error <= 2^-8 per
+    element, identical on both ranks, still an fp32 .grad); the packed small gradients stay exact fp32."""
+    mp.spawn(_worker_bf16, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / ("b%d.pt" % r), weights_only=False) for r in range(2))
+    for i, (a, b) in enumerate(zip(r0["reduced"], r1["reduced"])):
+        assert torch.equal(a, b) and a.dtype == torch.float32
+        mean = 0.5 * (r0["local"][i] + r1["local"][i])
+        if i == 0:                                                   # the 64 x 512 weight: bf16 message
+            assert not torch.equal(a, mean)
+            assert float((a - mean).abs().max()) <= 2.0 ** -7 * float(mean.abs().max())
+        else:
+            assert torch.allclose(a, mean, rtol=1e-6, atol=1e-9)
+
+
 def test_shard_batch_contract():
     from semantichuman_amd.parallel import shard_batch
     assert [shard_batch(512, r, 8) for r in (0, 7)] == [slice(0, 64), slice(448, 512)]
