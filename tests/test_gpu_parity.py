@@ -482,3 +482,34 @@ def test_c_abi_error_contract():
     with pytest.raises(RuntimeError, match="status -2"):
         ops.spiral_conv_fwd(x, "bm", table, torch.zeros((200, 12), device=d), None, torch.zeros((2, 9, 200), device=d), "bm", 9, 3, 2, 8)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("cfg", [("template6890.npz", 64), ("template6890.npz", 48), ("template27554.npz", 32)])
+def test_bench_launch_table_matches_the_library(golden_dir, cfg):
+    """bench.py prices the roofline with a table of (kernel instantiation -> algorithmic FLOPs) that mirrors the
+    library's dispatch rules; here the names and launch counts the library's profiler reports for one training step
+    are checked against that table, so a dispatch change cannot silently detach the roofline from the kernels."""
+    import bench
+    from semantichuman_amd import _lib, synthetic
+    name, B = cfg
+    h = load_hierarchy(os.path.join(golden_dir, name))
+    torch.manual_seed(1)
+    m = sh.SpiralAutoencoder(FE, FD, 256, h.sizes, h.spiral_sizes, h.spirals, h.D, h.U, dev())
+    x = torch.from_numpy(synthetic.synth_batch(h.verts, B, seed=1)).to(dev())
+
+    def step():
+        m.zero_grad(set_to_none=True)
+        sh.l1_loss(x, m(x)[0]).backward()
+    step()
+    torch.cuda.synchronize()
+    _lib.profile_enable(True)
+    step()
+    torch.cuda.synchronize()
+    recs = _lib.profile_records_by_kernel()
+    _lib.profile_enable(False)
+    seen = {}
+    for kname, _shape, _ms in recs:
+        if kname.startswith(("gather_gemm", "wgrad")):
+            seen[kname] = seen.get(kname, 0) + 1
+    table = bench.conv_launch_table(m, B)
+    assert seen == {k: v["launches"] for k, v in table.items()}
