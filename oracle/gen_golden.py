@@ -569,6 +569,41 @@ def gen_dataset():
     print("dataset.npz:", {k: a.shape for k, a in arrs.items() if k.startswith("verts")})
 
 
+def gen_spiral_layout():
+    """a8, layout stage (reference utils_spiral.generate_spirals :58-93): the per-vertex spiral LISTS the reference's
+    traversal (get_spirals) produces for the 170-vertex hierarchy, and what generate_spirals makes of them - with the
+    shipped dilation [2,2,1,1,1] and without dilation."""
+    v, f = synthetic.box_sphere(6, 6, 4)
+    M = [refstubs.Mesh(v=v, f=f)]
+    A = [refstubs.get_vert_connectivity(v, f)]
+    Fs = []
+    for factor in [1.0 / x for x in DS_FACTORS]:
+        ds_f, ds_D = ref_ms.qslim_decimator_transformer(M[-1], factor=factor)
+        Fs.append(ds_f)
+        new_v = ds_D.dot(M[-1].v)
+        M.append(refstubs.Mesh(v=new_v, f=ds_f))
+        A.append(refstubs.get_vert_connectivity(new_v, ds_f))
+    ref_pts = [[5]]
+    for i in range(len(DS_FACTORS)):
+        ref_pts.append([int(np.argmin(((M[i + 1].v - M[0].v[ref_pts[0]]) ** 2).sum(1)))])
+    Adj, Trigs = ref_us.get_adj_trigs(A, Fs, M[0], meshpackage="mpi-mesh")
+    arrs = {"levels": np.asarray(len(Adj))}
+    for i in range(len(Adj)):                        # the raw lists, exactly as generate_spirals obtains them (:52-53)
+        sp = ref_us.get_spirals(M[i].v, Adj[i], Trigs[i], ref_pts[i], n_steps=STEP_SIZES[i], padding="zero",
+                                counter_clockwise=True, random=False)
+        arrs["raw_flat_%d" % i] = np.asarray([x for s_ in sp for x in s_], dtype=np.int64)
+        arrs["raw_len_%d" % i] = np.asarray([len(s_) for s_ in sp], dtype=np.int64)
+    for tag, dil in (("dil", DILATION), ("nodil", None)):
+        spirals_np, sizes, _ = ref_us.generate_spirals(STEP_SIZES, M, Adj, Trigs, reference_points=ref_pts, dilation=dil,
+                                                       random=False, meshpackage="mpi-mesh", counter_clockwise=True)
+        arrs["sizes_" + tag] = np.asarray(sizes)
+        for i, S in enumerate(spirals_np):
+            arrs["S_%s_%d" % (tag, i)] = S
+    arrs["dilation"] = np.asarray(DILATION)
+    np.savez_compressed(os.path.join(GOLD, "spiral_layout.npz"), **arrs)
+    print("spiral_layout: sizes", arrs["sizes_dil"], arrs["sizes_nodil"])
+
+
 def gen_template27k():
     """BASELINE config 4: box_sphere(84,84,40) = 27 554 vertices (one midpoint subdivision of the 6890 template's
     size), levels by QSlim factors [2,2,2,2], spirals with step size 2 and NO dilation, every spiral then forced to

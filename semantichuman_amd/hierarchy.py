@@ -50,3 +50,28 @@ def load_hierarchy(path: str) -> Hierarchy:
         D.append(mesh_ops.pad_dummy(d))
         U.append(mesh_ops.pad_dummy(u))
     return Hierarchy(sizes, spiral_sizes, spirals, D, U, g["verts"], g["faces"].astype(np.int32))
+
+
+def layout_spirals(adj_spirals, dilation=None, nb_stds=2):
+    """The layout stage of the reference's spiral generation (utils_spiral.generate_spirals :58-93), applied to the
+    per-vertex spiral LISTS of every level (`adj_spirals[l][j]` = spiral of vertex j, as get_spirals returns them):
+      * dilation d_l: keep the centre and every d_l-th entry after it, `s[:1] + s[1::d_l]` (:58-66);
+      * spiral size of a level: int(mean + nb_stds * std) of its spiral lengths (:70-82);
+      * array float64 [1, N_l + 1, S_l] filled with -1, row j = the first S_l entries of spiral j, the extra last row
+        (the dummy vertex) all -1 (:87-93).
+    -> (list of arrays, list of sizes, dilated lists), the reference's return triple."""
+    adj_spirals = [list(map(list, level)) for level in adj_spirals]
+    if dilation:
+        for i, dil in enumerate(dilation):
+            adj_spirals[i] = [s[:1] + s[1::dil] for s in adj_spirals[i]]
+    sizes = []
+    for level in adj_spirals:
+        L = np.array([len(s) for s in level])
+        sizes.append(int(L.mean() + nb_stds * L.std()))
+    out = []
+    for level, size in zip(adj_spirals, sizes):
+        S = np.zeros((1, len(level) + 1, size)) - 1
+        for j, s in enumerate(level):
+            S[0, j, :len(s)] = s[:size]
+        out.append(S)
+    return out, sizes, adj_spirals
