@@ -17,11 +17,9 @@ from __future__ import annotations
 import argparse
 import json
 import os
-import re
 import sys
 import time
 
-import numpy as np
 import torch
 import torch.distributed as dist
 

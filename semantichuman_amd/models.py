@@ -23,7 +23,7 @@ import torch.nn as nn
 from . import mesh_ops, ops
 from .mesh_ops import CSR
 from .linear import grouped_linear, latent_linear
-from .stack import ConvStep, SpmmStep, Stack, StackFunction, run_stack
+from .stack import ConvStep, SpmmStep, Stack, run_stack
 
 
 def _as_csr(m) -> CSR:

@@ -9,7 +9,7 @@ from oracle import ref_cpu
 from semantichuman_amd import mesh_ops, models, synthetic
 from semantichuman_amd.hierarchy import load_hierarchy
 from semantichuman_amd.losses import FaceTables
-from semantichuman_amd.stack import ConvStep, Stack
+from semantichuman_amd.stack import ConvStep
 from tests import emulate
 
 FE = [[3, 16, 32, 64, 128], [[], [], [], [], []]]
