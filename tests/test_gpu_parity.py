@@ -75,7 +75,7 @@ SHAPES = [  # (B, n_rows, S, Cin, Cout)  - ragged / odd cases on purpose
     (4, 129, 7, 64, 128), (130, 20, 3, 8, 64), (2, 64, 4, 5, 7),
     # dispatch corners: 128 channels with >= 768 row tiles (eight channel tiles -> two direct four-tile workgroups), two
     # channel tiles at a batch that is not a multiple of 64 (stay direct, 64-row workgroups), spiral length 18 (config 4)
-    (64, 1600, 4, 16, 128), (48, 700, 5, 16, 32), (32, 500, 18, 32, 64),
+    (64, 1600, 4, 16, 128), (48, 1400, 5, 16, 32), (32, 3200, 18, 32, 64),
 ]
 
 
