@@ -2,8 +2,11 @@
 """Headline benchmark: training meshes/s of the plain spiral autoencoder at 6890 vertices,
 batch 64 per GPU, fp32 (BASELINE.json configs[1]); synthetic meshes resident in HBM.
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL gradient all-reduce)
+    python bench.py --gpus N --steps K --warmup W [--dtype f32|bf16]
+    N > 1: one rank per GPU, RCCL gradient all-reduce.  Either launched by torch.distributed.run
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or - when WORLD_SIZE is not set -
+    bench.py starts the N rank processes itself (fresh children, before this process touches the GPU),
+    waits for them and exits with the first non-zero status; rank 0 prints the JSON line.
 
 One "step" = the reference's training iteration (train_funcs.py:495-510): zero_grad, forward,
 L1 + 1e-2 * edge-ratio loss, backward, [gradient all-reduce], Adam(lr 1e-3, wd 5e-5) step.
@@ -97,6 +100,71 @@ def conv_launch_table(model, B):
     return out
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes of this script (one per GPU) with the
+    torch.distributed.run environment, wait, and return the first non-zero exit status.  Called BEFORE anything in this
+    process initialises the GPU (children are started with subprocess, never exec'd from a process that touched HIP)."""
+    import subprocess
+    env = dict(os.environ)
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e))
+    rc = 0
+    try:
+        while procs:
+            for p in list(procs):
+                st = p.poll()
+                if st is None:
+                    continue
+                procs.remove(p)
+                if st != 0 and rc == 0:
+                    rc = st
+                    for q in procs:                            # a dead rank leaves the others blocked in a collective
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            p.kill()
+    return rc
+
+
+def dry_run(args, world, rank):
+    """SH_BENCH_DRYRUN=1: the launch / rendezvous / timing / reporting skeleton of this script over gloo with no GPU work
+    (the CPU container has no device): rendezvous, warm-up, K barrier-bracketed empty steps, MAX over ranks, one JSON
+    line from rank 0.  tests/test_bench_launch.py runs it for N = 2 through the self-launcher."""
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "training meshes/sec at 6890 verts, batch=%d" % args.batch, "value": None, "unit": "meshes/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(1, args.steps),
+                          "dry_run": True, "config": {"global_batch": world * args.batch, "parallelism": "dp%d" % world}}))
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,9 +183,15 @@ def main():
                     help="mesh hierarchy fixture; tests/golden/template27554.npz + --batch 32 is BASELINE config 4")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("SH_BENCH_DRYRUN", "0") != "0":
+        if args.gpus != world:
+            sys.exit(2)
+        return dry_run(args, world, rank)
     # SH_BENCH_BACKEND=gloo lets the multi-rank control flow be exercised on a box with ONE GPU (all ranks share it,
     # collectives go through the host); the measured configuration is always nccl = RCCL, one rank per GPU
     backend = os.environ.get("SH_BENCH_BACKEND", "nccl")

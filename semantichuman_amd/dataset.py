@@ -123,28 +123,57 @@ class autoencoder_dataset:
         return item
 
 
+def shard_len(n: int, world_size: int, pad: bool = True) -> int:
+    """Samples per rank and epoch - the same on every rank."""
+    return -(-n // world_size) if pad else n // world_size
+
+
+def shard_order(order: torch.Tensor, rank: int, world_size: int, pad: bool = True) -> torch.Tensor:
+    """This rank's strided shard of an epoch's sample order, equal in length on every rank (ranks that ran different
+    numbers of batches would leave the longer ones blocked in the per-batch gradient all-reduce).  pad: repeat samples
+    from the start of the order until its length divides (torch DistributedSampler, drop_last=False); else drop the tail."""
+    if not 0 <= rank < world_size:
+        raise ValueError("rank %d outside world of %d" % (rank, world_size))
+    n = order.numel()
+    if world_size == 1:
+        return order
+    per = shard_len(n, world_size, pad)
+    if per == 0:
+        raise ValueError("%d samples cannot be sharded over %d ranks without padding" % (n, world_size))
+    total = per * world_size
+    if total > n:
+        reps = -(-total // n)
+        order = order.repeat(reps)[:total] if reps > 1 else torch.cat([order, order[:total - n]])
+    else:
+        order = order[:total]
+    return order[rank::world_size]
+
+
 class ResidentLoader:
     """DataLoader replacement for a resident `autoencoder_dataset`: iterating yields the dicts the reference's
     default collate produces (`verts` [b, N+1, 3], `idx` int64 [b], `measure` [b, M]) on the device.
-    With torch.distributed, pass rank/world_size to iterate a disjoint strided shard of each epoch's order
-    (DistributedSampler semantics without padding)."""
+    With torch.distributed, pass rank/world_size to iterate a disjoint strided shard of each epoch's order.  Every rank
+    gets the SAME number of samples (hence of batches - the training loops issue one collective per batch): the epoch's
+    order is padded by wrapping around, as torch's DistributedSampler does (`pad=True`, default), or truncated to a
+    multiple of the world size (`pad=False`)."""
 
-    def __init__(self, dataset, batch_size=1, shuffle=False, device=None, drop_last=False, seed=0, rank=0, world_size=1):
+    def __init__(self, dataset, batch_size=1, shuffle=False, device=None, drop_last=False, seed=0, rank=0, world_size=1,
+                 pad=True):
         if device is None and dataset.verts is None:
             raise ValueError("ResidentLoader: pass a device or make the dataset resident first")
         self.dataset = dataset.resident(device if device is not None else dataset.verts.device)
         self.batch_size, self.shuffle, self.drop_last = int(batch_size), shuffle, drop_last
-        self.rank, self.world_size = rank, world_size
+        self.rank, self.world_size, self.pad = rank, world_size, pad
         self._gen = torch.Generator().manual_seed(seed)
         self.epoch = 0
 
     def _order(self):
         n = len(self.dataset)
         order = torch.randperm(n, generator=self._gen) if self.shuffle else torch.arange(n)
-        return order[self.rank::self.world_size]
+        return shard_order(order, self.rank, self.world_size, self.pad)
 
     def __len__(self):
-        n = len(range(self.rank, len(self.dataset), self.world_size))
+        n = shard_len(len(self.dataset), self.world_size, self.pad)
         return n // self.batch_size if self.drop_last else -(-n // self.batch_size)
 
     def __iter__(self):

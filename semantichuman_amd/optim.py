@@ -7,7 +7,10 @@ reference's checkpoints load into it and its checkpoints load into torch's Adam,
 `torch.optim.lr_scheduler.StepLR` (main.py:263-264) drives it unchanged.
 
 All parameters of a group are updated by one multi-tensor launch (sh_adam_step).  Learning rate and
-step counts live in device memory, so a step captured in a hipGraph keeps following the schedule.
+step counts live in device memory, so a step captured in a hipGraph keeps counting its steps and reads
+the learning rate from the device scalar at replay time.  That scalar is refreshed from
+`param_groups[i]['lr']` by `step()` when it runs eagerly - a graph replay never re-enters `step()`, so
+after `scheduler.step()` call `optimizer.sync_lr()` (outside the graph) before the next replay.
 
 `overlap_backward(min_numel)`: the update is HBM-bound (7 passes over every parameter-sized array)
 while the backward pass is MFMA-bound, so large parameters can be updated on a side stream as soon
@@ -61,6 +64,15 @@ class Adam(torch.optim.Optimizer):
             cur = (cur[0], lr)
         self._lr_dev[id(group)] = cur
         return cur[0]
+
+    def sync_lr(self):
+        """Copy every group's current `lr` into its device scalar (in stream order).  `step()` does this itself when it
+        runs eagerly; a step that was captured into a hipGraph is replayed without re-entering Python, so a scheduler's
+        change only reaches the captured kernel through this call."""
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.is_cuda]
+            if ps:
+                self._lr_tensor(group, ps[0].device)
 
     def _apply(self, group, params):
         params = [p for p in params if p.grad is not None]

@@ -12,7 +12,12 @@ unchanged.  Differences, all invisible in the numbers:
   * the global yacs `cfg` is replaced by keyword options (`edgereg_epoch`, `edgereg_w`,
     `ck_frequency`; defaults = configure/traincfg.yaml:40-41,52);
   * optional data-parallel training: pass `reducer=parallel.GradientAllReducer(model)` and give
-    every rank its own shard of the data.
+    every rank its own shard of the data (`dataset.ResidentLoader(rank=, world_size=)`: equal
+    batch counts on every rank).  Epoch losses are then sums over all ranks divided by the number
+    of samples all ranks processed; checkpoints, sample dumps and logging happen on rank 0 only,
+    followed by a barrier (SURVEY 8e);
+  * `save_recons=True`: every 50 epochs the last validation and training batch are written through
+    `shapedata.save_meshes` exactly as the reference does (:571-582; one device-to-host copy each).
 
 Checkpoints: `{'epoch','autoencoder_state_dict','optimizer_state_dict','scheduler_state_dict'}`
 with CPU tensors, at `<metadata_dir>/<checkpoint_path><epoch>.pth.tar` (reference :562-567).
@@ -41,9 +46,15 @@ def save_checkpoint(path, epoch, model, optim, scheduler):
                 "scheduler_state_dict": scheduler.state_dict() if scheduler else None}, path)
 
 
-def load_checkpoint(path, model, optim=None, scheduler=None, finetune=False, map_location="cpu"):
+def load_checkpoint(path, model, optim=None, scheduler=None, finetune=False, map_location="cpu", trust_pickle=False):
     """main.py:277-292: returns the epoch to start from."""
-    ck = torch.load(path, map_location=map_location, weights_only=False)
+    try:                      # the saved layout is tensors + plain Python containers: no pickled code needed
+        ck = torch.load(path, map_location=map_location, weights_only=True)
+    except Exception as e:    # noqa: BLE001 - torch raises pickle.UnpicklingError / RuntimeError depending on the version
+        if not trust_pickle:
+            raise RuntimeError("load_checkpoint: %s does not load with weights_only=True (%s); pass trust_pickle=True only "
+                               "for a checkpoint you wrote yourself - unpickling executes code" % (path, e)) from e
+        ck = torch.load(path, map_location=map_location, weights_only=False)
     model.load_state_dict(ck["autoencoder_state_dict"])
     if finetune:
         return 1
@@ -54,12 +65,27 @@ def load_checkpoint(path, model, optim=None, scheduler=None, finetune=False, map
     return ck["epoch"] + 1
 
 
+def _save_recons(shapedata, samples_dir, epoch, tx_idx, tx_hat, tx_hat_val):
+    """Reference train_funcs.py:571-582: the first mesh of the epoch's last validation batch and of its last training
+    batch, written by `shapedata.save_meshes` under the file stems and with the sample index the reference uses (the
+    index of the last VALIDATION batch for both, :529,578,582)."""
+    ind = [int(tx_idx[0])]
+    for t, stem in ((tx_hat_val, "epoch_val{0}"), (tx_hat, "epoch_train{0}")):
+        if t is not None:
+            shapedata.save_meshes(os.path.join(samples_dir, stem.format(epoch)), t[0:1, 0:-1, :].detach().cpu().numpy(), ind)
+
+
 def train_autoencoder_dataloader(dataloader_train, dataloader_val, device, model, optim, loss_fn,
                                  start_epoch, n_epochs, eval_freq, dataloader_interp, scheduler,
                                  writer, shapedata, metadata_dir, samples_dir, checkpoint_path,
                                  J_regressor=None, vert_part_index_dict=None, partname_list=None, save_recons=False,
                                  *, edgereg_epoch=0, edgereg_w=1e-2, ck_frequency=50, reducer=None, verbose=True):
     loss_fn = _as_loss(loss_fn)
+    import torch.distributed as dist
+    world = dist.get_world_size() if (reducer is not None and dist.is_initialized()) else 1
+    rank = dist.get_rank() if world > 1 else 0
+    if rank != 0:
+        writer, verbose = None, False
     f_np = np.asarray(shapedata.reference_mesh.f).astype(np.int32)
     n_rows = None
     face_tables = None
@@ -72,6 +98,9 @@ def train_autoencoder_dataloader(dataloader_train, dataloader_val, device, model
         tloss = torch.zeros((), device=device)
         rec_loss = torch.zeros((), device=device)
         edgereg_loss = torch.zeros((), device=device)
+        n_seen, n_val = 0, 0
+        tx_hat = tx_hat_val = None
+        tx_idx = [0]
         for b, sample_dict in enumerate(dataloader_train):
             optim.zero_grad()
             tx = sample_dict["verts"].to(device)
@@ -97,6 +126,7 @@ def train_autoencoder_dataloader(dataloader_train, dataloader_val, device, model
             if reducer is not None:
                 reducer.finish()
             optim.step()
+            n_seen += cur_bsize
             tloss += cur_bsize * loss.detach()
             if writer and total_steps % eval_freq == 0:
                 writer.add_scalar("loss/loss/data_loss", loss.item(), total_steps)
@@ -110,17 +140,30 @@ def train_autoencoder_dataloader(dataloader_train, dataloader_val, device, model
             for b, sample_dict in enumerate(dataloader_val):
                 tx = sample_dict["verts"].to(device)
                 tx_hat_val = model(tx)[0]
+                if "idx" in sample_dict:
+                    tx_idx = sample_dict["idx"]
+                n_val += tx.shape[0]
                 vloss += tx.shape[0] * loss_fn(tx[:, :-1, :], tx_hat_val[:, :-1, :])   # dummy row dropped (:535)
 
         if scheduler:
             scheduler.step()
 
-        epoch_tloss = float(tloss) / float(len(dataloader_train.dataset))
+        if world > 1:
+            # every rank saw its own shard: sums of losses and of sample counts over all ranks (one tiny collective per epoch)
+            t = torch.stack([tloss.double(), vloss.double(), torch.tensor(float(n_seen), device=device, dtype=torch.float64),
+                             torch.tensor(float(n_val), device=device, dtype=torch.float64)])
+            dist.all_reduce(t)
+            epoch_tloss = float(t[0]) / max(1.0, float(t[2]))
+            tot_val = float(t[3])
+            vloss = t[1]
+        else:
+            epoch_tloss = float(tloss) / float(len(dataloader_train.dataset))
+            tot_val = float(len(dataloader_val.dataset))
         if writer:
             writer.add_scalar("avg_epoch_train_loss", epoch_tloss, epoch)
         epoch_vloss = None
-        if len(dataloader_val.dataset) > 0:
-            epoch_vloss = float(vloss) / float(len(dataloader_val.dataset))
+        if tot_val > 0:
+            epoch_vloss = float(vloss) / tot_val
             if writer:
                 writer.add_scalar("avg_epoch_valid_loss", epoch_vloss, epoch)
             if verbose:
@@ -130,7 +173,12 @@ def train_autoencoder_dataloader(dataloader_train, dataloader_val, device, model
         history.append((epoch, epoch_tloss, epoch_vloss))
 
         if epoch % ck_frequency == 0 and metadata_dir is not None:
-            save_checkpoint(os.path.join(metadata_dir, checkpoint_path + "%s.pth.tar" % epoch), epoch, model, optim, scheduler)
+            if rank == 0:
+                save_checkpoint(os.path.join(metadata_dir, checkpoint_path + "%s.pth.tar" % epoch), epoch, model, optim, scheduler)
+            if world > 1:
+                dist.barrier()            # nobody runs ahead of (or reads) a checkpoint that is still being written
+        if save_recons and epoch % 50 == 0 and rank == 0 and samples_dir is not None:
+            _save_recons(shapedata, samples_dir, epoch, tx_idx, tx_hat, tx_hat_val)
     if verbose:
         print("~FIN~")
     return history

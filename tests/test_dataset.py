@@ -52,17 +52,24 @@ def test_split_layout_and_flags(gd, tmp_path):
         d[0]
 
 
-def test_loader_sharding_is_disjoint_and_complete():
+def test_loader_sharding_is_complete_and_equal_on_every_rank():
+    """10 samples over 3 ranks: every rank iterates the SAME number of samples / batches (one collective per batch in the
+    training loops); padded by wrap-around every sample is seen, truncated the shards are disjoint."""
     class Fake:
         verts = torch.zeros(10, 2, 3); measure_flag = False
         def __len__(self): return 10
         def resident(self, device): return self
-    orders = []
-    for r in range(3):
-        ld = ds_mod.ResidentLoader(Fake(), batch_size=2, shuffle=True, device="cpu", seed=7, rank=r, world_size=3)
-        orders.append(ld._order().tolist())
-        assert len(ld) == -(-len(orders[-1]) // 2)
-    assert sorted(sum(orders, [])) == list(range(10))
+    for pad, per in ((True, 4), (False, 3)):
+        orders = []
+        for r in range(3):
+            ld = ds_mod.ResidentLoader(Fake(), batch_size=2, shuffle=True, device="cpu", seed=7, rank=r, world_size=3, pad=pad)
+            orders.append(ld._order().tolist())
+            assert len(orders[-1]) == per and len(ld) == -(-per // 2)
+        seen = sum(orders, [])
+        if pad:
+            assert set(seen) == set(range(10)) and len(seen) == 12
+        else:
+            assert len(set(seen)) == 9
 
 
 # ------------------------------------------------------------------------------------------ GPU

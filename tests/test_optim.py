@@ -99,3 +99,45 @@ def test_hip_adam_overlapped_update_is_identical():
         outs.append([p.detach().clone() for p in params])
     for p, q in zip(*outs):
         assert torch.equal(p, q)
+
+
+@pytest.mark.gpu
+def test_hip_adam_captured_step_follows_steplr_through_sync_lr():
+    """a step captured in a hipGraph reads the learning rate from a device scalar; a replay never re-enters
+    step(), so the scheduler's change reaches it through sync_lr().  Replayed-with-sync == eager, bit for bit."""
+    dev = torch.device("cuda:0")
+    outs = []
+    for captured in (False, True):
+        params = make(dev)
+        set_grads(params, 0)
+        opt = sh.optim.Adam(params, lr=1e-3, weight_decay=5e-5)
+        sched = torch.optim.lr_scheduler.StepLR(opt, 1, gamma=0.5)
+        graph = None
+        if captured:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                opt.step()                                    # warm-up: creates the state
+            torch.cuda.current_stream().wait_stream(s)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                opt.step()
+            # undo the two updates the warm-up and the capture... capture does not execute; undo the warm-up step
+            fresh = make(dev)
+            for p, q in zip(params, fresh):
+                p.data.copy_(q)
+            for st in opt.state.values():
+                for v in st.values():
+                    v.zero_()
+        for k in range(4):
+            if graph is not None:
+                graph.replay()
+            else:
+                opt.step()
+            sched.step()
+            opt.sync_lr()
+        torch.cuda.synchronize()
+        outs.append([p.detach().clone() for p in params])
+        assert opt.param_groups[0]["lr"] == pytest.approx(1e-3 * 0.5 ** 4)
+    for p, q in zip(*outs):
+        assert torch.equal(p, q)

@@ -132,3 +132,95 @@ def test_shard_batch_contract():
     assert [shard_batch(512, r, 8) for r in (0, 7)] == [slice(0, 64), slice(448, 512)]
     with pytest.raises(ValueError):
         shard_batch(10, 0, 4)
+
+
+def test_shard_order_gives_every_rank_the_same_number_of_batches():
+    from semantichuman_amd.dataset import shard_len, shard_order
+    order = torch.arange(10)
+    for pad, per in ((True, 3), (False, 2)):
+        shards = [shard_order(order, r, 4, pad) for r in range(4)]
+        assert [s.numel() for s in shards] == [per] * 4 and shard_len(10, 4, pad) == per
+        seen = torch.cat(shards).tolist()
+        assert set(seen) == (set(range(10)) if pad else set(range(8)))       # padding repeats, never invents, samples
+    assert torch.equal(shard_order(order, 0, 1), order)
+    assert [shard_order(torch.arange(2), r, 5).numel() for r in range(5)] == [1] * 5   # fewer samples than ranks: wrap around
+    with pytest.raises(ValueError):
+        shard_order(torch.arange(2), 0, 5, pad=False)
+
+
+class _ListLoader:
+    """The slice of the loader protocol the training loop uses (iteration, len, .dataset), over a rank's shard."""
+
+    def __init__(self, verts, idx, batch):
+        self.dataset = list(range(len(idx)))
+        self.batches = [{"verts": verts[idx[i:i + batch]], "idx": idx[i:i + batch]} for i in range(0, len(idx), batch)]
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __iter__(self):
+        return iter(self.batches)
+
+
+class _Writer:
+    def __init__(self):
+        self.rows = []
+
+    def add_scalar(self, tag, v, step):
+        self.rows.append((tag, float(v), step))
+
+
+class _TinyAE(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(3)
+        self.f = torch.nn.Linear(3, 3)
+
+    def forward(self, x):
+        return self.f(x), None
+
+
+def _loop_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from types import SimpleNamespace
+    from semantichuman_amd.dataset import shard_order
+    from semantichuman_amd.parallel import GradientAllReducer
+    from semantichuman_amd.train_funcs import train_autoencoder_dataloader
+    g = torch.Generator().manual_seed(0)
+    verts = torch.randn(5, 7, 3, generator=g)                    # 5 samples over 2 ranks: n % world != 0
+    vval = torch.randn(3, 7, 3, generator=g)
+    tr = _ListLoader(verts, shard_order(torch.arange(5), rank, world), 1)
+    va = _ListLoader(vval, shard_order(torch.arange(3), rank, world), 1)
+    assert len(tr) == 3                                          # the same on both ranks, or the loop below deadlocks
+    model = _TinyAE()
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    sched = torch.optim.lr_scheduler.StepLR(opt, 1, gamma=0.99)
+    w = _Writer()
+    shapedata = SimpleNamespace(reference_mesh=SimpleNamespace(f=np.zeros((1, 3), dtype=np.int32)))
+    l1 = lambda a, b: (a - b).abs().mean()                       # noqa: E731 - a torch loss: the loop itself is what is under test
+    hist = train_autoencoder_dataloader(tr, va, torch.device("cpu"), model, opt, l1, 1, 2, 1, None, sched, w, shapedata, out_dir,
+                                        out_dir, "ck", edgereg_w=0.0, ck_frequency=1, reducer=GradientAllReducer(model), verbose=False)
+    torch.save({"hist": hist, "w": model.state_dict(), "rows": w.rows}, os.path.join(out_dir, "loop%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_two_rank_training_loop_with_uneven_dataset(tmp_path):
+    """ADVICE r1: n % world != 0 must not leave ranks with different batch counts (deadlock in the per-batch all-reduce);
+    epoch losses are means over ALL ranks' samples; only rank 0 writes checkpoints and logs."""
+    mp.spawn(_loop_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / ("loop%d.pt" % r), weights_only=False) for r in range(2))
+    for k in r0["w"]:
+        assert torch.equal(r0["w"][k], r1["w"][k])
+    assert r0["hist"] == r1["hist"] and len(r0["hist"]) == 2
+    assert r1["rows"] == [] and any(t == "avg_epoch_train_loss" for t, _, _ in r0["rows"])
+    # epoch loss = sum over both ranks' (padded) shards / 6 samples: of the order of one sample's loss, not 1/world of it
+    e1 = r0["hist"][0][1]
+    assert 0.3 < e1 < 3.0
+    cks = sorted(p.name for p in tmp_path.iterdir() if p.name.startswith("ck"))
+    assert cks == ["ck1.pth.tar", "ck2.pth.tar"]
+    from semantichuman_amd.train_funcs import load_checkpoint
+    m = _TinyAE()
+    assert load_checkpoint(str(tmp_path / "ck2.pth.tar"), m) == 3                  # loads with weights_only=True
+    assert torch.equal(m.f.weight, r0["w"]["f.weight"])
