@@ -357,6 +357,37 @@ SH_API int sh_adam_step(int n_tensors, float* const* params, const float* const*
                  float* const* exp_avg_sq, float* const* steps, const int64_t* numel, const float* lr,
                  double beta1, double beta2, double eps, double weight_decay, sh_stream_t stream);
 
+/* =============================================================================================
+ * bf16 compute path (BASELINE.json configs[2]: "batch=512 bf16, DDP 8x"; the reference itself is fp32-only,
+ * models.py:45).  Same operators as above with bf16 activations and bf16 working copies of the weights,
+ * fp32 accumulation inside the kernels (v_mfma_f32_16x16x32_bf16), fp32 bias / activation arithmetic, and
+ * fp32 master weights, gradients and Adam state outside them.  Tensors carry an explicit element type:
+ */
+enum sh_dtype { SH_DTYPE_F32 = 0, SH_DTYPE_BF16 = 1 };
+
+/* Working copy of a SpiralConv weight: bf16, pre-ordered into the 1-KiB MFMA fragments the conv kernel keeps in
+ * LDS (frag[k-step][16-channel tile][lane][8]; layout in csrc/sh_bf16.h), zero-padded.  `transpose` = 0 gives the
+ * forward operand (Cg = Cin gathered channels, Nout = Cout), 1 the backward-data operand (Cg = Cout, Nout = Cin)
+ * of the same fp32 master weight [Cout][S*Cin] (models.py:17).  sh_conv_wfrag_bytes(S, Cg, Nout) sizes the buffer
+ * (16-byte aligned).  One launch converts all layers of a stack. */
+SH_API size_t sh_conv_wfrag_bytes(int S, int Cg, int Nout);
+SH_API int sh_conv_wfrag_prep_multi(int n_layers, const float* const* weight, void* const* wfrag, const int* S,
+                                    const int* Cin, const int* Cout, const int* transpose, sh_stream_t stream);
+
+/* sh_spiral_conv_fwd / sh_spiral_conv_bwd_data (models.py:40-51 and its autograd) in bf16.  Strides are in ELEMENTS
+ * of the tensor's own type.  x / dpre: bf16 with 16 or a multiple of 32 channels, or fp32 with exactly 3 channels
+ * (the xyz input of the first layer, the xyz gradient entering the last one); y / dx: bf16, or fp32 when it has
+ * <= 16 channels (x_hat, dL/dx).  bias fp32; yprev bf16.  Other shapes: SH_ERR_UNSUPPORTED (use the fp32 entry
+ * points, which take any shape). */
+SH_API int sh_spiral_conv_fwd_bf16(const void* x, int x_dtype, int64_t x_sv, int64_t x_sb, const int32_t* table,
+                                   const void* wfrag, const float* bias, void* y, int y_dtype, int64_t y_sv, int64_t y_sb,
+                                   int B, int R, int S, int Cin, int Cout, int act, int zero_row, sh_stream_t stream);
+SH_API int sh_spiral_conv_bwd_data_bf16(const void* dpre, int dp_dtype, int64_t dp_sv, int64_t dp_sb,
+                                        const int32_t* table_t, const void* wfrag_t, void* dx, int dx_dtype,
+                                        int64_t dx_sv, int64_t dx_sb, const void* yprev, int64_t yp_sv, int64_t yp_sb,
+                                        int act_prev, int zero_row, int B, int n_in, int S, int Cin, int Cout,
+                                        sh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,7 +59,13 @@ SIGNATURES = {
     "sh_dataset_normalize": (c_int, [_P, _P, _I, _I, _I, ctypes.c_uint, _P, _P, _P, _P, _P, _P]),
     "sh_gather_meshes": (c_int, [_P, _L, _P, _I, _P, _P]),
     "sh_adam_step": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P] + [ctypes.c_double] * 4 + [_P]),
+    # bf16 compute path
+    "sh_conv_wfrag_bytes": (c_size_t, [_I, _I, _I]),
+    "sh_conv_wfrag_prep_multi": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P]),
+    "sh_spiral_conv_fwd_bf16": (c_int, [_P, _I, _L, _L, _P, _P, _P, _P, _I, _L, _L, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "sh_spiral_conv_bwd_data_bf16": (c_int, [_P, _I, _L, _L, _P, _P, _P, _I, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _P]),
 }
+DTYPE_IDS = {"float32": 0, "bfloat16": 1}
 
 
 

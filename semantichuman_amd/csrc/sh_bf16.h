@@ -1,0 +1,31 @@
+// bf16 helpers shared by the reduced-precision kernels (BASELINE config 3: bf16 activations and working weights,
+// fp32 accumulation, fp32 master weights / gradients / Adam state).
+#pragma once
+#include "sh_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// fp32 -> bf16, round to nearest even (a plain cast: hipcc emits v_cvt_pk_bf16_f32, which keeps NaN a NaN)
+__device__ __forceinline__ bf16x4 sh_to_bf16x4(f32x4 v) {
+    return (bf16x4){(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+}
+__device__ __forceinline__ f32x4 sh_from_bf16x4(bf16x4 v) { return (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; }
+
+// Geometry of a fragment-ordered bf16 weight (the A operand of v_mfma_f32_16x16x32_bf16, one 1-KiB fragment per
+// (k-step, 16-row tile)):  frag[ks][nt][lane][j] = W'[16 nt + (lane & 15)][32 ks + 8 (lane >> 4) + j], zero outside W'.
+//   rows of W' = output channels, columns k = s * Cg + c   (Cg % 8 == 0)
+//                                          k = 4 s + c      (Cg == 3: every neighbour padded to a quad)
+struct ShFragGeom { int kp, nks, nt_tot; };
+static inline ShFragGeom sh_frag_geom(int S, int Cg, int Nout) {
+    ShFragGeom g;
+    const int k = Cg == 3 ? 4 * S : S * Cg;
+    g.kp = (k + 31) / 32 * 32;
+    g.nks = g.kp / 32;
+    const int nt = (Nout + 15) / 16;
+    g.nt_tot = nt <= 1 ? 1 : nt <= 2 ? 2 : nt <= 4 ? 4 : (nt + 7) / 8 * 8;
+    return g;
+}

@@ -14,10 +14,10 @@ from . import _lib
 from ._lib import ACT_IDS, check, ptr, stream_ptr
 
 
-def _dims(t: torch.Tensor, layout: str):
+def _dims(t: torch.Tensor, layout: str, dtypes=(torch.float32,)):
     """-> (B, rows, C, stride_row, stride_batch) for a contiguous 3-D tensor."""
-    if t.dim() != 3 or not t.is_contiguous() or t.dtype != torch.float32:
-        raise ValueError("expected a contiguous fp32 3-D tensor, got %s %s" % (tuple(t.shape), t.dtype))
+    if t.dim() != 3 or not t.is_contiguous() or t.dtype not in dtypes:
+        raise ValueError("expected a contiguous %s 3-D tensor, got %s %s" % ("/".join(str(d) for d in dtypes), tuple(t.shape), t.dtype))
     if not t.is_cuda:
         raise RuntimeError("semantichuman_amd kernels need a HIP device tensor (got %s); there is no CPU path" % t.device)
     if layout == "bm":
@@ -368,3 +368,53 @@ def gather_meshes(src, idx):
     if b:
         check(_lib.load().sh_gather_meshes(ptr(src), src[0].numel(), ptr(idx), b, ptr(out), stream_ptr()), "sh_gather_meshes")
     return out
+
+
+# ------------------------------------------------------------------------------------------ bf16 compute path
+_ANY = (torch.float32, torch.bfloat16)
+
+
+def dtype_id(t: torch.Tensor) -> int:
+    return _lib.DTYPE_IDS[str(t.dtype).replace("torch.", "")]
+
+
+def conv_wfrag_prep(weights, dims, transpose):
+    """fp32 master weights [Cout, S*Cin] -> bf16 fragment-ordered working copies (uint8 buffers), one launch.
+    dims: [(S, Cin, Cout)]; transpose: [0 forward operand | 1 backward-data operand]."""
+    import ctypes
+    lib = _lib.load()
+    outs = []
+    for w, (s, ci, co), tr in zip(weights, dims, transpose):
+        if not (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()):
+            raise RuntimeError("conv_wfrag_prep needs contiguous fp32 HIP weights; there is no CPU path")
+        nb = lib.sh_conv_wfrag_bytes(s, co if tr else ci, ci if tr else co)
+        outs.append(torch.empty(nb, dtype=torch.uint8, device=w.device))
+    cols = list(zip(*dims))
+    args = [_c_ptr_array(list(weights)), _c_ptr_array(outs)] + [_c_int_array(c) for c in cols] + [_c_int_array([int(t) for t in transpose])]
+    check(lib.sh_conv_wfrag_prep_multi(len(outs), *[ctypes.cast(a, ctypes.c_void_p) for a in args], stream_ptr()),
+          "sh_conv_wfrag_prep_multi")
+    return outs
+
+
+def spiral_conv_fwd_bf16(x, x_layout, table, wfrag, bias, y, y_layout, R, S, Cin, Cout, act, zero_row):
+    B, _, C1, xsv, xsb = _dims(x, x_layout, _ANY)
+    B2, Ry, C2, ysv, ysb = _dims(y, y_layout, _ANY)
+    assert B == B2 and Ry >= R and C1 == Cin and C2 == Cout and table.dtype == torch.int32
+    _check_index_range(x)
+    check(_lib.load().sh_spiral_conv_fwd_bf16(ptr(x), dtype_id(x), xsv, xsb, ptr(table), ptr(wfrag), ptr(bias), ptr(y), dtype_id(y),
+                                              ysv, ysb, B, R, S, Cin, Cout, act, zero_row, stream_ptr()), "sh_spiral_conv_fwd_bf16")
+
+
+def spiral_conv_bwd_data_bf16(dpre, dp_layout, table_t, wfrag_t, dx, dx_layout, yprev, yp_layout, act_prev, zero_row, n_in, S, Cin, Cout):
+    B, _, C1, dsv, dsb = _dims(dpre, dp_layout, _ANY)
+    B2, Rx, C2, xsv, xsb = _dims(dx, dx_layout, _ANY)
+    assert B == B2 and C1 == Cout and C2 == Cin and Rx >= n_in and tuple(table_t.shape) == (n_in, S)
+    _check_index_range(dpre)
+    if yprev is not None:
+        _, _, C3, ysv, ysb = _dims(yprev, yp_layout, (torch.bfloat16,))
+        assert C3 == Cin
+    else:
+        ysv = ysb = 0
+    check(_lib.load().sh_spiral_conv_bwd_data_bf16(ptr(dpre), dtype_id(dpre), dsv, dsb, ptr(table_t), ptr(wfrag_t), ptr(dx),
+                                                   dtype_id(dx), xsv, xsb, ptr(yprev), ysv, ysb, act_prev, zero_row, B, n_in, S,
+                                                   Cin, Cout, stream_ptr()), "sh_spiral_conv_bwd_data_bf16")

@@ -1,0 +1,143 @@
+"""bf16 compute path (BASELINE config 3): every bf16 kernel, through the C ABI, against a float64 evaluation of the same
+operator on the SAME bf16-rounded operands (so what is measured is the kernel - fp32 accumulation, one rounding of the
+result - not the quantisation of the inputs), and the whole model against the fp32 oracle within the tolerance SURVEY 8a
+states for this configuration (forward 1e-2 relative).
+
+Tolerances: a bf16 result carries one rounding of 2^-9 relative (half an ulp of 8 significant bits); sums of K <= 1024
+bf16 products accumulated in fp32 add <= 1e-6 relative.  Tensor checks use  max|err| <= 2^-8 * max|ref|  (one ulp at the
+tensor's scale) unless stated otherwise."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import semantichuman_amd as sh
+from semantichuman_amd import mesh_ops, ops
+from tests import emulate
+
+pytestmark = pytest.mark.gpu
+ULP = 2.0 ** -8
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def bf(t):
+    """round an fp32 tensor to bf16 and back (the value the kernels see)"""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def rand_table(R, n_in, S, seed):
+    g = np.random.RandomState(seed)
+    t = g.randint(0, n_in, size=(R, S)).astype(np.int32)
+    t[:, 0] = np.arange(R) % n_in
+    t[g.rand(R, S) < 0.1] = n_in - 1                # padding entries -> the dummy row
+    return t
+
+
+# (B, n_in, R, S, Cin, Cout, act): channel modes 16 / 32 / 64 / 128, odd spiral lengths (K % 32 != 0), odd batches,
+# R < n_in (fused row select), channel tiles 1 / 2 / 4 / 8
+CONV_SHAPES = [
+    (16, 50, 50, 9, 16, 32, "elu"), (3, 41, 20, 11, 16, 16, "relu"), (64, 70, 70, 8, 32, 64, "elu"),
+    (20, 33, 33, 8, 64, 128, "elu"), (16, 40, 40, 8, 128, 64, "tanh"), (5, 64, 64, 10, 32, 32, "identity"),
+    (32, 30, 30, 18, 64, 32, "leaky_relu"), (17, 45, 45, 7, 32, 16, "sigmoid"),
+]
+
+
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+@pytest.mark.parametrize("layouts", [("vm", "vm"), ("bm", "vm"), ("vm", "bm")])
+def test_conv_fwd_and_bwd_data_bf16(shape, layouts):
+    B, n_in, R, S, Cin, Cout, act = shape
+    li, lo = layouts
+    torch.manual_seed(0)
+    table = rand_table(R, n_in, S, 1)
+    x = bf(torch.randn(n_in, B, Cin))                                   # vertex-major master copy
+    x[-1] = 0.0 if act != "sigmoid" else x[-1]
+    W = bf(torch.randn(Cout, S * Cin) / np.sqrt(S * Cin))
+    bias = torch.randn(Cout) * 0.1
+    a = ops.act_id(act)
+    ref = emulate.conv_fwd(x.double().numpy(), table, W.double().numpy(), bias.double().numpy(), a, R - 1)
+
+    xd = (x if li == "vm" else x.permute(1, 0, 2).contiguous()).to(dev(), torch.bfloat16)
+    y = torch.full((R, B, Cout) if lo == "vm" else (B, R, Cout), float("nan"), dtype=torch.bfloat16, device=dev())
+    wf, wft = ops.conv_wfrag_prep([W.to(dev())] * 2, [(S, Cin, Cout)] * 2, [0, 1])
+    td = torch.from_numpy(table).to(dev())
+    ops.spiral_conv_fwd_bf16(xd, li, td, wf, bias.to(dev()), y, lo, R, S, Cin, Cout, a, R - 1)
+    got = y.float().cpu()
+    got = got if lo == "vm" else got.permute(1, 0, 2)
+    assert torch.isfinite(got).all()
+    err = float((got.double() - torch.from_numpy(ref)).abs().max())
+    assert err <= ULP * float(np.abs(ref).max()) + 1e-6, (err, np.abs(ref).max())
+    assert float(got[R - 1].abs().max()) == 0.0                         # masked dummy row (models.py:49-51)
+
+    # backward-data: the same kernel over the transposed table, epilogue x act'(yprev), zero row
+    tt = mesh_ops.transpose_table_dense(table, n_in, none_row=R - 1, skip_row=-1)
+    dpre = bf(torch.randn(R, B, Cout))
+    dpre[R - 1] = 0
+    ext = emulate.extend_dpre(dpre.double().numpy(), tt)
+    yprev = bf(torch.randn(n_in, B, Cin))
+    ref_dx = emulate.conv_bwd_data(ext, tt.table_t, W.double().numpy(), Cin) * emulate.DACT[a](yprev.double().numpy())
+    ref_dx[n_in - 1] = 0
+    dp_dev = torch.from_numpy(ext).to(torch.float32)
+    # extra rows are sums of bf16 rows: round them as the kernel chain would store them
+    dp_dev = bf(dp_dev)
+    ref_dx = emulate.conv_bwd_data(dp_dev.double().numpy(), tt.table_t, W.double().numpy(), Cin) * emulate.DACT[a](yprev.double().numpy())
+    ref_dx[n_in - 1] = 0
+    dpd = (dp_dev if lo == "vm" else dp_dev.permute(1, 0, 2).contiguous()).to(dev(), torch.bfloat16)
+    ypd = yprev.to(dev(), torch.bfloat16)
+    dx = torch.full((n_in, B, Cin) if li == "vm" else (B, n_in, Cin), float("nan"), dtype=torch.bfloat16, device=dev())
+    ops.spiral_conv_bwd_data_bf16(dpd, lo, torch.from_numpy(tt.table_t).to(dev()), wft, dx, li, ypd, "vm", a, n_in - 1, n_in, S, Cin, Cout)
+    gdx = dx.float().cpu()
+    gdx = gdx if li == "vm" else gdx.permute(1, 0, 2)
+    assert torch.isfinite(gdx).all()
+    err = float((gdx.double() - torch.from_numpy(ref_dx)).abs().max())
+    assert err <= ULP * float(np.abs(ref_dx).max()) + 1e-6, (err, np.abs(ref_dx).max())
+
+
+@pytest.mark.parametrize("B,N,S,Cout", [(16, 60, 10, 16), (5, 37, 9, 16), (64, 50, 3, 16)])
+def test_conv_bf16_three_channel_fp32_sides(B, N, S, Cout):
+    """First encoder layer: fp32 xyz in (batch-major, the reference layout), bf16 out.  Last decoder layer: bf16 in, fp32 xyz
+    out; and its backward-data: fp32 xyz gradient in, bf16 out."""
+    torch.manual_seed(1)
+    n1 = N + 1
+    table = rand_table(n1, n1, S, 2)
+    a = ops.act_id("elu")
+    # --- 3 (fp32) -> Cout (bf16)
+    x = torch.randn(B, n1, 3)
+    x[:, -1] = 0
+    W = bf(torch.randn(Cout, S * 3) / np.sqrt(S * 3))
+    bias = torch.randn(Cout) * 0.1
+    xr = bf(x)                                                           # the kernel rounds the fp32 input to bf16 on load
+    ref = emulate.conv_fwd(xr.permute(1, 0, 2).double().numpy(), table, W.double().numpy(), bias.double().numpy(), a, n1 - 1)
+    wf, = ops.conv_wfrag_prep([W.to(dev())], [(S, 3, Cout)], [0])
+    y = torch.full((n1, B, Cout), float("nan"), dtype=torch.bfloat16, device=dev())
+    td = torch.from_numpy(table).to(dev())
+    ops.spiral_conv_fwd_bf16(x.to(dev()), "bm", td, wf, bias.to(dev()), y, "vm", n1, S, 3, Cout, a, n1 - 1)
+    err = float((y.float().cpu().double() - torch.from_numpy(ref)).abs().max())
+    assert err <= ULP * float(np.abs(ref).max()) + 1e-6
+    # --- Cout (bf16) -> 3 (fp32, batch-major), identity activation
+    W2 = bf(torch.randn(3, S * Cout) / np.sqrt(S * Cout))
+    b2 = torch.randn(3) * 0.1
+    h = bf(torch.randn(n1, B, Cout))
+    ref2 = emulate.conv_fwd(h.double().numpy(), table, W2.double().numpy(), b2.double().numpy(), 0, n1 - 1)
+    wf2, wf2t = ops.conv_wfrag_prep([W2.to(dev())] * 2, [(S, Cout, 3)] * 2, [0, 1])
+    out = torch.full((B, n1, 3), float("nan"), dtype=torch.float32, device=dev())
+    ops.spiral_conv_fwd_bf16(h.to(dev(), torch.bfloat16), "vm", td, wf2, b2.to(dev()), out, "bm", n1, S, Cout, 3, 0, n1 - 1)
+    err = float((out.cpu().permute(1, 0, 2).double() - torch.from_numpy(ref2)).abs().max())
+    assert err <= 2e-6 * float(np.abs(ref2).max()) * S * Cout ** 0.5 + 1e-6        # fp32 result: accumulation noise only
+    assert float(out[:, -1].abs().max()) == 0.0
+    # --- its backward-data: dpre fp32 [n1, B, 3] (vertex-major) -> dx bf16 [n1, B, Cout]
+    tt = mesh_ops.transpose_table_dense(table, n1, none_row=n1 - 1, skip_row=-1)
+    dpre = torch.randn(n1, B, 3)
+    dpre[-1] = 0
+    ext = torch.from_numpy(emulate.extend_dpre(dpre.double().numpy(), tt)).float()
+    yprev = bf(torch.randn(n1, B, Cout))
+    ref3 = emulate.conv_bwd_data(bf(ext).double().numpy(), tt.table_t, W2.double().numpy(), Cout) * emulate.DACT[a](yprev.double().numpy())
+    ref3[n1 - 1] = 0
+    dx = torch.full((n1, B, Cout), float("nan"), dtype=torch.bfloat16, device=dev())
+    ops.spiral_conv_bwd_data_bf16(ext.to(dev()), "vm", torch.from_numpy(tt.table_t).to(dev()), wf2t, dx, "vm",
+                                  yprev.to(dev(), torch.bfloat16), "vm", a, n1 - 1, n1, S, Cout, 3)
+    err = float((dx.float().cpu().double() - torch.from_numpy(ref3)).abs().max())
+    assert err <= ULP * float(np.abs(ref3).max()) + 1e-6
