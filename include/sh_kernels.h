@@ -388,6 +388,30 @@ SH_API int sh_spiral_conv_bwd_data_bf16(const void* dpre, int dp_dtype, int64_t 
                                         int act_prev, int zero_row, int B, int n_in, int S, int Cin, int Cout,
                                         sh_stream_t stream);
 
+/* sh_spiral_conv_bwd_wgt in bf16: x / dpre bf16 (channels % 8 == 0) or fp32 with exactly 3 channels; writes fp32 partial
+ * slabs into `workspace` (>= sh_spiral_conv_bwd_wgt_workspace_bf16 bytes); sh_spiral_conv_bwd_wgt_reduce_multi_bf16 sums
+ * the slabs of up to 16 layers into fp32 dW / dbias (same contract as the fp32 pair above). */
+SH_API size_t sh_spiral_conv_bwd_wgt_workspace_bf16(int B, int R, int S, int Cin, int Cout);
+SH_API int sh_spiral_conv_bwd_wgt_bf16(const void* dpre, int dp_dtype, int64_t dp_sv, int64_t dp_sb, const void* x, int x_dtype,
+                                       int64_t x_sv, int64_t x_sb, const int32_t* table, void* workspace,
+                                       size_t workspace_bytes, int B, int R, int S, int Cin, int Cout, sh_stream_t stream);
+SH_API int sh_spiral_conv_bwd_wgt_reduce_multi_bf16(int n_layers, const void* const* workspaces, float* const* dW,
+                                                    float* const* dbias, const int* B, const int* R, const int* S,
+                                                    const int* Cin, const int* Cout, sh_stream_t stream);
+
+/* The latent dense layers (models.py:85-86,130,144) in bf16: `weight_bf16` is a bf16 working copy [N][K] of the fp32
+ * master weight (sh_cast_f32_to_bf16, or written by sh_adam_step_bf16 as it updates the master); x / dy / y / dx are bf16
+ * or fp32 (the latent code and its gradient stay fp32); bias, dW, dbias fp32.  N and K must be multiples of 8, M is free.
+ * workspace >= sh_linear_workspace_bf16(M, N, K) bytes, 16-byte aligned (split-reduction partials). */
+SH_API size_t sh_linear_workspace_bf16(int M, int N, int K);
+SH_API int sh_cast_f32_to_bf16(const float* src, void* dst, int64_t n, sh_stream_t stream);
+SH_API int sh_linear_fwd_bf16(const void* x, int x_dtype, const void* weight_bf16, const float* bias, void* y, int y_dtype,
+                              int M, int N, int K, void* workspace, size_t workspace_bytes, sh_stream_t stream);
+SH_API int sh_linear_bwd_data_bf16(const void* dy, int dy_dtype, const void* weight_bf16, void* dx, int dx_dtype, int M, int N,
+                                   int K, void* workspace, size_t workspace_bytes, sh_stream_t stream);
+SH_API int sh_linear_bwd_wgt_bf16(const void* dy, int dy_dtype, const void* x, int x_dtype, float* dW, float* dbias, int M,
+                                  int N, int K, sh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,6 +64,14 @@ SIGNATURES = {
     "sh_conv_wfrag_prep_multi": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P]),
     "sh_spiral_conv_fwd_bf16": (c_int, [_P, _I, _L, _L, _P, _P, _P, _P, _I, _L, _L, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sh_spiral_conv_bwd_data_bf16": (c_int, [_P, _I, _L, _L, _P, _P, _P, _I, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "sh_spiral_conv_bwd_wgt_workspace_bf16": (c_size_t, [_I, _I, _I, _I, _I]),
+    "sh_spiral_conv_bwd_wgt_bf16": (c_int, [_P, _I, _L, _L, _P, _I, _L, _L, _P, _P, c_size_t, _I, _I, _I, _I, _I, _P]),
+    "sh_spiral_conv_bwd_wgt_reduce_multi_bf16": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "sh_linear_workspace_bf16": (c_size_t, [_I, _I, _I]),
+    "sh_cast_f32_to_bf16": (c_int, [_P, _P, _L, _P]),
+    "sh_linear_fwd_bf16": (c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P, c_size_t, _P]),
+    "sh_linear_bwd_data_bf16": (c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _P, c_size_t, _P]),
+    "sh_linear_bwd_wgt_bf16": (c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _P]),
 }
 DTYPE_IDS = {"float32": 0, "bfloat16": 1}
 

@@ -1,0 +1,234 @@
+// Spiral-convolution weight gradient in bf16 (BASELINE config 3):
+//
+//   dW[co][s*Cin + ci] = sum_{v,b} dpre[v,b,co] * x[table[v,s], b, ci]        dbias[co] = sum_{v,b} dpre[v,b,co]
+//                                                                            (autograd of reference models.py:45)
+// The reduction runs over the (vertex, batch) rows, which is the SLOW index of both operands in memory (channels are
+// contiguous), so both go through the transposed LDS image of sh_bf16_tiles.h and come back through
+// ds_read_b64_tr_b16 as v_mfma_f32_16x16x32_bf16 fragments; the gathered [rows, S*Cin] matrix is re-gathered on the
+// fly, 16 bytes (8 channels of one neighbour) per lane.  A workgroup owns 64 weight columns x 64 output channels and a
+// contiguous range of 64-row stages; it writes an fp32 partial slab, and the slabs are summed in a fixed order by the
+// same reduction kernel the fp32 path uses (deterministic, no atomics).  fp32 master gradients out.
+// 3-channel fp32 operands (the xyz input of the first layer, the xyz gradient of the last) are converted on the way in.
+#include "sh_bf16_tiles.h"
+
+namespace {
+
+struct BWParams {
+    const char* dpre; long dp_rb, dp_bb;      // byte strides (row, batch entry)
+    const char* x; long x_rb, x_bb;
+    const int* table;                          // [R][S]
+    float* slab; long slab_stride, bias_off;   // [nsplit][Cout * K], then [nsplit][Cout]
+    int B, R, S, Cin, Cout, K, Kq;             // Kq = gathered columns as staged (K, or 4 S for 3-channel inputs)
+    int n_qt, n_pt, nsplit, stages_per_split;
+    long rows;                                 // R * B
+};
+
+struct __attribute__((packed, aligned(4))) bw_f3 { float a, b, c; };
+__device__ __forceinline__ u32x4 bw_pack(const bw_f3& u, const bw_f3& v) {
+    const bf16x8 o = {(__bf16)u.a, (__bf16)u.b, (__bf16)u.c, (__bf16)0.f, (__bf16)v.a, (__bf16)v.b, (__bf16)v.c, (__bf16)0.f};
+    return *reinterpret_cast<const u32x4*>(&o);
+}
+
+// XC3: x is fp32 with 3 channels (columns staged as zero-padded quads q' = 4 s + c); PC3: dpre is fp32 with 3 channels
+template <bool XC3, bool PC3>
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const BWParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TG_IMG_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bid = blockIdx.x;
+    const int qt = bid % p.n_qt; bid /= p.n_qt;
+    const int pt = bid % p.n_pt; const int split = bid / p.n_pt;
+    const int q0 = qt * 64, p0 = pt * 64;
+    const long st0 = (long)split * p.stages_per_split;
+    const long nst_all = (p.rows + 63) >> 6;
+    const int nst = (int)min((long)p.stages_per_split, nst_all - st0);
+    const int qh = wave & 1, ph = wave >> 1;
+
+    // this thread's two pieces per operand and stage: rows (tid >> 3) and (tid >> 3) + 32, 8-column group c8 = tid & 7
+    const int c8 = tid & 7, prow = tid >> 3;
+    // gathered operand: column group -> (spiral position, channel) is the same for every stage
+    const int kq = q0 + 8 * c8;
+    const bool a_ok = kq < p.Kq;
+    int sa, sb = 0, ca = 0;                    // XC3: two neighbours sa, sb per piece; else one neighbour sa, channel ca
+    if (XC3) { sa = a_ok ? kq >> 2 : 0; sb = sa + 1 < p.S ? sa + 1 : sa; }
+    else { sa = a_ok ? kq / p.Cin : 0; ca = a_ok ? kq - sa * p.Cin : 0; }
+    const bool sb_ok = XC3 && a_ok && (kq >> 2) + 1 < p.S;
+    const int cb = p0 + 8 * c8;                // dpre channel group
+    const bool b_ok = cb < p.Cout;
+
+    struct Idx { int v[2], b[2], ta[2], tb[2]; bool ok[2]; };
+    auto rows_of = [&](long st, Idx& ix) {     // (vertex, batch) of the stage's two rows + their gather-table entries
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const long r = (st << 6) + prow + 32 * k;
+            ix.ok[k] = r < p.rows;
+            const long rc = ix.ok[k] ? r : 0;
+            ix.v[k] = (int)(rc / p.B); ix.b[k] = (int)(rc - (long)ix.v[k] * p.B);
+            ix.ta[k] = p.table[(long)ix.v[k] * p.S + sa];
+            ix.tb[k] = XC3 ? p.table[(long)ix.v[k] * p.S + sb] : 0;
+        }
+    };
+    auto load = [&](const Idx& ix, u32x4 (&ra)[2], u32x4 (&rb)[2]) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            if (XC3) {
+                const char* xb = p.x + (long)ix.b[k] * p.x_bb;
+                const bw_f3 u = *reinterpret_cast<const bw_f3*>(xb + (long)ix.ta[k] * p.x_rb);
+                bw_f3 w = *reinterpret_cast<const bw_f3*>(xb + (long)ix.tb[k] * p.x_rb);
+                if (!sb_ok) w = bw_f3{0.f, 0.f, 0.f};
+                ra[k] = (ix.ok[k] && a_ok) ? bw_pack(u, w) : z;
+            } else {
+                const u32x4 g = *reinterpret_cast<const u32x4*>(p.x + (long)ix.ta[k] * p.x_rb + (long)ix.b[k] * p.x_bb + 2 * ca);
+                ra[k] = (ix.ok[k] && a_ok) ? g : z;
+            }
+            const char* dp = p.dpre + (long)ix.v[k] * p.dp_rb + (long)ix.b[k] * p.dp_bb;
+            if (PC3) {
+                const bw_f3 u = *reinterpret_cast<const bw_f3*>(dp);
+                const bf16x8 o = {(__bf16)u.a, (__bf16)u.b, (__bf16)u.c, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+                rb[k] = (ix.ok[k] && c8 == 0 && p0 == 0) ? *reinterpret_cast<const u32x4*>(&o) : z;
+            } else {
+                const u32x4 g = *reinterpret_cast<const u32x4*>(dp + (b_ok ? 2 * cb : 0));
+                rb[k] = (ix.ok[k] && b_ok) ? g : z;
+            }
+        }
+    };
+    auto store = [&](char* img, const u32x4 (&ra)[2], const u32x4 (&rb)[2]) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            *reinterpret_cast<u32x4*>(img + tg_tr_piece(prow + 32 * k, c8)) = ra[k];
+            *reinterpret_cast<u32x4*>(img + TG_IMG_BYTES + tg_tr_piece(prow + 32 * k, c8)) = rb[k];
+        }
+    };
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float csum = 0.f;
+
+    // pipeline: gather-table entries two stages ahead, operand loads one stage ahead, LDS double-buffered
+    Idx ixa, ixb;
+    u32x4 ra[2], rb[2];
+    if (nst > 0) {
+        rows_of(st0, ixa);
+        load(ixa, ra, rb);
+        rows_of(st0 + (nst > 1 ? 1 : 0), ixb);
+        store(smem, ra, rb);
+    }
+    __syncthreads();
+    for (int st = 0; st < nst; ++st) {
+        const int cur = st & 1;
+        if (st + 1 < nst) {
+            load(ixb, ra, rb);                                          // stage st + 1 (its table entries arrived a stage ago)
+            rows_of(st0 + (st + 2 < nst ? st + 2 : st + 1), ixb);       // stage st + 2
+        }
+        const char* ia = smem + cur * 2 * TG_IMG_BYTES;
+        const char* ib = ia + TG_IMG_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fa[i] = tg_tr_frag(ia, 2 * qh + i, kk, lane);
+                fb[i] = tg_tr_frag(ib, 2 * ph + i, kk, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (qt == 0 && tid < 64) {                                      // bias gradient: column sums of the dpre tile
+            const char* col = ib + (tid >> 4) * TG_TR_BLK + (tid & 15) * 2;
+#pragma unroll 8
+            for (int r = 0; r < 64; ++r) csum += (float)*reinterpret_cast<const __bf16*>(col + (r >> 5) * TG_TR_KS + (r & 31) * 32);
+        }
+        if (st + 1 < nst) store(smem + (cur ^ 1) * 2 * TG_IMG_BYTES, ra, rb);
+        __syncthreads();
+    }
+
+    // lane holds columns q .. q+3 of output channel co
+    float* slab = p.slab + (long)split * p.slab_stride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = q0 + 32 * qh + 16 * i + 4 * (lane >> 4), co = p0 + 32 * ph + 16 * j + (lane & 15);
+            if (q >= p.Kq || co >= p.Cout) continue;
+            if (XC3) {                                                  // quad q / 4 = spiral position; element 3 is the padding
+                float* dst = slab + (long)co * p.K + 3 * (q >> 2);
+                dst[0] = acc[i][j][0]; dst[1] = acc[i][j][1]; dst[2] = acc[i][j][2];
+            } else {
+                *reinterpret_cast<f32x4*>(slab + (long)co * p.K + q) = acc[i][j];
+            }
+        }
+    if (qt == 0 && tid < 64 && p0 + tid < p.Cout) p.slab[p.bias_off + (long)split * p.Cout + p0 + tid] = csum;
+}
+
+}  // namespace
+
+// shared with the slab reduction in spiral_conv.hip
+int sh_wgrad_bf16_nsplit(int B, int R, int S, int Cin, int Cout) {
+    const int Kq = Cin == 3 ? 4 * S : S * Cin, K = S * Cin;
+    const long tiles = (long)sh_cdiv(Kq, 64) * sh_cdiv(Cout, 64);
+    const long nst = ((long)R * B + 63) >> 6;
+    static const int wg_target = sh_env_int("SH_BW_BLOCKS", 2048, 64, 1 << 16);
+    static const int slab_mb = sh_env_int("SH_BW_SLAB_MB", 32, 1, 4096);
+    long ns = wg_target / tiles;
+    const long cap = ((long)slab_mb << 20) / ((long)Cout * K * 4);       // partial slabs are written and re-read once
+    if (ns > cap) ns = cap;
+    if (ns > nst / 4) ns = nst / 4;                                      // >= 4 stages per split
+    if (ns < 1) ns = 1;
+    const long sps = (nst + ns - 1) / ns;
+    return (int)((nst + sps - 1) / sps);
+}
+
+extern "C" {
+
+size_t sh_spiral_conv_bwd_wgt_workspace_bf16(int B, int R, int S, int Cin, int Cout) {
+    if (B <= 0 || R <= 0 || S <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    return (size_t)sh_wgrad_bf16_nsplit(B, R, S, Cin, Cout) * ((size_t)Cout * S * Cin + Cout) * sizeof(float);
+}
+
+int sh_spiral_conv_bwd_wgt_bf16(const void* dpre, int dp_dtype, int64_t dp_sv, int64_t dp_sb, const void* x, int x_dtype, int64_t x_sv,
+                                int64_t x_sb, const int32_t* table, void* workspace, size_t workspace_bytes, int B, int R, int S, int Cin,
+                                int Cout, sh_stream_t stream) {
+    SH_REQUIRE(dpre && x && table && workspace, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_wgt_bf16: null pointer");
+    SH_REQUIRE(B > 0 && R > 0 && S > 0 && Cin > 0 && Cout > 0, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_wgt_bf16: non-positive size");
+    SH_REQUIRE(workspace_bytes >= sh_spiral_conv_bwd_wgt_workspace_bf16(B, R, S, Cin, Cout), SH_ERR_WORKSPACE,
+               "sh_spiral_conv_bwd_wgt_bf16: workspace too small");
+    const bool xc3 = x_dtype == SH_DTYPE_F32, pc3 = dp_dtype == SH_DTYPE_F32;
+    SH_REQUIRE(xc3 ? Cin == 3 : (x_dtype == SH_DTYPE_BF16 && Cin % 8 == 0), SH_ERR_UNSUPPORTED,
+               "sh_spiral_conv_bwd_wgt_bf16: input must be bf16 with channels %% 8 == 0 or fp32 with 3 channels (got %d)", Cin);
+    SH_REQUIRE(pc3 ? Cout == 3 : (dp_dtype == SH_DTYPE_BF16 && Cout % 8 == 0), SH_ERR_UNSUPPORTED,
+               "sh_spiral_conv_bwd_wgt_bf16: gradient must be bf16 with channels %% 8 == 0 or fp32 with 3 channels (got %d)", Cout);
+    SH_REQUIRE(!(xc3 && pc3), SH_ERR_UNSUPPORTED, "sh_spiral_conv_bwd_wgt_bf16: 3 -> 3 channel layers are not built in bf16");
+    const long xe = xc3 ? 4 : 2, pe = pc3 ? 4 : 2;
+    SH_REQUIRE(xc3 || ((reinterpret_cast<uintptr_t>(x) | (uintptr_t)(x_sv * xe) | (uintptr_t)(x_sb * xe)) & 15) == 0, SH_ERR_INVALID_ARG,
+               "sh_spiral_conv_bwd_wgt_bf16: x must be 16-byte aligned with 16-byte-multiple strides");
+    SH_REQUIRE(pc3 || ((reinterpret_cast<uintptr_t>(dpre) | (uintptr_t)(dp_sv * pe) | (uintptr_t)(dp_sb * pe)) & 15) == 0, SH_ERR_INVALID_ARG,
+               "sh_spiral_conv_bwd_wgt_bf16: dpre must be 16-byte aligned with 16-byte-multiple strides");
+    BWParams p{};
+    p.dpre = static_cast<const char*>(dpre); p.dp_rb = dp_sv * pe; p.dp_bb = dp_sb * pe;
+    p.x = static_cast<const char*>(x); p.x_rb = x_sv * xe; p.x_bb = x_sb * xe;
+    p.table = table;
+    p.B = B; p.R = R; p.S = S; p.Cin = Cin; p.Cout = Cout; p.K = S * Cin; p.Kq = xc3 ? 4 * S : p.K;
+    p.rows = (long)R * B;
+    p.n_qt = sh_cdiv(p.Kq, 64); p.n_pt = sh_cdiv(Cout, 64);
+    p.nsplit = sh_wgrad_bf16_nsplit(B, R, S, Cin, Cout);
+    const long nst = (p.rows + 63) >> 6;
+    p.stages_per_split = (int)((nst + p.nsplit - 1) / p.nsplit);
+    p.slab = static_cast<float*>(workspace);
+    p.slab_stride = (long)Cout * p.K;
+    p.bias_off = (long)p.nsplit * p.slab_stride;
+    const int grid = p.n_qt * p.n_pt * p.nsplit;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ShProfScope ps(st, "wgrad_bf16_kernel<%d, %d>|R=%d B=%d K=%d N=%d grid=%d split=%d", (int)xc3, (int)pc3, R, B, p.K, Cout, grid, p.nsplit);
+    if (xc3) SH_LAUNCH_PS(ps, (wgrad_bf16_kernel<true, false>), dim3(grid), dim3(256), 0, st, p);
+    else if (pc3) SH_LAUNCH_PS(ps, (wgrad_bf16_kernel<false, true>), dim3(grid), dim3(256), 0, st, p);
+    else SH_LAUNCH_PS(ps, (wgrad_bf16_kernel<false, false>), dim3(grid), dim3(256), 0, st, p);
+    SH_CHECK_LAUNCH("wgrad_bf16");
+    return SH_OK;
+}
+
+}  // extern "C"

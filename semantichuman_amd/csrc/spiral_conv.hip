@@ -26,6 +26,8 @@
 
 #include <type_traits>
 
+int sh_wgrad_bf16_nsplit(int B, int R, int S, int Cin, int Cout);      // csrc/bf16_wgrad.hip
+
 namespace {
 
 constexpr int TM = 128;
@@ -1318,22 +1320,21 @@ int sh_spiral_conv_bwd_wgt(const float* dpre, int64_t dp_sv, int64_t dp_sb, cons
     return SH_OK;
 }
 
-int sh_spiral_conv_bwd_wgt_reduce_multi(int n_layers, const void* const* workspaces, float* const* dW, float* const* dbias,
-                                        const int* B, const int* R, const int* S, const int* Cin, const int* Cout,
-                                        sh_stream_t stream) {
+static int reduce_multi_impl(int n_layers, const void* const* workspaces, float* const* dW, float* const* dbias, const int* B,
+                             const int* R, const int* S, const int* Cin, const int* Cout, bool bf16_plan, sh_stream_t stream) {
     SH_REQUIRE(n_layers > 0 && 2 * n_layers <= MR_MAX && workspaces && dW && dbias && B && R && S && Cin && Cout,
                SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_wgt_reduce_multi: bad argument (at most %d layers)", MR_MAX / 2);
     MultiReduce m{};
     int nd = 0, blocks = 0;
     for (int i = 0; i < n_layers; ++i) {
         SH_REQUIRE(workspaces[i] && dW[i], SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_wgt_reduce_multi: null pointer in layer %d", i);
-        const WGPlan w = plan_wgrad(B[i], R[i], S[i], Cin[i], Cout[i]);
+        const int nrc = bf16_plan ? sh_wgrad_bf16_nsplit(B[i], R[i], S[i], Cin[i], Cout[i]) : plan_wgrad(B[i], R[i], S[i], Cin[i], Cout[i]).nrc;
         const long stride = (long)Cout[i] * S[i] * Cin[i];
         const float* slab = static_cast<const float*>(workspaces[i]);
-        m.slab[nd] = slab; m.stride[nd] = stride; m.nslab[nd] = w.nrc; m.n[nd] = stride; m.out[nd] = dW[i]; m.block0[nd] = blocks;
+        m.slab[nd] = slab; m.stride[nd] = stride; m.nslab[nd] = nrc; m.n[nd] = stride; m.out[nd] = dW[i]; m.block0[nd] = blocks;
         blocks += (int)((stride + 63) / 64); ++nd;
         if (dbias[i]) {
-            m.slab[nd] = slab + (long)w.nrc * stride; m.stride[nd] = Cout[i]; m.nslab[nd] = w.nrc; m.n[nd] = Cout[i];
+            m.slab[nd] = slab + (long)nrc * stride; m.stride[nd] = Cout[i]; m.nslab[nd] = nrc; m.n[nd] = Cout[i];
             m.out[nd] = dbias[i]; m.block0[nd] = blocks;
             blocks += (Cout[i] + 63) / 64; ++nd;
         }
@@ -1344,6 +1345,18 @@ int sh_spiral_conv_bwd_wgt_reduce_multi(int n_layers, const void* const* workspa
     SH_LAUNCH_PS(ps, slab_reduce_multi_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, m);
     SH_CHECK_LAUNCH("slab_reduce_multi");
     return SH_OK;
+}
+
+int sh_spiral_conv_bwd_wgt_reduce_multi(int n_layers, const void* const* workspaces, float* const* dW, float* const* dbias,
+                                        const int* B, const int* R, const int* S, const int* Cin, const int* Cout,
+                                        sh_stream_t stream) {
+    return reduce_multi_impl(n_layers, workspaces, dW, dbias, B, R, S, Cin, Cout, false, stream);
+}
+
+int sh_spiral_conv_bwd_wgt_reduce_multi_bf16(int n_layers, const void* const* workspaces, float* const* dW, float* const* dbias,
+                                             const int* B, const int* R, const int* S, const int* Cin, const int* Cout,
+                                             sh_stream_t stream) {
+    return reduce_multi_impl(n_layers, workspaces, dW, dbias, B, R, S, Cin, Cout, true, stream);
 }
 
 int sh_weight_transpose_multi(int n_layers, const float* const* weight, float* const* weight_t, const int* S, const int* Cin,

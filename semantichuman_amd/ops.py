@@ -418,3 +418,78 @@ def spiral_conv_bwd_data_bf16(dpre, dp_layout, table_t, wfrag_t, dx, dx_layout, 
     check(_lib.load().sh_spiral_conv_bwd_data_bf16(ptr(dpre), dtype_id(dpre), dsv, dsb, ptr(table_t), ptr(wfrag_t), ptr(dx),
                                                    dtype_id(dx), xsv, xsb, ptr(yprev), ysv, ysb, act_prev, zero_row, B, n_in, S,
                                                    Cin, Cout, stream_ptr()), "sh_spiral_conv_bwd_data_bf16")
+
+
+def spiral_conv_bwd_wgt_bf16(dpre, dp_layout, x, x_layout, table, R, S, Cin, Cout, want_bias=True):
+    """-> (dW fp32 [Cout, S*Cin], dbias fp32 [Cout] or None)"""
+    import ctypes
+    B, _, C1, dsv, dsb = _dims(dpre, dp_layout, _ANY)
+    B2, _, C2, xsv, xsb = _dims(x, x_layout, _ANY)
+    assert B == B2 and C1 == Cout and C2 == Cin
+    lib = _lib.load()
+    nbytes = lib.sh_spiral_conv_bwd_wgt_workspace_bf16(B, R, S, Cin, Cout)
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
+    check(lib.sh_spiral_conv_bwd_wgt_bf16(ptr(dpre), dtype_id(dpre), dsv, dsb, ptr(x), dtype_id(x), xsv, xsb, ptr(table), ptr(ws), nbytes,
+                                          B, R, S, Cin, Cout, stream_ptr()), "sh_spiral_conv_bwd_wgt_bf16")
+    dW = torch.empty((Cout, S * Cin), dtype=torch.float32, device=x.device)
+    db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
+    args = [_c_ptr_array([ws]), _c_ptr_array([dW]), _c_ptr_array([db])] + [_c_int_array([v]) for v in (B, R, S, Cin, Cout)]
+    check(lib.sh_spiral_conv_bwd_wgt_reduce_multi_bf16(1, *[ctypes.cast(a, ctypes.c_void_p) for a in args], stream_ptr()),
+          "sh_spiral_conv_bwd_wgt_reduce_multi_bf16")
+    return dW, db
+
+
+def cast_bf16(src):
+    """fp32 HIP tensor -> bf16 copy (one streaming kernel)."""
+    if not (src.is_cuda and src.dtype == torch.float32 and src.is_contiguous()):
+        raise RuntimeError("cast_bf16 needs a contiguous fp32 HIP tensor; there is no CPU path")
+    dst = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
+    if src.numel():
+        check(_lib.load().sh_cast_f32_to_bf16(ptr(src), ptr(dst), src.numel(), stream_ptr()), "sh_cast_f32_to_bf16")
+    return dst
+
+
+def _check2d_any(*ts):
+    for t in ts:
+        if t is not None and not (t.is_cuda and t.dtype in _ANY and t.is_contiguous()):
+            raise RuntimeError("semantichuman_amd bf16 linear kernels need contiguous bf16/fp32 HIP tensors (got %s %s); there is no "
+                               "CPU path" % (t.device, t.dtype))
+
+
+def _linear_ws_bf16(M, N, K, device):
+    nbytes = _lib.load().sh_linear_workspace_bf16(M, N, K)
+    return torch.empty(max(4, (nbytes + 3) // 4), dtype=torch.float32, device=device), nbytes
+
+
+def linear_fwd_bf16(x, w_bf16, bias, out_dtype):
+    _check2d_any(x)
+    M, K = x.shape
+    N = w_bf16.shape[0]
+    assert w_bf16.dtype == torch.bfloat16 and w_bf16.shape[1] == K and w_bf16.is_contiguous()
+    y = torch.empty((M, N), dtype=out_dtype, device=x.device)
+    ws, nb = _linear_ws_bf16(M, N, K, x.device)
+    check(_lib.load().sh_linear_fwd_bf16(ptr(x), dtype_id(x), ptr(w_bf16), ptr(bias), ptr(y), dtype_id(y), M, N, K, ptr(ws), nb,
+                                         stream_ptr()), "sh_linear_fwd_bf16")
+    return y
+
+
+def linear_bwd_data_bf16(dy, w_bf16, out_dtype):
+    _check2d_any(dy)
+    M, N = dy.shape
+    K = w_bf16.shape[1]
+    dx = torch.empty((M, K), dtype=out_dtype, device=dy.device)
+    ws, nb = _linear_ws_bf16(M, N, K, dy.device)
+    check(_lib.load().sh_linear_bwd_data_bf16(ptr(dy), dtype_id(dy), ptr(w_bf16), ptr(dx), dtype_id(dx), M, N, K, ptr(ws), nb,
+                                              stream_ptr()), "sh_linear_bwd_data_bf16")
+    return dx
+
+
+def linear_bwd_wgt_bf16(dy, x, want_bias=True):
+    _check2d_any(dy, x)
+    M, N = dy.shape
+    K = x.shape[1]
+    dW = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+    db = torch.empty((N,), dtype=torch.float32, device=dy.device) if want_bias else None
+    check(_lib.load().sh_linear_bwd_wgt_bf16(ptr(dy), dtype_id(dy), ptr(x), dtype_id(x), ptr(dW), ptr(db), M, N, K, stream_ptr()),
+          "sh_linear_bwd_wgt_bf16")
+    return dW, db

@@ -141,3 +141,79 @@ def test_conv_bf16_three_channel_fp32_sides(B, N, S, Cout):
                                   yprev.to(dev(), torch.bfloat16), "vm", a, n1 - 1, n1, S, Cout, 3)
     err = float((dx.float().cpu().double() - torch.from_numpy(ref3)).abs().max())
     assert err <= ULP * float(np.abs(ref3).max()) + 1e-6
+
+
+@pytest.mark.parametrize("shape", CONV_SHAPES + [(64, 40, 40, 10, 16, 8, "elu"), (7, 25, 25, 6, 8, 24, "elu")])
+def test_conv_bwd_wgt_bf16(shape):
+    B, n_in, R, S, Cin, Cout, _ = shape
+    torch.manual_seed(2)
+    table = rand_table(R, n_in, S, 3)
+    x = bf(torch.randn(n_in, B, Cin))
+    dpre = bf(torch.randn(R, B, Cout))
+    dW_ref, db_ref = emulate.conv_bwd_wgt(dpre.double().numpy(), x.double().numpy(), table)
+    td = torch.from_numpy(table).to(dev())
+    for xl, dl in (("vm", "vm"), ("bm", "vm")):
+        xd = (x if xl == "vm" else x.permute(1, 0, 2).contiguous()).to(dev(), torch.bfloat16)
+        dW, db = ops.spiral_conv_bwd_wgt_bf16(dpre.to(dev(), torch.bfloat16), dl, xd, xl, td, R, S, Cin, Cout)
+        # fp32 accumulation of exact bf16 products over R*B rows: relative error ~ sqrt(rows) * 2^-24
+        tol = 2e-6 * np.sqrt(R * B) + 1e-6
+        assert float(np.abs(dW.cpu().double().numpy() - dW_ref).max()) <= tol * float(np.abs(dW_ref).max()) + 1e-5
+        assert float(np.abs(db.cpu().double().numpy() - db_ref).max()) <= tol * float(np.abs(db_ref).max()) + 1e-4
+    a, _ = ops.spiral_conv_bwd_wgt_bf16(dpre.to(dev(), torch.bfloat16), "vm", x.to(dev(), torch.bfloat16), "vm", td, R, S, Cin, Cout)
+    b, _ = ops.spiral_conv_bwd_wgt_bf16(dpre.to(dev(), torch.bfloat16), "vm", x.to(dev(), torch.bfloat16), "vm", td, R, S, Cin, Cout)
+    assert torch.equal(a, b)                                             # fixed-order slab reduction: bitwise reproducible
+
+
+@pytest.mark.parametrize("B,N,S,C", [(16, 60, 10, 16), (5, 37, 9, 16), (64, 130, 3, 16)])
+def test_conv_bwd_wgt_bf16_three_channel_fp32_sides(B, N, S, C):
+    torch.manual_seed(3)
+    n1 = N + 1
+    table = rand_table(n1, n1, S, 4)
+    td = torch.from_numpy(table).to(dev())
+    # first layer: x fp32 [B, n1, 3] (batch-major), dpre bf16 [n1, B, C]
+    x = torch.randn(B, n1, 3)
+    dpre = bf(torch.randn(n1, B, C))
+    dW_ref, db_ref = emulate.conv_bwd_wgt(dpre.double().numpy(), bf(x).permute(1, 0, 2).double().numpy(), table)
+    dW, db = ops.spiral_conv_bwd_wgt_bf16(dpre.to(dev(), torch.bfloat16), "vm", x.to(dev()), "bm", td, n1, S, 3, C)
+    tol = 2e-6 * np.sqrt(n1 * B) + 1e-6
+    assert float(np.abs(dW.cpu().double().numpy() - dW_ref).max()) <= tol * float(np.abs(dW_ref).max()) + 1e-5
+    assert float(np.abs(db.cpu().double().numpy() - db_ref).max()) <= tol * float(np.abs(db_ref).max()) + 1e-4
+    # last layer: x bf16 [n1, B, C], dpre fp32 [n1, B, 3]
+    h = bf(torch.randn(n1, B, C))
+    g = torch.randn(n1, B, 3)
+    dW_ref, db_ref = emulate.conv_bwd_wgt(bf(g).double().numpy(), h.double().numpy(), table)
+    dW, db = ops.spiral_conv_bwd_wgt_bf16(g.to(dev()), "vm", h.to(dev(), torch.bfloat16), "vm", td, n1, S, C, 3)
+    assert float(np.abs(dW.cpu().double().numpy() - dW_ref).max()) <= tol * float(np.abs(dW_ref).max()) + 1e-5
+    assert float(np.abs(db.cpu().double().numpy() - db_ref).max()) <= tol * float(np.abs(db_ref).max()) + 1e-4
+
+
+@pytest.mark.parametrize("mnk", [(64, 256, 55296), (64, 55296, 256), (3, 16, 1376), (16, 1376, 16), (130, 72, 200), (1, 8, 8)])
+@pytest.mark.parametrize("xf32", [False, True])
+def test_latent_linear_bf16(mnk, xf32):
+    """fwd / bwd_data / bwd_wgt of the latent FCs with bf16 working weights; x or dy may be fp32 (the latent code)."""
+    M, N, K = mnk
+    torch.manual_seed(4)
+    W = bf(torch.randn(N, K) / np.sqrt(K))
+    x = torch.randn(M, K)
+    dy = torch.randn(M, N) / np.sqrt(N)
+    bias = torch.randn(N) * 0.1
+    xr, dyr = bf(x), bf(dy)                         # what the kernels multiply (fp32 operands are rounded on load)
+    wd = ops.cast_bf16(W.to(dev()))
+    assert torch.equal(wd.float().cpu(), W)
+    xd = x.to(dev()) if xf32 else x.to(dev(), torch.bfloat16)
+    dyd = dy.to(dev()) if xf32 else dy.to(dev(), torch.bfloat16)
+    acc_tol = 4e-6
+    for out_dtype in (torch.float32, torch.bfloat16):
+        tol = acc_tol if out_dtype == torch.float32 else ULP
+        y = ops.linear_fwd_bf16(xd, wd, bias.to(dev()), out_dtype)
+        ref = xr.double() @ W.double().T + bias.double()
+        assert float((y.double().cpu() - ref).abs().max()) <= tol * float(ref.abs().max()) * max(1.0, np.sqrt(K) / 8) + 1e-6
+        dx = ops.linear_bwd_data_bf16(dyd, wd, out_dtype)
+        ref = dyr.double() @ W.double()
+        assert float((dx.double().cpu() - ref).abs().max()) <= tol * float(ref.abs().max()) * max(1.0, np.sqrt(N) / 8) + 1e-6
+    dW, db = ops.linear_bwd_wgt_bf16(dyd, xd)
+    ref = dyr.double().T @ xr.double()
+    assert float((dW.double().cpu() - ref).abs().max()) <= acc_tol * float(ref.abs().max()) * max(1.0, np.sqrt(M) / 4) + 1e-6
+    assert float((db.double().cpu() - dyr.double().sum(0)).abs().max()) <= acc_tol * float(dyr.abs().sum(0).max()) + 1e-6
+    dW2, _ = ops.linear_bwd_wgt_bf16(dyd, xd)
+    assert torch.equal(dW, dW2)
