@@ -100,6 +100,45 @@ def conv_launch_table(model, B):
     return out
 
 
+def bf16_work_table(model, B):
+    """Algorithmic FLOPs / HBM bytes of every bf16 conv-family launch, keyed by (kernel family, backward?, R, S, gathered
+    channels, output channels) - the fields of the shape tag the library's profiler attaches to each launch.  Bytes = every
+    tensor the launch needs read once + its output written once (fused ideal): bf16 activations (the 3-channel
+    xyz tensors are fp32), bf16 weight fragments, fp32 partial slabs are not counted (they are overhead, not algorithm)."""
+    out = {}
+    first = True
+    for stack in (model._enc_stack, model._dec_stack):
+        for st in stack.steps:
+            if st.kind != "conv":
+                continue
+            K = st.S * st.cin
+            fl = 2.0 * B * st.R * K * st.cout
+            e_in = 4 if st.cin == 3 else 2
+            e_out = 4 if st.cout == 3 else 2
+            byt = B * st.n_in * st.cin * e_in + B * st.R * st.cout * e_out + 2.0 * st.cout * K
+            out[("conv_bf16_kernel", False, st.R, st.S, st.cin, st.cout)] = (fl, byt)
+            if not (first and stack is model._enc_stack):
+                out[("conv_bf16_kernel", True, st.n_in, st.S, st.cout, st.cin)] = (fl, byt)
+            out[("wgrad_bf16_kernel", None, st.R, st.S, st.cin, st.cout)] = (fl, byt + 2.0 * st.cout * K)   # + fp32 dW out
+            first = False
+    return out
+
+
+def parse_tag(name, shape):
+    """(family, bwd, R, S, C, N) of a profiler record of the bf16 conv family, or None."""
+    fam = name.split("<")[0]
+    if fam not in ("conv_bf16_kernel", "wgrad_bf16_kernel"):
+        return None
+    f = dict(kv.split("=") for kv in shape.split() if "=" in kv)
+    try:
+        if fam == "conv_bf16_kernel":
+            bwd = name.split("<")[1].split(",")[3].strip() == "true"
+            return (fam, bwd, int(f["R"]), int(f["S"]), int(f["Cg"]), int(f["N"]))
+        return (fam, None, int(f["R"]), int(f["S"]), int(f["Cin"]), int(f["N"]))
+    except (KeyError, ValueError, IndexError):
+        return None
+
+
 def _free_port():
     import socket
     with socket.socket() as s:
@@ -178,6 +217,9 @@ def main():
     ap.add_argument("--adam-overlap", action="store_true", help="update the big parameters on a side stream underneath backward (measured: no gain, the GPU is already saturated)")
     ap.add_argument("--grad-comm", choices=["fp32", "bf16"], default="fp32",
                     help="N > 1: type of the two large gradient messages (bf16 halves the xGMI bytes; fp32 is the measured default)")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="arithmetic of the kernels: f32 = BASELINE configs[1] (the headline), bf16 = configs[2] (bf16 activations and "
+                         "working weights, fp32 accumulation, fp32 master weights / gradients / Adam)")
     ap.add_argument("--cpu-iters", type=int, default=8, help="timed CPU-baseline steps (8 steps at batch 64 = ~13 s of host work)")
     ap.add_argument("--template", default=os.path.join("tests", "golden", "template6890.npz"),
                     help="mesh hierarchy fixture; tests/golden/template27554.npz + --batch 32 is BASELINE config 4")
@@ -228,6 +270,8 @@ def main():
     B = args.batch
     torch.manual_seed(2)                          # cfgs.py:46 seed; identical replicas on every rank
     model = sh.SpiralAutoencoder(FE, FD, 256, h.sizes, h.spiral_sizes, h.spirals, h.D, h.U, dev)
+    if args.dtype == "bf16":
+        model.set_compute_dtype(torch.bfloat16)
     init_state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     if args.adam == "hip":                        # main.py:262
         optim = sh.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-5)
@@ -317,8 +361,9 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "plain spiral AE training step (fwd + L1 + 1e-2*edge loss + bwd + Adam), %s, levels %s, "
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": ("" if args.dtype == "f32" else "[bf16 kernels, fp32 master weights] ") +
+                               "plain spiral AE training step (fwd + L1 + 1e-2*edge loss + bwd + Adam), %s, levels %s, "
                                "spiral sizes %s, nz 256, %.2fM params"
                                % ("box_sphere(42,42,20) 6890-vertex template" if h.sizes[0] == 6890 else "%d-vertex template" % h.sizes[0],
                                   h.sizes, h.spiral_sizes[:-1], sum(p.numel() for p in model.parameters()) / 1e6),
@@ -350,7 +395,42 @@ def main():
             optim.step()
         torch.cuda.synchronize()
         _stack.OVERLAP_WGRAD = overlap_was
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and args.dtype == "bf16":
+        recs = _lib.profile_records_by_kernel()
+        _lib.profile_enable(False)
+        work = bf16_work_table(model, B)
+        agg = {}
+        for name, shape, ms in recs:
+            a = agg.setdefault(name, {"n": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "matched": 0})
+            a["n"] += 1; a["ms"] += ms
+            key = parse_tag(name, shape)
+            if key in work:
+                a["flops"] += work[key][0]; a["bytes"] += work[key][1]; a["matched"] += 1
+        kernels = []
+        for name, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+            e = {"kernel": name, "launches_per_step": a["n"] / nprof, "avg_ms": a["ms"] / a["n"], "ms_per_step": a["ms"] / nprof}
+            if a["matched"] == a["n"] and a["n"]:
+                e["gbps"] = a["bytes"] / (a["ms"] * 1e-3) / 1e9
+                e["tflops"] = a["flops"] / (a["ms"] * 1e-3) / 1e12
+            kernels.append(e)
+        fam = {}
+        for k in kernels:
+            f = fam.setdefault(k["kernel"].split("<")[0].split("|")[0], 0.0)
+            fam[k["kernel"].split("<")[0].split("|")[0]] = f + k["ms_per_step"]
+        conv = [k for k in kernels if "gbps" in k]
+        dom = conv[0] if conv else kernels[0]
+        a = agg[dom["kernel"]]
+        # bf16: ridge of the chip ~ 2.5 PF / 8 TB/s = 300 FLOP/B, these layers have 30-250 FLOP/B -> HBM roof
+        result["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom.get("gbps"), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                              "frac": (dom["gbps"] / PEAK_HBM_GBS) if "gbps" in dom else None, "traffic": None,
+                              "avg_launch_ms": dom["avg_ms"], "launches_per_step": dom["launches_per_step"],
+                              "algorithmic_bytes_per_launch": a["bytes"] / a["n"] if a["n"] else None,
+                              "flops_per_launch": a["flops"] / a["n"] if a["n"] else None,
+                              "mfma_tflops": dom.get("tflops"), "mfma_peak_tflops": 2500.0}
+        result["kernel_families"] = {n: {"ms_per_step": v} for n, v in sorted(fam.items(), key=lambda kv: -kv[1])[:10]}
+        result["kernel_breakdown"] = kernels[:10]
+        result["hip_kernel_ms_per_step"] = sum(k["ms_per_step"] for k in kernels)
+    elif rank == 0 and not args.no_roofline:
         recs = _lib.profile_records_by_kernel()
         _lib.profile_enable(False)
         agg = {}

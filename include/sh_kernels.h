@@ -412,6 +412,35 @@ SH_API int sh_linear_bwd_data_bf16(const void* dy, int dy_dtype, const void* wei
 SH_API int sh_linear_bwd_wgt_bf16(const void* dy, int dy_dtype, const void* x, int x_dtype, float* dW, float* dbias, int M,
                                   int N, int K, sh_stream_t stream);
 
+/* sh_spmm / sh_act_backward on bf16 tensors (channels % 8 == 0, 16-byte aligned rows; strides in bf16 elements; CSR values
+ * fp32; arithmetic fp32, one rounding of the result). */
+SH_API int sh_spmm_bf16(const int32_t* rowptr, const int32_t* col, const float* val, const void* x, int64_t x_sv, int64_t x_sb,
+                        void* y, int64_t y_sv, int64_t y_sb, const void* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev,
+                        int zero_row, int B, int rows, int C, sh_stream_t stream);
+SH_API int sh_act_backward_bf16(const void* dy, int64_t dy_sv, int64_t dy_sb, const void* y, int64_t y_sv, int64_t y_sb,
+                                void* dpre, int64_t dp_sv, int64_t dp_sb, int B, int R, int C, int act, int zero_row,
+                                sh_stream_t stream);
+
+/* sh_adam_step that also rewrites, for every tensor with shadow_bf16[i] != NULL, a bf16 working copy of the updated fp32
+ * parameter (same element order): the next forward pass reads the working copy without a separate conversion pass. */
+SH_API int sh_adam_step_bf16(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                             float* const* exp_avg_sq, float* const* steps, void* const* shadow_bf16, const int64_t* numel,
+                             const float* lr, double beta1, double beta2, double eps, double weight_decay, sh_stream_t stream);
+
+/* sh_stack_forward / sh_stack_backward for the bf16 path.  Tensors between steps are bf16 vertex-major; x is bf16, or fp32
+ * with 3 channels; the output of the last step has type out_dtype (fp32 only for <= 16 channels), g the same type; gin[0]
+ * has type gx_dtype; dpre_last has the type of the last step's output.  wfrag[i] / wfrag_t[i]: per conv step, buffers of
+ * sh_conv_wfrag_bytes(S, cin, cout) / (S, cout, cin) bytes which the call fills from the fp32 master `weights` (one
+ * conversion launch per pass).  workspace[i] >= sh_spiral_conv_bwd_wgt_workspace_bf16.  Everything else as above. */
+SH_API int sh_stack_forward_bf16(int n_steps, const sh_stack_step* steps, const void* x, int x_dtype, int x_layout, int rows0,
+                                 int c0, int B, const float* const* weights, const float* const* biases, void* const* wfrag,
+                                 void* const* outs, int out_dtype, int out_layout, sh_stream_t stream);
+SH_API int sh_stack_backward_bf16(int n_steps, const sh_stack_step* steps, const void* x, int x_dtype, int x_layout, int rows0,
+                                  int c0, int B, const void* const* acts, const void* g, int out_dtype, int out_layout,
+                                  const float* const* weights, void* const* gin, int gx_dtype, void* dpre_last,
+                                  void* const* wfrag_t, void* const* workspace, const size_t* workspace_bytes,
+                                  float* const* dW, float* const* dbias, int need_x_grad, sh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,7 +4,7 @@
 // the 28.55 M-parameter autoencoder, so the kernel is a plain float4 stream.  Everything that
 // changes from step to step (learning rate, step counts) is read from DEVICE memory, which keeps
 // the launch replayable inside a hipGraph.
-#include "sh_common.h"
+#include "sh_bf16.h"
 
 #include <math.h>
 
@@ -20,6 +20,7 @@ struct AdamArgs {
     float* m[AT];
     float* v[AT];
     float* step[AT];
+    __bf16* shadow[AT];           // optional bf16 working copy of the parameter, rewritten with the update (may be null)
     long n[AT];
     int blk_start[AT + 1];
     int nt, nontemporal;
@@ -57,6 +58,7 @@ __global__ __launch_bounds__(ANT) void adam_kernel(const AdamArgs a) {
     const float* __restrict__ g = a.g[t];
     float* __restrict__ m = a.m[t];
     float* __restrict__ v = a.v[t];
+    __bf16* __restrict__ sw = a.shadow[t];
     const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
                        reinterpret_cast<uintptr_t>(v)) & 15) == 0;
     if (vec && base + ACH <= n) {
@@ -81,6 +83,7 @@ __global__ __launch_bounds__(ANT) void adam_kernel(const AdamArgs a) {
                 adam_update(p1, gg[j], m1, v1, a.w1, a.b2, a.w2, a.eps, a.wd, step_size, bc2_sqrt);
                 pp[j] = p1; mm[j] = m1; vv[j] = v1;
             }
+            if (sw) *reinterpret_cast<bf16x4*>(sw + o) = sh_to_bf16x4(pp);      // read by the next forward pass: keep it cached
             if (a.nontemporal) {
                 __builtin_nontemporal_store(pp, reinterpret_cast<f32x4*>(p + o));
                 __builtin_nontemporal_store(mm, reinterpret_cast<f32x4*>(m + o));
@@ -96,6 +99,7 @@ __global__ __launch_bounds__(ANT) void adam_kernel(const AdamArgs a) {
             float pp = p[o], mm = m[o], vv = v[o];
             adam_update(pp, g[o], mm, vv, a.w1, a.b2, a.w2, a.eps, a.wd, step_size, bc2_sqrt);
             p[o] = pp; m[o] = mm; v[o] = vv;
+            if (sw) sw[o] = (__bf16)pp;
         }
     }
 }
@@ -109,9 +113,9 @@ __global__ void adam_bump_kernel(const AdamArgs a) {
 
 extern "C" {
 
-int sh_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
-                 float* const* steps, const int64_t* numel, const float* lr, double beta1, double beta2, double eps,
-                 double weight_decay, sh_stream_t stream) {
+static int adam_impl(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                     float* const* steps, void* const* shadow, const int64_t* numel, const float* lr, double beta1, double beta2,
+                     double eps, double weight_decay, sh_stream_t stream) {
     SH_REQUIRE(n_tensors >= 0, SH_ERR_INVALID_ARG, "sh_adam_step: negative tensor count");
     if (n_tensors == 0) return SH_OK;
     SH_REQUIRE(params && grads && exp_avg && exp_avg_sq && steps && numel && lr, SH_ERR_INVALID_ARG, "sh_adam_step: null pointer");
@@ -128,6 +132,8 @@ int sh_adam_step(int n_tensors, float* const* params, const float* const* grads,
             SH_REQUIRE(params[k] && grads[k] && exp_avg[k] && exp_avg_sq[k] && steps[k] && numel[k] > 0, SH_ERR_INVALID_ARG,
                        "sh_adam_step: tensor %d has a null pointer or no elements", k);
             a.p[i] = params[k]; a.g[i] = grads[k]; a.m[i] = exp_avg[k]; a.v[i] = exp_avg_sq[k]; a.step[i] = steps[k];
+            a.shadow[i] = shadow ? static_cast<__bf16*>(shadow[k]) : nullptr;
+            SH_REQUIRE(!a.shadow[i] || (reinterpret_cast<uintptr_t>(a.shadow[i]) & 7) == 0, SH_ERR_INVALID_ARG, "sh_adam_step_bf16: shadow %d misaligned", k);
             a.n[i] = numel[k];
             a.blk_start[i] = (int)blocks;
             blocks += (numel[k] + ACH - 1) / ACH;
@@ -145,6 +151,18 @@ int sh_adam_step(int n_tensors, float* const* params, const float* const* grads,
         SH_CHECK_LAUNCH("adam_step");
     }
     return SH_OK;
+}
+
+int sh_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                 float* const* steps, const int64_t* numel, const float* lr, double beta1, double beta2, double eps,
+                 double weight_decay, sh_stream_t stream) {
+    return adam_impl(n_tensors, params, grads, exp_avg, exp_avg_sq, steps, nullptr, numel, lr, beta1, beta2, eps, weight_decay, stream);
+}
+
+int sh_adam_step_bf16(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                      float* const* steps, void* const* shadow_bf16, const int64_t* numel, const float* lr, double beta1, double beta2,
+                      double eps, double weight_decay, sh_stream_t stream) {
+    return adam_impl(n_tensors, params, grads, exp_avg, exp_avg_sq, steps, shadow_bf16, numel, lr, beta1, beta2, eps, weight_decay, stream);
 }
 
 }  // extern "C"

@@ -298,8 +298,8 @@ int launch_bc(BCParams& p, hipStream_t st) {
     if (groups < 8) groups = 8;
     groups = (groups + 7) / 8 * 8;                               // a multiple of 8 per slice -> every XCD label has all slices
     const int grid = (int)groups * p.nsplit;
-    ShProfScope ps(st, "conv_bf16_kernel<%d, %d, %d, %s, %s>|R=%d B=%d K=%d N=%d grid=%dx%d", NT, RT, MODE, BWD ? "true" : "false",
-                   OUTF32 ? "true" : "false", p.R, p.B, p.nks * 32, p.Nout, grid, nw * 64);
+    ShProfScope ps(st, "conv_bf16_kernel<%d, %d, %d, %s, %s>|R=%d B=%d S=%d Cg=%d N=%d grid=%dx%d", NT, RT, MODE, BWD ? "true" : "false",
+                   OUTF32 ? "true" : "false", p.R, p.B, p.S, p.Cg, p.Nout, grid, nw * 64);
     SH_LAUNCH_PS(ps, kern, dim3(grid), dim3(nw * 64), smem, st, p);
     SH_CHECK_LAUNCH("conv_bf16");
     return SH_OK;

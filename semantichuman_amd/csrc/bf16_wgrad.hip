@@ -223,7 +223,7 @@ int sh_spiral_conv_bwd_wgt_bf16(const void* dpre, int dp_dtype, int64_t dp_sv, i
     p.bias_off = (long)p.nsplit * p.slab_stride;
     const int grid = p.n_qt * p.n_pt * p.nsplit;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    ShProfScope ps(st, "wgrad_bf16_kernel<%d, %d>|R=%d B=%d K=%d N=%d grid=%d split=%d", (int)xc3, (int)pc3, R, B, p.K, Cout, grid, p.nsplit);
+    ShProfScope ps(st, "wgrad_bf16_kernel<%d, %d>|R=%d B=%d S=%d Cin=%d N=%d grid=%d split=%d", (int)xc3, (int)pc3, R, B, S, Cin, Cout, grid, p.nsplit);
     if (xc3) SH_LAUNCH_PS(ps, (wgrad_bf16_kernel<true, false>), dim3(grid), dim3(256), 0, st, p);
     else if (pc3) SH_LAUNCH_PS(ps, (wgrad_bf16_kernel<false, true>), dim3(grid), dim3(256), 0, st, p);
     else SH_LAUNCH_PS(ps, (wgrad_bf16_kernel<false, false>), dim3(grid), dim3(256), 0, st, p);

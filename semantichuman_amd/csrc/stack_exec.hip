@@ -163,4 +163,168 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
     return SH_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same two sequencers for the bf16 compute path (BASELINE config 3).  Tensors between steps are bf16 vertex-major;
+// the stack input may be fp32 with 3 channels (xyz), the stack output fp32 when it has <= 16 channels (x_hat).  The
+// working copies of the conv weights are converted from the fp32 masters by ONE launch at the start of each pass.
+static inline long esz_of(int dtype) { return dtype == SH_DTYPE_BF16 ? 2 : 4; }
+
+int sh_stack_forward_bf16(int n_steps, const sh_stack_step* steps, const void* x, int x_dtype, int x_layout, int rows0, int c0, int B,
+                          const float* const* weights, const float* const* biases, void* const* wfrag, void* const* outs,
+                          int out_dtype, int out_layout, sh_stream_t stream) {
+    int rc = check_steps(n_steps, steps, c0, "sh_stack_forward_bf16");
+    if (rc != SH_OK) return rc;
+    SH_REQUIRE(x && weights && outs && wfrag && B > 0, SH_ERR_INVALID_ARG, "sh_stack_forward_bf16: null pointer or empty batch");
+    SH_REQUIRE(n_steps <= 64, SH_ERR_UNSUPPORTED, "sh_stack_forward_bf16: more than 64 steps");
+    {
+        const float* w[64]; void* wf[64]; int S[64], Ci[64], Co[64], tr[64];
+        int n = 0;
+        for (int i = 0; i < n_steps; ++i) {
+            if (steps[i].kind != 0) continue;
+            SH_REQUIRE(wfrag[i], SH_ERR_INVALID_ARG, "sh_stack_forward_bf16: no weight-fragment buffer for step %d", i);
+            w[n] = weights[steps[i].param]; wf[n] = wfrag[i]; S[n] = steps[i].S; Ci[n] = steps[i].cin; Co[n] = steps[i].cout; tr[n] = 0;
+            ++n;
+        }
+        if (n) {
+            rc = sh_conv_wfrag_prep_multi(n, w, wf, S, Ci, Co, tr, stream);
+            if (rc != SH_OK) return rc;
+        }
+    }
+    const void* cur = x;
+    int cd = x_dtype;
+    Lay cl = lay(x_layout, rows0, B, c0);
+    int c = c0;
+    for (int i = 0; i < n_steps; ++i) {
+        const sh_stack_step& s = steps[i];
+        const bool is_last = i == n_steps - 1;
+        const int co = s.kind == 0 ? s.cout : c;
+        const int od = is_last ? out_dtype : SH_DTYPE_BF16;
+        const Lay ol = lay(is_last ? out_layout : 0, out_rows(s), B, co);
+        SH_REQUIRE(outs[i], SH_ERR_INVALID_ARG, "sh_stack_forward_bf16: no output buffer for step %d", i);
+        if (s.kind == 0) {
+            rc = sh_spiral_conv_fwd_bf16(cur, cd, cl.sv, cl.sb, s.table, wfrag[i], biases ? biases[s.param] : nullptr, outs[i], od, ol.sv,
+                                         ol.sb, B, s.R, s.S, s.cin, s.cout, s.act, s.zero_row, stream);
+        } else {
+            SH_REQUIRE(cd == SH_DTYPE_BF16 && od == SH_DTYPE_BF16, SH_ERR_UNSUPPORTED,
+                       "sh_stack_forward_bf16: re-sampling step %d needs bf16 on both sides", i);
+            rc = sh_spmm_bf16(s.m.rowptr, s.m.col, s.m.val, cur, cl.sv, cl.sb, outs[i], ol.sv, ol.sb, nullptr, 0, 0, 0, -1, B, s.m_rows, c,
+                              stream);
+        }
+        if (rc != SH_OK) return rc;
+        cur = outs[i]; cd = od; cl = ol; c = co;
+    }
+    return SH_OK;
+}
+
+int sh_stack_backward_bf16(int n_steps, const sh_stack_step* steps, const void* x, int x_dtype, int x_layout, int rows0, int c0, int B,
+                           const void* const* acts, const void* g, int out_dtype, int out_layout, const float* const* weights,
+                           void* const* gin, int gx_dtype, void* dpre_last, void* const* wfrag_t, void* const* workspace,
+                           const size_t* workspace_bytes, float* const* dW, float* const* dbias, int need_x_grad, sh_stream_t stream) {
+    int rc = check_steps(n_steps, steps, c0, "sh_stack_backward_bf16");
+    if (rc != SH_OK) return rc;
+    SH_REQUIRE(x && acts && g && weights && gin && dW && B > 0, SH_ERR_INVALID_ARG, "sh_stack_backward_bf16: null pointer or empty batch");
+    SH_REQUIRE(n_steps <= 64, SH_ERR_UNSUPPORTED, "sh_stack_backward_bf16: more than 64 steps");
+    const int last = n_steps - 1;
+    int cin_of[64];
+    {
+        int c = c0;
+        for (int i = 0; i < n_steps; ++i) { cin_of[i] = c; if (steps[i].kind == 0) c = steps[i].cout; }
+    }
+    {   // backward-data operands of all conv steps: one conversion launch
+        const float* w[64]; void* wf[64]; int S[64], Ci[64], Co[64], tr[64];
+        int n = 0;
+        for (int i = 0; i < n_steps; ++i) {
+            if (steps[i].kind != 0 || !(i > 0 || need_x_grad)) continue;
+            SH_REQUIRE(wfrag_t && wfrag_t[i], SH_ERR_INVALID_ARG, "sh_stack_backward_bf16: no weight-fragment buffer for step %d", i);
+            w[n] = weights[steps[i].param]; wf[n] = wfrag_t[i]; S[n] = steps[i].S; Ci[n] = steps[i].cin; Co[n] = steps[i].cout; tr[n] = 1;
+            ++n;
+        }
+        if (n) {
+            rc = sh_conv_wfrag_prep_multi(n, w, wf, S, Ci, Co, tr, stream);
+            if (rc != SH_OK) return rc;
+        }
+    }
+    const void* cur; Lay cl; int cd;
+    {
+        const sh_stack_step& s = steps[last];
+        if (s.kind == 0) {
+            SH_REQUIRE(dpre_last, SH_ERR_INVALID_ARG, "sh_stack_backward_bf16: no dpre_last buffer");
+            const Lay ol = lay(out_layout, s.R, B, s.cout), dl = lay(0, 0, B, s.cout);
+            if (out_dtype == SH_DTYPE_F32)
+                rc = sh_act_backward(static_cast<const float*>(g), ol.sv, ol.sb, static_cast<const float*>(acts[last]), ol.sv, ol.sb,
+                                     static_cast<float*>(dpre_last), dl.sv, dl.sb, B, s.R, s.cout, s.act, s.zero_row, stream);
+            else
+                rc = sh_act_backward_bf16(g, ol.sv, ol.sb, acts[last], ol.sv, ol.sb, dpre_last, dl.sv, dl.sb, B, s.R, s.cout, s.act, s.zero_row,
+                                          stream);
+            if (rc != SH_OK) return rc;
+            cur = dpre_last; cl = dl; cd = out_dtype;
+        } else {
+            SH_REQUIRE(out_dtype == SH_DTYPE_BF16, SH_ERR_UNSUPPORTED, "sh_stack_backward_bf16: a re-sampling last step needs a bf16 gradient");
+            cur = g; cl = lay(out_layout, s.m_rows, B, cin_of[last]); cd = out_dtype;
+        }
+    }
+    const void* job_ws[64]; float* job_dW[64]; float* job_db[64]; int jB[64], jR[64], jS[64], jCi[64], jCo[64];
+    int njobs = 0;
+    for (int i = last; i >= 0; --i) {
+        const sh_stack_step& s = steps[i];
+        const bool want_in = i > 0 || need_x_grad;
+        const void* inp = i == 0 ? x : acts[i - 1];
+        const int ind = i == 0 ? x_dtype : SH_DTYPE_BF16;
+        const Lay il = i == 0 ? lay(x_layout, rows0, B, c0) : lay(0, 0, B, cin_of[i]);
+        void* gi = want_in ? gin[i] : nullptr;
+        const int gd = i == 0 ? gx_dtype : SH_DTYPE_BF16;
+        SH_REQUIRE(!want_in || gi, SH_ERR_INVALID_ARG, "sh_stack_backward_bf16: no gradient buffer for the input of step %d", i);
+        const Lay gl = i == 0 ? lay(x_layout, rows0, B, c0) : lay(0, 0, B, cin_of[i]);
+        const void* yprev = nullptr; Lay yl{0, 0}; int act_prev = 0, zero_prev = -1;
+        if (i > 0 && steps[i - 1].kind == 0) {
+            yprev = acts[i - 1]; yl = lay(0, 0, B, steps[i - 1].cout); act_prev = steps[i - 1].act; zero_prev = steps[i - 1].zero_row;
+        }
+        if (s.kind == 0) {
+            SH_REQUIRE(workspace && workspace[i], SH_ERR_INVALID_ARG, "sh_stack_backward_bf16: no workspace for step %d", i);
+            rc = sh_spiral_conv_bwd_wgt_bf16(cur, cd, cl.sv, cl.sb, inp, ind, il.sv, il.sb, s.table, workspace[i], workspace_bytes[i], B, s.R,
+                                             s.S, s.cin, s.cout, stream);
+            if (rc != SH_OK) return rc;
+            job_ws[njobs] = workspace[i]; job_dW[njobs] = dW[s.param]; job_db[njobs] = dbias ? dbias[s.param] : nullptr;
+            jB[njobs] = B; jR[njobs] = s.R; jS[njobs] = s.S; jCi[njobs] = s.cin; jCo[njobs] = s.cout;
+            SH_REQUIRE(job_dW[njobs], SH_ERR_INVALID_ARG, "sh_stack_backward_bf16: no dW buffer for parameter %d", s.param);
+            ++njobs;
+            if (want_in) {
+                SH_REQUIRE(s.table_t, SH_ERR_INVALID_ARG, "sh_stack_backward_bf16: step %d has no transposed table", i);
+                char* mut = static_cast<char*>(const_cast<void*>(cur));      // extra rows behind the R real ones of this step's buffer
+                const long rb = cl.sv * esz_of(cd);
+                for (int lev = 0; lev < 2; ++lev) {
+                    const int n = lev == 0 ? s.n1 : s.n2;
+                    if (!n) continue;
+                    const sh_csr_ref& m = lev == 0 ? s.sum1 : s.sum2;
+                    void* dst = mut + (long)(s.R + (lev == 0 ? 0 : s.n1)) * rb;
+                    if (cd == SH_DTYPE_F32)
+                        rc = sh_spmm(m.rowptr, m.col, m.val, static_cast<const float*>(cur), cl.sv, cl.sb, static_cast<float*>(dst), cl.sv, cl.sb,
+                                     nullptr, 0, 0, 0, -1, B, n, s.cout, stream);
+                    else
+                        rc = sh_spmm_bf16(m.rowptr, m.col, m.val, cur, cl.sv, cl.sb, dst, cl.sv, cl.sb, nullptr, 0, 0, 0, -1, B, n, s.cout, stream);
+                    if (rc != SH_OK) return rc;
+                }
+                rc = sh_spiral_conv_bwd_data_bf16(cur, cd, cl.sv, cl.sb, s.table_t, wfrag_t[i], gi, gd, gl.sv, gl.sb, yprev, yl.sv, yl.sb,
+                                                  act_prev, zero_prev, B, s.n_in, s.S, s.cin, s.cout, stream);
+                if (rc != SH_OK) return rc;
+            }
+        } else if (want_in) {
+            SH_REQUIRE(s.mt.rowptr && s.mt.col && s.mt.val, SH_ERR_INVALID_ARG, "sh_stack_backward_bf16: step %d has no transposed matrix", i);
+            SH_REQUIRE(cd == SH_DTYPE_BF16 && gd == SH_DTYPE_BF16, SH_ERR_UNSUPPORTED,
+                       "sh_stack_backward_bf16: re-sampling step %d needs bf16 on both sides", i);
+            rc = sh_spmm_bf16(s.mt.rowptr, s.mt.col, s.mt.val, cur, cl.sv, cl.sb, gi, gl.sv, gl.sb, yprev, yl.sv, yl.sb, act_prev, zero_prev, B,
+                              s.m_cols, cin_of[i], stream);
+            if (rc != SH_OK) return rc;
+        }
+        if (want_in) { cur = gi; cl = gl; cd = gd; }
+    }
+    for (int k = 0; k < njobs; k += 16) {
+        const int n = njobs - k < 16 ? njobs - k : 16;
+        rc = sh_spiral_conv_bwd_wgt_reduce_multi_bf16(n, job_ws + k, job_dW + k, job_db + k, jB + k, jR + k, jS + k, jCi + k, jCo + k, stream);
+        if (rc != SH_OK) return rc;
+    }
+    return SH_OK;
+}
+
 }  // extern "C"

@@ -36,6 +36,37 @@ def latent_linear(x: torch.Tensor, weight: torch.Tensor, bias) -> torch.Tensor:
     return _LatentLinear.apply(x, weight, bias)
 
 
+class _LatentLinearBF16(torch.autograd.Function):
+    """The same layer on the bf16 path: bf16 working copy of the weight (semantichuman_amd.shadow), x / y bf16 or fp32,
+    fp32 accumulation, fp32 master-weight gradients."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, out_dtype):
+        from . import shadow
+        x = x.contiguous()
+        w16 = shadow.get(weight)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return ops.linear_fwd_bf16(x, w16, bias, out_dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import shadow
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = ops.linear_bwd_data_bf16(dy, shadow.get(weight), x.dtype) if ctx.needs_input_grad[0] else None
+        dW = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dW, db = ops.linear_bwd_wgt_bf16(dy, x, want_bias=ctx.has_bias and ctx.needs_input_grad[2])
+        return dx, dW, db, None
+
+
+def latent_linear_bf16(x: torch.Tensor, weight: torch.Tensor, bias, out_dtype) -> torch.Tensor:
+    if x.dim() != 2:
+        raise RuntimeError("latent_linear_bf16 expects a 2-D input, got %s" % (tuple(x.shape),))
+    return _LatentLinearBF16.apply(x, weight, bias, out_dtype)
+
+
 class _GroupedLinear(torch.autograd.Function):
     """All groups of one family of per-part layers in one launch per direction (csrc/grouped_linear.hip).
     forward(x, x_off, y_cols, y_off, n_groups, w_0..w_{G-1}, b_0..b_{G-1})"""

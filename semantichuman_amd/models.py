@@ -22,8 +22,8 @@ import torch.nn as nn
 
 from . import mesh_ops, ops
 from .mesh_ops import CSR
-from .linear import grouped_linear, latent_linear
-from .stack import ConvStep, SpmmStep, Stack, run_stack
+from .linear import grouped_linear, latent_linear, latent_linear_bf16
+from .stack import ConvStep, SpmmStep, Stack, run_stack, run_stack_bf16
 
 
 def _as_csr(m) -> CSR:
@@ -166,10 +166,23 @@ class SpiralAutoencoder(nn.Module):
             self.device = dev
         return out
 
+    def set_compute_dtype(self, dtype):
+        """torch.float32 (default: the reference's arithmetic) or torch.bfloat16 (BASELINE config 3): bf16 activations and
+        bf16 working copies of the weights inside the kernels, fp32 accumulation; parameters, gradients, optimizer state,
+        the input x, the latent code z and the output x_hat stay fp32, so the module's API and `state_dict` do not change."""
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
+        self.compute_dtype = dtype
+        return self
+
     def encode(self, x, VAE_flag=None):
         bsize = x.size(0)
-        h = run_stack(self._enc_stack, x, "bm", "bm", self.conv)        # [B, N_last+1, C]
-        z = latent_linear(h.reshape(bsize, -1), self.fc_latent_enc.weight, self.fc_latent_enc.bias)
+        if getattr(self, "compute_dtype", torch.float32) == torch.bfloat16:
+            h = run_stack_bf16(self._enc_stack, x, "bm", "bm", torch.bfloat16, self.conv)
+            z = latent_linear_bf16(h.reshape(bsize, -1), self.fc_latent_enc.weight, self.fc_latent_enc.bias, torch.float32)
+        else:
+            h = run_stack(self._enc_stack, x, "bm", "bm", self.conv)        # [B, N_last+1, C]
+            z = latent_linear(h.reshape(bsize, -1), self.fc_latent_enc.weight, self.fc_latent_enc.bias)
         if VAE_flag if VAE_flag is not None else self.VAE_flag:         # models.py:131-136
             self.z_mu = z[..., :self.latent_size]
             self.z_var = z[..., self.latent_size:]
@@ -179,6 +192,9 @@ class SpiralAutoencoder(nn.Module):
 
     def decode(self, z):
         bsize = z.size(0)
+        if getattr(self, "compute_dtype", torch.float32) == torch.bfloat16:
+            h = latent_linear_bf16(z.float(), self.fc_latent_dec.weight, self.fc_latent_dec.bias, torch.bfloat16)
+            return run_stack_bf16(self._dec_stack, h.view(bsize, self.sizes[-1] + 1, -1), "bm", "bm", torch.float32, self.dconv)
         h = latent_linear(z, self.fc_latent_dec.weight, self.fc_latent_dec.bias).view(bsize, self.sizes[-1] + 1, -1)
         return run_stack(self._dec_stack, h, "bm", "bm", self.dconv)
 

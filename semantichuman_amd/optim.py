@@ -81,6 +81,8 @@ class Adam(torch.optim.Optimizer):
         n = len(params)
         arr = lambda: (ctypes.c_void_p * n)()                      # noqa: E731
         P, G, M, V, S, N = arr(), arr(), arr(), arr(), arr(), (ctypes.c_int64 * n)()
+        W16, any16 = arr(), False           # bf16 working copies the bf16 compute path keeps of some parameters (shadow.py)
+        from . import shadow
         keep = []
         for i, p in enumerate(params):
             g = p.grad
@@ -93,10 +95,17 @@ class Adam(torch.optim.Optimizer):
             P[i], G[i], M[i], V[i], S[i] = p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), \
                 st["step"].data_ptr()
             N[i] = p.numel()
+            w16 = shadow.lookup(p)
+            if w16 is not None:
+                W16[i], any16 = w16.data_ptr(), True
         lr = self._lr_tensor(group, params[0].device)
         b1, b2 = group["betas"]
-        _lib.check(_lib.load().sh_adam_step(n, P, G, M, V, S, N, _lib.ptr(lr), float(b1), float(b2), float(group["eps"]),
-                                            float(group["weight_decay"]), _lib.stream_ptr()), "sh_adam_step")
+        if any16:       # the update rewrites the registered bf16 copies in the same kernel
+            _lib.check(_lib.load().sh_adam_step_bf16(n, P, G, M, V, S, W16, N, _lib.ptr(lr), float(b1), float(b2), float(group["eps"]),
+                                                     float(group["weight_decay"]), _lib.stream_ptr()), "sh_adam_step_bf16")
+        else:
+            _lib.check(_lib.load().sh_adam_step(n, P, G, M, V, S, N, _lib.ptr(lr), float(b1), float(b2), float(group["eps"]),
+                                                float(group["weight_decay"]), _lib.stream_ptr()), "sh_adam_step")
 
     # ---------------------------------------------------------------------------------- overlap with backward
     def overlap_backward(self, min_numel=1 << 20):

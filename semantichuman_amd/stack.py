@@ -313,6 +313,137 @@ class Stack:
             grads[j] = (dWj, flat[o:o + shp[0]] if need_bias[j] else None)
         return gx, grads
 
+    # ------------------------------------------------------------------ bf16 compute path (BASELINE config 3)
+    def _plan_bf16(self, B: int, c0: int, x_is_f32: bool, out_is_f32: bool):
+        """Arena offsets in BYTES for the bf16 path: activations / gradients between steps are bf16, the fragment-ordered
+        working copies of the conv weights and the fp32 partial slabs of the weight gradients live in the same arenas."""
+        key = ("bf16", B, c0, x_is_f32, out_is_f32)
+        plans = self.__dict__.setdefault("_plans", {})
+        if key in plans:
+            return plans[key]
+        lib = _lib.load()
+        al = lambda nbytes: (int(nbytes) + 255) // 256 * 256          # noqa: E731
+        n = len(self.steps)
+        cin_of, c = [], c0
+        for st in self.steps:
+            cin_of.append(c)
+            c = st.cout if st.kind == "conv" else c
+        out_rows = [st.R if st.kind == "conv" else st.csr.rows for st in self.steps]
+        out_ch = [st.cout if st.kind == "conv" else cin_of[i] for i, st in enumerate(self.steps)]
+        f_off, wf_off, wf_mask, o = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64), 0
+        for i in range(n - 1):
+            f_off[i] = o
+            o += al(out_rows[i] * B * out_ch[i] * 2)
+        for i, st in enumerate(self.steps):
+            if st.kind == "conv":
+                wf_off[i], wf_mask[i] = o, 1
+                o += al(lib.sh_conv_wfrag_bytes(st.S, st.cin, st.cout))
+        f_total = o
+        last = self.steps[-1]
+        o = 0
+        if last.kind == "conv":
+            o += al((last.R + last.n_extra) * B * last.cout * (4 if out_is_f32 else 2))
+        gin_size = [0] * n
+        for i in range(1, n):
+            st, prev = self.steps[i], self.steps[i - 1]
+            rows_in = st.n_in if st.kind == "conv" else st.csr.cols
+            gin_size[i] = (rows_in + (prev.n_extra if prev.kind == "conv" else 0)) * B * cin_of[i] * 2
+        region = [al(max([gin_size[i] for i in range(1, n) if i % 2 == par] + [0])) for par in (0, 1)]
+        region_off = [o, o + region[0]]
+        o += region[0] + region[1]
+        g_off, g_mask = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+        for i in range(1, n):
+            g_off[i], g_mask[i] = region_off[i % 2], 1
+        wt_off, wt_mask = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+        ws_off, ws_mask, ws_bytes = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+        for i, st in enumerate(self.steps):
+            if st.kind != "conv":
+                continue
+            wt_off[i], wt_mask[i] = o, 1
+            o += al(lib.sh_conv_wfrag_bytes(st.S, st.cout, st.cin))
+            nb = int(lib.sh_spiral_conv_bwd_wgt_workspace_bf16(B, st.R, st.S, st.cin, st.cout))
+            ws_off[i], ws_mask[i], ws_bytes[i] = o, 1, nb
+            o += al(nb)
+        b_total = o
+        npar = 1 + max([st.param for st in self.steps if st.kind == "conv"], default=-1)
+        dW_off, db_off, shapes, o = np.zeros(npar, dtype=np.uint64), np.zeros(npar, dtype=np.uint64), [None] * npar, 0
+        for st in self.steps:
+            if st.kind != "conv":
+                continue
+            dW_off[st.param] = o
+            o += _round(st.cout * st.S * st.cin)
+            db_off[st.param] = o
+            o += _round(st.cout)
+            shapes[st.param] = (st.cout, st.S * st.cin)
+        plan = dict(f_off=f_off, wf_off=wf_off, wf_mask=wf_mask, f_total=f_total, g_off=g_off, g_mask=g_mask, wt_off=wt_off,
+                    wt_mask=wt_mask, ws_off=ws_off, ws_mask=ws_mask, ws_bytes=ws_bytes, b_total=b_total, dW_off=dW_off * 4,
+                    db_off=db_off * 4, dW_off_f=dW_off, db_off_f=db_off, shapes=shapes, p_total=o, npar=npar, out_rows=out_rows,
+                    out_ch=out_ch)
+        plans[key] = plan
+        return plan
+
+    @staticmethod
+    def _io_dims(x, layout):
+        B = x.shape[0] if layout == "bm" else x.shape[1]
+        rows = x.shape[1] if layout == "bm" else x.shape[0]
+        return B, rows, x.shape[2]
+
+    def native_forward_bf16(self, x, in_layout, out_layout, out_dtype, weights, biases):
+        """x: bf16, or fp32 with 3 channels.  -> (output of type out_dtype, byte arena holding the inner activations)."""
+        B, rows0, c0 = self._io_dims(x, in_layout)
+        if not (x.is_contiguous() and x.dtype in (torch.float32, torch.bfloat16)):
+            raise ValueError("expected a contiguous fp32 / bf16 3-D tensor, got %s %s" % (tuple(x.shape), x.dtype))
+        if x.numel() >= 2 ** 32:
+            raise RuntimeError("semantichuman_amd: gathered tensors are addressed with 32-bit element offsets; "
+                               "%d elements is too large - split the batch" % x.numel())
+        plan = self._plan_bf16(B, c0, x.dtype == torch.float32, out_dtype == torch.float32)
+        n = len(self.steps)
+        arena = torch.empty(max(256, plan["f_total"]), dtype=torch.uint8, device=x.device)
+        rows_o, ch_o = plan["out_rows"][-1], plan["out_ch"][-1]
+        out = torch.empty((B, rows_o, ch_o) if out_layout == "bm" else (rows_o, B, ch_o), dtype=out_dtype, device=x.device)
+        base = np.uint64(arena.data_ptr())
+        outs = plan["f_off"] + base
+        outs[n - 1] = out.data_ptr()
+        wf = (plan["wf_off"] + base) * plan["wf_mask"]
+        _lib.check(_lib.load().sh_stack_forward_bf16(
+            n, self._native_steps(), _lib.ptr(x), ops.dtype_id(x), _LAYOUT_ID[in_layout], rows0, c0, B, self._ptr_array(weights),
+            self._ptr_array(biases), wf.ctypes.data, outs.ctypes.data, ops.dtype_id(out), _LAYOUT_ID[out_layout], _lib.stream_ptr()),
+            "sh_stack_forward_bf16")
+        return out, arena
+
+    def native_backward_bf16(self, x, in_layout, out_layout, arena, out, g, weights, need_x_grad, need_bias):
+        B, rows0, c0 = self._io_dims(x, in_layout)
+        plan = self._plan_bf16(B, c0, x.dtype == torch.float32, out.dtype == torch.float32)
+        n = len(self.steps)
+        dev = x.device
+        work = torch.empty(max(256, plan["b_total"]), dtype=torch.uint8, device=dev)
+        flat = torch.empty(max(1, plan["p_total"]), dtype=torch.float32, device=dev)
+        gx = torch.empty_like(x) if need_x_grad else None
+        abase, wbase, fbase = np.uint64(arena.data_ptr()), np.uint64(work.data_ptr()), np.uint64(flat.data_ptr())
+        acts = plan["f_off"] + abase
+        acts[n - 1] = out.data_ptr()
+        gin = (plan["g_off"] + wbase) * plan["g_mask"]
+        gin[0] = gx.data_ptr() if need_x_grad else 0
+        wt = (plan["wt_off"] + wbase) * plan["wt_mask"]
+        ws = (plan["ws_off"] + wbase) * plan["ws_mask"]
+        dW = plan["dW_off"] + fbase
+        assert len(need_bias) == plan["npar"] == len(weights)
+        db = (plan["db_off"] + fbase) * np.array([1 if nb else 0 for nb in need_bias], dtype=np.uint64)
+        _lib.check(_lib.load().sh_stack_backward_bf16(
+            n, self._native_steps(), _lib.ptr(x), ops.dtype_id(x), _LAYOUT_ID[in_layout], rows0, c0, B, acts.ctypes.data, _lib.ptr(g),
+            ops.dtype_id(out), _LAYOUT_ID[out_layout], self._ptr_array(weights), gin.ctypes.data, ops.dtype_id(x),
+            ctypes.c_void_p(int(wbase)), wt.ctypes.data, ws.ctypes.data, plan["ws_bytes"].ctypes.data, dW.ctypes.data, db.ctypes.data,
+            1 if need_x_grad else 0, _lib.stream_ptr()), "sh_stack_backward_bf16")
+        grads = {}
+        for j, shp in enumerate(plan["shapes"]):
+            if shp is None:
+                continue
+            o = int(plan["dW_off_f"][j])
+            dWj = flat[o:o + shp[0] * shp[1]].view(shp)
+            o = int(plan["db_off_f"][j])
+            grads[j] = (dWj, flat[o:o + shp[0]] if need_bias[j] else None)
+        return gx, grads
+
     def _side_stream(self, dev):
         s = getattr(self, "_side", None)
         if s is None or s.device != dev:
@@ -489,6 +620,51 @@ class StackFunction(torch.autograd.Function):
             dW, db = grads.get(j, (None, None))
             res += [dW, db]
         return tuple(res)
+
+
+class StackFunctionBF16(torch.autograd.Function):
+    """autograd node of a whole Stack on the bf16 path: fp32 master parameters in, fp32 parameter gradients out;
+    x is bf16 (or fp32 xyz), the output has `out_dtype`, gradients flow in the tensors' own types."""
+
+    @staticmethod
+    def forward(ctx, stack: Stack, in_layout: str, out_layout: str, out_dtype, x, *params):
+        weights, biases = list(params[0::2]), list(params[1::2])
+        x = x.contiguous()
+        ctx.stack, ctx.layouts = stack, (in_layout, out_layout)
+        ctx.has_bias = [b is not None for b in biases]
+        out, arena = stack.native_forward_bf16(x, in_layout, out_layout, out_dtype, weights, biases)
+        ctx.save_for_backward(x, out, arena, *weights)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, out, arena, *weights = ctx.saved_tensors
+        in_layout, out_layout = ctx.layouts
+        g = g.contiguous()
+        # forward args: (stack, in_layout, out_layout, out_dtype, x, w_0, b_0, ...)
+        need_bias = [hb and ctx.needs_input_grad[6 + 2 * j] for j, hb in enumerate(ctx.has_bias)]
+        gx, grads = ctx.stack.native_backward_bf16(x, in_layout, out_layout, arena, out, g, weights, ctx.needs_input_grad[4], need_bias)
+        res = [None, None, None, None, gx]
+        for j in range(len(weights)):
+            dW, db = grads.get(j, (None, None))
+            res += [dW, db]
+        return tuple(res)
+
+
+def run_stack_bf16(stack: Stack, x, in_layout, out_layout, out_dtype, convs):
+    """bf16 compute path of `run_stack`: x bf16 (or fp32 with 3 channels), output of type out_dtype."""
+    if not x.is_cuda:
+        raise RuntimeError("semantichuman_amd: input is on %s; the spiral-convolution kernels run on a HIP device "
+                           "only (there is no CPU fallback)" % x.device)
+    if stack.device is None or stack.device != x.device:
+        raise RuntimeError("semantichuman_amd: model tables are on %s but the input is on %s - move the module with "
+                           ".to(device)" % (stack.device, x.device))
+    params = []
+    for m in convs:
+        params += [m.conv.weight, m.conv.bias]
+    if torch.is_grad_enabled() and (x.requires_grad or any(p is not None and p.requires_grad for p in params)):
+        return StackFunctionBF16.apply(stack, in_layout, out_layout, out_dtype, x, *params)
+    return stack.native_forward_bf16(x.contiguous(), in_layout, out_layout, out_dtype, params[0::2], params[1::2])[0]
 
 
 def run_stack(stack: Stack, x, in_layout, out_layout, convs):
