@@ -26,7 +26,10 @@
 
 namespace {
 
-enum { BC_C32 = 0, BC_C16 = 1, BC_C3F = 2 };   // gathered channels % 32 == 0 | == 16 | == 3 (fp32 triples)
+// gathered channels % 32 == 0 | == 16 | == 3 (fp32 triples) | % 64 == 0 with a ring slot of TWO k-steps = a full 128-byte line per
+// row, both halves requested back to back (experiment, SH_BC_C64=1: one k-step touches 16 rows x 64 B; requesting the halves
+// together changed nothing measurable, so half-line requests are not what bounds the wide-channel layers)
+enum { BC_C32 = 0, BC_C16 = 1, BC_C3F = 2, BC_C64 = 3 };
 
 struct BCParams {
     const char* x; long x_rb, x_bb;            // byte strides of (row, batch entry)
@@ -42,9 +45,31 @@ struct BCParams {
 
 struct __attribute__((packed, aligned(4))) bc_f3 { float a, b, c; };
 
+constexpr int bc_depth(int NT, int RT, int MODE) {
+    const int per = RT * (MODE == BC_C3F ? 6 : MODE == BC_C64 ? 8 : 4);        // registers of one ring slot
+    const int room = 88 - NT * RT * 4 - RT * 4;            // minus accumulators and the converted operands
+    const int d = room / per;
+    const int cap = MODE == BC_C3F ? 4 : 8;
+    const int lo = MODE == BC_C64 ? 2 : 3;
+    return d < lo ? lo : d > cap ? cap : d;
+}
+
+template <int J, int D, class F>
+__device__ __forceinline__ bool bc_ring_steps(int ks, int nks, F&& f) {
+    f(std::integral_constant<int, J>{}, ks + J);
+    if constexpr (J + 1 < D) {
+        if (ks + J + 1 >= nks) return false;               // explicit early exit: the compiler must see that a skipped step ends the loop
+        return bc_ring_steps<J + 1, D>(ks, nks, f);
+    } else {
+        return true;
+    }
+}
+
 template <int NT, int RT, int MODE, bool BWD, bool OUTF32>
 __global__ __launch_bounds__(1024) void conv_bf16_kernel(const BCParams p) {
-    constexpr int D = (RT >= 4 || NT * RT >= 16) ? 3 : 4;  // k-steps of gathered loads in flight per wave (<= 128 VGPRs)
+    // k-steps of gathered loads in flight per wave: what bounds these layers is bytes in flight per CU (a wave's k-step is
+    // RT KiB, the round trip ~2 us), so as deep as the 128-VGPR budget allows next to the accumulators
+    constexpr int D = bc_depth(NT, RT, MODE);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u32x4* Wl = reinterpret_cast<u32x4*>(smem);            // [nks][NT][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
@@ -52,15 +77,6 @@ __global__ __launch_bounds__(1024) void conv_bf16_kernel(const BCParams p) {
     const int nwg_x = ((int)gridDim.x - xcd + 7) >> 3;
     const int slice = li % p.nsplit, lj = li / p.nsplit;   // the host launches a multiple of 8 * nsplit workgroups
     const int ngrp = nwg_x / p.nsplit;
-    {
-        const int total = p.nks * NT * 64;
-        for (int i = tid; i < total; i += (int)blockDim.x) {
-            const int f = i >> 6, n = f % NT, ks = f / NT;
-            Wl[i] = p.wfrag[((long)ks * p.nt_tot + slice * NT + n) * 64 + (i & 63)];
-        }
-    }
-    __syncthreads();
-
     const int q8 = p.n_tiles >> 3, r8 = p.n_tiles & 7;
     const int t_begin = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
     const int t_end = t_begin + (xcd < r8 ? q8 + 1 : q8);
@@ -70,7 +86,7 @@ __global__ __launch_bounds__(1024) void conv_bf16_kernel(const BCParams p) {
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     auto load_table = [&](int t, int (&tv)[RT]) {
-        const int tt = t < t_end ? t : t_end - 1;
+        const int tt = t < t_end ? t : (t_end > 0 ? t_end - 1 : 0);      // clamped: a valid (possibly unused) table line
         const int vg = tt % p.n_vg;
 #pragma unroll
         for (int m = 0; m < RT; ++m) {
@@ -80,19 +96,27 @@ __global__ __launch_bounds__(1024) void conv_bf16_kernel(const BCParams p) {
     };
 
     int t = t_begin + lj * nw + wave;
-    if (t >= t_end) return;
     int tv[RT], tvn[RT];
-    load_table(t, tv);
+    load_table(t, tv);                                     // first table line: in flight under the weight copy
+    {
+        const int total = p.nks * NT * 64;
+        for (int i = tid; i < total; i += (int)blockDim.x) {
+            const int f = i >> 6, n = f % NT, ks = f / NT;
+            Wl[i] = p.wfrag[((long)ks * p.nt_tot + slice * NT + n) * 64 + (i & 63)];
+        }
+    }
+    __syncthreads();
     for (; t < t_end; t += stride) {
         load_table(t + stride, tvn);                       // next item's table line: in flight under this item's k loop
         const int bs = t / p.n_vg, vg = t - bs * p.n_vg;
         const int b0 = bs << 4, v0 = vg * RT;
         const int bl = b0 + r16 < p.B ? b0 + r16 : p.B - 1;            // rows past B read the last entry; never stored
-        const char* xl = p.x + (long)bl * p.x_bb + (MODE == BC_C32 ? kq * 16 : MODE == BC_C16 ? (kq & 1) * 16 : 0);
+        const char* xl = p.x + (long)bl * p.x_bb + ((MODE == BC_C32 || MODE == BC_C64) ? kq * 16 : MODE == BC_C16 ? (kq & 1) * 16 : 0);
 
         // running load position (uniform): spiral position and channel offset of the next k-step to load
         int ls = 0, lc = 0;
-        using raw_t = typename std::conditional<MODE == BC_C3F, bc_f3[2], bf16x8>::type;
+        constexpr int KPS = MODE == BC_C64 ? 2 : 1;        // k-steps per ring slot
+        using raw_t = typename std::conditional<MODE == BC_C3F, bc_f3[2], typename std::conditional<MODE == BC_C64, bf16x8[2], bf16x8>::type>::type;
         raw_t ring[D][RT];
         auto issue = [&](raw_t (&a)[RT]) {
             if constexpr (MODE == BC_C32) {
@@ -103,6 +127,18 @@ __global__ __launch_bounds__(1024) void conv_bf16_kernel(const BCParams p) {
                     *reinterpret_cast<bf16x8*>(&a[m]) = *reinterpret_cast<const bf16x8*>(xl + (long)row * p.x_rb + 2 * lc);
                 }
                 lc += 32;
+                if (lc >= p.Cg) { lc = 0; ++ls; }
+            } else if constexpr (MODE == BC_C64) {
+                const int s = ls < S ? ls : S - 1;
+#pragma unroll
+                for (int m = 0; m < RT; ++m) {
+                    const int row = __builtin_amdgcn_readlane(tv[m], s);
+                    const char* src = xl + (long)row * p.x_rb + 2 * lc;
+                    bf16x8* dst = reinterpret_cast<bf16x8*>(&a[m]);
+                    dst[0] = *reinterpret_cast<const bf16x8*>(src);
+                    dst[1] = *reinterpret_cast<const bf16x8*>(src + 64);
+                }
+                lc += 64;
                 if (lc >= p.Cg) { lc = 0; ++ls; }
             } else if constexpr (MODE == BC_C16) {
                 const int s0 = ls < S ? ls : S - 1, s1 = ls + 1 < S ? ls + 1 : S - 1;
@@ -131,25 +167,28 @@ __global__ __launch_bounds__(1024) void conv_bf16_kernel(const BCParams p) {
         for (int m = 0; m < RT; ++m)
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[m][n] = zero4;
-        auto compute = [&](int ks, const raw_t (&a)[RT]) {
-            bf16x8 g[RT];
+        auto compute = [&](int slot, const raw_t (&a)[RT]) {
 #pragma unroll
-            for (int m = 0; m < RT; ++m) {
-                if constexpr (MODE == BC_C3F) {
-                    const bc_f3* s2 = reinterpret_cast<const bc_f3*>(&a[m]);
-                    g[m] = (bf16x8){(__bf16)s2[0].a, (__bf16)s2[0].b, (__bf16)s2[0].c, (__bf16)0.f,
-                                    (__bf16)s2[1].a, (__bf16)s2[1].b, (__bf16)s2[1].c, (__bf16)0.f};
-                } else {
-                    g[m] = *reinterpret_cast<const bf16x8*>(&a[m]);
+            for (int h = 0; h < KPS; ++h) {
+                bf16x8 g[RT];
+#pragma unroll
+                for (int m = 0; m < RT; ++m) {
+                    if constexpr (MODE == BC_C3F) {
+                        const bc_f3* s2 = reinterpret_cast<const bc_f3*>(&a[m]);
+                        g[m] = (bf16x8){(__bf16)s2[0].a, (__bf16)s2[0].b, (__bf16)s2[0].c, (__bf16)0.f,
+                                        (__bf16)s2[1].a, (__bf16)s2[1].b, (__bf16)s2[1].c, (__bf16)0.f};
+                    } else {
+                        g[m] = reinterpret_cast<const bf16x8*>(&a[m])[h];
+                    }
                 }
-            }
-            const u32x4* wk = Wl + ((long)ks * NT) * 64 + lane;
+                const u32x4* wk = Wl + ((long)(slot * KPS + h) * NT) * 64 + lane;
 #pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const u32x4 wraw = wk[n * 64];
-                const bf16x8 w = *reinterpret_cast<const bf16x8*>(&wraw);
+                for (int n = 0; n < NT; ++n) {
+                    const u32x4 wraw = wk[n * 64];
+                    const bf16x8 w = *reinterpret_cast<const bf16x8*>(&wraw);
 #pragma unroll
-                for (int m = 0; m < RT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, g[m], acc[m][n], 0, 0, 0);
+                    for (int m = 0; m < RT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, g[m], acc[m][n], 0, 0, 0);
+                }
             }
         };
 
@@ -162,17 +201,9 @@ __global__ __launch_bounds__(1024) void conv_bf16_kernel(const BCParams p) {
             __builtin_amdgcn_sched_barrier(0);             // the prefetch loads stay ahead of the MFMAs
             compute(ks, ring[j]);
         };
-        for (int ks = 0; ks < p.nks; ks += D) {
-            step(std::integral_constant<int, 0>{}, ks);
-            if (ks + 1 >= p.nks) break;
-            step(std::integral_constant<int, 1>{}, ks + 1);
-            if (ks + 2 >= p.nks) break;
-            step(std::integral_constant<int, 2>{}, ks + 2);
-            if (D > 3) {
-                if (ks + 3 >= p.nks) break;
-                step(std::integral_constant<int, (D > 3 ? 3 : 0)>{}, ks + 3);
-            }
-        }
+        const int nslots = p.nks / KPS;
+        for (int ks = 0; ks < nslots; ks += D)
+            if (!bc_ring_steps<0, D>(ks, nslots, step)) break;
 
         // ---- epilogue: lane holds channels c0..c0+3 (c0 = 16 n + 4 kq) of row (v0 + m, b0 + r16)
         const int b = b0 + r16;
@@ -289,9 +320,9 @@ int launch_bc(BCParams& p, hipStream_t st) {
     // kernel is built for <= 128 VGPRs)
     const int per_cu = smem <= 36 * 1024 ? 4 : smem <= 76 * 1024 ? 2 : 1;
     int nw = 16 / per_cu;
-    // few work items (coarse levels): fewer waves per workgroup rather than idle ones
-    const long want_waves = (tiles * p.nsplit + 1) / 2;          // at least ~2 items per wave
-    while (nw > 4 && (long)num_cus() * per_cu * nw > want_waves * 2) nw >>= 1;
+    // few work items (coarse levels): as many resident waves as there are items (loads in flight per CU are what these
+    // launches live on), fewer waves per workgroup only when even one item per wave leaves waves idle
+    while (nw > 4 && (long)num_cus() * per_cu * (nw >> 1) >= tiles * p.nsplit) nw >>= 1;
     long groups = (tiles + nw - 1) / nw;                         // workgroups (per channel slice) that still get an item
     const long cap = (long)num_cus() * per_cu / p.nsplit;
     if (groups > cap) groups = cap;
@@ -319,8 +350,9 @@ int dispatch_bc_nt(BCParams& p, hipStream_t st) {
                    p.Nout);
         return launch_bc<1, (MODE == BC_C3F ? 2 : 4), MODE, BWD, OUTF32>(p, st);
     } else {
-        if (nt == 1) return launch_bc<1, 4, MODE, BWD, false>(p, st);
-        if (nt == 2) return tiles16 / 4 >= fill ? launch_bc<2, 4, MODE, BWD, false>(p, st) : launch_bc<2, 2, MODE, BWD, false>(p, st);
+        constexpr int R4 = MODE == BC_C64 ? 2 : 4;              // a C64 ring slot is two k-steps: 4 vertices per wave would not fit 128 VGPRs
+        if (nt == 1) return launch_bc<1, R4, MODE, BWD, false>(p, st);
+        if (nt == 2) return tiles16 / 4 >= fill ? launch_bc<2, R4, MODE, BWD, false>(p, st) : launch_bc<2, 2, MODE, BWD, false>(p, st);
         if (nt == 4) return tiles16 / 2 >= fill ? launch_bc<4, 2, MODE, BWD, false>(p, st) : launch_bc<4, 1, MODE, BWD, false>(p, st);
         return tiles16 / 2 >= fill ? launch_bc<8, 2, MODE, BWD, false>(p, st) : launch_bc<8, 1, MODE, BWD, false>(p, st);
     }
@@ -344,10 +376,12 @@ int dispatch_bc(BCParams& p, int in_f32, int out_f32, hipStream_t st) {
         SH_REQUIRE(p.Nout <= 16, SH_ERR_UNSUPPORTED, "conv_bf16: an fp32 output has <= 16 channels (got %d)", p.Nout);
         return p.Cg == 16 ? dispatch_bc_nt<BC_C16, BWD, true>(p, st) : dispatch_bc_nt<BC_C32, BWD, true>(p, st);
     }
+    static const int c64_on = sh_env_int("SH_BC_C64", 0, 0, 1);      // measured on MI355X: no gain (21-30 us either way), off
     SH_REQUIRE(p.Nout % 4 == 0 && ((reinterpret_cast<uintptr_t>(p.y) | (uintptr_t)p.y_rb | (uintptr_t)p.y_bb) & 7) == 0 &&
                (!p.yprev || ((reinterpret_cast<uintptr_t>(p.yprev) | (uintptr_t)p.yp_rb | (uintptr_t)p.yp_bb) & 7) == 0) &&
                (!p.bias || (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0),
                SH_ERR_UNSUPPORTED, "conv_bf16: bf16 output needs channels %% 4 == 0 and 8-byte aligned rows");
+    if (p.Cg % 64 == 0 && c64_on) return dispatch_bc_nt<BC_C64, BWD, false>(p, st);
     return p.Cg == 16 ? dispatch_bc_nt<BC_C16, BWD, false>(p, st) : dispatch_bc_nt<BC_C32, BWD, false>(p, st);
 }
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-launch timing of one training step (library HIP events), with shapes and achieved TFLOP/s.
-Run on the GPU box:  python tools/layer_report.py [batch] [template.npz]"""
+Run on the GPU box:  python tools/layer_report.py [batch] [template.npz] [f32|bf16]"""
 import os
 import re
 import sys
@@ -21,6 +21,9 @@ TEMPLATE = sys.argv[2] if len(sys.argv) > 2 else os.path.join("tests", "golden",
 h = load_hierarchy(TEMPLATE if os.path.isabs(TEMPLATE) else os.path.join(ROOT, TEMPLATE))
 torch.manual_seed(2)
 model = sh.SpiralAutoencoder(FE, FD, 256, h.sizes, h.spiral_sizes, h.spirals, h.D, h.U, dev)
+DTYPE = sys.argv[3] if len(sys.argv) > 3 else "f32"
+if DTYPE == "bf16":
+    model.set_compute_dtype(torch.bfloat16)
 ft = sh.FaceTables(h.faces, h.sizes[0] + 1, dev)
 x = torch.from_numpy(synthetic.synth_batch(h.verts, B, seed=1)).to(dev)
 
@@ -51,8 +54,12 @@ for i in range(per):
     kern, _, shape = name.partition("|")
     tf = ""
     m = re.search(r"R=(\d+) B=(\d+) K=(\d+) N=(\d+)", shape)
+    m2 = re.search(r"R=(\d+) B=(\d+) S=(\d+) C(?:g|in)=(\d+) N=(\d+)", shape)
     if m:
         R, Bb, K, Nn = map(int, m.groups())
         tf = "%.1f" % (2.0 * R * Bb * K * Nn / (us * 1e-6) / 1e12)
+    elif m2:
+        R, Bb, S, C, Nn = map(int, m2.groups())
+        tf = "%.1f" % (2.0 * R * Bb * S * C * Nn / (us * 1e-6) / 1e12)
     print("%-44s %-40s %8.1f %7s" % (kern.replace("_kernel", ""), shape, us, tf))
 print("total library kernels: %.1f us/step" % tot)
