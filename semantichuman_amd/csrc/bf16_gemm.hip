@@ -130,17 +130,36 @@ __global__ __launch_bounds__(256) void tgemm_bf16_kernel(const TGParams p) {
     if (BT && p.colsum && qt == 0 && tid < 64 && p0 + tid < p.P) p.colsum[p0 + tid] = csum;
 }
 
-// out[p][q] = sum_s slab[s][p][q] (+ bias[q]), s in increasing order: deterministic
+// out[p][q] = sum_s slab[s][p][q] (+ bias[q]): a wave owns 64 consecutive quads... a workgroup owns 16 quads x 16 slab lanes; lane l
+// sums slabs l, l+16, ... (8 independent loads in flight), the 16 lanes are combined in a fixed order: deterministic
 template <bool OUTBF16>
 __global__ __launch_bounds__(256) void tg_reduce_kernel(const float* __restrict__ slab, int nsplit, long n, int Q, const float* __restrict__ bias,
                                                         void* __restrict__ out) {
-    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i >= n) return;
-    f32x4 s = *reinterpret_cast<const f32x4*>(slab + i);
-    for (int k = 1; k < nsplit; ++k) s += *reinterpret_cast<const f32x4*>(slab + (long)k * n + i);
-    if (bias) s += *reinterpret_cast<const f32x4*>(bias + (int)(i % Q));
-    if (OUTBF16) *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(out) + i) = sh_to_bf16x4(s);
-    else *reinterpret_cast<f32x4*>(static_cast<float*>(out) + i) = s;
+    __shared__ f32x4 red[16][16];
+    const int qx = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const long i = ((long)blockIdx.x * 16 + qx) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i < n) {
+        int k = sl;
+        for (; k + 112 < nsplit; k += 128) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(slab + (long)(k + 16 * u) * n + i);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < nsplit; k += 16) s += *reinterpret_cast<const f32x4*>(slab + (long)k * n + i);
+    }
+    red[sl][qx] = s;
+    __syncthreads();
+    if (sl == 0 && i < n) {
+        f32x4 t = red[0][qx];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += red[k][qx];
+        if (bias) t += *reinterpret_cast<const f32x4*>(bias + (int)(i % Q));
+        if (OUTBF16) *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(out) + i) = sh_to_bf16x4(t);
+        else *reinterpret_cast<f32x4*>(static_cast<float*>(out) + i) = t;
+    }
 }
 
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long n) {
@@ -179,7 +198,7 @@ int launch_tg(TGParams& p, const TGPlan& t, int out_dtype, void* ws, hipStream_t
         p.out = ws; p.bias = nullptr;
         SH_LAUNCH_PS(ps, (tgemm_bf16_kernel<AT, BT, AF32, BF32, TG_OUT_PARTIAL>), dim3(grid), dim3(256), 0, st, p);
         const long n = (long)p.P * p.Q;
-        const int rb = (int)((n / 4 + 255) / 256);
+        const int rb = (int)((n / 4 + 15) / 16);
         if (out_dtype == SH_DTYPE_BF16)
             hipLaunchKernelGGL(tg_reduce_kernel<true>, dim3(rb), dim3(256), 0, st, static_cast<const float*>(ws), t.nsplit, n, p.Q, bias, out);
         else
