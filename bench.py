@@ -139,6 +139,65 @@ def parse_tag(name, shape):
         return None
 
 
+def lib_sha16():
+    import hashlib
+    from semantichuman_amd import _lib
+    return hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16]
+
+
+def measured_traffic(kernel, dtype):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE
+    in separate passes, gfx950 corrections applied) - quoted only while the profile was taken on THIS build of the kernel
+    library (hash stamp); a stale profile yields (None, reason) instead of a silently wrong number."""
+    for name in ("r02_pmc_traffic_%s.json" % dtype,):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            pmc = json.load(open(path))
+        except (OSError, ValueError):
+            return None, "no PMC profile (%s)" % name
+        meta = pmc.get("_meta", {})
+        if meta.get("lib_sha16") != lib_sha16():
+            return None, "PMC profile %s was taken on another build of the kernel library (%s != %s)" % (name, meta.get("lib_sha16"), lib_sha16())
+        if kernel not in pmc:
+            return None, "kernel not in %s" % name
+        return pmc[kernel]["hbm_bytes_per_launch"], "bytes/launch, rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE (profiles/%s, same library build)" % name
+    return None, "no PMC profile"
+
+
+def step_work(model, B, dtype):
+    """Algorithmic FLOPs and fused-ideal HBM bytes of ONE training step (SURVEY 8d formulae, from the live shapes): conv layers
+    forward + backward-data (not for the first layer) + weight gradient, the two latent FCs x 3, every activation read once
+    and written once per pass, plus the per-step constants (weights, weight gradients, Adam's 7 passes)."""
+    e = 2 if dtype == "bf16" else 4
+    flops = byt = 0.0
+    n_par = sum(p.numel() for p in model.parameters())
+    first = True
+    for stack in (model._enc_stack, model._dec_stack):
+        for st in stack.steps:
+            if st.kind == "conv":
+                f = 2.0 * B * st.R * st.S * st.cin * st.cout
+                a_in = B * st.n_in * st.cin * (4 if st.cin == 3 else e)
+                a_out = B * st.R * st.cout * (4 if st.cout == 3 else e)
+                flops += f * (2 if (first and stack is model._enc_stack) else 3)
+                byt += 3 * (a_in + a_out)                      # forward, backward-data and weight-gradient passes touch both once
+                first = False
+            else:
+                c = None
+                for prev in stack.steps:                        # channels passing through the re-sampling step
+                    if prev is st:
+                        break
+                    if prev.kind == "conv":
+                        c = prev.cout
+                c = c if c is not None else (model.filters_dec[0][0] if stack is model._dec_stack else 3)
+                flops += 2.0 * 2 * st.csr.val.size * B * c
+                byt += 2.0 * B * c * e * (st.csr.rows + st.csr.cols)
+    for fc in (model.fc_latent_enc, model.fc_latent_dec):
+        flops += 3 * 2.0 * B * fc.in_features * fc.out_features
+    w_bytes = n_par * (2 if dtype == "bf16" else 4)
+    byt += 2 * w_bytes + 4.0 * n_par + 7 * 4.0 * n_par + (2.0 * n_par if dtype == "bf16" else 0)   # weights fwd + dgrad, dW, Adam (+ bf16 copies)
+    return flops, byt
+
+
 def _free_port():
     import socket
     with socket.socket() as s:
@@ -376,6 +435,13 @@ def main():
         "recon_l2_mm_after_run": l2mm,
     }
 
+    fl_step, by_step = step_work(model, B, args.dtype)
+    result["whole_step"] = {"flops": fl_step, "hbm_bytes_ideal": by_step, "tflops": fl_step / (elapsed / args.steps) / 1e12,
+                            "gbps": by_step / (elapsed / args.steps) / 1e9,
+                            "frac_mfma": fl_step / (elapsed / args.steps) / 1e12 / (2500.0 if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS),
+                            "frac_hbm": by_step / (elapsed / args.steps) / 1e9 / PEAK_HBM_GBS,
+                            "note": "algorithmic FLOPs and fused-ideal bytes of one step (SURVEY 8d) / measured ms_per_step, per GPU"}
+
     # ---- roofline of the dominant kernel: HIP events recorded by the library around every launch
     if not args.no_roofline:
         # EVERY rank runs these steps (the gradient all-reduce inside them is a collective); only rank 0 records
@@ -421,8 +487,9 @@ def main():
         dom = conv[0] if conv else kernels[0]
         a = agg[dom["kernel"]]
         # bf16: ridge of the chip ~ 2.5 PF / 8 TB/s = 300 FLOP/B, these layers have 30-250 FLOP/B -> HBM roof
+        traffic, traffic_note = measured_traffic(dom["kernel"], "bf16")
         result["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom.get("gbps"), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                              "frac": (dom["gbps"] / PEAK_HBM_GBS) if "gbps" in dom else None, "traffic": None,
+                              "frac": (dom["gbps"] / PEAK_HBM_GBS) if "gbps" in dom else None, "traffic": traffic, "traffic_unit": traffic_note,
                               "avg_launch_ms": dom["avg_ms"], "launches_per_step": dom["launches_per_step"],
                               "algorithmic_bytes_per_launch": a["bytes"] / a["n"] if a["n"] else None,
                               "flops_per_launch": a["flops"] / a["n"] if a["n"] else None,
@@ -459,16 +526,11 @@ def main():
                 f[1] += table[k["kernel"]]["flops"]
         # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
         # collected separately; tools/pmc_traffic.py) - measured on the same workload, not in this run
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            traffic = pmc[dom["kernel"]]["hbm_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
+        traffic, traffic_note = measured_traffic(dom["kernel"], "f32")
         if "tflops" in dom:
             result["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
                                   "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                                  "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)",
+                                  "traffic_unit": traffic_note,
                                   "avg_launch_ms": dom["avg_ms"], "launches_per_step": dom["launches_per_step"],
                                   "flops_per_launch": table[dom["kernel"]]["flops"] / table[dom["kernel"]]["launches"],
                                   "algorithmic_bytes_per_launch": table[dom["kernel"]]["bytes"] / table[dom["kernel"]]["launches"]}
@@ -503,7 +565,8 @@ def main():
         ncores = best[1]
         torch.set_num_threads(ncores)
         om.load_state_dict(init_state)
-        ref_cpu.train_step(om, oopt, xc, faces=h.faces, edgereg_w=1e-2)          # warm-up
+        oopt = torch.optim.Adam(om.parameters(), lr=1e-3, weight_decay=5e-5)     # fresh moments: the timed steps are also the
+        ref_cpu.train_step(om, oopt, xc, faces=h.faces, edgereg_w=1e-2)          # matched-L2 trajectory (1 warm-up + cpu_iters)
         t0 = time.perf_counter()
         for _ in range(args.cpu_iters):
             ref_cpu.train_step(om, oopt, xc, faces=h.faces, edgereg_w=1e-2)
@@ -512,6 +575,41 @@ def main():
                                   "sample": "%d training steps at batch %d (same template, same init) after 1 warm-up, torch CPU fp32, "
                                             "oracle/ref_cpu.py; %d threads = the fastest of {8,16,32,64} in a one-step calibration at "
                                             "batch 16 (host has %d)" % (args.cpu_iters, B, ncores, ncpu)}
+        # ---- matched L2: the SAME trajectory on the HIP path (same init, same batch, same number of steps, Adam from zero
+        # moments), held-out per-vertex L2 (test_funcs.py:46-49) of both
+        with torch.no_grad():
+            l2_cpu = float(ref_cpu.eval_metrics(om(test.cpu())[0], test.cpu())[1])
+        m2 = sh.SpiralAutoencoder(FE, FD, 256, h.sizes, h.spiral_sizes, h.spirals, h.D, h.U, dev)
+        if args.dtype == "bf16":
+            m2.set_compute_dtype(torch.bfloat16)
+        m2.load_state_dict(init_state)
+        o2 = sh.optim.Adam(m2.parameters(), lr=1e-3, weight_decay=5e-5)
+        xg = data[:B]
+        for _ in range(1 + args.cpu_iters):
+            o2.zero_grad(set_to_none=True)
+            l2loss, _ = sh.recon_loss(m2(xg)[0], xg, ft, 1e-2)
+            l2loss.backward()
+            o2.step()
+        with torch.no_grad():
+            l2_hip = float(sh.vertex_l2_mm(m2(test)[0], test).item())
+        result["matched_l2"] = {"steps": 1 + args.cpu_iters, "batch": B, "hip_mm": l2_hip, "cpu_oracle_mm": l2_cpu,
+                                "rel_diff": abs(l2_hip - l2_cpu) / l2_cpu,
+                                "note": "held-out per-vertex L2 after the same training steps from the same weights on the same batch: "
+                                        "HIP path (%s kernels) vs the fp32 CPU oracle" % args.dtype}
+        del m2, o2
+        # ---- the two thread counts SURVEY 8d asks for beside the calibrated one, on a bounded sample (batch 4, one timed step)
+        for label, nt, nb, warm in (("one_thread", 1, 4, 1), ("all_cores", ncpu, 2, 0)):    # all 256 threads: ~10 s per mesh, no warm-up
+            xs4 = xc[:nb]
+            torch.set_num_threads(nt)
+            om.load_state_dict(init_state)
+            o4 = torch.optim.Adam(om.parameters(), lr=1e-3, weight_decay=5e-5)
+            for _ in range(warm):
+                ref_cpu.train_step(om, o4, xs4, faces=h.faces, edgereg_w=1e-2)
+            t0 = time.perf_counter()
+            ref_cpu.train_step(om, o4, xs4, faces=h.faces, edgereg_w=1e-2)
+            result["cpu_baseline"][label] = {"value": nb / (time.perf_counter() - t0), "unit": "meshes/s", "cores": nt,
+                                             "sample": "1 training step at batch %d after %d warm-up" % (nb, warm)}
+        torch.set_num_threads(ncores)
 
     if rank == 0:
         print(json.dumps(result))

@@ -4,14 +4,19 @@ MI355X_MICROARCH.md 'HBM / rocprofv3 PMC slots' prescribes) of `python3 tools/la
 
     rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/pmc_fetch -o fetch --output-format csv -- python3 tools/layer_report.py
     rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/pmc_write -o write --output-format csv -- python3 tools/layer_report.py
-    python3 tools/pmc_traffic.py gpurun_out/pmc_fetch/fetch_counter_collection.csv gpurun_out/pmc_write/write_counter_collection.csv profiles/r01_pmc_traffic
+    python3 tools/pmc_traffic.py gpurun_out/pmc_fetch/fetch_counter_collection.csv gpurun_out/pmc_write/write_counter_collection.csv profiles/r02_pmc_traffic_f32
+(layer_report.py takes `64 tests/golden/template6890.npz bf16` for the bf16 path -> profiles/r02_pmc_traffic_bf16).  Run it ON THE
+BOX that took the passes: the result is stamped with the hash of the kernel library it was measured on ("_meta"), and
+bench.py only quotes it as `roofline.traffic` while that hash matches the library it runs.
 
 Units / corrections (same guide): both counters are in KiB; on gfx950 FETCH_SIZE tallies the 128-byte requests of wide
 coalesced reads at 64 bytes, so it is doubled; WRITE_SIZE is exact.  Writes <out>.json (kernel name -> mean bytes per
 launch, keyed like rocprofv3 --stats prints the name minus the 'void (anonymous namespace)::' prefix and the
 argument list) and <out>.txt (one line per launch of one training step)."""
 import csv
+import hashlib
 import json
+import os
 import re
 import sys
 from collections import OrderedDict, defaultdict
@@ -34,7 +39,8 @@ def read(path, counter):
 
 def main():
     fetch, write, out = read(sys.argv[1], "FETCH_SIZE"), read(sys.argv[2], "WRITE_SIZE"), sys.argv[3]
-    ours = lambda n: any(k in n for k in ("gather_gemm", "wgrad", "spmm", "skinny", "linear_", "adam", "slab_reduce", "split_reduce"))  # noqa: E731
+    ours = lambda n: any(k in n for k in ("gather_gemm", "wgrad", "spmm", "skinny", "linear_", "adam", "slab_reduce", "split_reduce",  # noqa: E731
+                                          "conv_bf16", "tgemm", "tg_reduce", "wfrag"))
     agg = defaultdict(lambda: [0, 0.0, 0.0])
     for (_, n, _, v) in fetch:
         if ours(n):
@@ -47,11 +53,16 @@ def main():
     for n, (c, fb, wb) in sorted(agg.items(), key=lambda kv: -(kv[1][1] + kv[1][2])):
         res[n] = {"launches_profiled": c, "fetch_bytes_per_launch": fb / c, "write_bytes_per_launch": wb / max(1, cnt_w[n]),
                   "hbm_bytes_per_launch": fb / c + wb / max(1, cnt_w[n])}
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "semantichuman_amd", "lib", "libsh_kernels.so")
+    res["_meta"] = {"lib_sha16": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16] if os.path.exists(lib) else None,
+                    "corrections": "FETCH_SIZE x 2 (gfx950 tallies 128-byte requests at 64 bytes), WRITE_SIZE exact; KiB units"}
     json.dump(res, open(out + ".json", "w"), indent=1)
     with open(out + ".txt", "w") as f:
         f.write("# HBM bytes per launch, mean over the profiled launches (FETCH_SIZE x2 correction applied; see tools/pmc_traffic.py)\n")
         f.write("%-60s %8s %12s %12s\n" % ("kernel", "launches", "fetch MB", "write MB"))
         for n, r in res.items():
+            if n == "_meta":
+                continue
             f.write("%-60s %8d %12.1f %12.1f\n" % (n, r["launches_profiled"], r["fetch_bytes_per_launch"] / 1e6, r["write_bytes_per_launch"] / 1e6))
     print(open(out + ".txt").read())
 
