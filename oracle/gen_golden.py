@@ -604,6 +604,46 @@ def gen_spiral_layout():
     print("spiral_layout: sizes", arrs["sizes_dil"], arrs["sizes_nodil"])
 
 
+def gen_preprocess():
+    """f3: the reference's own preprocessing on ASYMMETRIC meshes (box_sphere + a seeded jitter of 2 % of the mean edge length,
+    so that no two edge-collapse costs tie exactly - on the symmetric synthetic templates the reference itself breaks ties by
+    the rounding noise of numpy's SVD): per level the QSlim selection and faces (mesh_sampling.qslim_decimator_transformer),
+    the raw spiral lists (utils_spiral.get_spirals, 2 rings) and the shortest-path reference points.  Two meshes: 578 and
+    1538 vertices."""
+    arrs = {}
+    for tag, dims, seed in (("a", (12, 12, 6), 11), ("b", (20, 20, 9), 12)):
+        v, f = synthetic.box_sphere(*dims)
+        rs = np.random.RandomState(seed)
+        e = np.linalg.norm(v[f[:, 0]] - v[f[:, 1]], axis=1).mean()
+        v = v + 0.02 * e * rs.randn(*v.shape)
+        t0 = time.time()
+        M = [refstubs.Mesh(v=v, f=f)]
+        A = [refstubs.get_vert_connectivity(v, f)]
+        Fs = []
+        arrs[tag + "/verts"], arrs[tag + "/faces"] = v, f.astype(np.int32)
+        for l, factor in enumerate([1.0 / x for x in DS_FACTORS]):
+            ds_f, ds_D = ref_ms.qslim_decimator_transformer(M[-1], factor=factor)
+            d = ds_D.tocsr()
+            assert np.all(np.diff(d.indptr) == 1) and np.all(d.data == 1.0)
+            arrs["%s/D_sel_%d" % (tag, l)] = d.indices.astype(np.int32)
+            arrs["%s/faces_%d" % (tag, l + 1)] = ds_f.astype(np.int32)
+            Fs.append(ds_f)
+            new_v = ds_D.dot(M[-1].v)
+            M.append(refstubs.Mesh(v=new_v, f=ds_f))
+            A.append(refstubs.get_vert_connectivity(new_v, ds_f))
+        ref_pts = [[7]]
+        for i in range(len(DS_FACTORS)):
+            ref_pts.append([int(np.argmin(((M[i + 1].v - M[0].v[ref_pts[0]]) ** 2).sum(1)))])
+        arrs[tag + "/ref_pts"] = np.asarray([r[0] for r in ref_pts], dtype=np.int32)
+        Adj, Trigs = ref_us.get_adj_trigs(A, Fs, M[0], meshpackage="mpi-mesh")
+        for i in range(len(Adj)):
+            sp = ref_us.get_spirals(M[i].v, Adj[i], Trigs[i], ref_pts[i], n_steps=2, padding="zero", counter_clockwise=True, random=False)
+            arrs["%s/spiral_flat_%d" % (tag, i)] = np.asarray([x for s_ in sp for x in s_], dtype=np.int32)
+            arrs["%s/spiral_len_%d" % (tag, i)] = np.asarray([len(s_) for s_ in sp], dtype=np.int32)
+        print("preprocess", tag, [m.v.shape[0] for m in M], "%.1fs" % (time.time() - t0))
+    np.savez_compressed(os.path.join(GOLD, "preprocess.npz"), **arrs)
+
+
 def gen_template27k():
     """BASELINE config 4: box_sphere(84,84,40) = 27 554 vertices (one midpoint subdivision of the 6890 template's
     size), levels by QSlim factors [2,2,2,2], spirals with step size 2 and NO dilation, every spiral then forced to
