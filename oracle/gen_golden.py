@@ -414,6 +414,96 @@ def gen_semantic():
     print("semantic.npz: sizes", sizes, "S", spiral_sizes, "pair", arrs["pair_loss_relat"], arrs["pair_loss_abs"], "vol", float(vol))
 
 
+from tests.semloop_inputs import SEM_LOOP, semantic_loop_inputs      # noqa: E402  (shared with tests/test_semantic.py)
+
+
+class _RefLoader:
+    """What the reference loop needs of a DataLoader: len(), .dataset, iteration, and an iterator with the pre-torch-2
+    `.next()` method (train_funcs.py:155-158,288-291) - supplied by the CALLER, so the reference loop runs unmodified."""
+
+    class _It:
+        def __init__(self, b):
+            self.b, self.i = b, 0
+
+        def __iter__(self):
+            return self
+
+        def __next__(self):
+            if self.i >= len(self.b):
+                raise StopIteration
+            self.i += 1
+            return self.b[self.i - 1]
+        next = __next__
+
+    def __init__(self, batches):
+        self.batches = batches
+        self.dataset = range(sum(b["verts"].shape[0] for b in batches))
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __iter__(self):
+        return self._It(self.batches)
+
+
+def gen_semantic_loop():
+    """a17: the reference's OWN semantic training loop, train_funcs.train_autoencoder_dataloader_nonormal (:73-472), run
+    unmodified at 6890 vertices / 13776 faces (sizes it hard-codes, :81,:84) on the synthetic template with the shipped
+    traincfg.yaml: 4 epochs of one batch of 2 (so that every step is logged, :397-406), interp / exc inputs from a 3-batch
+    loader (exercises the restart-and-skip path :154-158), StepLR.  Stored: every writer scalar, the random draws the
+    loop made, a sample of the final weights."""
+    import random
+    import tempfile
+    from types import SimpleNamespace
+    from configure.cfgs import cfg
+    from semantichuman_amd import constants as C
+    from semantichuman_amd.hierarchy import load_hierarchy
+    cfg.merge_from_file(os.path.join(refstubs.REFERENCE_ROOT, "configure", "traincfg.yaml"))
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "asset"))
+    cfg.PATH.root_dir = tmp
+    cfg.TRAIN.ck_frequency = 2
+    h = load_hierarchy(os.path.join(GOLD, "template6890.npz"))
+    np.save(os.path.join(tmp, "asset", "edge_verts_index.npy"), np.zeros((4, 2), dtype=np.int64))     # loaded (:104), never used
+    part_coarse, part_fine, J, train, interp, val = semantic_loop_inputs(h.verts, h.sizes)
+    S, D, U = h.dense_constants()
+    dev = torch.device("cpu")
+    model = ref_models.SpiralAutoencoder_multiz_partkps(cfg.CONSTANTS.kps_index_list, part_coarse, FILTERS_ENC, FILTERS_DEC, 8, 8,
+                                                        h.sizes, h.spiral_sizes, S, D, U, dev)
+    fill_params(model, scale=SEM_LOOP["init_scale"])
+    optim = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-5)
+    sched = torch.optim.lr_scheduler.StepLR(optim, 1, gamma=0.99)
+    rows = []
+    writer = SimpleNamespace(add_scalar=lambda tag, val, step: rows.append((tag, float(val), int(step))))
+    shapedata = SimpleNamespace(reference_mesh=SimpleNamespace(f=h.faces))
+    draws = []
+    real_rand, real_nprand = torch.rand, np.random.rand
+    torch.rand = lambda *a, **k: (lambda t: (draws.append(("torch", float(t.reshape(-1)[0]))), t)[1])(real_rand(*a, **k))
+    np.random.rand = lambda *a: (lambda t: (draws.append(("numpy", float(np.asarray(t).reshape(-1)[0]))), t)[1])(real_nprand(*a))
+    torch.manual_seed(SEM_LOOP["seed"]); np.random.seed(SEM_LOOP["seed"]); random.seed(SEM_LOOP["seed"])
+    t0 = time.time()
+    try:
+        ref_train.train_autoencoder_dataloader_nonormal(_RefLoader(train), _RefLoader(val), dev, model, optim, torch.nn.functional.l1_loss,
+                                                        1, SEM_LOOP["n_epochs"], 1, _RefLoader(interp), sched, writer, shapedata, tmp, tmp,
+                                                        "checkpoint", J, part_fine, list(C.PART_LIST), False)
+    finally:
+        torch.rand, np.random.rand = real_rand, real_nprand
+    ck = torch.load(os.path.join(tmp, "checkpoint2.pth.tar"), weights_only=False)
+    arrs = {"tags": np.asarray([r[0] for r in rows]), "values": np.asarray([r[1] for r in rows]), "steps": np.asarray([r[2] for r in rows]),
+            "draw_kind": np.asarray([d[0] for d in draws]), "draw_value": np.asarray([d[1] for d in draws]),
+            "ckpt_keys": np.asarray(sorted(ck.keys())), "lr_final": np.asarray(optim.param_groups[0]["lr"])}
+    for k, n in enumerate(C.PART_LIST):
+        arrs["part_coarse_%d" % k], arrs["part_fine_%d" % k] = part_coarse[n], part_fine[n]
+    for name, p in model.named_parameters():
+        w = p.detach().cpu().numpy().ravel()
+        arrs["w_head/" + name] = w[:32].copy()
+        arrs["w_norm/" + name] = np.asarray(float(np.linalg.norm(w.astype(np.float64))))
+    np.savez_compressed(os.path.join(GOLD, "semantic_loop.npz"), **arrs)
+    print("semantic_loop.npz: %d scalars, %d draws, %.1fs" % (len(rows), len(draws), time.time() - t0))
+    for r in rows[:12]:
+        print("  ", r)
+
+
 def gen_measure():
     """Body measurements: reference utils_SH.cal_girth on plane cuts of the 578-vertex
     mesh (girth, intersection points X, ring order), then utils_SH.measure_body_quick / cal_length on a

@@ -105,11 +105,12 @@ def _edit_scales(ctx, opts, B, epoch, measure=None, draw=None):
                 if leaf in part_index:
                     part_index.remove(leaf)
                     break
-        a = torch.rand(len(part_index), device=dev) * lo + hi
+        a = torch.rand(len(part_index)).to(dev) * lo + hi            # drawn on the host generator, like the reference (:207)
         return part_index, a[None].repeat(B, 1)
     if opts.edit_mode == "equal":
         if draw is None:
-            return ctx.part_index_in_allpart, torch.ones((B, len(opts.noleaf_part_list)), device=dev) * (torch.rand(1, device=dev) * lo + hi)
+            # `torch.rand(1).to(device)` (:220): the HOST generator, so a seeded run draws the reference's own stream
+            return ctx.part_index_in_allpart, torch.ones((B, len(opts.noleaf_part_list)), device=dev) * (torch.rand(1).to(dev) * lo + hi)
         return ctx.part_index_in_allpart, torch.full((B, len(opts.noleaf_part_list)), float(draw), device=dev)
     if opts.edit_mode == "exc":
         return ctx.part_index_in_allpart, torch.flip(measure, dims=[0]) / measure
@@ -144,7 +145,7 @@ def semantic_losses(model, ctx, tx, tx_interp, tx_exc, epoch, measure=None, inte
         kps_i = ctx.joints(tx_interp)
         if o.editskl_flag:
             n = len(ctx.skl_keep) if o.edit_mode == "rand" else 1
-            f = torch.rand(n, device=ctx.device) * o.factor[0] + o.factor[1]
+            f = torch.rand(n).to(ctx.device) * o.factor[0] + o.factor[1]
             skl = part_losses.kps2skl(kps_i, "ori_m", o.newskl_list)
             skl[:, ctx.skl_keep_t, 3] = skl[:, ctx.skl_keep_t, 3] * (f[None] if n > 1 else f)
             new_kps_i = part_losses.skl2kps(skl, "ori_m", o.newskl_list)

@@ -249,3 +249,71 @@ def test_hip_semantic_iteration_and_loop(sem, tmp_path):
     ck = torch.load(tmp_path / "checkpoint3.pth.tar", map_location="cpu", weights_only=False)
     assert sorted(ck) == ["autoencoder_state_dict", "epoch", "optimizer_state_dict", "scheduler_state_dict"]
     assert list(ck["autoencoder_state_dict"].keys()) == [str(k) for k in g["state_dict_keys"]]
+
+
+@pytest.mark.gpu
+def test_hip_semantic_loop_matches_the_reference_loop(golden_dir, tmp_path):
+    """Row a17, semantic loop: tests/golden/semantic_loop.npz holds what the REFERENCE's own
+    train_autoencoder_dataloader_nonormal (train_funcs.py:73-472) logged when oracle/gen_golden.py drove it, unmodified, at
+    6890 vertices with the shipped traincfg.yaml (caller-side loaders whose iterators still have `.next()`), 4 epochs.
+    The drop-in loop, seeded the same way, must log the same tags at the same steps with the same values, draw the same
+    random stream (host generators, like the reference), end at the same weights, learning rate and checkpoint layout.
+    Tolerances: step 0 is one forward pass (1e-4 relative on every term); later steps carry Adam's trajectory (1e-3)."""
+    import random
+    from types import SimpleNamespace
+    import semantichuman_amd as sh
+    from semantichuman_amd import train_semantic as ts
+    from tests.semloop_inputs import SEM_LOOP, fill_params, semantic_loop_inputs
+    g = np.load(os.path.join(golden_dir, "semantic_loop.npz"))
+    h = load_hierarchy(os.path.join(golden_dir, "template6890.npz"))
+    dev = torch.device("cuda:0")
+    part_coarse, part_fine, J, train, interp, val = semantic_loop_inputs(h.verts, h.sizes)
+    for k, n in enumerate(C.PART_LIST):
+        assert np.array_equal(part_coarse[n], g["part_coarse_%d" % k]) and np.array_equal(part_fine[n], g["part_fine_%d" % k])
+    m = sh.SpiralAutoencoder_multiz_partkps(C.KPS_INDEX_LIST, part_coarse, C.FILTER_SIZES_ENC, C.FILTER_SIZES_DEC, 8, 8, h.sizes,
+                                            h.spiral_sizes, h.spirals, h.D, h.U, dev)
+    fill_params(m, scale=SEM_LOOP["init_scale"])
+
+    class Loader:                                   # the loader protocol the loops use: len, .dataset, iteration
+        def __init__(self, batches):
+            self.batches, self.dataset = batches, range(sum(b["verts"].shape[0] for b in batches))
+        def __len__(self): return len(self.batches)
+        def __iter__(self): return iter(self.batches)
+    rows, draws = [], []
+    writer = SimpleNamespace(add_scalar=lambda t, v, s: rows.append((t, float(v), int(s))))
+    opt = sh.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-5)
+    sched = torch.optim.lr_scheduler.StepLR(opt, 1, gamma=0.99)
+    real_rand, real_nprand = torch.rand, np.random.rand
+    torch.rand = lambda *a, **k: (lambda t: (draws.append(("torch", float(t.reshape(-1)[0]))), t)[1])(real_rand(*a, **k))
+    np.random.rand = lambda *a: (lambda t: (draws.append(("numpy", float(np.asarray(t).reshape(-1)[0]))), t)[1])(real_nprand(*a))
+    torch.manual_seed(SEM_LOOP["seed"]); np.random.seed(SEM_LOOP["seed"]); random.seed(SEM_LOOP["seed"])
+    try:
+        ts.train_autoencoder_dataloader_nonormal(Loader(train), Loader(val), dev, m, opt, torch.nn.functional.l1_loss, 1,
+                                                 SEM_LOOP["n_epochs"], 1, Loader(interp), sched, writer,
+                                                 SimpleNamespace(reference_mesh=SimpleNamespace(f=h.faces)), str(tmp_path), str(tmp_path),
+                                                 "checkpoint", J, part_fine, list(C.PART_LIST), False,
+                                                 options=ts.SemanticTrainOptions(ck_frequency=2), verbose=False)
+    finally:
+        torch.rand, np.random.rand = real_rand, real_nprand
+    # the same random stream, in the same order
+    assert [d[0] for d in draws] == [str(k) for k in g["draw_kind"]]
+    np.testing.assert_allclose([d[1] for d in draws], g["draw_value"], rtol=0, atol=0)
+    # the same log: tags, steps, values
+    assert [r[0] for r in rows] == [str(t) for t in g["tags"]]
+    assert [r[2] for r in rows] == [int(s) for s in g["steps"]]
+    for (tag, val, step), ref in zip(rows, g["values"]):
+        tol = 1e-4 if step == 0 and not tag.startswith("avg") else 1e-3
+        if tag.endswith("_euc_loss"):
+            # the reference forms its distance matrices as relu(r - 2 x x^T + r^T) ** 0.5 in fp32 (utils_distance.py:366-376):
+            # cancellation noise of ~1e-4 relative per distance, and pairs next to the angle threshold can change sides
+            tol *= 5
+        assert val == pytest.approx(float(ref), rel=tol, abs=1e-7), (tag, step, val, float(ref))
+    assert opt.param_groups[0]["lr"] == pytest.approx(float(g["lr_final"]), rel=1e-12)
+    ck = torch.load(tmp_path / "checkpoint2.pth.tar", map_location="cpu", weights_only=True)
+    assert sorted(ck) == [str(k) for k in g["ckpt_keys"]]
+    # the same weights after 4 Adam steps (each step moves a weight by <= lr: compare at that scale)
+    for name, p in m.named_parameters():
+        w = p.detach().cpu().numpy().ravel()
+        assert np.abs(w[:32] - g["w_head/" + name]).max() <= 2e-4, name
+        # Adam turns rounding noise on ~zero gradients into +-lr moves of single elements: norms agree to a few 1e-4
+        assert float(np.linalg.norm(w.astype(np.float64))) == pytest.approx(float(g["w_norm/" + name]), rel=5e-4), name
