@@ -311,9 +311,11 @@ def test_hip_semantic_loop_matches_the_reference_loop(golden_dir, tmp_path):
     assert opt.param_groups[0]["lr"] == pytest.approx(float(g["lr_final"]), rel=1e-12)
     ck = torch.load(tmp_path / "checkpoint2.pth.tar", map_location="cpu", weights_only=True)
     assert sorted(ck) == [str(k) for k in g["ckpt_keys"]]
-    # the same weights after 4 Adam steps (each step moves a weight by <= lr: compare at that scale)
+    # the same weights after 4 Adam steps.  A step moves a weight by <= lr = 1e-3 whatever the gradient's size, so rounding
+    # noise on small gradients shows up as differences of a fraction of lr: worst element < lr, mean far below
     for name, p in m.named_parameters():
         w = p.detach().cpu().numpy().ravel()
-        assert np.abs(w[:32] - g["w_head/" + name]).max() <= 2e-4, name
+        d = np.abs(w[:32] - g["w_head/" + name])
+        assert d.max() <= 1e-3 and d.mean() <= 3e-4, (name, d.max(), d.mean())      # (pair-distance gradients: 5e-3 relative noise, see above)
         # Adam turns rounding noise on ~zero gradients into +-lr moves of single elements: norms agree to a few 1e-4
         assert float(np.linalg.norm(w.astype(np.float64))) == pytest.approx(float(g["w_norm/" + name]), rel=5e-4), name
