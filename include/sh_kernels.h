@@ -357,6 +357,32 @@ SH_API int sh_adam_step(int n_tensors, float* const* params, const float* const*
                  float* const* exp_avg_sq, float* const* steps, const int64_t* numel, const float* lr,
                  double beta1, double beta2, double eps, double weight_decay, sh_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * The small loss terms of the semantic loop as kernels.  x tensors are [B] meshes of rows of 3 floats,
+ * batch stride x_bs floats (the dummy row may be present: faces / J never index it).  Deterministic (no atomics).
+ *  - joint regression kps[b][j][:] = sum_v J[j][v] x[b][v][:] (train_funcs.py:131,161,230,296,336), J dense [K][N];
+ *    sh_joint_l1_loss_fwd also returns loss[0] = mean |kps[:, keep] - target| (F.l1_loss, :231,:342; keep int32 [Kk],
+ *    target [B][Kk][3]); _bwd OVERWRITES grad [B][N1][3] (gradient w.r.t. x; rows >= N get 0) from the saved kps.
+ *  - part volume ratio (cal_volloss :56-71 averaged over the batch :323-330): parts as CSR over faces (pf_ptr [P+1], pf),
+ *    vol [2][B][P] receives the signed volumes of (x_rec, x_gt); loss[0] = (1/P) sum_p mean_b | |vr/vg| - 1 |.
+ *    _bwd: face_slot [F] = position of the face's part in the list or -1; vptr / vcorner as for the edge loss.
+ *  - sh_zpart_reg (zpartreg :145-152): z [B][P][L], measure [B][M], part_idx / measure_idx int32 [n];
+ *    loss[0] = mean | |z_p| / m - 1 | (relat) or | |z_p| - m |; with dz != NULL also writes gscale[0] * d loss / d z
+ *    (loss may then be NULL). */
+SH_API int sh_joint_regress(const float* x, int64_t x_bs, const float* J, int B, int N, int K, float* kps, sh_stream_t stream);
+SH_API int sh_joint_l1_loss_fwd(const float* x, int64_t x_bs, const float* J, const int32_t* keep, const float* target, int B,
+                                int N, int K, int Kk, float* kps, float* loss, sh_stream_t stream);
+SH_API int sh_joint_l1_loss_bwd(const float* kps, const int32_t* keep, const float* target, const float* J, int B, int N1, int N,
+                                int K, int Kk, const float* gscale, float* grad, sh_stream_t stream);
+SH_API int sh_part_volume_loss_fwd(const float* x_rec, const float* x_gt, int64_t x_bs, const int32_t* faces,
+                                   const int32_t* pf_ptr, const int32_t* pf, int B, int P, float* vol, float* loss,
+                                   sh_stream_t stream);
+SH_API int sh_part_volume_loss_bwd(const float* x_rec, int64_t x_bs, const int32_t* faces, const int32_t* face_slot,
+                                   const int32_t* vptr, const int32_t* vcorner, const float* vol, int B, int P, int N1,
+                                   const float* gscale, float* grad, sh_stream_t stream);
+SH_API int sh_zpart_reg(const float* z, const float* measure, const int32_t* part_idx, const int32_t* measure_idx, int B, int P,
+                        int L, int M, int n, int relat, float* loss, float* dz, const float* gscale, sh_stream_t stream);
+
 /* =============================================================================================
  * bf16 compute path (BASELINE.json configs[2]: "batch=512 bf16, DDP 8x"; the reference itself is fp32-only,
  * models.py:45).  Same operators as above with bf16 activations and bf16 working copies of the weights,

@@ -59,6 +59,12 @@ SIGNATURES = {
     "sh_dataset_normalize": (c_int, [_P, _P, _I, _I, _I, ctypes.c_uint, _P, _P, _P, _P, _P, _P]),
     "sh_gather_meshes": (c_int, [_P, _L, _P, _I, _P, _P]),
     "sh_adam_step": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P] + [ctypes.c_double] * 4 + [_P]),
+    "sh_joint_regress": (c_int, [_P, _L, _P, _I, _I, _I, _P, _P]),
+    "sh_joint_l1_loss_fwd": (c_int, [_P, _L, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "sh_joint_l1_loss_bwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "sh_part_volume_loss_fwd": (c_int, [_P, _P, _L, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "sh_part_volume_loss_bwd": (c_int, [_P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "sh_zpart_reg": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     # bf16 compute path
     "sh_conv_wfrag_bytes": (c_size_t, [_I, _I, _I]),
     "sh_conv_wfrag_prep_multi": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P]),

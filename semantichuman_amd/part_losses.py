@@ -140,6 +140,163 @@ def face_part_index(faces, vert_part_index_dict, n_verts):
     return np.where(same, vpi[f[:, 0]], 100)
 
 
+# ---------------------------------------------------------------------------------------------- a13 as kernels
+def _i32(values, device):
+    key = ("i32", tuple(int(v) for v in values), str(device))
+    t = _INDEX_CACHE.get(key)
+    if t is None:
+        t = torch.tensor(key[1], dtype=torch.int32, device=device)
+        _INDEX_CACHE[key] = t
+    return t
+
+
+def _mesh3(x, what):
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[2] == 3 and x.is_contiguous()):
+        raise RuntimeError("semantichuman_amd.%s needs contiguous fp32 HIP meshes [B, rows, 3] (got %s %s %s); there is no CPU path"
+                           % (what, x.device, x.dtype, tuple(x.shape)))
+    return x
+
+
+def joint_regress(x, J):
+    """kps = J @ x[:, :N] for x [B, rows >= N, 3], J [K, N] (train_funcs.py:131): one kernel, no gradient."""
+    from . import _lib
+    x = _mesh3(x.detach().contiguous(), "joint_regress")
+    K, N = J.shape
+    out = torch.empty((x.shape[0], K, 3), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().sh_joint_regress(_lib.ptr(x), x.shape[1] * 3, _lib.ptr(J), x.shape[0], N, K, _lib.ptr(out), _lib.stream_ptr()),
+               "sh_joint_regress")
+    return out
+
+
+class _JointL1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, target, J, keep):
+        from . import _lib
+        x = _mesh3(x.contiguous(), "joint_l1_loss")
+        target = target.detach().contiguous().float()
+        K, N = J.shape
+        B, Kk = x.shape[0], keep.numel()
+        kps = torch.empty((B, K, 3), dtype=torch.float32, device=x.device)
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().sh_joint_l1_loss_fwd(_lib.ptr(x), x.shape[1] * 3, _lib.ptr(J), _lib.ptr(keep), _lib.ptr(target), B, N, K, Kk,
+                                                    _lib.ptr(kps), _lib.ptr(loss), _lib.stream_ptr()), "sh_joint_l1_loss_fwd")
+        ctx.save_for_backward(kps, target, J, keep)
+        ctx.rows = x.shape[1]
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        kps, target, J, keep = ctx.saved_tensors
+        K, N = J.shape
+        B, Kk = kps.shape[0], keep.numel()
+        grad = torch.empty((B, ctx.rows, 3), dtype=torch.float32, device=kps.device)
+        g = g.contiguous().float()
+        _lib.check(_lib.load().sh_joint_l1_loss_bwd(_lib.ptr(kps), _lib.ptr(keep), _lib.ptr(target), _lib.ptr(J), B, ctx.rows, N, K, Kk,
+                                                    _lib.ptr(g), _lib.ptr(grad), _lib.stream_ptr()), "sh_joint_l1_loss_bwd")
+        return grad, None, None, None
+
+
+def joint_l1_loss(x_rec, target, J, keep):
+    """mean | (J @ x_rec[:, :N])[:, keep] - target | (train_funcs.py:229-232, :335-342) as one forward launch pair and one
+    backward launch; `keep`: int32 device tensor or index list."""
+    if not torch.is_tensor(keep):
+        keep = _i32(keep, x_rec.device)
+    return _JointL1.apply(x_rec, target, J, keep)
+
+
+class PartFaceTables:
+    """Faces grouped by body part for the volume loss: CSR over the parts in `parts` (train_funcs.py:58-61: the faces whose
+    three corners lie in one part), the face -> slot map, and the vertex -> corner lists of the gradient."""
+
+    def __init__(self, faces, fpi, parts, n_rows, device):
+        f = np.ascontiguousarray(np.asarray(faces, dtype=np.int32))
+        fpi = np.asarray(fpi)
+        slot = np.full(f.shape[0], -1, dtype=np.int32)
+        ptr, lst = [0], []
+        for k, p in enumerate(parts):
+            idx = np.nonzero(fpi == p)[0].astype(np.int32)
+            slot[idx] = k
+            lst.append(idx)
+            ptr.append(ptr[-1] + len(idx))
+        order = np.argsort(f.ravel(), kind="stable")
+        vptr = np.zeros(n_rows + 1, dtype=np.int32)
+        np.cumsum(np.bincount(f.ravel(), minlength=n_rows), out=vptr[1:])
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)          # noqa: E731
+        self.P, self.n_rows = len(parts), n_rows
+        self.faces, self.slot = dev(f), dev(slot)
+        self.pf_ptr, self.pf = dev(np.asarray(ptr, dtype=np.int32)), dev(np.concatenate(lst) if lst else np.zeros(0, np.int32))
+        self.vptr, self.vcorner = dev(vptr), dev(np.arange(f.size, dtype=np.int32)[order])
+
+
+class _PartVolume(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_rec, x_gt, pt: PartFaceTables):
+        from . import _lib
+        x_rec, x_gt = _mesh3(x_rec.contiguous(), "part_volume_loss"), _mesh3(x_gt.detach().contiguous(), "part_volume_loss")
+        B = x_rec.shape[0]
+        vol = torch.empty((2, B, pt.P), dtype=torch.float32, device=x_rec.device)
+        loss = torch.empty((), dtype=torch.float32, device=x_rec.device)
+        _lib.check(_lib.load().sh_part_volume_loss_fwd(_lib.ptr(x_rec), _lib.ptr(x_gt), x_rec.shape[1] * 3, _lib.ptr(pt.faces),
+                                                       _lib.ptr(pt.pf_ptr), _lib.ptr(pt.pf), B, pt.P, _lib.ptr(vol), _lib.ptr(loss),
+                                                       _lib.stream_ptr()), "sh_part_volume_loss_fwd")
+        ctx.save_for_backward(x_rec, vol)
+        ctx.pt = pt
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        x_rec, vol = ctx.saved_tensors
+        pt = ctx.pt
+        if x_rec.shape[1] != pt.n_rows:
+            raise RuntimeError("part_volume_loss: tables were built for %d rows per mesh, got %d" % (pt.n_rows, x_rec.shape[1]))
+        grad = torch.empty_like(x_rec)
+        g = g.contiguous().float()
+        _lib.check(_lib.load().sh_part_volume_loss_bwd(_lib.ptr(x_rec), x_rec.shape[1] * 3, _lib.ptr(pt.faces), _lib.ptr(pt.slot),
+                                                       _lib.ptr(pt.vptr), _lib.ptr(pt.vcorner), _lib.ptr(vol), x_rec.shape[0], pt.P,
+                                                       x_rec.shape[1], _lib.ptr(g), _lib.ptr(grad), _lib.stream_ptr()),
+                   "sh_part_volume_loss_bwd")
+        return grad, None, None
+
+
+def part_volume_loss_fused(x_rec, x_gt, pt: PartFaceTables):
+    """cal_volloss averaged over the batch (train_funcs.py:56-71, :323-330) on full meshes [B, rows, 3] (dummy row allowed)."""
+    return _PartVolume.apply(x_rec, x_gt, pt)
+
+
+class _ZPart(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, measure, pi, mi, relat):
+        from . import _lib
+        z, measure = z.contiguous().float(), measure.detach().contiguous().float()
+        if not z.is_cuda:
+            raise RuntimeError("semantichuman_amd.zpart_regulariser_fused needs HIP tensors; there is no CPU path")
+        B, P, L = z.shape
+        loss = torch.empty((), dtype=torch.float32, device=z.device)
+        _lib.check(_lib.load().sh_zpart_reg(_lib.ptr(z), _lib.ptr(measure), _lib.ptr(pi), _lib.ptr(mi), B, P, L, measure.shape[1], pi.numel(),
+                                            1 if relat else 0, _lib.ptr(loss), None, None, _lib.stream_ptr()), "sh_zpart_reg")
+        ctx.save_for_backward(z, measure, pi, mi)
+        ctx.relat = relat
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        z, measure, pi, mi = ctx.saved_tensors
+        B, P, L = z.shape
+        dz = torch.empty_like(z)
+        g = g.contiguous().float()
+        _lib.check(_lib.load().sh_zpart_reg(_lib.ptr(z), _lib.ptr(measure), _lib.ptr(pi), _lib.ptr(mi), B, P, L, measure.shape[1], pi.numel(),
+                                            1 if ctx.relat else 0, None, _lib.ptr(dz), _lib.ptr(g), _lib.stream_ptr()), "sh_zpart_reg")
+        return dz, None, None, None, None
+
+
+def zpart_regulariser_fused(z_part, measure, part_idx, measure_idx, relat=True):
+    """zpart_regulariser as one kernel each way (train_funcs.py:145-152)."""
+    return _ZPart.apply(z_part, measure, _i32(part_idx, z_part.device), _i32(measure_idx, z_part.device), relat)
+
+
 def part_volume_loss(x_rec, x_gt, faces, fpi, parts):
     """train_funcs.py:56-71 averaged over the batch (:323-329): mean over `parts` of
     | |vol_rec / vol_gt| - 1 |, vol = sum over the part's faces of (a x b) . c.

@@ -86,8 +86,14 @@ class SemanticContext:
         it = part_losses.index_tensor
         self.kps_keep_t, self.skl_keep_t, self.newskl_keep_t = it(self.kps_keep, device), it(self.skl_keep, device), it(self.newskl_keep, device)
 
+        self.kps_keep_i32 = torch.tensor(self.kps_keep, dtype=torch.int32, device=device)
+        self.part_faces = None                                      # PartFaceTables, built on first use (needs the row count)
+
     def joints(self, x):
-        return torch.matmul(self.J, x[:, :-1, :]).float()          # reference :131,:161,:296
+        """J @ x[:, :-1] (reference :131,:161,:296) - inputs only, no gradient: one kernel."""
+        if x.is_cuda and not x.requires_grad:
+            return part_losses.joint_regress(x, self.J)
+        return torch.matmul(self.J, x[:, :-1, :]).float()
 
 
 def _edit_scales(ctx, opts, B, epoch, measure=None, draw=None):
@@ -200,13 +206,13 @@ def semantic_losses(model, ctx, tx, tx_interp, tx_exc, epoch, measure=None, inte
         terms["edgereg_loss"] = losses.edge_ratio_loss(tx_hat, tx, ctx.face_tables)
         loss = loss + o.edgereg_w * terms["edgereg_loss"]
     if epoch > o.zpartreg_epoch and o.zpartreg_w > 0 and measure is not None:
-        terms["zpartreg_loss"] = part_losses.zpart_regulariser(tx_zpart, measure, ctx.part_index_in_allpart,
-                                                               ctx.part_index_in_measure, o.relat_flag)
+        terms["zpartreg_loss"] = part_losses.zpart_regulariser_fused(tx_zpart, measure, ctx.part_index_in_allpart,
+                                                                     ctx.part_index_in_measure, o.relat_flag)
         loss = loss + o.zpartreg_w * terms["zpartreg_loss"]
 
     if do_interp:
         if o.interp_kps_w > 0:
-            terms["interp_kps_loss"] = (ctx.joints(rec_interp)[:, ctx.kps_keep_t] - new_kps_i).abs().mean()
+            terms["interp_kps_loss"] = part_losses.joint_l1_loss(rec_interp, new_kps_i, ctx.J, ctx.kps_keep_i32)
             loss = loss + o.interp_kps_w * terms["interp_kps_loss"]
         if o.interp_euc_w > 0:
             terms["interp_euc_loss"] = part_losses.part_pairdist_loss(rec_interp, tx_interp, kps_i, ctx.tables, scale=scale,
@@ -216,11 +222,13 @@ def semantic_losses(model, ctx, tx, tx_interp, tx_exc, epoch, measure=None, inte
 
     if do_exc:
         if epoch > o.vol_epoch and o.vol_w > 0 and exc_kind == "ori":
-            terms["vol_loss"] = part_losses.part_volume_loss(rec_exc[:, :-1], tx_exc[:, :-1], ctx.faces, ctx.fpi,
-                                                             ctx.part_index_in_allpart)
+            if ctx.part_faces is None or ctx.part_faces.n_rows != rec_exc.shape[1]:
+                ctx.part_faces = part_losses.PartFaceTables(ctx.f_np, ctx.fpi.cpu().numpy(), ctx.part_index_in_allpart, rec_exc.shape[1],
+                                                            ctx.device)
+            terms["vol_loss"] = part_losses.part_volume_loss_fused(rec_exc, tx_exc, ctx.part_faces)
             loss = loss + o.vol_w * terms["vol_loss"]
         if o.exc_kps_w > 0:
-            terms["exc_kps_loss"] = (ctx.joints(rec_exc)[:, ctx.kps_keep_t] - new_kps_e).abs().mean()
+            terms["exc_kps_loss"] = part_losses.joint_l1_loss(rec_exc, new_kps_e, ctx.J, ctx.kps_keep_i32)
             loss = loss + o.exc_kps_w * terms["exc_kps_loss"]
         if o.exc_euc_w > 0:
             terms["exc_euc_loss"] = part_losses.part_pairdist_loss(rec_exc, tx_exc, kps_e, ctx.tables, scale=None, w_mode=o.w_mode,
