@@ -165,10 +165,216 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const BWParams p) {
     if (qt == 0 && tid < 64 && p0 + tid < p.Cout) p.slab[p.bias_off + (long)split * p.Cout + p0 + tid] = csum;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// LDS-DMA form (bf16 x and dpre, channel counts % 16 == 0, (R * B) % 32 == 0).  The staged kernel above is bound by the
+// round trip of one stage's loads (registers hold one stage, a barrier per stage).  Here a WAVE owns a whole output tile
+// (QT x 16 weight columns by PT x 16 output channels) over a range of 32-row stages and never synchronises with another
+// wave: operand tiles go from memory straight into the wave's private LDS ring by `global_load_lds_dwordx4` (no staging
+// registers, no ds_write; per-lane source addresses make the A tile a gather, and lane = 2 row + half lands every 16-byte
+// piece exactly where the transposed image [16-column block][32 rows][16] wants it), R - 1 stages in flight behind a
+// counted s_waitcnt; fragments come back through ds_read_b64_tr_b16.  The gather-table lines of the wave's vertices are
+// copied into LDS first, so the loop contains no ordinary vector load (one would make hipcc drain the DMA queue).
+struct BDParams {
+    const char* dpre; long dp_rb, dp_bb;
+    const char* x; long x_rb, x_bb;
+    const int* table;
+    float* slab; long slab_stride, bias_off;
+    int B, R, S, Cin, Cout, K;
+    int n_qg, n_pt, nsplit, stages_per_split, n_items;
+    long n_stages;
+};
+constexpr int BD_TBL_INTS = 256;                      // table lines a wave may hold (planner: vertices per wave * S <= this)
+
+template <int QT, int PT>
+constexpr int bd_ring() { return (QT + PT) <= 9 ? 4 : 3; }       // 4 waves x ring <= 160 KiB of LDS
+template <int QT, int PT>
+constexpr int bd_wave_lds() { return bd_ring<QT, PT>() * (QT + PT) * TG_TR_BLK + BD_TBL_INTS * 4; }
+
+template <int QT, int PT>
+__global__ __launch_bounds__(256) void wgrad_bf16_dma_kernel(const BDParams p) {
+    constexpr int R = bd_ring<QT, PT>(), NL = QT + PT, SLOT = NL * TG_TR_BLK;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // XCD-contiguous item order: an XCD works through a contiguous range of row chunks (all column groups of a chunk side by
+    // side), so the rows it gathers - a 1/8 slice of x plus its spiral neighbourhood - stay in its own 4 MiB L2
+    const int item = sh_xcd_remap((int)blockIdx.x, (int)gridDim.x) * 4 + wave;
+    if (item >= p.n_items) return;                                   // whole waves only; no barrier anywhere below
+    char* ring = smem + wave * bd_wave_lds<QT, PT>();
+    int* Tl = reinterpret_cast<int*>(ring + R * SLOT);
+    int it = item;
+    const int qg = it % p.n_qg; it /= p.n_qg;
+    const int pt = it % p.n_pt; const int split = it / p.n_pt;
+    const long st0 = (long)split * p.stages_per_split;
+    const int nst = (int)min((long)p.stages_per_split, p.n_stages - st0);
+    if (nst <= 0) return;
+    const int S = p.S, B = p.B;
+    const int v_first = (int)((st0 * 32) / B);
+    {   // this wave's table lines -> LDS (ordinary loads, finished before the DMA loop starts)
+        const int v_last = (int)(((st0 + nst) * 32 - 1) / B);
+        const int n = (v_last - v_first + 1) * S;
+        for (int i = lane; i < n; i += 64) Tl[i] = p.table[(long)v_first * S + i];
+    }
+    // per 16-column block: (spiral position, first channel); blocks past K / Cout duplicate block 0 (their products are never stored)
+    int s_blk[QT], c_blk[QT], co_blk[PT];
+    const int q0 = qg * (16 * QT), p0 = pt * (16 * PT);
+#pragma unroll
+    for (int k = 0; k < QT; ++k) {
+        const int col = q0 + 16 * k < p.K ? q0 + 16 * k : q0;
+        s_blk[k] = col / p.Cin; c_blk[k] = col - s_blk[k] * p.Cin;
+    }
+#pragma unroll
+    for (int k = 0; k < PT; ++k) co_blk[k] = p0 + 16 * k < p.Cout ? p0 + 16 * k : p0;
+    const int row = lane >> 1, half8 = (lane & 1) * 8;
+    typedef __attribute__((address_space(3))) char* lptr_t;
+    // LDS-DMA through inline asm: issued through the builtin, hipcc protects every later LDS read with s_waitcnt vmcnt(0)
+    // (it cannot see that the read slot is not the slot being filled) and the ring never holds more than one stage in
+    // flight.  M0 = wave-uniform LDS byte address of the 1-KiB block, lane l lands at + 16 l (cdna_hip_programming.md 5.7).
+    auto dma16 = [](const char* gsrc, unsigned lds_dst) {
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory", "m0");
+    };
+    const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_t)ring);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // the table lines are in LDS
+
+    // (vertex, batch entry) of this lane's row in the NEXT stage to issue: advanced by 32 rows per stage, no division in the loop
+    int iv, ib;
+    {
+        const long r_lin = st0 * 32 + row;
+        iv = (int)(r_lin / B); ib = (int)(r_lin - (long)iv * B);
+    }
+    int issued = 0;
+    auto issue = [&]() {                                             // next stage (the last one again past the end) -> slot issued % R
+        const unsigned slot = ring_lds + (unsigned)((issued % R) * SLOT);
+        const int* tl = Tl + (iv - v_first) * S;
+        const char* xb = p.x + (long)ib * p.x_bb + 2 * half8;
+        const char* db = p.dpre + (long)iv * p.dp_rb + (long)ib * p.dp_bb + 2 * half8;
+#pragma unroll
+        for (int k = 0; k < QT; ++k) dma16(xb + (unsigned long)(unsigned)tl[s_blk[k]] * (unsigned long)p.x_rb + 2 * c_blk[k], slot + (unsigned)(k * TG_TR_BLK));
+#pragma unroll
+        for (int k = 0; k < PT; ++k) dma16(db + 2 * co_blk[k], slot + (unsigned)((QT + k) * TG_TR_BLK));
+        ++issued;
+        if (issued < nst) {                                          // advance by 32 rows (uniform branch; B >= 1)
+            ib += 32;
+            while (ib >= B) { ib -= B; ++iv; }
+        }
+    };
+
+    f32x4 acc[QT][PT], accb[PT];
+#pragma unroll
+    for (int i = 0; i < QT; ++i)
+#pragma unroll
+        for (int j = 0; j < PT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < PT; ++j) accb[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bf16x8 ones = {(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f};
+    const bool want_bias = qg == 0;
+
+#pragma unroll
+    for (int d = 0; d < R - 1; ++d) issue();
+    for (int st = 0; st < nst; ++st) {
+        // stages st .. st+R-2 are in flight (clamped repeats past the end keep the count constant): wait for the oldest
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * NL) : "memory");
+        issue();                                                     // stage st+R-1 into the slot stage st-1 was read from
+        const char* slot = ring + (st % R) * SLOT;
+        bf16x8 fb[PT];
+#pragma unroll
+        for (int j = 0; j < PT; ++j) fb[j] = tg_tr_frag(slot + QT * TG_TR_BLK, j, 0, lane);
+#pragma unroll
+        for (int i = 0; i < QT; ++i) {
+            const bf16x8 fa = tg_tr_frag(slot, i, 0, lane);
+#pragma unroll
+            for (int j = 0; j < PT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (want_bias) {                                             // column sums of the dpre tile: ones^T . P
+#pragma unroll
+            for (int j = 0; j < PT; ++j) accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fb[j], accb[j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // this slot's reads are done before a later DMA may overwrite it
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the clamped tail loads still write this wave's LDS
+
+    float* slab = p.slab + (long)split * p.slab_stride;
+#pragma unroll
+    for (int i = 0; i < QT; ++i)
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+            const int q = q0 + 16 * i + 4 * (lane >> 4), co = p0 + 16 * j + (lane & 15);
+            if (q < p.K && co < p.Cout) *reinterpret_cast<f32x4*>(slab + (long)co * p.K + q) = acc[i][j];
+        }
+    if (want_bias && lane < 16) {
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+            const int co = p0 + 16 * j + lane;
+            if (co < p.Cout) p.slab[p.bias_off + (long)split * p.Cout + co] = accb[j][0];      // row 0 of ones^T . P
+        }
+    }
+}
+
+struct BWPlan { int dma, qt, pt, n_qg, n_pt, nsplit, sps; long n_stages; };
+BWPlan plan_bw(int B, int R, int S, int Cin, int Cout) {
+    BWPlan w{};
+    static const int dma_on = sh_env_int("SH_BW_DMA", 1, 0, 1);
+    const int K = S * Cin;
+    const long rows = (long)R * B;
+    w.dma = dma_on && Cin % 16 == 0 && Cout % 16 == 0 && rows % 32 == 0;
+    if (!w.dma) return w;
+    const int pb = sh_cdiv(Cout, 16);
+    w.pt = pb >= 4 ? 4 : pb >= 2 ? 2 : 1;
+    w.qt = w.pt == 4 ? 4 : w.pt == 2 ? 6 : 8;                            // QT + PT <= 9: a ring of 4 stages per wave fits
+    if (K <= 16 * 4) w.qt = 4;
+    w.n_qg = sh_cdiv(K, 16 * w.qt);
+    w.n_pt = sh_cdiv(Cout, 16 * w.pt);
+    w.n_stages = rows / 32;
+    static const int wave_target = sh_env_int("SH_BW_WAVES", 2048, 64, 1 << 16);
+    static const int slab_mb = sh_env_int("SH_BW_SLAB_MB", 32, 1, 4096);
+    const long tiles = (long)w.n_qg * w.n_pt;
+    long ns = wave_target / tiles;
+    const long cap = ((long)slab_mb << 20) / ((long)Cout * K * 4);
+    if (ns > cap) ns = cap;
+    if (ns > w.n_stages / 6) ns = w.n_stages / 6;                        // >= 6 stages per wave (the ring holds 3-4)
+    if (ns < 1) ns = 1;
+    long sps = (w.n_stages + ns - 1) / ns;
+    // the wave's table lines must fit its LDS area: vertices per wave <= BD_TBL_INTS / S
+    const long max_v = BD_TBL_INTS / S - 2;
+    const long max_sps = max_v * B / 32;
+    if (max_sps < 1) { w.dma = 0; return w; }
+    if (sps > max_sps) sps = max_sps;
+    w.sps = (int)sps;
+    w.nsplit = (int)((w.n_stages + sps - 1) / sps);
+    if ((long)w.nsplit > 4 * cap + 64) { w.dma = 0; return w; }          // a table-bound split would need too many slabs: staged form
+    return w;
+}
+
+template <int QT, int PT>
+int launch_bd(BDParams& p, hipStream_t st) {
+    auto kern = wgrad_bf16_dma_kernel<QT, PT>;
+    const size_t smem = (size_t)4 * bd_wave_lds<QT, PT>();
+    static bool attr_set = false;
+    if (smem > 65536 && !attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            (void)hipGetLastError();
+            sh_set_error("wgrad_bf16_dma: cannot raise the dynamic LDS limit to %zu bytes", smem);
+            return SH_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    const int grid = sh_cdiv(p.n_items, 4);
+    ShProfScope ps(st, "wgrad_bf16_dma_kernel<%d, %d>|R=%d B=%d S=%d Cin=%d N=%d grid=%d split=%d", QT, PT, p.R, p.B, p.S, p.Cin, p.Cout, grid,
+                   p.nsplit);
+    SH_LAUNCH_PS(ps, kern, dim3(grid), dim3(256), smem, st, p);
+    SH_CHECK_LAUNCH("wgrad_bf16_dma");
+    return SH_OK;
+}
+
 }  // namespace
 
 // shared with the slab reduction in spiral_conv.hip
 int sh_wgrad_bf16_nsplit(int B, int R, int S, int Cin, int Cout) {
+    {
+        const BWPlan w = plan_bw(B, R, S, Cin, Cout);
+        if (w.dma) return w.nsplit;
+    }
     const int Kq = Cin == 3 ? 4 * S : S * Cin, K = S * Cin;
     const long tiles = (long)sh_cdiv(Kq, 64) * sh_cdiv(Cout, 64);
     const long nst = ((long)R * B + 63) >> 6;
@@ -208,6 +414,25 @@ int sh_spiral_conv_bwd_wgt_bf16(const void* dpre, int dp_dtype, int64_t dp_sv, i
                "sh_spiral_conv_bwd_wgt_bf16: x must be 16-byte aligned with 16-byte-multiple strides");
     SH_REQUIRE(pc3 || ((reinterpret_cast<uintptr_t>(dpre) | (uintptr_t)(dp_sv * pe) | (uintptr_t)(dp_sb * pe)) & 15) == 0, SH_ERR_INVALID_ARG,
                "sh_spiral_conv_bwd_wgt_bf16: dpre must be 16-byte aligned with 16-byte-multiple strides");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!xc3 && !pc3) {
+        const BWPlan w = plan_bw(B, R, S, Cin, Cout);
+        if (w.dma) {
+            BDParams d{};
+            d.dpre = static_cast<const char*>(dpre); d.dp_rb = dp_sv * 2; d.dp_bb = dp_sb * 2;
+            d.x = static_cast<const char*>(x); d.x_rb = x_sv * 2; d.x_bb = x_sb * 2;
+            d.table = table; d.slab = static_cast<float*>(workspace);
+            d.B = B; d.R = R; d.S = S; d.Cin = Cin; d.Cout = Cout; d.K = S * Cin;
+            d.slab_stride = (long)Cout * d.K; d.bias_off = (long)w.nsplit * d.slab_stride;
+            d.n_qg = w.n_qg; d.n_pt = w.n_pt; d.nsplit = w.nsplit; d.stages_per_split = w.sps; d.n_stages = w.n_stages;
+            d.n_items = w.n_qg * w.n_pt * w.nsplit;
+            if (w.qt == 4 && w.pt == 4) return launch_bd<4, 4>(d, st);
+            if (w.qt == 6 && w.pt == 2) return launch_bd<6, 2>(d, st);
+            if (w.qt == 8 && w.pt == 1) return launch_bd<8, 1>(d, st);
+            if (w.qt == 4 && w.pt == 2) return launch_bd<4, 2>(d, st);
+            return launch_bd<4, 1>(d, st);
+        }
+    }
     BWParams p{};
     p.dpre = static_cast<const char*>(dpre); p.dp_rb = dp_sv * pe; p.dp_bb = dp_sb * pe;
     p.x = static_cast<const char*>(x); p.x_rb = x_sv * xe; p.x_bb = x_sb * xe;
@@ -222,7 +447,6 @@ int sh_spiral_conv_bwd_wgt_bf16(const void* dpre, int dp_dtype, int64_t dp_sv, i
     p.slab_stride = (long)Cout * p.K;
     p.bias_off = (long)p.nsplit * p.slab_stride;
     const int grid = p.n_qt * p.n_pt * p.nsplit;
-    hipStream_t st = static_cast<hipStream_t>(stream);
     ShProfScope ps(st, "wgrad_bf16_kernel<%d, %d>|R=%d B=%d S=%d Cin=%d N=%d grid=%d split=%d", (int)xc3, (int)pc3, R, B, S, Cin, Cout, grid, p.nsplit);
     if (xc3) SH_LAUNCH_PS(ps, (wgrad_bf16_kernel<true, false>), dim3(grid), dim3(256), 0, st, p);
     else if (pc3) SH_LAUNCH_PS(ps, (wgrad_bf16_kernel<false, true>), dim3(grid), dim3(256), 0, st, p);
