@@ -38,6 +38,7 @@ PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
 def conv_launch_table(model, B):
     """Algorithmic FLOPs / bytes per launch of every conv kernel instance, keyed by the kernel
     name the library's profiler reports (DESIGN.md 'Roofline accounting')."""
+    from semantichuman_amd import _lib
     out = {}
 
     def add(name, flops, nbytes):
@@ -86,7 +87,11 @@ def conv_launch_table(model, B):
                 # backward-data = the same kernel over the transposed table; algorithmic FLOPs are
                 # those of the R*S real (row, position) pairs, not of the padded n_in*S table
                 add(gg_name(*nt_split(st.n_in, st.cin, st.cout), cg=st.cout, bwd="true"), fl, byt)
-            if st.cin % 4 == 0 or st.cin == 3:         # same choices as plan_wgrad() in csrc/spiral_conv.hip
+            not_first = not (first and stack is model._enc_stack)
+            if not_first and st.R == st.n_in and _lib.load().sh_spiral_conv_bwd_wgt_thin_ok(B, st.n_in, st.S, st.cin, st.cout, 0):
+                # the 16 -> 3 channel layer: role-swapped weight gradient (csrc/wgrad_thin.hip), same algorithmic work
+                add("wgrad_thin_kernel<f32>", fl, byt)
+            elif st.cin % 4 == 0 or st.cin == 3:       # same choices as plan_wgrad() in csrc/spiral_conv.hip
                 cot = nt(st.cout)
                 add("wgrad_stream_kernel<%d, %d, %d, %s, %s>" % (cot, 1 if B <= 4 else 4, 3 if cot <= 2 else 2,
                                                                  "true" if B % (4 if B <= 4 else 16) == 0 else "false",
@@ -127,6 +132,8 @@ def bf16_work_table(model, B):
 def parse_tag(name, shape):
     """(family, bwd, R, S, C, N) of a profiler record of the bf16 conv family, or None."""
     fam = name.split("<")[0]
+    if fam in ("wgrad_bf16_dma_kernel", "wgrad_thin_kernel"):       # the other two forms of the bf16 weight gradient
+        fam = "wgrad_bf16_kernel"
     if fam not in ("conv_bf16_kernel", "wgrad_bf16_kernel"):
         return None
     f = dict(kv.split("=") for kv in shape.split() if "=" in kv)
@@ -349,6 +356,7 @@ def main():
 
     xin = torch.empty((B, h.sizes[0] + 1, 3), dtype=torch.float32, device=dev)
     last = {}                                     # the step's loss tensor (a fixed address inside the graph's pool when captured)
+    unit = torch.ones((), dtype=torch.float32, device=dev)   # d loss / d loss, made once instead of one fill launch per step
 
     def fwd_bwd():
         optim.zero_grad(set_to_none=True)
@@ -356,7 +364,7 @@ def main():
         loss, _ = sh.recon_loss(x_hat, xin, ft, 1e-2)     # l1 + 1e-2 * edge (train_funcs.py:501-508, traincfg.yaml:41), fused
         if reducer:
             reducer.prepare()
-        loss.backward()
+        loss.backward(unit)
         last["loss"] = loss.detach()
 
     use_graph = (not args.no_graph) and world == 1 and not force_reducer

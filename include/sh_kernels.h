@@ -270,15 +270,17 @@ SH_API int sh_edge_ratio_loss_bwd(const float* x_hat, const float* x, const int3
                            const float* gscale, float* grad, sh_stream_t stream);
 
 /* The reconstruction loss of the plain training loop in one piece (train_funcs.py:501-508):
- *   out3[0] = out3[1] + edge_w * out3[2],  out3[1] = mean |x - x_hat| (all N1 rows),  out3[2] = the edge-ratio term above;
- * bwd writes grad = gscale[0] * d out3[0] / d x_hat.  Three launches instead of eleven; same arithmetic as the separate
- * kernels.  workspace: sh_recon_loss_workspace() bytes. */
+ *   total[0] = parts[0] + edge_w * parts[1],  parts[0] = mean |x - x_hat| (all N1 rows),  parts[1] = the edge-ratio term above;
+ * bwd writes grad = gscale[0] * d total / d x_hat.  Three launches instead of eleven; same arithmetic as the separate
+ * kernels.  workspace: sh_recon_loss_workspace() bytes.
+ * bwd takes the vertex -> neighbour lists instead of the corner lists: vptr [N1+1] counts the corners of every vertex (as
+ * above), vnbr int32 [2 * 3F] holds, corner by corner in that order, the two other vertices of the corner's face
+ * (faces[f][(k+1)%3], faces[f][(k+2)%3]) - the same sum in the same order without the corner -> face indirection. */
 SH_API size_t sh_recon_loss_workspace(void);
 SH_API int sh_recon_loss_fwd(const float* x_hat, const float* x, const int32_t* faces, int B, int N1, int F, float edge_w,
-                      float* out3, void* workspace, sh_stream_t stream);
-SH_API int sh_recon_loss_bwd(const float* x_hat, const float* x, const int32_t* faces, const int32_t* vptr,
-                      const int32_t* vcorner, int B, int N1, int F, float edge_w, const float* gscale, float* grad,
-                      sh_stream_t stream);
+                      float* total, float* parts, void* workspace, sh_stream_t stream);
+SH_API int sh_recon_loss_bwd(const float* x_hat, const float* x, const int32_t* vptr, const int32_t* vnbr, int B, int N1, int F,
+                      float edge_w, const float* gscale, float* grad, sh_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Part-wise pairwise-distance loss of the semantic training loop (train_funcs.py:243-284 and
@@ -413,6 +415,19 @@ SH_API int sh_spiral_conv_bwd_data_bf16(const void* dpre, int dp_dtype, int64_t 
                                         int64_t dx_sv, int64_t dx_sb, const void* yprev, int64_t yp_sv, int64_t yp_sb,
                                         int act_prev, int zero_row, int B, int n_in, int S, int Cin, int Cout,
                                         sh_stream_t stream);
+
+/* Weight gradient of a 16 -> 3 channel layer (the decoder's last conv, models.py:146-153) in role-swapped form:
+ *   dW[co][s][ci] = sum_{u,b} x[u,b,ci] * dpre_ext[table_t[u,s], b, co]
+ * x is read once and the three-channel gradient is gathered through the TRANSPOSED table - the table and the extended
+ * gradient buffer (rows of irregular vertices pre-summed behind the R real rows) that sh_spiral_conv_bwd_data[_bf16] takes,
+ * so the caller runs the pre-sum launches first.  dpre_ext fp32 [rows][B][3], x [n_in][B][16] of the path's dtype, both
+ * vertex-major and contiguous; needs R == n_in, S <= 10, B % 32 == 0 (sh_spiral_conv_bwd_wgt_thin_ok() tells).  Writes
+ * partial slabs into `workspace` in the layout and count of sh_spiral_conv_bwd_wgt (path_dtype SH_DTYPE_F32) or
+ * sh_spiral_conv_bwd_wgt_bf16 (SH_DTYPE_BF16): the matching ..._reduce_multi launch finishes dW and dbias. */
+SH_API int sh_spiral_conv_bwd_wgt_thin_ok(int B, int n_in, int S, int Cin, int Cout, int path_dtype);
+SH_API int sh_spiral_conv_bwd_wgt_thin(const float* dpre_ext, int64_t dp_sv, int64_t dp_sb, const void* x, int x_dtype, int64_t x_sv,
+                                int64_t x_sb, const int32_t* table_t, void* workspace, size_t workspace_bytes, int B, int R,
+                                int n_in, int S, int Cin, int Cout, int path_dtype, sh_stream_t stream);
 
 /* sh_spiral_conv_bwd_wgt in bf16: x / dpre bf16 (channels % 8 == 0) or fp32 with exactly 3 channels; writes fp32 partial
  * slabs into `workspace` (>= sh_spiral_conv_bwd_wgt_workspace_bf16 bytes); sh_spiral_conv_bwd_wgt_reduce_multi_bf16 sums

@@ -1262,6 +1262,11 @@ int sh_weight_transpose(const float* weight, float* weight_t, int S, int Cin, in
     return SH_OK;
 }
 
+}  // extern "C"
+// slab count of the fp32 weight-gradient plan; shared with the thin-layer kernel in wgrad_thin.hip
+int sh_wgrad_f32_nsplit(int B, int R, int S, int Cin, int Cout) { return plan_wgrad(B, R, S, Cin, Cout).nrc; }
+extern "C" {
+
 size_t sh_spiral_conv_bwd_wgt_workspace(int B, int R, int S, int Cin, int Cout) {
     if (B <= 0 || R <= 0 || S <= 0 || Cin <= 0 || Cout <= 0) return 0;
     const WGPlan w = plan_wgrad(B, R, S, Cin, Cout);

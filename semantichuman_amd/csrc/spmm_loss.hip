@@ -6,7 +6,7 @@
 
 namespace {
 
-constexpr int RED_BLOCKS = 1024;   // partial sums of the first reduction stage
+constexpr int RED_BLOCKS = 2048;   // partial sums of the first reduction stage
 
 // y[r,b,:] = sum_e val[e] * x[col[e],b,:]   (+ optional act'(yprev) epilogue, zero_row)
 // One workgroup per output row (grid-stride over rows): the row's CSR entries are wave-uniform
@@ -131,6 +131,27 @@ __global__ void vertex_l2_partial_kernel(const float* __restrict__ a, const floa
     if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
 
+// one 12-byte point / index triple as a single dwordx3 access (4-byte aligned)
+struct __attribute__((packed, aligned(4))) P3 { float x, y, z; };
+struct __attribute__((packed, aligned(4))) I3 { int a, b, c; };
+__device__ __forceinline__ P3 ld3(const float* p, int i) { return *reinterpret_cast<const P3*>(p + 3 * i); }
+__device__ __forceinline__ float edge_len3(const P3& a, const P3& b) {
+    const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+    return sqrtf(dx * dx + dy * dy + dz * dz);
+}
+// same arithmetic as edge_grad below on points already in registers
+__device__ __forceinline__ void edge_grad3(const P3& hv, const P3& gv, const P3& ho, const P3& go, float* g) {
+    const float dx = hv.x - ho.x, dy = hv.y - ho.y, dz = hv.z - ho.z;
+    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float t = edge_len3(gv, go) + 0.00001f;
+    const float r = len / t - 1.f;
+    const float sg = r > 0.f ? 1.f : (r < 0.f ? -1.f : 0.f);
+    if (len > 0.f) {
+        const float k = sg / (len * t);
+        g[0] += k * dx; g[1] += k * dy; g[2] += k * dz;
+    }
+}
+
 __device__ __forceinline__ float edge_len(const float* p, int i, int j) {
     const float dx = p[3 * i] - p[3 * j], dy = p[3 * i + 1] - p[3 * j + 1], dz = p[3 * i + 2] - p[3 * j + 2];
     return sqrtf(dx * dx + dy * dy + dz * dz);
@@ -207,19 +228,21 @@ __global__ void recon_partial_kernel(const float* __restrict__ xh, const float* 
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nf; i += (long)gridDim.x * blockDim.x) {
         const long bb = i / F;
         const int f = (int)(i - bb * F);
-        const int ia = faces[3 * f], ib = faces[3 * f + 1], ic = faces[3 * f + 2];
+        const I3 fc = *reinterpret_cast<const I3*>(faces + 3 * f);
         const float* ph = xh + bb * N1 * 3;
         const float* pg = x + bb * N1 * 3;
-        s += fabsf(edge_len(ph, ia, ib) / (edge_len(pg, ia, ib) + 0.00001f) - 1.f);
-        s += fabsf(edge_len(ph, ib, ic) / (edge_len(pg, ib, ic) + 0.00001f) - 1.f);
-        s += fabsf(edge_len(ph, ia, ic) / (edge_len(pg, ia, ic) + 0.00001f) - 1.f);
+        const P3 ha = ld3(ph, fc.a), hb = ld3(ph, fc.b), hc = ld3(ph, fc.c), ga = ld3(pg, fc.a), gb = ld3(pg, fc.b), gc = ld3(pg, fc.c);
+        s += fabsf(edge_len3(ha, hb) / (edge_len3(ga, gb) + 0.00001f) - 1.f);
+        s += fabsf(edge_len3(hb, hc) / (edge_len3(gb, gc) + 0.00001f) - 1.f);
+        s += fabsf(edge_len3(ha, hc) / (edge_len3(ga, gc) + 0.00001f) - 1.f);
     }
     const float t2 = block_sum(s, red);
     if (threadIdx.x == 0) part[RED_BLOCKS + blockIdx.x] = t2;
 }
 
-// out[0] = rec + w * edge, out[1] = rec, out[2] = edge (fixed-order double sums)
-__global__ void recon_final_kernel(const float* __restrict__ part, int np, double scale1, double scale2, float w, float* __restrict__ out) {
+// total[0] = rec + w * edge, parts[0] = rec, parts[1] = edge (fixed-order double sums)
+__global__ void recon_final_kernel(const float* __restrict__ part, int np, double scale1, double scale2, float w, float* __restrict__ total,
+                                   float* __restrict__ parts) {
     __shared__ double red[2][256];
     double s1 = 0.0, s2 = 0.0;
     for (int i = threadIdx.x; i < np; i += 256) { s1 += (double)part[i]; s2 += (double)part[RED_BLOCKS + i]; }
@@ -231,14 +254,16 @@ __global__ void recon_final_kernel(const float* __restrict__ part, int np, doubl
     }
     if (threadIdx.x == 0) {
         const float rec = (float)(red[0][0] * scale1), edge = (float)(red[1][0] * scale2);
-        out[0] = rec + w * edge; out[1] = rec; out[2] = edge;
+        total[0] = rec + w * edge; parts[0] = rec; parts[1] = edge;
     }
 }
 
 // grad[b,v,:] = g * ( sign(x_hat - x) / n  +  w / (B F) * d edge / d x_hat[b,v,:] )
-__global__ void recon_bwd_kernel(const float* __restrict__ xh, const float* __restrict__ x, const int* __restrict__ faces,
-                                 const int* __restrict__ vptr, const int* __restrict__ vcorner, int B, int N1, int F, float w,
-                                 const float* __restrict__ gscale, float* __restrict__ grad) {
+// vnbr lists, per vertex and in corner order, the other end of every incident face edge (two per corner, vptr counts
+// corners): the gradient is a gather without the corner -> face -> vertex indirection, four neighbours in flight.
+__global__ __launch_bounds__(256) void recon_bwd_kernel(const float* __restrict__ xh, const float* __restrict__ x, const int* __restrict__ vptr,
+                                                        const int* __restrict__ vnbr, int B, int N1, int F, float w,
+                                                        const float* __restrict__ gscale, float* __restrict__ grad) {
     const float g0 = gscale[0];
     const float s1 = g0 / ((float)B * (float)N1 * 3.f), s2 = g0 * w / ((float)B * (float)F);
     const long n = (long)B * N1;
@@ -247,18 +272,26 @@ __global__ void recon_bwd_kernel(const float* __restrict__ xh, const float* __re
         const int v = (int)(i - bb * N1);
         const float* ph = xh + bb * N1 * 3;
         const float* pg = x + bb * N1 * 3;
+        const int p0 = 2 * vptr[v], p1 = 2 * vptr[v + 1];
+        const P3 hv = ld3(ph, v), gv = ld3(pg, v);
         float g[3] = {0.f, 0.f, 0.f};
-        for (int e = vptr[v]; e < vptr[v + 1]; ++e) {
-            const int c = vcorner[e], f = c / 3, kx = c - 3 * f;
-            const int o1 = faces[3 * f + (kx + 1) % 3], o2 = faces[3 * f + (kx + 2) % 3];
-            edge_grad(ph, pg, v, o1, g);
-            edge_grad(ph, pg, v, o2, g);
-        }
+        for (int e = p0; e < p1; e += 4) {
+            int o[4];
+            P3 ho[4], go[4];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const float df = ph[3 * v + d] - pg[3 * v + d];
-            grad[i * 3 + d] = s2 * g[d] + (df > 0.f ? s1 : (df < 0.f ? -s1 : 0.f));
+            for (int k = 0; k < 4; ++k) o[k] = vnbr[e + k < p1 ? e + k : p1 - 1];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { ho[k] = ld3(ph, o[k]); go[k] = ld3(pg, o[k]); }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (e + k < p1) edge_grad3(hv, gv, ho[k], go[k], g);
         }
+        const float df[3] = {hv.x - gv.x, hv.y - gv.y, hv.z - gv.z};
+        P3 o3;
+        o3.x = s2 * g[0] + (df[0] > 0.f ? s1 : (df[0] < 0.f ? -s1 : 0.f));
+        o3.y = s2 * g[1] + (df[1] > 0.f ? s1 : (df[1] < 0.f ? -s1 : 0.f));
+        o3.z = s2 * g[2] + (df[2] > 0.f ? s1 : (df[2] < 0.f ? -s1 : 0.f));
+        *reinterpret_cast<P3*>(grad + i * 3) = o3;
     }
 }
 
@@ -348,26 +381,27 @@ int sh_edge_ratio_loss_fwd(const float* x_hat, const float* x, const int32_t* fa
 
 size_t sh_recon_loss_workspace(void) { return (size_t)2 * RED_BLOCKS * sizeof(float); }
 
-int sh_recon_loss_fwd(const float* x_hat, const float* x, const int32_t* faces, int B, int N1, int F, float edge_w, float* out3,
-                      void* workspace, sh_stream_t stream) {
-    SH_REQUIRE(x_hat && x && faces && out3 && workspace && B > 0 && N1 > 0 && F > 0, SH_ERR_INVALID_ARG, "sh_recon_loss_fwd: bad argument");
+int sh_recon_loss_fwd(const float* x_hat, const float* x, const int32_t* faces, int B, int N1, int F, float edge_w, float* total,
+                      float* parts, void* workspace, sh_stream_t stream) {
+    SH_REQUIRE(x_hat && x && faces && total && parts && workspace && B > 0 && N1 > 0 && F > 0, SH_ERR_INVALID_ARG,
+               "sh_recon_loss_fwd: bad argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* part = static_cast<float*>(workspace);
     const long n = (long)B * N1 * 3;
-    const int nb = grid_for(n, 2048) < RED_BLOCKS ? grid_for(n, 2048) : RED_BLOCKS;
+    const int nb = grid_for(n, 1024) < RED_BLOCKS ? grid_for(n, 1024) : RED_BLOCKS;
     hipLaunchKernelGGL(recon_partial_kernel, dim3(nb), dim3(256), 0, st, x_hat, x, faces, B, N1, F, part);
-    hipLaunchKernelGGL(recon_final_kernel, dim3(1), dim3(256), 0, st, part, nb, 1.0 / (double)n, 1.0 / ((double)B * F), edge_w, out3);
+    hipLaunchKernelGGL(recon_final_kernel, dim3(1), dim3(256), 0, st, part, nb, 1.0 / (double)n, 1.0 / ((double)B * F), edge_w, total, parts);
     SH_CHECK_LAUNCH("recon_loss_fwd");
     return SH_OK;
 }
 
-int sh_recon_loss_bwd(const float* x_hat, const float* x, const int32_t* faces, const int32_t* vptr, const int32_t* vcorner, int B,
-                      int N1, int F, float edge_w, const float* gscale, float* grad, sh_stream_t stream) {
-    SH_REQUIRE(x_hat && x && faces && vptr && vcorner && gscale && grad && B > 0 && N1 > 0 && F > 0, SH_ERR_INVALID_ARG,
+int sh_recon_loss_bwd(const float* x_hat, const float* x, const int32_t* vptr, const int32_t* vnbr, int B, int N1, int F, float edge_w,
+                      const float* gscale, float* grad, sh_stream_t stream) {
+    SH_REQUIRE(x_hat && x && vptr && vnbr && gscale && grad && B > 0 && N1 > 0 && F > 0, SH_ERR_INVALID_ARG,
                "sh_recon_loss_bwd: bad argument");
     const long n = (long)B * N1;
-    hipLaunchKernelGGL(recon_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x_hat, x, faces, vptr,
-                       vcorner, B, N1, F, edge_w, gscale, grad);
+    hipLaunchKernelGGL(recon_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x_hat, x, vptr, vnbr, B,
+                       N1, F, edge_w, gscale, grad);
     SH_CHECK_LAUNCH("recon_loss_bwd");
     return SH_OK;
 }

@@ -123,9 +123,15 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
         }
         if (s.kind == 0) {
             SH_REQUIRE(workspace && workspace[i], SH_ERR_INVALID_ARG, "sh_stack_backward: no workspace for step %d", i);
-            rc = sh_spiral_conv_bwd_wgt(cur, cl.sv, cl.sb, inp, il.sv, il.sb, s.table, nullptr, nullptr, workspace[i],
-                                        workspace_bytes[i], B, s.R, s.S, s.cin, s.cout, stream);
-            if (rc != SH_OK) return rc;
+            // a 16 -> 3 channel layer takes its weight gradient in role-swapped form (wgrad_thin.hip): it reads the extended
+            // gradient buffer through the transposed table, so it runs after the pre-sum launches below
+            const bool thin = want_in && s.table_t && s.R == s.n_in && il.sb == s.cin && il.sv == (long)B * s.cin && cl.sb == s.cout &&
+                              cl.sv == (long)B * s.cout && sh_spiral_conv_bwd_wgt_thin_ok(B, s.n_in, s.S, s.cin, s.cout, SH_DTYPE_F32);
+            if (!thin) {
+                rc = sh_spiral_conv_bwd_wgt(cur, cl.sv, cl.sb, inp, il.sv, il.sb, s.table, nullptr, nullptr, workspace[i],
+                                            workspace_bytes[i], B, s.R, s.S, s.cin, s.cout, stream);
+                if (rc != SH_OK) return rc;
+            }
             job_ws[njobs] = workspace[i]; job_dW[njobs] = dW[s.param]; job_db[njobs] = dbias ? dbias[s.param] : nullptr;
             jB[njobs] = B; jR[njobs] = s.R; jS[njobs] = s.S; jCi[njobs] = s.cin; jCo[njobs] = s.cout;
             SH_REQUIRE(job_dW[njobs], SH_ERR_INVALID_ARG, "sh_stack_backward: no dW buffer for parameter %d", s.param);
@@ -141,6 +147,11 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
                 if (s.n2) {
                     rc = sh_spmm(s.sum2.rowptr, s.sum2.col, s.sum2.val, cur, cl.sv, cl.sb, mut + (long)(s.R + s.n1) * cl.sv,
                                  cl.sv, cl.sb, nullptr, 0, 0, 0, -1, B, s.n2, s.cout, stream);
+                    if (rc != SH_OK) return rc;
+                }
+                if (thin) {
+                    rc = sh_spiral_conv_bwd_wgt_thin(cur, cl.sv, cl.sb, inp, SH_DTYPE_F32, il.sv, il.sb, s.table_t, workspace[i],
+                                                     workspace_bytes[i], B, s.R, s.n_in, s.S, s.cin, s.cout, SH_DTYPE_F32, stream);
                     if (rc != SH_OK) return rc;
                 }
                 rc = sh_spiral_conv_bwd_data(cur, cl.sv, cl.sb, s.table_t, weight_t[i], gi, gl.sv, gl.sb, yprev, yl.sv, yl.sb,
@@ -282,9 +293,15 @@ int sh_stack_backward_bf16(int n_steps, const sh_stack_step* steps, const void* 
         }
         if (s.kind == 0) {
             SH_REQUIRE(workspace && workspace[i], SH_ERR_INVALID_ARG, "sh_stack_backward_bf16: no workspace for step %d", i);
-            rc = sh_spiral_conv_bwd_wgt_bf16(cur, cd, cl.sv, cl.sb, inp, ind, il.sv, il.sb, s.table, workspace[i], workspace_bytes[i], B, s.R,
-                                             s.S, s.cin, s.cout, stream);
-            if (rc != SH_OK) return rc;
+            // role-swapped weight gradient of a 16 -> 3 channel layer (see sh_stack_backward)
+            const bool thin = want_in && s.table_t && cd == SH_DTYPE_F32 && ind == SH_DTYPE_BF16 && s.R == s.n_in && il.sb == s.cin &&
+                              il.sv == (long)B * s.cin && cl.sb == s.cout && cl.sv == (long)B * s.cout &&
+                              sh_spiral_conv_bwd_wgt_thin_ok(B, s.n_in, s.S, s.cin, s.cout, SH_DTYPE_BF16);
+            if (!thin) {
+                rc = sh_spiral_conv_bwd_wgt_bf16(cur, cd, cl.sv, cl.sb, inp, ind, il.sv, il.sb, s.table, workspace[i], workspace_bytes[i], B,
+                                                 s.R, s.S, s.cin, s.cout, stream);
+                if (rc != SH_OK) return rc;
+            }
             job_ws[njobs] = workspace[i]; job_dW[njobs] = dW[s.param]; job_db[njobs] = dbias ? dbias[s.param] : nullptr;
             jB[njobs] = B; jR[njobs] = s.R; jS[njobs] = s.S; jCi[njobs] = s.cin; jCo[njobs] = s.cout;
             SH_REQUIRE(job_dW[njobs], SH_ERR_INVALID_ARG, "sh_stack_backward_bf16: no dW buffer for parameter %d", s.param);
@@ -303,6 +320,11 @@ int sh_stack_backward_bf16(int n_steps, const sh_stack_step* steps, const void* 
                                      nullptr, 0, 0, 0, -1, B, n, s.cout, stream);
                     else
                         rc = sh_spmm_bf16(m.rowptr, m.col, m.val, cur, cl.sv, cl.sb, dst, cl.sv, cl.sb, nullptr, 0, 0, 0, -1, B, n, s.cout, stream);
+                    if (rc != SH_OK) return rc;
+                }
+                if (thin) {
+                    rc = sh_spiral_conv_bwd_wgt_thin(static_cast<const float*>(cur), cl.sv, cl.sb, inp, SH_DTYPE_BF16, il.sv, il.sb, s.table_t,
+                                                     workspace[i], workspace_bytes[i], B, s.R, s.n_in, s.S, s.cin, s.cout, SH_DTYPE_BF16, stream);
                     if (rc != SH_OK) return rc;
                 }
                 rc = sh_spiral_conv_bwd_data_bf16(cur, cd, cl.sv, cl.sb, s.table_t, wfrag_t[i], gi, gd, gl.sv, gl.sb, yprev, yl.sv, yl.sb,

@@ -50,6 +50,12 @@ class FaceTables:
         self.faces = torch.from_numpy(f).to(device)
         self.vptr = torch.from_numpy(vptr).to(device)
         self.vcorner = torch.from_numpy(corners[order]).to(device)
+        # per vertex and in the same corner order: the two other vertices of the corner's face (the fused loss gradient
+        # gathers straight from this list)
+        cs = corners[order]
+        ff, kk = cs // 3, cs % 3
+        nbr = np.stack([f[ff, (kk + 1) % 3], f[ff, (kk + 2) % 3]], axis=1).astype(np.int32)
+        self.vnbr = torch.from_numpy(np.ascontiguousarray(nbr.reshape(-1))).to(device)
 
 
 class _EdgeRatioLoss(torch.autograd.Function):
@@ -79,15 +85,16 @@ class _ReconLoss(torch.autograd.Function):
         x_hat, x = x_hat.contiguous(), x.contiguous()
         ctx.save_for_backward(x_hat, x)
         ctx.ft, ctx.edge_w = ft, float(edge_w)
-        out = ops.recon_loss_fwd(x_hat, x, ft.faces, edge_w)
-        ctx.mark_non_differentiable(out[1:])
-        return out[0], out[1:]
+        ctx.set_materialize_grads(False)             # no zeros for the (non-differentiable) parts output
+        total, parts = ops.recon_loss_fwd(x_hat, x, ft.faces, edge_w)
+        ctx.mark_non_differentiable(parts)
+        return total, parts
 
     @staticmethod
     def backward(ctx, g, _unused):
         x_hat, x = ctx.saved_tensors
         ft = ctx.ft
-        return ops.recon_loss_bwd(x_hat, x, ft.faces, ft.vptr, ft.vcorner, ctx.edge_w, g.contiguous()), None, None, None
+        return ops.recon_loss_bwd(x_hat, x, ft.n_faces, ft.vptr, ft.vnbr, ctx.edge_w, g.contiguous()), None, None, None
 
 
 def recon_loss(x_hat, x, ft: FaceTables, edge_w: float):

@@ -294,19 +294,21 @@ def edge_ratio_loss_fwd(x_hat, x, faces):
 
 
 def recon_loss_fwd(x_hat, x, faces, edge_w):
-    """-> float32 [3] = (l1 + edge_w * edge, l1, edge) for contiguous [B, N1, 3] tensors."""
+    """-> (total float32 [], parts float32 [2] = (l1, edge)) for contiguous [B, N1, 3] tensors; two separate allocations,
+    so that neither is a view autograd would have to copy through."""
     assert x_hat.shape == x.shape and x.shape[2] == 3 and x_hat.is_contiguous() and x.is_contiguous() and x.is_cuda
-    out = torch.empty((3,), dtype=torch.float32, device=x.device)
+    total = torch.empty((), dtype=torch.float32, device=x.device)
+    parts = torch.empty((2,), dtype=torch.float32, device=x.device)
     ws = torch.empty(_lib.load().sh_recon_loss_workspace() // 4, dtype=torch.float32, device=x.device)
     check(_lib.load().sh_recon_loss_fwd(ptr(x_hat), ptr(x), ptr(faces), x.shape[0], x.shape[1], faces.shape[0], float(edge_w),
-                                        ptr(out), ptr(ws), stream_ptr()), "sh_recon_loss_fwd")
-    return out
+                                        ptr(total), ptr(parts), ptr(ws), stream_ptr()), "sh_recon_loss_fwd")
+    return total, parts
 
 
-def recon_loss_bwd(x_hat, x, faces, vptr, vcorner, edge_w, gscale):
+def recon_loss_bwd(x_hat, x, n_faces, vptr, vnbr, edge_w, gscale):
     g = torch.empty_like(x_hat)
-    check(_lib.load().sh_recon_loss_bwd(ptr(x_hat), ptr(x), ptr(faces), ptr(vptr), ptr(vcorner), x.shape[0], x.shape[1],
-                                        faces.shape[0], float(edge_w), ptr(gscale), ptr(g), stream_ptr()), "sh_recon_loss_bwd")
+    check(_lib.load().sh_recon_loss_bwd(ptr(x_hat), ptr(x), ptr(vptr), ptr(vnbr), x.shape[0], x.shape[1], int(n_faces),
+                                        float(edge_w), ptr(gscale), ptr(g), stream_ptr()), "sh_recon_loss_bwd")
     return g
 
 
@@ -436,6 +438,49 @@ def spiral_conv_bwd_wgt_bf16(dpre, dp_layout, x, x_layout, table, R, S, Cin, Cou
     args = [_c_ptr_array([ws]), _c_ptr_array([dW]), _c_ptr_array([db])] + [_c_int_array([v]) for v in (B, R, S, Cin, Cout)]
     check(lib.sh_spiral_conv_bwd_wgt_reduce_multi_bf16(1, *[ctypes.cast(a, ctypes.c_void_p) for a in args], stream_ptr()),
           "sh_spiral_conv_bwd_wgt_reduce_multi_bf16")
+    return dW, db
+
+
+def wgrad_thin_ok(B, n_in, S, Cin, Cout, dtype) -> bool:
+    return bool(_lib.load().sh_spiral_conv_bwd_wgt_thin_ok(B, n_in, S, Cin, Cout, _lib.DTYPE_IDS[str(dtype).replace("torch.", "")]))
+
+
+def spiral_conv_bwd_wgt_thin_deferred(dpre_ext, x, table_t, R, S, Cin, Cout, want_bias=True):
+    """fp32 path: slabs only; the job goes to `spiral_conv_bwd_wgt_reduce` with the other layers of the stack."""
+    B, _, C1, dsv, dsb = _dims(dpre_ext, "vm")
+    B2, rows_x, C2, xsv, xsb = _dims(x, "vm")
+    assert B == B2 and C1 == Cout and C2 == Cin and rows_x == R
+    lib = _lib.load()
+    nbytes = lib.sh_spiral_conv_bwd_wgt_workspace(B, R, S, Cin, Cout)
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
+    check(lib.sh_spiral_conv_bwd_wgt_thin(ptr(dpre_ext), dsv, dsb, ptr(x), dtype_id(x), xsv, xsb, ptr(table_t), ptr(ws), nbytes, B, R, R, S,
+                                          Cin, Cout, dtype_id(x), stream_ptr()), "sh_spiral_conv_bwd_wgt_thin")
+    dW = torch.empty((Cout, S * Cin), dtype=torch.float32, device=x.device)
+    db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
+    return dict(ws=ws, dW=dW, db=db, dims=(B, R, S, Cin, Cout))
+
+
+def spiral_conv_bwd_wgt_thin(dpre_ext, x, table_t, R, S, Cin, Cout, want_bias=True):
+    """Role-swapped weight gradient of a 16 -> 3 channel layer (wgrad_thin.hip): dpre_ext fp32 [rows >= R (+ pre-summed extra
+    rows), B, 3] and x [R, B, 16] (fp32 or bf16: selects the path), both vertex-major; table_t int32 [R, S] the transposed
+    table backward-data uses.  -> (dW fp32 [Cout, S*Cin], dbias fp32 [Cout] or None)."""
+    import ctypes
+    B, _, C1, dsv, dsb = _dims(dpre_ext, "vm", _ANY)
+    B2, rows_x, C2, xsv, xsb = _dims(x, "vm", _ANY)
+    assert B == B2 and C1 == Cout and C2 == Cin and rows_x == R and dpre_ext.dtype == torch.float32
+    lib = _lib.load()
+    b16 = x.dtype == torch.bfloat16
+    if not lib.sh_spiral_conv_bwd_wgt_thin_ok(B, R, S, Cin, Cout, dtype_id(x)):
+        raise RuntimeError("spiral_conv_bwd_wgt_thin: shape not covered (B %d R %d S %d Cin %d Cout %d)" % (B, R, S, Cin, Cout))
+    nbytes = (lib.sh_spiral_conv_bwd_wgt_workspace_bf16 if b16 else lib.sh_spiral_conv_bwd_wgt_workspace)(B, R, S, Cin, Cout)
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
+    check(lib.sh_spiral_conv_bwd_wgt_thin(ptr(dpre_ext), dsv, dsb, ptr(x), dtype_id(x), xsv, xsb, ptr(table_t), ptr(ws), nbytes, B, R, R, S,
+                                          Cin, Cout, dtype_id(x), stream_ptr()), "sh_spiral_conv_bwd_wgt_thin")
+    dW = torch.empty((Cout, S * Cin), dtype=torch.float32, device=x.device)
+    db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
+    args = [_c_ptr_array([ws]), _c_ptr_array([dW]), _c_ptr_array([db])] + [_c_int_array([v]) for v in (B, R, S, Cin, Cout)]
+    red = lib.sh_spiral_conv_bwd_wgt_reduce_multi_bf16 if b16 else lib.sh_spiral_conv_bwd_wgt_reduce_multi
+    check(red(1, *[ctypes.cast(a, ctypes.c_void_p) for a in args], stream_ptr()), "sh_spiral_conv_bwd_wgt_reduce_multi")
     return dW, db
 
 

@@ -545,18 +545,27 @@ class Stack:
                     ps.wait_stream(main)                       # dpre_i is complete on main
                     with torch.cuda.stream(ps):
                         presum()                               # writes rows >= R; the weight gradient reads rows < R
-                if side is not None:
-                    side.wait_stream(main)                     # dpre_i (and input_i) are complete on main
-                    keep_alive.append(cur)
-                with torch.cuda.stream(side if side is not None else main):
-                    job = ops.spiral_conv_bwd_wgt_deferred(cur, cur_layout, inp, inp_layout, st.dev["table"], st.R, st.S,
-                                                           st.cin, st.cout, want_bias=need_bias[st.param])
+                # a 16 -> 3 channel layer takes the role-swapped weight gradient (wgrad_thin.hip), which reads the
+                # pre-summed rows: same order as sh_stack_backward
+                thin = (want_in and side is None and not presum_side and cur_layout == "vm" and inp_layout == "vm"
+                        and st.R == st.n_in and ops.wgrad_thin_ok(B, st.n_in, st.S, st.cin, st.cout, cur.dtype))
+                if thin:
+                    presum()
+                    job = ops.spiral_conv_bwd_wgt_thin_deferred(cur, inp, st.dev["table_t"], st.R, st.S, st.cin, st.cout,
+                                                                want_bias=need_bias[st.param])
+                else:
+                    if side is not None:
+                        side.wait_stream(main)                 # dpre_i (and input_i) are complete on main
+                        keep_alive.append(cur)
+                    with torch.cuda.stream(side if side is not None else main):
+                        job = ops.spiral_conv_bwd_wgt_deferred(cur, cur_layout, inp, inp_layout, st.dev["table"], st.R, st.S,
+                                                               st.cin, st.cout, want_bias=need_bias[st.param])
                 jobs.append(job)
                 grads[st.param] = (job["dW"], job["db"])
                 if want_in:
                     if presum_side:
                         main.wait_stream(ps)
-                    else:
+                    elif not thin:
                         presum()
                     ops.spiral_conv_bwd_data(cur, cur_layout, st.dev["table_t"], wts[i], g_in, g_layout,
                                              ep["yprev"], ep["yp_layout"], ep["act_prev"], ep["zero_row"],

@@ -49,6 +49,16 @@ def conv_bwd_wgt(dpre, x, table):
     return P.T @ G, P.sum(0)
 
 
+def conv_bwd_wgt_swapped(dpre_ext, x, table_t):
+    """The same weight gradient over the transposed table (sh_spiral_conv_bwd_wgt_thin):
+    dW[co, s*cin + ci] = sum_{u,b} x[u,b,ci] * dpre_ext[table_t[u,s],b,co]; the bias sum runs over the first n_in rows."""
+    n_in, S = table_t.shape
+    B, cin, cout = x.shape[1], x.shape[2], dpre_ext.shape[2]
+    G = dpre_ext[table_t]                                   # [n_in, S, B, cout]
+    dW = np.einsum("ubi,usbo->osi", x, G).reshape(cout, S * cin)
+    return dW, dpre_ext[:n_in].reshape(n_in * B, cout).sum(0)
+
+
 def spmm(csr, x):
     y = np.zeros((csr.rows,) + x.shape[1:])
     for r in range(csr.rows):
