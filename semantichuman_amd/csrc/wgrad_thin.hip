@@ -36,7 +36,7 @@ struct WTParams {
 
 template <bool XB16> constexpr int wt_ring() { return XB16 ? 4 : 3; }     // items in flight per wave + 1
 constexpr int WT_NG = 5;                               // DMA instructions for the S + 1 <= 11 chunks of 384 bytes, packed
-constexpr int WT_G_BYTES = WT_NG * 1024;
+constexpr int WT_G_BYTES = 4352;                      // 11 chunks = 4224 bytes (the last instruction carries 128 of them), 256-byte multiple
 constexpr int WT_TBL_INTS = 256;
 template <bool XB16> constexpr int wt_x_bytes() { return XB16 ? 1024 : 2048; }
 template <bool XB16> constexpr int wt_stage() { return wt_x_bytes<XB16>() + WT_G_BYTES; }
