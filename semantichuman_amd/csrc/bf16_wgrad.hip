@@ -199,19 +199,19 @@ __global__ __launch_bounds__(256) void wgrad_bf16_dma_kernel(const BDParams p) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // XCD-contiguous item order: an XCD works through a contiguous range of row chunks (all column groups of a chunk side by
     // side), so the rows it gathers - a 1/8 slice of x plus its spiral neighbourhood - stay in its own 4 MiB L2
-    const int item = sh_xcd_remap((int)blockIdx.x, (int)gridDim.x) * 4 + wave;
-    if (item >= p.n_items) return;                                   // whole waves only; no barrier anywhere below
+    // The four waves of a workgroup take four consecutive row chunks of ONE output tile and add their results in LDS at the
+    // end (fixed order), so a workgroup writes one partial slab instead of four.
     char* ring = smem + wave * bd_wave_lds<QT, PT>();
     int* Tl = reinterpret_cast<int*>(ring + R * SLOT);
-    int it = item;
+    int it = sh_xcd_remap((int)blockIdx.x, (int)gridDim.x);
     const int qg = it % p.n_qg; it /= p.n_qg;
-    const int pt = it % p.n_pt; const int split = it / p.n_pt;
+    const int pt = it % p.n_pt; const int sgroup = it / p.n_pt;
+    const int split = sgroup * 4 + wave;
     const long st0 = (long)split * p.stages_per_split;
-    const int nst = (int)min((long)p.stages_per_split, p.n_stages - st0);
-    if (nst <= 0) return;
+    const int nst = (int)max(0L, min((long)p.stages_per_split, p.n_stages - st0));
     const int S = p.S, B = p.B;
     const int v_first = (int)((st0 * 32) / B);
-    {   // this wave's table lines -> LDS (ordinary loads, finished before the DMA loop starts)
+    if (nst > 0) {   // this wave's table lines -> LDS (ordinary loads, finished before the DMA loop starts)
         const int v_last = (int)(((st0 + nst) * 32 - 1) / B);
         const int n = (v_last - v_first + 1) * S;
         for (int i = lane; i < n; i += 64) Tl[i] = p.table[(long)v_first * S + i];
@@ -270,8 +270,10 @@ __global__ __launch_bounds__(256) void wgrad_bf16_dma_kernel(const BDParams p) {
     const bf16x8 ones = {(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f};
     const bool want_bias = qg == 0;
 
+    if (nst > 0) {
 #pragma unroll
     for (int d = 0; d < R - 1; ++d) issue();
+    }
     for (int st = 0; st < nst; ++st) {
         // stages st .. st+R-2 are in flight (clamped repeats past the end keep the count constant): wait for the oldest
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * NL) : "memory");
@@ -293,25 +295,37 @@ __global__ __launch_bounds__(256) void wgrad_bf16_dma_kernel(const BDParams p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // this slot's reads are done before a later DMA may overwrite it
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the clamped tail loads still write this wave's LDS
-
-    float* slab = p.slab + (long)split * p.slab_stride;
+    __syncthreads();                                                 // every wave is done with its ring: reuse it for the sum
+    constexpr int TILE_F = QT * PT * 256, WAVE_F = TILE_F + PT * 16;
+    float* red = reinterpret_cast<float*>(smem);                     // [4][tiles as 64 lanes x f32x4 | bias PT x 16]
+    {
+        float* mine = red + wave * WAVE_F;
 #pragma unroll
-    for (int i = 0; i < QT; ++i)
+        for (int i = 0; i < QT; ++i)
 #pragma unroll
-        for (int j = 0; j < PT; ++j) {
-            const int q = q0 + 16 * i + 4 * (lane >> 4), co = p0 + 16 * j + (lane & 15);
-            if (q < p.K && co < p.Cout) *reinterpret_cast<f32x4*>(slab + (long)co * p.K + q) = acc[i][j];
+            for (int j = 0; j < PT; ++j) *reinterpret_cast<f32x4*>(mine + (i * PT + j) * 256 + lane * 4) = acc[i][j];
+        if (lane < 16) {
+#pragma unroll
+            for (int j = 0; j < PT; ++j) mine[TILE_F + j * 16 + lane] = accb[j][0];            // row 0 of ones^T . P
         }
-    if (want_bias && lane < 16) {
-#pragma unroll
-        for (int j = 0; j < PT; ++j) {
-            const int co = p0 + 16 * j + lane;
-            if (co < p.Cout) p.slab[p.bias_off + (long)split * p.Cout + co] = accb[j][0];      // row 0 of ones^T . P
-        }
+    }
+    __syncthreads();
+    float* slab = p.slab + (long)sgroup * p.slab_stride;
+    for (int t = threadIdx.x; t < QT * PT * 64; t += 256) {
+        const int tile = t >> 6, l = t & 63, i = tile / PT, j = tile - i * PT;
+        const f32x4 v = ((*reinterpret_cast<const f32x4*>(red + t * 4) + *reinterpret_cast<const f32x4*>(red + WAVE_F + t * 4)) +
+                         *reinterpret_cast<const f32x4*>(red + 2 * WAVE_F + t * 4)) + *reinterpret_cast<const f32x4*>(red + 3 * WAVE_F + t * 4);
+        const int q = q0 + 16 * i + 4 * (l >> 4), co = p0 + 16 * j + (l & 15);
+        if (q < p.K && co < p.Cout) *reinterpret_cast<f32x4*>(slab + (long)co * p.K + q) = v;
+    }
+    if (want_bias && threadIdx.x < PT * 16) {
+        const int t = threadIdx.x, co = p0 + t;
+        const float v = ((red[TILE_F + t] + red[WAVE_F + TILE_F + t]) + red[2 * WAVE_F + TILE_F + t]) + red[3 * WAVE_F + TILE_F + t];
+        if (co < p.Cout) p.slab[p.bias_off + (long)sgroup * p.Cout + co] = v;
     }
 }
 
-struct BWPlan { int dma, qt, pt, n_qg, n_pt, nsplit, sps; long n_stages; };
+struct BWPlan { int dma, qt, pt, n_qg, n_pt, nsplit, nslab, sps; long n_stages; };   // nsplit row chunks (one per wave), nslab = ceil(nsplit / 4) slabs
 BWPlan plan_bw(int B, int R, int S, int Cin, int Cout) {
     BWPlan w{};
     static const int dma_on = sh_env_int("SH_BW_DMA", 1, 0, 1);
@@ -330,7 +344,7 @@ BWPlan plan_bw(int B, int R, int S, int Cin, int Cout) {
     static const int slab_mb = sh_env_int("SH_BW_SLAB_MB", 32, 1, 4096);
     const long tiles = (long)w.n_qg * w.n_pt;
     long ns = wave_target / tiles;
-    const long cap = ((long)slab_mb << 20) / ((long)Cout * K * 4);
+    const long cap = 4 * (((long)slab_mb << 20) / ((long)Cout * K * 4));  // four row chunks share a slab
     if (ns > cap) ns = cap;
     if (ns > w.n_stages / 6) ns = w.n_stages / 6;                        // >= 6 stages per wave (the ring holds 3-4)
     if (ns < 1) ns = 1;
@@ -343,6 +357,7 @@ BWPlan plan_bw(int B, int R, int S, int Cin, int Cout) {
     w.sps = (int)sps;
     w.nsplit = (int)((w.n_stages + sps - 1) / sps);
     if ((long)w.nsplit > 4 * cap + 64) { w.dma = 0; return w; }          // a table-bound split would need too many slabs: staged form
+    w.nslab = sh_cdiv(w.nsplit, 4);
     return w;
 }
 
@@ -359,7 +374,7 @@ int launch_bd(BDParams& p, hipStream_t st) {
         }
         attr_set = true;
     }
-    const int grid = sh_cdiv(p.n_items, 4);
+    const int grid = p.n_items;
     ShProfScope ps(st, "wgrad_bf16_dma_kernel<%d, %d>|R=%d B=%d S=%d Cin=%d N=%d grid=%d split=%d", QT, PT, p.R, p.B, p.S, p.Cin, p.Cout, grid,
                    p.nsplit);
     SH_LAUNCH_PS(ps, kern, dim3(grid), dim3(256), smem, st, p);
@@ -373,7 +388,7 @@ int launch_bd(BDParams& p, hipStream_t st) {
 int sh_wgrad_bf16_nsplit(int B, int R, int S, int Cin, int Cout) {
     {
         const BWPlan w = plan_bw(B, R, S, Cin, Cout);
-        if (w.dma) return w.nsplit;
+        if (w.dma) return w.nslab;
     }
     const int Kq = Cin == 3 ? 4 * S : S * Cin, K = S * Cin;
     const long tiles = (long)sh_cdiv(Kq, 64) * sh_cdiv(Cout, 64);
@@ -423,9 +438,9 @@ int sh_spiral_conv_bwd_wgt_bf16(const void* dpre, int dp_dtype, int64_t dp_sv, i
             d.x = static_cast<const char*>(x); d.x_rb = x_sv * 2; d.x_bb = x_sb * 2;
             d.table = table; d.slab = static_cast<float*>(workspace);
             d.B = B; d.R = R; d.S = S; d.Cin = Cin; d.Cout = Cout; d.K = S * Cin;
-            d.slab_stride = (long)Cout * d.K; d.bias_off = (long)w.nsplit * d.slab_stride;
+            d.slab_stride = (long)Cout * d.K; d.bias_off = (long)w.nslab * d.slab_stride;
             d.n_qg = w.n_qg; d.n_pt = w.n_pt; d.nsplit = w.nsplit; d.stages_per_split = w.sps; d.n_stages = w.n_stages;
-            d.n_items = w.n_qg * w.n_pt * w.nsplit;
+            d.n_items = w.n_qg * w.n_pt * w.nslab;                  // workgroups
             if (w.qt == 4 && w.pt == 4) return launch_bd<4, 4>(d, st);
             if (w.qt == 6 && w.pt == 2) return launch_bd<6, 2>(d, st);
             if (w.qt == 8 && w.pt == 1) return launch_bd<8, 1>(d, st);
