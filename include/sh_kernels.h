@@ -472,15 +472,18 @@ SH_API int sh_adam_step_bf16(int n_tensors, float* const* params, const float* c
  * with 3 channels; the output of the last step has type out_dtype (fp32 only for <= 16 channels), g the same type; gin[0]
  * has type gx_dtype; dpre_last has the type of the last step's output.  wfrag[i] / wfrag_t[i]: per conv step, buffers of
  * sh_conv_wfrag_bytes(S, cin, cout) / (S, cout, cin) bytes which the call fills from the fp32 master `weights` (one
- * conversion launch per pass).  workspace[i] >= sh_spiral_conv_bwd_wgt_workspace_bf16.  Everything else as above. */
+ * conversion launch per pass) - unless wfrag_ready != 0: then they already hold the converted CURRENT weights (the caller
+ * ran sh_conv_wfrag_prep_multi itself, e.g. once for both stacks and both orientations of a training step) and no
+ * conversion is launched.  workspace[i] >= sh_spiral_conv_bwd_wgt_workspace_bf16.  Everything else as above. */
 SH_API int sh_stack_forward_bf16(int n_steps, const sh_stack_step* steps, const void* x, int x_dtype, int x_layout, int rows0,
                                  int c0, int B, const float* const* weights, const float* const* biases, void* const* wfrag,
-                                 void* const* outs, int out_dtype, int out_layout, sh_stream_t stream);
+                                 int wfrag_ready, void* const* outs, int out_dtype, int out_layout, sh_stream_t stream);
 SH_API int sh_stack_backward_bf16(int n_steps, const sh_stack_step* steps, const void* x, int x_dtype, int x_layout, int rows0,
                                   int c0, int B, const void* const* acts, const void* g, int out_dtype, int out_layout,
                                   const float* const* weights, void* const* gin, int gx_dtype, void* dpre_last,
-                                  void* const* wfrag_t, void* const* workspace, const size_t* workspace_bytes,
-                                  float* const* dW, float* const* dbias, int need_x_grad, sh_stream_t stream);
+                                  void* const* wfrag_t, int wfrag_ready, void* const* workspace,
+                                  const size_t* workspace_bytes, float* const* dW, float* const* dbias, int need_x_grad,
+                                  sh_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -83,8 +83,8 @@ SIGNATURES = {
     "sh_spmm_bf16": (c_int, [_P, _P, _P, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _P]),
     "sh_act_backward_bf16": (c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _P]),
     "sh_adam_step_bf16": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P] + [ctypes.c_double] * 4 + [_P]),
-    "sh_stack_forward_bf16": (c_int, [_I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P]),
-    "sh_stack_backward_bf16": (c_int, [_I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "sh_stack_forward_bf16": (c_int, [_I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _P]),
+    "sh_stack_backward_bf16": (c_int, [_I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _P]),
 }
 DTYPE_IDS = {"float32": 0, "bfloat16": 1}
 

@@ -182,8 +182,8 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
 static inline long esz_of(int dtype) { return dtype == SH_DTYPE_BF16 ? 2 : 4; }
 
 int sh_stack_forward_bf16(int n_steps, const sh_stack_step* steps, const void* x, int x_dtype, int x_layout, int rows0, int c0, int B,
-                          const float* const* weights, const float* const* biases, void* const* wfrag, void* const* outs,
-                          int out_dtype, int out_layout, sh_stream_t stream) {
+                          const float* const* weights, const float* const* biases, void* const* wfrag, int wfrag_ready,
+                          void* const* outs, int out_dtype, int out_layout, sh_stream_t stream) {
     int rc = check_steps(n_steps, steps, c0, "sh_stack_forward_bf16");
     if (rc != SH_OK) return rc;
     SH_REQUIRE(x && weights && outs && wfrag && B > 0, SH_ERR_INVALID_ARG, "sh_stack_forward_bf16: null pointer or empty batch");
@@ -197,7 +197,7 @@ int sh_stack_forward_bf16(int n_steps, const sh_stack_step* steps, const void* x
             w[n] = weights[steps[i].param]; wf[n] = wfrag[i]; S[n] = steps[i].S; Ci[n] = steps[i].cin; Co[n] = steps[i].cout; tr[n] = 0;
             ++n;
         }
-        if (n) {
+        if (n && !wfrag_ready) {
             rc = sh_conv_wfrag_prep_multi(n, w, wf, S, Ci, Co, tr, stream);
             if (rc != SH_OK) return rc;
         }
@@ -230,8 +230,9 @@ int sh_stack_forward_bf16(int n_steps, const sh_stack_step* steps, const void* x
 
 int sh_stack_backward_bf16(int n_steps, const sh_stack_step* steps, const void* x, int x_dtype, int x_layout, int rows0, int c0, int B,
                            const void* const* acts, const void* g, int out_dtype, int out_layout, const float* const* weights,
-                           void* const* gin, int gx_dtype, void* dpre_last, void* const* wfrag_t, void* const* workspace,
-                           const size_t* workspace_bytes, float* const* dW, float* const* dbias, int need_x_grad, sh_stream_t stream) {
+                           void* const* gin, int gx_dtype, void* dpre_last, void* const* wfrag_t, int wfrag_ready,
+                           void* const* workspace, const size_t* workspace_bytes, float* const* dW, float* const* dbias, int need_x_grad,
+                           sh_stream_t stream) {
     int rc = check_steps(n_steps, steps, c0, "sh_stack_backward_bf16");
     if (rc != SH_OK) return rc;
     SH_REQUIRE(x && acts && g && weights && gin && dW && B > 0, SH_ERR_INVALID_ARG, "sh_stack_backward_bf16: null pointer or empty batch");
@@ -251,7 +252,7 @@ int sh_stack_backward_bf16(int n_steps, const sh_stack_step* steps, const void* 
             w[n] = weights[steps[i].param]; wf[n] = wfrag_t[i]; S[n] = steps[i].S; Ci[n] = steps[i].cin; Co[n] = steps[i].cout; tr[n] = 1;
             ++n;
         }
-        if (n) {
+        if (n && !wfrag_ready) {
             rc = sh_conv_wfrag_prep_multi(n, w, wf, S, Ci, Co, tr, stream);
             if (rc != SH_OK) return rc;
         }

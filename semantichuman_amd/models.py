@@ -23,7 +23,7 @@ import torch.nn as nn
 from . import mesh_ops, ops
 from .mesh_ops import CSR
 from .linear import grouped_linear, latent_linear, latent_linear_bf16
-from .stack import ConvStep, SpmmStep, Stack, run_stack, run_stack_bf16
+from .stack import ConvStep, SpmmStep, Stack, prepare_wfrags, run_stack, run_stack_bf16
 
 
 def _as_csr(m) -> CSR:
@@ -175,10 +175,10 @@ class SpiralAutoencoder(nn.Module):
         self.compute_dtype = dtype
         return self
 
-    def encode(self, x, VAE_flag=None):
+    def encode(self, x, VAE_flag=None, _wf=None):
         bsize = x.size(0)
         if getattr(self, "compute_dtype", torch.float32) == torch.bfloat16:
-            h = run_stack_bf16(self._enc_stack, x, "bm", "bm", torch.bfloat16, self.conv)
+            h = run_stack_bf16(self._enc_stack, x, "bm", "bm", torch.bfloat16, self.conv, _wf)
             z = latent_linear_bf16(h.reshape(bsize, -1), self.fc_latent_enc.weight, self.fc_latent_enc.bias, torch.float32)
         else:
             h = run_stack(self._enc_stack, x, "bm", "bm", self.conv)        # [B, N_last+1, C]
@@ -190,17 +190,21 @@ class SpiralAutoencoder(nn.Module):
             z = torch.randn_like(std).mul(std).add_(self.z_mu)
         return z
 
-    def decode(self, z):
+    def decode(self, z, _wf=None):
         bsize = z.size(0)
         if getattr(self, "compute_dtype", torch.float32) == torch.bfloat16:
             h = latent_linear_bf16(z.float(), self.fc_latent_dec.weight, self.fc_latent_dec.bias, torch.bfloat16)
-            return run_stack_bf16(self._dec_stack, h.view(bsize, self.sizes[-1] + 1, -1), "bm", "bm", torch.float32, self.dconv)
+            return run_stack_bf16(self._dec_stack, h.view(bsize, self.sizes[-1] + 1, -1), "bm", "bm", torch.float32, self.dconv, _wf)
         h = latent_linear(z, self.fc_latent_dec.weight, self.fc_latent_dec.bias).view(bsize, self.sizes[-1] + 1, -1)
         return run_stack(self._dec_stack, h, "bm", "bm", self.dconv)
 
     def forward(self, x):
-        z = self.encode(x, self.VAE_flag)
-        return self.decode(z), z
+        wf = None
+        if getattr(self, "compute_dtype", torch.float32) == torch.bfloat16 and x.is_cuda:
+            # the bf16 working copies of all conv weights (encoder and decoder, forward and backward-data operand): one launch
+            wf = prepare_wfrags([(self._enc_stack, self.conv), (self._dec_stack, self.dconv)])
+        z = self.encode(x, self.VAE_flag, wf)
+        return self.decode(z, wf), z
 
 
 class SpiralAutoencoder_multiz_partkps(nn.Module):

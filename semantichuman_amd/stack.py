@@ -388,8 +388,9 @@ class Stack:
         rows = x.shape[1] if layout == "bm" else x.shape[0]
         return B, rows, x.shape[2]
 
-    def native_forward_bf16(self, x, in_layout, out_layout, out_dtype, weights, biases):
-        """x: bf16, or fp32 with 3 channels.  -> (output of type out_dtype, byte arena holding the inner activations)."""
+    def native_forward_bf16(self, x, in_layout, out_layout, out_dtype, weights, biases, wf=None):
+        """x: bf16, or fp32 with 3 channels.  -> (output of type out_dtype, byte arena holding the inner activations).
+        wf: a WFrags holding this stack's converted weights (then no conversion launch), or None."""
         B, rows0, c0 = self._io_dims(x, in_layout)
         if not (x.is_contiguous() and x.dtype in (torch.float32, torch.bfloat16)):
             raise ValueError("expected a contiguous fp32 / bf16 3-D tensor, got %s %s" % (tuple(x.shape), x.dtype))
@@ -404,14 +405,14 @@ class Stack:
         base = np.uint64(arena.data_ptr())
         outs = plan["f_off"] + base
         outs[n - 1] = out.data_ptr()
-        wf = (plan["wf_off"] + base) * plan["wf_mask"]
+        wfp = wf.fwd[id(self)] if wf is not None else (plan["wf_off"] + base) * plan["wf_mask"]
         _lib.check(_lib.load().sh_stack_forward_bf16(
             n, self._native_steps(), _lib.ptr(x), ops.dtype_id(x), _LAYOUT_ID[in_layout], rows0, c0, B, self._ptr_array(weights),
-            self._ptr_array(biases), wf.ctypes.data, outs.ctypes.data, ops.dtype_id(out), _LAYOUT_ID[out_layout], _lib.stream_ptr()),
-            "sh_stack_forward_bf16")
+            self._ptr_array(biases), wfp.ctypes.data, 1 if wf is not None else 0, outs.ctypes.data, ops.dtype_id(out),
+            _LAYOUT_ID[out_layout], _lib.stream_ptr()), "sh_stack_forward_bf16")
         return out, arena
 
-    def native_backward_bf16(self, x, in_layout, out_layout, arena, out, g, weights, need_x_grad, need_bias):
+    def native_backward_bf16(self, x, in_layout, out_layout, arena, out, g, weights, need_x_grad, need_bias, wf=None):
         B, rows0, c0 = self._io_dims(x, in_layout)
         plan = self._plan_bf16(B, c0, x.dtype == torch.float32, out.dtype == torch.float32)
         n = len(self.steps)
@@ -424,7 +425,8 @@ class Stack:
         acts[n - 1] = out.data_ptr()
         gin = (plan["g_off"] + wbase) * plan["g_mask"]
         gin[0] = gx.data_ptr() if need_x_grad else 0
-        wt = (plan["wt_off"] + wbase) * plan["wt_mask"]
+        ready = wf is not None and wf.bwd is not None
+        wt = wf.bwd[id(self)] if ready else (plan["wt_off"] + wbase) * plan["wt_mask"]
         ws = (plan["ws_off"] + wbase) * plan["ws_mask"]
         dW = plan["dW_off"] + fbase
         assert len(need_bias) == plan["npar"] == len(weights)
@@ -432,8 +434,8 @@ class Stack:
         _lib.check(_lib.load().sh_stack_backward_bf16(
             n, self._native_steps(), _lib.ptr(x), ops.dtype_id(x), _LAYOUT_ID[in_layout], rows0, c0, B, acts.ctypes.data, _lib.ptr(g),
             ops.dtype_id(out), _LAYOUT_ID[out_layout], self._ptr_array(weights), gin.ctypes.data, ops.dtype_id(x),
-            ctypes.c_void_p(int(wbase)), wt.ctypes.data, ws.ctypes.data, plan["ws_bytes"].ctypes.data, dW.ctypes.data, db.ctypes.data,
-            1 if need_x_grad else 0, _lib.stream_ptr()), "sh_stack_backward_bf16")
+            ctypes.c_void_p(int(wbase)), wt.ctypes.data, 1 if ready else 0, ws.ctypes.data, plan["ws_bytes"].ctypes.data, dW.ctypes.data,
+            db.ctypes.data, 1 if need_x_grad else 0, _lib.stream_ptr()), "sh_stack_backward_bf16")
         grads = {}
         for j, shp in enumerate(plan["shapes"]):
             if shp is None:
@@ -631,17 +633,61 @@ class StackFunction(torch.autograd.Function):
         return tuple(res)
 
 
+class WFrags:
+    """bf16 fragment-ordered working copies of the conv weights of one or more stacks, written by ONE conversion launch:
+    the forward operand of every conv step and, when a backward pass will follow, the backward-data operand too.  The
+    buffer is a fresh allocation per call (an autograd graph that still refers to an older one keeps it alive), so the
+    copies always belong to the weights as they were when the forward pass ran."""
+
+    def __init__(self, stacks_and_weights, with_backward: bool):
+        lib = _lib.load()
+        jobs, total = [], 0                                              # (stack, step, weight, transpose, byte offset)
+        al = lambda n: (n + 255) // 256 * 256                            # noqa: E731
+        for stack, weights in stacks_and_weights:
+            for i, st in enumerate(stack.steps):
+                if st.kind != "conv":
+                    continue
+                for tr in ((0, 1) if with_backward else (0,)):
+                    nb = lib.sh_conv_wfrag_bytes(st.S, st.cout if tr else st.cin, st.cin if tr else st.cout)
+                    jobs.append((stack, i, st, weights[st.param], tr, total))
+                    total += al(nb)
+        dev = stacks_and_weights[0][1][0].device
+        self.buf = torch.empty(max(256, total), dtype=torch.uint8, device=dev)
+        base = self.buf.data_ptr()
+        self.fwd = {id(stack): np.zeros(len(stack.steps), dtype=np.uint64) for stack, _ in stacks_and_weights}
+        self.bwd = {id(stack): np.zeros(len(stack.steps), dtype=np.uint64) for stack, _ in stacks_and_weights} if with_backward else None
+        for stack, i, st, w, tr, off in jobs:
+            (self.bwd if tr else self.fwd)[id(stack)][i] = base + off
+            if not (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()):
+                raise RuntimeError("semantichuman_amd: conv weights must be contiguous fp32 HIP tensors (bf16 working copies are made from them)")
+        n = len(jobs)
+        arr = lambda vals, ct: (ct * n)(*vals)                           # noqa: E731
+        _lib.check(lib.sh_conv_wfrag_prep_multi(
+            n, arr([j[3].data_ptr() for j in jobs], ctypes.c_void_p), arr([base + j[5] for j in jobs], ctypes.c_void_p),
+            arr([j[2].S for j in jobs], ctypes.c_int), arr([j[2].cin for j in jobs], ctypes.c_int),
+            arr([j[2].cout for j in jobs], ctypes.c_int), arr([j[4] for j in jobs], ctypes.c_int), _lib.stream_ptr()),
+            "sh_conv_wfrag_prep_multi")
+
+
+def prepare_wfrags(stacks_and_convs):
+    """One conversion launch for all the given (stack, ModuleList of SpiralConv) pairs; both operand orientations when a
+    backward pass can follow."""
+    pairs = [(stack, [m.conv.weight for m in convs]) for stack, convs in stacks_and_convs]
+    with_backward = torch.is_grad_enabled() and any(w.requires_grad for _, ws in pairs for w in ws)
+    return WFrags(pairs, with_backward)
+
+
 class StackFunctionBF16(torch.autograd.Function):
     """autograd node of a whole Stack on the bf16 path: fp32 master parameters in, fp32 parameter gradients out;
     x is bf16 (or fp32 xyz), the output has `out_dtype`, gradients flow in the tensors' own types."""
 
     @staticmethod
-    def forward(ctx, stack: Stack, in_layout: str, out_layout: str, out_dtype, x, *params):
+    def forward(ctx, stack: Stack, in_layout: str, out_layout: str, out_dtype, wf, x, *params):
         weights, biases = list(params[0::2]), list(params[1::2])
         x = x.contiguous()
-        ctx.stack, ctx.layouts = stack, (in_layout, out_layout)
+        ctx.stack, ctx.layouts, ctx.wf = stack, (in_layout, out_layout), wf
         ctx.has_bias = [b is not None for b in biases]
-        out, arena = stack.native_forward_bf16(x, in_layout, out_layout, out_dtype, weights, biases)
+        out, arena = stack.native_forward_bf16(x, in_layout, out_layout, out_dtype, weights, biases, wf)
         ctx.save_for_backward(x, out, arena, *weights)
         return out
 
@@ -650,18 +696,20 @@ class StackFunctionBF16(torch.autograd.Function):
         x, out, arena, *weights = ctx.saved_tensors
         in_layout, out_layout = ctx.layouts
         g = g.contiguous()
-        # forward args: (stack, in_layout, out_layout, out_dtype, x, w_0, b_0, ...)
-        need_bias = [hb and ctx.needs_input_grad[6 + 2 * j] for j, hb in enumerate(ctx.has_bias)]
-        gx, grads = ctx.stack.native_backward_bf16(x, in_layout, out_layout, arena, out, g, weights, ctx.needs_input_grad[4], need_bias)
-        res = [None, None, None, None, gx]
+        # forward args: (stack, in_layout, out_layout, out_dtype, wf, x, w_0, b_0, ...)
+        need_bias = [hb and ctx.needs_input_grad[7 + 2 * j] for j, hb in enumerate(ctx.has_bias)]
+        gx, grads = ctx.stack.native_backward_bf16(x, in_layout, out_layout, arena, out, g, weights, ctx.needs_input_grad[5], need_bias,
+                                                   ctx.wf)
+        res = [None, None, None, None, None, gx]
         for j in range(len(weights)):
             dW, db = grads.get(j, (None, None))
             res += [dW, db]
         return tuple(res)
 
 
-def run_stack_bf16(stack: Stack, x, in_layout, out_layout, out_dtype, convs):
-    """bf16 compute path of `run_stack`: x bf16 (or fp32 with 3 channels), output of type out_dtype."""
+def run_stack_bf16(stack: Stack, x, in_layout, out_layout, out_dtype, convs, wf=None):
+    """bf16 compute path of `run_stack`: x bf16 (or fp32 with 3 channels), output of type out_dtype.  wf: a WFrags made by
+    `prepare_wfrags` for (at least) this stack in this forward pass; None = the stack converts its own weights."""
     if not x.is_cuda:
         raise RuntimeError("semantichuman_amd: input is on %s; the spiral-convolution kernels run on a HIP device "
                            "only (there is no CPU fallback)" % x.device)
@@ -671,9 +719,11 @@ def run_stack_bf16(stack: Stack, x, in_layout, out_layout, out_dtype, convs):
     params = []
     for m in convs:
         params += [m.conv.weight, m.conv.bias]
+    if wf is None:
+        wf = prepare_wfrags([(stack, convs)])
     if torch.is_grad_enabled() and (x.requires_grad or any(p is not None and p.requires_grad for p in params)):
-        return StackFunctionBF16.apply(stack, in_layout, out_layout, out_dtype, x, *params)
-    return stack.native_forward_bf16(x.contiguous(), in_layout, out_layout, out_dtype, params[0::2], params[1::2])[0]
+        return StackFunctionBF16.apply(stack, in_layout, out_layout, out_dtype, wf, x, *params)
+    return stack.native_forward_bf16(x.contiguous(), in_layout, out_layout, out_dtype, params[0::2], params[1::2], wf)[0]
 
 
 def run_stack(stack: Stack, x, in_layout, out_layout, convs):
