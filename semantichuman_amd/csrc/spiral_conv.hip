@@ -1216,6 +1216,31 @@ __global__ void act_backward_kernel(const float* __restrict__ dy, long dy_sv, lo
     }
 }
 
+// The same for a batch-major gradient / output pair and a vertex-major result (the stack's last layer: x_hat and its
+// gradient are [B][rows][C] like the reference's tensors, dpre is [rows][B][C]) with few channels: the element-per-thread
+// form reads one 12-byte entry per cache line.  Here a workgroup takes TV consecutive rows: it reads each batch entry's
+// TV * C contiguous floats, turns the tile in LDS and writes TV contiguous B * C rows.
+constexpr int AB_TV = 16;
+__global__ __launch_bounds__(256) void act_backward_turn_kernel(const float* __restrict__ dy, const float* __restrict__ y, long src_sb,
+                                                                float* __restrict__ dp, int B, int R, int C, int act, int zero_row) {
+    extern __shared__ float tile[];                    // [TV][B * C + 1]
+    const int r0 = blockIdx.x * AB_TV, tv = min(AB_TV, R - r0);
+    const int seg = tv * C, pitch = B * C + 1;
+    for (int i = threadIdx.x; i < B * seg; i += 256) {
+        const int b = i / seg, j = i - b * seg;        // j = (row, channel) inside the segment
+        const long o = (long)b * src_sb + (long)r0 * C + j;
+        const int v = j / C, c = j - v * C;
+        const float g = dy[o] * sh_act_grad_from_out(y[o], act);
+        tile[v * pitch + b * C + c] = (r0 + v == zero_row) ? 0.f : g;
+    }
+    __syncthreads();
+    const int row_len = B * C;
+    for (int i = threadIdx.x; i < tv * row_len; i += 256) {
+        const int v = i / row_len, k = i - v * row_len;
+        dp[(long)(r0 + v) * row_len + k] = tile[v * pitch + k];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1391,6 +1416,15 @@ int sh_act_backward(const float* dy, int64_t dy_sv, int64_t dy_sb, const float* 
     const long items = (long)R * (((long)B * (vec ? C / 4 : C) + 255) / 256);
     const int blocks = (int)(items < 8192 ? items : 8192);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // batch-major in, vertex-major out, few channels: turn tiles through LDS
+    const bool turn = C <= 8 && dy_sv == C && y_sv == C && dy_sb == y_sb && dy_sb >= (int64_t)R * C && dp_sb == C && dp_sv == (int64_t)B * C &&
+                      (size_t)AB_TV * ((size_t)B * C + 1) * sizeof(float) <= 64 * 1024;
+    if (turn) {
+        hipLaunchKernelGGL(act_backward_turn_kernel, dim3((R + AB_TV - 1) / AB_TV), dim3(256), (size_t)AB_TV * ((size_t)B * C + 1) * sizeof(float), st,
+                           dy, y, (long)dy_sb, dpre, B, R, C, act, zero_row);
+        SH_CHECK_LAUNCH("act_backward");
+        return SH_OK;
+    }
     if (vec)
         hipLaunchKernelGGL(act_backward_kernel<true>, dim3(blocks), dim3(256), 0, st, dy, dy_sv, dy_sb, y, y_sv, y_sb, dpre, dp_sv, dp_sb,
                            B, R, C, act, zero_row);

@@ -536,3 +536,21 @@ def test_bench_launch_table_matches_the_library(golden_dir, cfg):
             seen[kname] = seen.get(kname, 0) + 1
     table = bench.conv_launch_table(m, B)
     assert seen == {k: v["launches"] for k, v in table.items()}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N1,C,act", [(64, 171, 3, "identity"), (5, 37, 3, "elu"), (33, 100, 8, "tanh"), (64, 6891, 3, "identity")])
+def test_act_backward_batch_major_to_vertex_major(B, N1, C, act):
+    """The tile-turning form of sh_act_backward (batch-major gradient / output, vertex-major result, few channels - the
+    stack's last layer) is the element-wise definition dpre = dy * act'(y) with the dummy row forced to zero: exact."""
+    torch.manual_seed(3)
+    dy, y = torch.randn(B, N1, C), torch.randn(B, N1, C)
+    a = ops.act_id(act)
+    dpre = torch.full((N1 + 2, B, C), float("nan"), device=dev())              # extra rows must stay untouched
+    ops.act_backward(dy.to(dev()), "bm", y.to(dev()), "bm", dpre, "vm", N1, a, N1 - 1)
+    yd = y.double()
+    der = {"identity": torch.ones_like(yd), "elu": torch.where(yd > 0, torch.ones_like(yd), yd + 1), "tanh": 1 - yd * yd}[act]
+    ref = (dy * der.float()).permute(1, 0, 2).clone()
+    ref[N1 - 1] = 0
+    assert torch.equal(dpre[:N1].cpu(), ref)
+    assert torch.isnan(dpre[N1:]).all()
