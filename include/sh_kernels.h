@@ -182,6 +182,11 @@ typedef struct sh_stack_step {
     /* spmm */
     sh_csr_ref m, mt;                 /* y = M x and its transpose */
     int m_rows, m_cols;
+    /* extend != 0: the step follows a conv whose output buffer has room for m_rows more rows behind its m_cols real ones;
+     * M (m_rows x m_cols) holds only the NON-identity rows of the up-sampling and the forward pass appends M x there: the
+     * next step reads Z = [x ; M x] (m_cols + m_rows rows) through a table composed with the row map, outs[i] must equal
+     * outs[i-1], and mt is the transpose of [I ; M] (m_cols x (m_cols + m_rows)), so the backward pass is the plain one. */
+    int extend;
 } sh_stack_step;
 
 /* outs[i]: output of step i, vertex-major, except outs[n_steps-1] which has layout out_layout.

@@ -98,7 +98,7 @@ class StackStep(ctypes.Structure):                     # sh_stack_step (include/
     _fields_ = [("kind", c_int), ("param", c_int), ("table", c_void_p), ("table_t", c_void_p),
                 ("R", c_int), ("S", c_int), ("n_in", c_int), ("cin", c_int), ("cout", c_int), ("act", c_int), ("zero_row", c_int),
                 ("n1", c_int), ("n2", c_int), ("sum1", CsrRef), ("sum2", CsrRef), ("m", CsrRef), ("mt", CsrRef),
-                ("m_rows", c_int), ("m_cols", c_int)]
+                ("m_rows", c_int), ("m_cols", c_int), ("extend", c_int)]
 
 
 _lib = None

@@ -12,6 +12,7 @@ inline Lay lay(int layout, int rows, int B, int C) {
     return layout == 0 ? Lay{(long)B * C, (long)C} : Lay{(long)C, (long)rows * C};
 }
 inline int out_rows(const sh_stack_step& s) { return s.kind == 0 ? s.R : s.m_rows; }
+inline bool is_last_step(int i, int n) { return i == n - 1; }
 inline int in_rows(const sh_stack_step& s) { return s.kind == 0 ? s.n_in : s.m_cols; }
 
 int check_steps(int n, const sh_stack_step* st, int c0, const char* what) {
@@ -51,7 +52,12 @@ int sh_stack_forward(int n_steps, const sh_stack_step* steps, const float* x, in
         if (s.kind == 0)
             rc = sh_spiral_conv_fwd(cur, cl.sv, cl.sb, s.table, weights[s.param], biases ? biases[s.param] : nullptr, outs[i],
                                     ol.sv, ol.sb, B, s.R, s.S, s.cin, s.cout, s.act, s.zero_row, stream);
-        else
+        else if (s.extend) {
+            SH_REQUIRE(i > 0 && !is_last_step(i, n_steps) && outs[i] == outs[i - 1] && cl.sb == c, SH_ERR_INVALID_ARG,
+                       "sh_stack_forward: step %d appends to its input, which must be the vertex-major output buffer of step %d", i, i - 1);
+            rc = sh_spmm(s.m.rowptr, s.m.col, s.m.val, cur, cl.sv, cl.sb, outs[i] + (long)s.m_cols * cl.sv, cl.sv, cl.sb, nullptr, 0, 0, 0, -1,
+                         B, s.m_rows, c, stream);
+        } else
             rc = sh_spmm(s.m.rowptr, s.m.col, s.m.val, cur, cl.sv, cl.sb, outs[i], ol.sv, ol.sb, nullptr, 0, 0, 0, -1, B,
                          s.m_rows, c, stream);
         if (rc != SH_OK) return rc;
@@ -219,8 +225,15 @@ int sh_stack_forward_bf16(int n_steps, const sh_stack_step* steps, const void* x
         } else {
             SH_REQUIRE(cd == SH_DTYPE_BF16 && od == SH_DTYPE_BF16, SH_ERR_UNSUPPORTED,
                        "sh_stack_forward_bf16: re-sampling step %d needs bf16 on both sides", i);
-            rc = sh_spmm_bf16(s.m.rowptr, s.m.col, s.m.val, cur, cl.sv, cl.sb, outs[i], ol.sv, ol.sb, nullptr, 0, 0, 0, -1, B, s.m_rows, c,
-                              stream);
+            if (s.extend) {
+                SH_REQUIRE(i > 0 && !is_last && outs[i] == outs[i - 1] && cl.sb == c, SH_ERR_INVALID_ARG,
+                           "sh_stack_forward_bf16: step %d appends to its input, which must be the vertex-major output buffer of step %d", i, i - 1);
+                rc = sh_spmm_bf16(s.m.rowptr, s.m.col, s.m.val, cur, cl.sv, cl.sb, static_cast<char*>(outs[i]) + (long)s.m_cols * cl.sv * 2, cl.sv,
+                                  cl.sb, nullptr, 0, 0, 0, -1, B, s.m_rows, c, stream);
+            } else {
+                rc = sh_spmm_bf16(s.m.rowptr, s.m.col, s.m.val, cur, cl.sv, cl.sb, outs[i], ol.sv, ol.sb, nullptr, 0, 0, 0, -1, B, s.m_rows, c,
+                                  stream);
+            }
         }
         if (rc != SH_OK) return rc;
         cur = outs[i]; cd = od; cl = ol; c = co;

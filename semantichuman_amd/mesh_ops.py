@@ -75,6 +75,34 @@ class CSR:
         return m
 
 
+def split_identity_rows(u: CSR):
+    """Split a re-sampling matrix into its identity rows and the rest.
+
+    A row is an identity row when it stores exactly one entry and that entry is exactly 1.0 - the rows of an up-sampling
+    U that belong to vertices the coarse mesh kept, and the padded dummy row (main.py:190-191): y[r] = x[col], a bit-exact
+    copy.  With Z = [x ; U_b x] (the input rows followed by the non-identity rows of the product) every output row r of
+    U x is row `row_map[r]` of Z, so a consumer that gathers rows - the next SpiralConv - can read Z through a composed
+    table and U has to produce only the n_b blended rows.
+    -> (row_map int32 [rows], u_b CSR [n_b, cols], m CSR [cols + n_b, cols] = [I ; U_b])   (u_b.rows == rows: nothing to fold)"""
+    nnz = np.diff(u.rowptr)
+    first = u.val[np.minimum(u.rowptr[:-1], max(u.nnz - 1, 0))] if u.nnz else np.zeros(u.rows, np.float32)
+    ident = (nnz == 1) & (first == np.float32(1.0))
+    bl = np.nonzero(~ident)[0]
+    row_map = np.empty(u.rows, dtype=np.int32)
+    row_map[ident] = u.col[u.rowptr[:-1][ident]]
+    row_map[bl] = u.cols + np.arange(bl.size, dtype=np.int32)
+    cnt = nnz[bl]
+    rp = np.zeros(bl.size + 1, dtype=np.int32)
+    np.cumsum(cnt, out=rp[1:])
+    sel = np.concatenate([np.arange(u.rowptr[r], u.rowptr[r + 1]) for r in bl]) if bl.size else np.zeros(0, dtype=np.int64)
+    u_b = CSR(int(bl.size), u.cols, rp, u.col[sel].astype(np.int32), u.val[sel].astype(np.float32))
+    m = CSR(u.cols + int(bl.size), u.cols,
+            np.concatenate([np.arange(u.cols, dtype=np.int32), u.cols + rp]).astype(np.int32),
+            np.concatenate([np.arange(u.cols, dtype=np.int32), u_b.col]).astype(np.int32),
+            np.concatenate([np.ones(u.cols, dtype=np.float32), u_b.val]).astype(np.float32))
+    return row_map, u_b, m
+
+
 def dense_to_csr(m) -> CSR:
     """Dense [1,R,C] or [R,C] matrix -> CSR keeping exact fp32 values.  Entries
     are kept in increasing column order (the order a dense dot product visits

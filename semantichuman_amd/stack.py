@@ -71,7 +71,8 @@ class ConvStep:
     cin: int
     cout: int
     act: int
-    dead_dummy_grad: bool = False   # gradient w.r.t. input row n_in-1 is provably zero
+    dead_dummy_grad: bool = False   # gradient w.r.t. the input's dummy row is provably zero
+    dummy_in: int = -1              # that row (default n_in - 1; elsewhere once an up-sampling was folded into the table)
     kind: str = "conv"
     # filled by finalize()
     R: int = 0
@@ -86,8 +87,9 @@ class ConvStep:
         self.zero_row = self.R - 1                       # the dummy row of the output (models.py:49-51)
         # "no source" entries point at dpre's own dummy row, which every producer of dpre forces to
         # zero (act_backward / the zero_row epilogues).
+        dummy = self.dummy_in if self.dummy_in >= 0 else self.n_in - 1
         self.tt = mesh_ops.transpose_table_dense(self.table, self.n_in, none_row=self.zero_row,
-                                                 skip_row=self.n_in - 1 if self.dead_dummy_grad else -1)
+                                                 skip_row=dummy if self.dead_dummy_grad else -1)
         self.n_extra = self.tt.n_extra
         return self
 
@@ -102,26 +104,70 @@ class ConvStep:
 
 @dataclass
 class SpmmStep:
-    """y = M x for a sparse re-sampling matrix (U, or a D that is not a pure row select)."""
+    """y = M x for a sparse re-sampling matrix (U, or a D that is not a pure row select).
+
+    Folded form (`extend`, see fold_identity_rows): the step's input buffer has room for n_b more rows behind its `cols`
+    real ones and the launch computes only those - the non-identity rows of U (`csr_fwd`); the tensor the next step sees is
+    Z = [x ; U_b x], i.e. `csr` is then the matrix [I ; U_b] (its transpose serves the backward pass unchanged)."""
     csr: CSR
     kind: str = "spmm"
     csr_t: Optional[CSR] = None
+    extend: bool = False
+    csr_fwd: Optional[CSR] = None      # what the forward launch multiplies with (csr itself unless folded)
+    dummy_out: int = -1                # row of the output that carries the dummy vertex (default: the last)
     dev: dict = field(default_factory=dict)
 
     def finalize(self):
-        self.csr_t = self.csr.transpose()
+        if self.csr_t is None:
+            self.csr_t = self.csr.transpose()
+        if self.csr_fwd is None:
+            self.csr_fwd = self.csr
+        if self.dummy_out < 0:
+            self.dummy_out = self.csr.rows - 1
         return self
 
     def to(self, device):
-        self.dev = {"m": _csr_dev(self.csr, device), "mt": _csr_dev(self.csr_t, device)}
+        self.dev = {"m": _csr_dev(self.csr_fwd, device), "mt": _csr_dev(self.csr_t, device)}
         return self
 
     def passes_dummy_only_to_dummy(self) -> bool:
-        """True if the last input column feeds only the last output row (the padded 1 of
+        """True if the last input column feeds only the output's dummy row (the padded 1 of
         main.py:190-191), i.e. a dead gradient on the output dummy row stays confined."""
         t = self.csr_t
         lo, hi = t.rowptr[t.rows - 1], t.rowptr[t.rows]
-        return hi - lo == 1 and t.col[lo] == self.csr.rows - 1
+        return hi - lo == 1 and t.col[lo] == self.dummy_out
+
+
+FOLD_U = os.environ.get("SH_FOLD_U", "1") != "0"
+
+
+def fold_identity_rows(steps):
+    """conv -> U -> conv: half of U's rows are identity rows (the vertices the coarse mesh kept, and the dummy row), exact
+    copies of rows the first conv just wrote.  Compose the second conv's gather table with the row map of
+    mesh_ops.split_identity_rows and let U append only its blended rows to the first conv's output buffer: same values in
+    every gathered row (bit-identical results), half the rows written by the re-sampling launch."""
+    if not FOLD_U:
+        return steps
+    for i in range(1, len(steps) - 1):
+        prev, sp, nxt = steps[i - 1], steps[i], steps[i + 1]
+        if not (sp.kind == "spmm" and prev.kind == "conv" and nxt.kind == "conv") or sp.extend:
+            continue
+        if nxt.n_in != sp.csr.rows or prev.table.shape[0] != sp.csr.cols:
+            continue
+        row_map, u_b, m = mesh_ops.split_identity_rows(sp.csr)
+        if u_b.rows == sp.csr.rows:
+            continue
+        old_dummy = nxt.dummy_in if nxt.dummy_in >= 0 else nxt.n_in - 1
+        nxt.table = np.ascontiguousarray(row_map[nxt.table]).astype(np.int32)
+        nxt.dummy_in = int(row_map[old_dummy])
+        nxt.n_in = m.rows
+        sp.dummy_out = int(row_map[sp.csr.rows - 1])
+        # the transposed matrix keeps U^T's entry order (increasing ORIGINAL row), so the backward sums - and with them
+        # every gradient - stay bit-identical to the unfolded form
+        ut = sp.csr.transpose()
+        sp.csr_t = CSR(ut.rows, m.rows, ut.rowptr, row_map[ut.col].astype(np.int32), ut.val)
+        sp.csr, sp.csr_fwd, sp.extend = m, u_b, True
+    return steps
 
 
 def mark_dead_dummy(steps, input_dummy_dead: bool = False):
@@ -140,6 +186,7 @@ def mark_dead_dummy(steps, input_dummy_dead: bool = False):
 
 class Stack:
     def __init__(self, steps, input_dummy_dead: bool = False):
+        fold_identity_rows(steps)
         for s in steps:
             if s.kind == "spmm":
                 s.finalize()
@@ -156,6 +203,18 @@ class Stack:
         self.device = torch.empty(0, device=device).device      # normalised ('cuda' -> 'cuda:0')
         self._nsteps = None                                      # the step table holds device pointers of the old upload
         return self
+
+    def _extends(self, i: int) -> bool:
+        st = self.steps[i]
+        return st.kind == "spmm" and st.extend
+
+    def _buffer_rows(self, i: int) -> int:
+        """Rows of the buffer step i writes: its own, plus the rows a folded up-sampling appends behind them."""
+        st = self.steps[i]
+        rows = st.R if st.kind == "conv" else st.csr.rows
+        if i + 1 < len(self.steps) and self._extends(i + 1):
+            rows = max(rows, self.steps[i + 1].csr.rows)
+        return rows
 
     def conv_steps(self):
         return [s for s in self.steps if s.kind == "conv"]
@@ -181,7 +240,7 @@ class Stack:
                 e.kind, e.param = 1, -1
                 e.m.rowptr, e.m.col, e.m.val = (P(t) for t in st.dev["m"])
                 e.mt.rowptr, e.mt.col, e.mt.val = (P(t) for t in st.dev["mt"])
-                e.m_rows, e.m_cols = st.csr.rows, st.csr.cols
+                e.m_rows, e.m_cols, e.extend = st.csr_fwd.rows, st.csr.cols, 1 if st.extend else 0
         self._nsteps = arr
         return arr
 
@@ -202,8 +261,11 @@ class Stack:
         # forward arena: outputs of all steps but the last
         f_off, o = np.zeros(n, dtype=np.uint64), 0
         for i in range(n - 1):
+            if self._extends(i):                       # appends its rows to the previous step's buffer
+                f_off[i] = f_off[i - 1]
+                continue
             f_off[i] = o
-            o += _round(out_rows[i] * B * out_ch[i])
+            o += _round(self._buffer_rows(i) * B * out_ch[i])
         f_total = o
         # backward arena: dpre of the last step | two alternating regions for the input-gradient chain | weight_t | slabs
         last = self.steps[-1]
@@ -332,8 +394,11 @@ class Stack:
         out_ch = [st.cout if st.kind == "conv" else cin_of[i] for i, st in enumerate(self.steps)]
         f_off, wf_off, wf_mask, o = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64), 0
         for i in range(n - 1):
+            if self._extends(i):
+                f_off[i] = f_off[i - 1]
+                continue
             f_off[i] = o
-            o += al(out_rows[i] * B * out_ch[i] * 2)
+            o += al(self._buffer_rows(i) * B * out_ch[i] * 2)
         for i, st in enumerate(self.steps):
             if st.kind == "conv":
                 wf_off[i], wf_mask[i] = o, 1
@@ -462,9 +527,12 @@ class Stack:
         for i, st in enumerate(self.steps):
             lay = out_layout if i == last else "vm"
             if st.kind == "conv":
-                y = ops.alloc(B, st.R, st.cout, lay, x.device)
+                y = ops.alloc(B, st.R, st.cout, lay, x.device, extra_rows=self._buffer_rows(i) - st.R)
                 ops.spiral_conv_fwd(cur, cur_layout, st.dev["table"], weights[st.param], biases[st.param], y, lay,
                                     st.R, st.S, st.act, st.zero_row)
+            elif st.extend:                              # the blended rows go behind the rows the previous conv wrote
+                y = cur
+                ops.spmm(st.dev["m"], cur, "vm", cur[st.csr.cols:], "vm", st.csr_fwd.rows)
             else:
                 C = cur.shape[2]
                 y = ops.alloc(B, st.csr.rows, C, lay, x.device)

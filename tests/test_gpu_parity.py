@@ -554,3 +554,32 @@ def test_act_backward_batch_major_to_vertex_major(B, N1, C, act):
     ref[N1 - 1] = 0
     assert torch.equal(dpre[:N1].cpu(), ref)
     assert torch.isnan(dpre[N1:]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_folded_upsampling_is_bitwise_the_unfolded_one(golden_dir, dtype):
+    """stack.fold_identity_rows (identity rows of U served from the coarse tensor through a composed gather table, U
+    appends only the blended rows): output and every parameter gradient of a training step are bit-identical to the stack
+    built without the fold, on both compute paths."""
+    from semantichuman_amd import stack as stack_mod, synthetic
+    h = load_hierarchy(os.path.join(golden_dir, "small_ae.npz"))
+    x = torch.from_numpy(synthetic.synth_batch(h.verts, 32, seed=1)).to(dev())
+    ft = sh.FaceTables(h.faces, h.sizes[0] + 1, dev())
+    res = {}
+    for fold in (True, False):
+        old = stack_mod.FOLD_U
+        stack_mod.FOLD_U = fold
+        try:
+            torch.manual_seed(0)
+            m = sh.SpiralAutoencoder(FE, FD, 32, h.sizes, h.spiral_sizes, h.spirals, h.D, h.U, dev())
+        finally:
+            stack_mod.FOLD_U = old
+        assert any(s.kind == "spmm" and s.extend for s in m._dec_stack.steps) == fold
+        m.set_compute_dtype(dtype)
+        xh = m(x)[0]
+        sh.recon_loss(xh, x, ft, 1e-2)[0].backward()
+        res[fold] = (xh.detach().clone(), {n: p.grad.clone() for n, p in m.named_parameters()})
+    assert torch.equal(res[True][0], res[False][0])
+    for n, g in res[True][1].items():
+        assert torch.equal(g, res[False][1][n]), n

@@ -218,3 +218,36 @@ def test_synthetic_batch_contract():
     x = synthetic.synth_batch(v, 3, seed=0)
     assert x.shape == (3, 6891, 3) and x.dtype == np.float32 and np.all(x[:, -1] == 0)
     assert np.array_equal(x, synthetic.synth_batch(v, 3, seed=0))
+
+
+def test_split_identity_rows_and_folded_stack(small):
+    """mesh_ops.split_identity_rows: Z = [x ; U_b x] read through row_map is U x, bit for bit; and a decoder stack built
+    with the fold has the same step outputs (float64 emulation) as one built without it."""
+    from semantichuman_amd import stack as stack_mod
+    _, h = small
+    rs = np.random.RandomState(0)
+    for U in h.U:
+        row_map, u_b, m = mesh_ops.split_identity_rows(U)
+        assert u_b.rows < U.rows and m.rows == U.cols + u_b.rows and m.cols == U.cols
+        x = rs.randn(U.cols, 3, 4).astype(np.float32)
+        full = U.todense() @ x.reshape(U.cols, -1)
+        z = np.concatenate([x.reshape(U.cols, -1), u_b.todense() @ x.reshape(U.cols, -1)], 0)
+        assert np.array_equal(z[row_map], full)
+        assert np.array_equal(m.todense() @ x.reshape(U.cols, -1), z)
+    # the same model with and without the fold
+    outs = {}
+    for fold in (True, False):
+        old = stack_mod.FOLD_U
+        stack_mod.FOLD_U = fold
+        try:
+            torch.manual_seed(0)
+            m_ = models.SpiralAutoencoder(FE, FD, 8, h.sizes, h.spiral_sizes, h.spirals, h.D, h.U, torch.device("cpu"))
+        finally:
+            stack_mod.FOLD_U = old
+        st = m_._dec_stack
+        assert any(s.kind == "spmm" and s.extend for s in st.steps) == fold
+        W = [c.conv.weight.detach().double().numpy() for c in m_.dconv]
+        Bs = [c.conv.bias.detach().double().numpy() for c in m_.dconv]
+        hv = np.random.RandomState(1).randn(h.sizes[-1] + 1, 2, FD[0][0])
+        outs[fold] = emulate.stack_forward(st, hv, W, Bs)[-1]
+    assert np.array_equal(outs[True], outs[False])
