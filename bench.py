@@ -83,14 +83,15 @@ def conv_launch_table(model, B):
             # fwd: read each needed input row once + weights, write output
             byt = 4.0 * (B * st.n_in * st.cin + B * st.R * st.cout + st.cout * K)
             add(gg_name(*nt_split(st.R, st.cout, st.cin), cg=st.cin, bwd="false"), fl, byt)
-            if not (first and stack is model._enc_stack):
+            not_first = not (first and stack is model._enc_stack)
+            thin = not_first and st.R == st.n_in and bool(_lib.load().sh_spiral_conv_bwd_wgt_thin_ok(B, st.n_in, st.S, st.cin, st.cout, 0))
+            if not_first and not thin:
                 # backward-data = the same kernel over the transposed table; algorithmic FLOPs are
                 # those of the R*S real (row, position) pairs, not of the padded n_in*S table
                 add(gg_name(*nt_split(st.n_in, st.cin, st.cout), cg=st.cout, bwd="true"), fl, byt)
-            not_first = not (first and stack is model._enc_stack)
-            if not_first and st.R == st.n_in and _lib.load().sh_spiral_conv_bwd_wgt_thin_ok(B, st.n_in, st.S, st.cin, st.cout, 0):
-                # the 16 -> 3 channel layer: role-swapped weight gradient (csrc/wgrad_thin.hip), same algorithmic work
-                add("wgrad_thin_kernel<f32>", fl, byt)
+            if thin:
+                # the 16 -> 3 channel layer: role-swapped weight gradient AND backward-data in one launch (csrc/wgrad_thin.hip)
+                add("wgrad_thin_kernel<f32>", 2 * fl, 2 * byt)
             elif st.cin % 4 == 0 or st.cin == 3:       # same choices as plan_wgrad() in csrc/spiral_conv.hip
                 cot = nt(st.cout)
                 add("wgrad_stream_kernel<%d, %d, %d, %s, %s>" % (cot, 1 if B <= 4 else 4, 3 if cot <= 2 else 2,
@@ -110,6 +111,7 @@ def bf16_work_table(model, B):
     channels, output channels) - the fields of the shape tag the library's profiler attaches to each launch.  Bytes = every
     tensor the launch needs read once + its output written once (fused ideal): bf16 activations (the 3-channel
     xyz tensors are fp32), bf16 weight fragments, fp32 partial slabs are not counted (they are overhead, not algorithm)."""
+    from semantichuman_amd import _lib
     out = {}
     first = True
     for stack in (model._enc_stack, model._dec_stack):
@@ -122,9 +124,13 @@ def bf16_work_table(model, B):
             e_out = 4 if st.cout == 3 else 2
             byt = B * st.n_in * st.cin * e_in + B * st.R * st.cout * e_out + 2.0 * st.cout * K
             out[("conv_bf16_kernel", False, st.R, st.S, st.cin, st.cout)] = (fl, byt)
-            if not (first and stack is model._enc_stack):
+            not_first = not (first and stack is model._enc_stack)
+            # the 16 -> 3 channel layer: weight gradient and backward-data share one launch (csrc/wgrad_thin.hip)
+            thin = not_first and st.R == st.n_in and bool(_lib.load().sh_spiral_conv_bwd_wgt_thin_ok(B, st.n_in, st.S, st.cin, st.cout, 1))
+            if not_first and not thin:
                 out[("conv_bf16_kernel", True, st.n_in, st.S, st.cout, st.cin)] = (fl, byt)
-            out[("wgrad_bf16_kernel", None, st.R, st.S, st.cin, st.cout)] = (fl, byt + 2.0 * st.cout * K)   # + fp32 dW out
+            wg = (fl, byt + 2.0 * st.cout * K)                                                                # + fp32 dW out
+            out[("wgrad_bf16_kernel", None, st.R, st.S, st.cin, st.cout)] = (wg[0] + fl, wg[1] + byt) if thin else wg
             first = False
     return out
 

@@ -428,11 +428,17 @@ SH_API int sh_spiral_conv_bwd_data_bf16(const void* dpre, int dp_dtype, int64_t 
  * so the caller runs the pre-sum launches first.  dpre_ext fp32 [rows][B][3], x [n_in][B][16] of the path's dtype, both
  * vertex-major and contiguous; needs R == n_in, S <= 10, B % 32 == 0 (sh_spiral_conv_bwd_wgt_thin_ok() tells).  Writes
  * partial slabs into `workspace` in the layout and count of sh_spiral_conv_bwd_wgt (path_dtype SH_DTYPE_F32) or
- * sh_spiral_conv_bwd_wgt_bf16 (SH_DTYPE_BF16): the matching ..._reduce_multi launch finishes dW and dbias. */
+ * sh_spiral_conv_bwd_wgt_bf16 (SH_DTYPE_BF16): the matching ..._reduce_multi launch finishes dW and dbias.
+ * dx != NULL: the same launch also writes the layer's backward-data (what sh_spiral_conv_bwd_data[_bf16] computes from the
+ * same table and buffer): dx[u,b,:] = act_prev'(x[u,b,:]) * sum_s dpre_ext[table_t[u,s],b,:] . W[:, s, :], row zero_prev
+ * forced to zero; dx [n_in (+ extra)][B][16] vertex-major of the path's dtype, weight = the fp32 master [3][S*16] (rounded to
+ * bf16 in the kernel on the bf16 path, like the fragment copies); x is both the layer input and the activation output
+ * whose derivative multiplies (act_prev = SH_ACT_IDENTITY: no factor). */
 SH_API int sh_spiral_conv_bwd_wgt_thin_ok(int B, int n_in, int S, int Cin, int Cout, int path_dtype);
 SH_API int sh_spiral_conv_bwd_wgt_thin(const float* dpre_ext, int64_t dp_sv, int64_t dp_sb, const void* x, int x_dtype, int64_t x_sv,
-                                int64_t x_sb, const int32_t* table_t, void* workspace, size_t workspace_bytes, int B, int R,
-                                int n_in, int S, int Cin, int Cout, int path_dtype, sh_stream_t stream);
+                                int64_t x_sb, const int32_t* table_t, void* workspace, size_t workspace_bytes,
+                                const float* weight, void* dx, int64_t dx_sv, int64_t dx_sb, int act_prev, int zero_prev,
+                                int B, int R, int n_in, int S, int Cin, int Cout, int path_dtype, sh_stream_t stream);
 
 /* sh_spiral_conv_bwd_wgt in bf16: x / dpre bf16 (channels % 8 == 0) or fp32 with exactly 3 channels; writes fp32 partial
  * slabs into `workspace` (>= sh_spiral_conv_bwd_wgt_workspace_bf16 bytes); sh_spiral_conv_bwd_wgt_reduce_multi_bf16 sums

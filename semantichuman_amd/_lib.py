@@ -49,7 +49,7 @@ SIGNATURES = {
     "sh_edge_ratio_loss_fwd": (c_int, [_P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "sh_edge_ratio_loss_bwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "sh_spiral_conv_bwd_wgt_thin_ok": (c_int, [_I, _I, _I, _I, _I, _I]),
-    "sh_spiral_conv_bwd_wgt_thin": (c_int, [_P, _L, _L, _P, _I, _L, _L, _P, _P, c_size_t, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "sh_spiral_conv_bwd_wgt_thin": (c_int, [_P, _L, _L, _P, _I, _L, _L, _P, _P, c_size_t, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sh_recon_loss_workspace": (c_size_t, []),
     "sh_recon_loss_fwd": (c_int, [_P, _P, _P, _I, _I, _I, c_float, _P, _P, _P, _P]),
     "sh_recon_loss_bwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, c_float, _P, _P, _P]),

@@ -155,14 +155,21 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
                                  cl.sv, cl.sb, nullptr, 0, 0, 0, -1, B, s.n2, s.cout, stream);
                     if (rc != SH_OK) return rc;
                 }
+                // ... and computes the input gradient from the same staged gradient rows when that buffer is plain vertex-major
+                // and the activation to differentiate (if any) produced the layer input itself
+                const bool thin_dx = thin && gl.sb == s.cin && gl.sv == (long)B * s.cin && (!yprev || yprev == inp);
                 if (thin) {
                     rc = sh_spiral_conv_bwd_wgt_thin(cur, cl.sv, cl.sb, inp, SH_DTYPE_F32, il.sv, il.sb, s.table_t, workspace[i],
-                                                     workspace_bytes[i], B, s.R, s.n_in, s.S, s.cin, s.cout, SH_DTYPE_F32, stream);
+                                                     workspace_bytes[i], weights[s.param], thin_dx ? gi : nullptr, gl.sv, gl.sb,
+                                                     yprev ? act_prev : SH_ACT_IDENTITY, zero_prev, B, s.R, s.n_in, s.S, s.cin, s.cout,
+                                                     SH_DTYPE_F32, stream);
                     if (rc != SH_OK) return rc;
                 }
-                rc = sh_spiral_conv_bwd_data(cur, cl.sv, cl.sb, s.table_t, weight_t[i], gi, gl.sv, gl.sb, yprev, yl.sv, yl.sb,
-                                             act_prev, zero_prev, B, s.n_in, s.S, s.cin, s.cout, stream);
-                if (rc != SH_OK) return rc;
+                if (!thin_dx) {
+                    rc = sh_spiral_conv_bwd_data(cur, cl.sv, cl.sb, s.table_t, weight_t[i], gi, gl.sv, gl.sb, yprev, yl.sv, yl.sb,
+                                                 act_prev, zero_prev, B, s.n_in, s.S, s.cin, s.cout, stream);
+                    if (rc != SH_OK) return rc;
+                }
             }
         } else if (want_in) {
             SH_REQUIRE(s.mt.rowptr && s.mt.col && s.mt.val, SH_ERR_INVALID_ARG, "sh_stack_backward: step %d has no transposed matrix", i);
@@ -336,11 +343,15 @@ int sh_stack_backward_bf16(int n_steps, const sh_stack_step* steps, const void* 
                         rc = sh_spmm_bf16(m.rowptr, m.col, m.val, cur, cl.sv, cl.sb, dst, cl.sv, cl.sb, nullptr, 0, 0, 0, -1, B, n, s.cout, stream);
                     if (rc != SH_OK) return rc;
                 }
+                const bool thin_dx = thin && gd == SH_DTYPE_BF16 && gl.sb == s.cin && gl.sv == (long)B * s.cin && (!yprev || yprev == inp);
                 if (thin) {
                     rc = sh_spiral_conv_bwd_wgt_thin(static_cast<const float*>(cur), cl.sv, cl.sb, inp, SH_DTYPE_BF16, il.sv, il.sb, s.table_t,
-                                                     workspace[i], workspace_bytes[i], B, s.R, s.n_in, s.S, s.cin, s.cout, SH_DTYPE_BF16, stream);
+                                                     workspace[i], workspace_bytes[i], weights[s.param], thin_dx ? gi : nullptr, gl.sv, gl.sb,
+                                                     yprev ? act_prev : SH_ACT_IDENTITY, zero_prev, B, s.R, s.n_in, s.S, s.cin, s.cout,
+                                                     SH_DTYPE_BF16, stream);
                     if (rc != SH_OK) return rc;
                 }
+                if (!thin_dx)
                 rc = sh_spiral_conv_bwd_data_bf16(cur, cd, cl.sv, cl.sb, s.table_t, wfrag_t[i], gi, gd, gl.sv, gl.sb, yprev, yl.sv, yl.sb,
                                                   act_prev, zero_prev, B, s.n_in, s.S, s.cin, s.cout, stream);
                 if (rc != SH_OK) return rc;

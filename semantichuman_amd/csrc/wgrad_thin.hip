@@ -32,6 +32,11 @@ struct WTParams {
     const int* tt;                       // table_t [n_in][S]
     float* slab; long slab_stride, bias_off;
     int B, n_in, S, nblk, n_items, ipw;  // nblk = B / 32 items per vertex; ipw = items per wave
+    // optional backward-data of the same layer, from the same staged gradient chunks: dx[u,b,ci] = act'(x[u,b,ci]) * sum_{s,co}
+    // dpre_ext[table_t[u,s],b,co] * W[co][s][ci]  (dx null: weight gradient only)
+    const float* w;                      // fp32 master weight [3][S * 16]
+    char* dx; long dx_rb;                // [n_in (+ extra rows)][B][16] of the path's dtype, rows contiguous
+    int act_prev, zero_prev;             // activation whose output x is (identity: no factor), row of dx forced to zero (-1: none)
 };
 
 template <bool XB16> constexpr int wt_ring() { return XB16 ? 4 : 3; }     // items in flight per wave + 1
@@ -113,6 +118,24 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(const WTParams p) {
     }
     const int self_off = XB + S * 384 + lane * 16;    // lanes < 24: 4 floats of dpre[u][32 b][3]
 
+    // fused backward-data: D[ci][b] = sum_n W[n][ci] * G[b][n], n = 3 s + co; operands swapped so that a lane ends up with
+    // four consecutive channels of one batch entry (one 8 / 16-byte store).  bf16: one 16x16x32 step, lane (ci, kq) holds
+    // W[8 kq + j][ci]; fp32: eight 16x16x4 steps, lane (ci, k) holds W[4 t + k][ci].
+    const bool want_dx = p.dx != nullptr;
+    bf16x8 wf16 = {};
+    float wf32[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int doff[8];                                                       // byte offset of G[n][.] for this lane's eight n
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int n = XB16 ? 8 * g4 + j : 4 * j + g4;
+        const bool ok = n < 3 * S;
+        const int s = ok ? n / 3 : 0, co = ok ? n - 3 * s : 0;
+        doff[j] = XB + s * 384 + co * 4;                                // n past 3 S: reads column 0 against a zero weight
+        const float wv = (want_dx && ok) ? p.w[(long)co * S * 16 + s * 16 + (lane & 15)] : 0.f;
+        if (XB16) wf16[j] = (__bf16)wv; else wf32[j] = wv;
+    }
+    int cu = u_first, cb = it0 - u_first * nblk;                       // (vertex, batch block) of the item being consumed
+
     if (nst > 0) {
 #pragma unroll
         for (int d = 0; d < R - 1; ++d) issue();
@@ -147,6 +170,37 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(const WTParams p) {
                 }
             }
             if (lane < 24) bsum += *reinterpret_cast<const f32x4*>(slot + self_off);
+            if (want_dx) {
+                const bool zrow = cu == p.zero_prev;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int b = 16 * h + (lane & 15);
+                    f32x4 d = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (XB16) {
+                        bf16x8 fg;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) fg[j] = (__bf16)*reinterpret_cast<const float*>(slot + doff[j] + b * 12);
+                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf16, fg, d, 0, 0, 0);
+                        const bf16x4 yv = *reinterpret_cast<const bf16x4*>(slot + b * 32 + g4 * 8);
+                        f32x4 o;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = zrow ? 0.f : d[r] * sh_act_grad_from_out((float)yv[r], p.act_prev);
+                        *reinterpret_cast<bf16x4*>(p.dx + (long)cu * p.dx_rb + (long)(cb * 32 + b) * 32 + g4 * 8) = sh_to_bf16x4(o);
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) {
+                            const float gv = *reinterpret_cast<const float*>(slot + doff[t] + b * 12);
+                            d = __builtin_amdgcn_mfma_f32_16x16x4f32(wf32[t], gv, d, 0, 0, 0);
+                        }
+                        const f32x4 yv = *reinterpret_cast<const f32x4*>(slot + b * 64 + g4 * 16);
+                        f32x4 o;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = zrow ? 0.f : d[r] * sh_act_grad_from_out(yv[r], p.act_prev);
+                        *reinterpret_cast<f32x4*>(p.dx + (long)cu * p.dx_rb + (long)(cb * 32 + b) * 64 + g4 * 16) = o;
+                    }
+                }
+            }
+            if (++cb == nblk) { cb = 0; ++cu; }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -202,8 +256,9 @@ int sh_spiral_conv_bwd_wgt_thin_ok(int B, int n_in, int S, int Cin, int Cout, in
 }
 
 int sh_spiral_conv_bwd_wgt_thin(const float* dpre_ext, int64_t dp_sv, int64_t dp_sb, const void* x, int x_dtype, int64_t x_sv, int64_t x_sb,
-                                const int32_t* table_t, void* workspace, size_t workspace_bytes, int B, int R, int n_in, int S, int Cin,
-                                int Cout, int path_dtype, sh_stream_t stream) {
+                                const int32_t* table_t, void* workspace, size_t workspace_bytes, const float* weight, void* dx, int64_t dx_sv,
+                                int64_t dx_sb, int act_prev, int zero_prev, int B, int R, int n_in, int S, int Cin, int Cout, int path_dtype,
+                                sh_stream_t stream) {
     SH_REQUIRE(R == n_in, SH_ERR_UNSUPPORTED, "sh_spiral_conv_bwd_wgt_thin: the layer must keep the vertex count (R %d, n_in %d)", R, n_in);
     SH_REQUIRE(dpre_ext && x && table_t && workspace, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_wgt_thin: null pointer");
     SH_REQUIRE(path_dtype == SH_DTYPE_F32 || path_dtype == SH_DTYPE_BF16, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_wgt_thin: unknown path dtype");
@@ -218,7 +273,11 @@ int sh_spiral_conv_bwd_wgt_thin(const float* dpre_ext, int64_t dp_sv, int64_t dp
     const int nslab = path_dtype == SH_DTYPE_BF16 ? sh_wgrad_bf16_nsplit(B, n_in, S, Cin, Cout) : sh_wgrad_f32_nsplit(B, n_in, S, Cin, Cout);
     const size_t need = (size_t)nslab * ((size_t)Cout * S * Cin + Cout) * sizeof(float);
     SH_REQUIRE(workspace_bytes >= need, SH_ERR_WORKSPACE, "sh_spiral_conv_bwd_wgt_thin: workspace too small");
+    SH_REQUIRE(!dx || (weight && dx_sb == 16 && dx_sv == (int64_t)B * 16 && (reinterpret_cast<uintptr_t>(dx) & 15) == 0 &&
+                       act_prev >= SH_ACT_IDENTITY && act_prev <= SH_ACT_TANH), SH_ERR_INVALID_ARG,
+               "sh_spiral_conv_bwd_wgt_thin: the fused input gradient needs the weight and a contiguous vertex-major 16-channel buffer");
     WTParams p{};
+    p.w = weight; p.dx = static_cast<char*>(dx); p.dx_rb = dx_sv * xe; p.act_prev = act_prev; p.zero_prev = zero_prev;
     p.g = reinterpret_cast<const char*>(dpre_ext); p.g_rb = dp_sv * 4;
     p.x = static_cast<const char*>(x); p.x_rb = x_sv * xe;
     p.tt = table_t; p.slab = static_cast<float*>(workspace);
@@ -239,7 +298,7 @@ int sh_spiral_conv_bwd_wgt_thin(const float* dpre_ext, int64_t dp_sv, int64_t dp
         }
         attr_set[b16] = true;
     }
-    ShProfScope ps(st, "wgrad_thin_kernel<%s>|R=%d B=%d S=%d Cin=%d N=%d grid=%d waves=%d", b16 ? "bf16" : "f32", n_in, B, S, Cin, Cout, nslab, nw);
+    ShProfScope ps(st, "wgrad_thin_kernel<%s>|R=%d B=%d S=%d Cin=%d N=%d grid=%d waves=%d dx=%d", b16 ? "bf16" : "f32", n_in, B, S, Cin, Cout, nslab, nw, dx ? 1 : 0);
     if (b16) SH_LAUNCH_PS(ps, wgrad_thin_kernel<true>, dim3(nslab), dim3(64 * nw), smem, st, p);
     else SH_LAUNCH_PS(ps, wgrad_thin_kernel<false>, dim3(nslab), dim3(64 * nw), smem, st, p);
     SH_CHECK_LAUNCH("wgrad_thin");

@@ -445,37 +445,49 @@ def wgrad_thin_ok(B, n_in, S, Cin, Cout, dtype) -> bool:
     return bool(_lib.load().sh_spiral_conv_bwd_wgt_thin_ok(B, n_in, S, Cin, Cout, _lib.DTYPE_IDS[str(dtype).replace("torch.", "")]))
 
 
-def spiral_conv_bwd_wgt_thin_deferred(dpre_ext, x, table_t, R, S, Cin, Cout, want_bias=True):
-    """fp32 path: slabs only; the job goes to `spiral_conv_bwd_wgt_reduce` with the other layers of the stack."""
+def _thin_dx_args(dx, weight, B, Cin, act_prev, zero_prev):
+    if dx is None:
+        return [None, None, 0, 0, 0, -1]
+    _, _, Cd, gsv, gsb = _dims(dx, "vm", _ANY)
+    assert Cd == Cin and weight is not None
+    return [ptr(weight), ptr(dx), gsv, gsb, int(act_prev), int(zero_prev)]
+
+
+def spiral_conv_bwd_wgt_thin_deferred(dpre_ext, x, table_t, R, S, Cin, Cout, want_bias=True, weight=None, dx=None, act_prev=0,
+                                      zero_prev=-1):
+    """fp32 path: slabs only; the job goes to `spiral_conv_bwd_wgt_reduce` with the other layers of the stack.
+    dx (vertex-major [>= R, B, Cin]) given: the launch also writes the layer's input gradient (see sh_kernels.h)."""
     B, _, C1, dsv, dsb = _dims(dpre_ext, "vm")
     B2, rows_x, C2, xsv, xsb = _dims(x, "vm")
-    assert B == B2 and C1 == Cout and C2 == Cin and rows_x == R
+    assert B == B2 and C1 == Cout and C2 == Cin and rows_x >= R
     lib = _lib.load()
     nbytes = lib.sh_spiral_conv_bwd_wgt_workspace(B, R, S, Cin, Cout)
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
-    check(lib.sh_spiral_conv_bwd_wgt_thin(ptr(dpre_ext), dsv, dsb, ptr(x), dtype_id(x), xsv, xsb, ptr(table_t), ptr(ws), nbytes, B, R, R, S,
-                                          Cin, Cout, dtype_id(x), stream_ptr()), "sh_spiral_conv_bwd_wgt_thin")
+    check(lib.sh_spiral_conv_bwd_wgt_thin(ptr(dpre_ext), dsv, dsb, ptr(x), dtype_id(x), xsv, xsb, ptr(table_t), ptr(ws), nbytes,
+                                          *_thin_dx_args(dx, weight, B, Cin, act_prev, zero_prev), B, R, R, S, Cin, Cout, dtype_id(x),
+                                          stream_ptr()), "sh_spiral_conv_bwd_wgt_thin")
     dW = torch.empty((Cout, S * Cin), dtype=torch.float32, device=x.device)
     db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
     return dict(ws=ws, dW=dW, db=db, dims=(B, R, S, Cin, Cout))
 
 
-def spiral_conv_bwd_wgt_thin(dpre_ext, x, table_t, R, S, Cin, Cout, want_bias=True):
+def spiral_conv_bwd_wgt_thin(dpre_ext, x, table_t, R, S, Cin, Cout, want_bias=True, weight=None, dx=None, act_prev=0, zero_prev=-1):
     """Role-swapped weight gradient of a 16 -> 3 channel layer (wgrad_thin.hip): dpre_ext fp32 [rows >= R (+ pre-summed extra
     rows), B, 3] and x [R, B, 16] (fp32 or bf16: selects the path), both vertex-major; table_t int32 [R, S] the transposed
     table backward-data uses.  -> (dW fp32 [Cout, S*Cin], dbias fp32 [Cout] or None)."""
     import ctypes
     B, _, C1, dsv, dsb = _dims(dpre_ext, "vm", _ANY)
     B2, rows_x, C2, xsv, xsb = _dims(x, "vm", _ANY)
-    assert B == B2 and C1 == Cout and C2 == Cin and rows_x == R and dpre_ext.dtype == torch.float32
+    assert B == B2 and C1 == Cout and C2 == Cin and rows_x >= R and dpre_ext.dtype == torch.float32
     lib = _lib.load()
     b16 = x.dtype == torch.bfloat16
     if not lib.sh_spiral_conv_bwd_wgt_thin_ok(B, R, S, Cin, Cout, dtype_id(x)):
         raise RuntimeError("spiral_conv_bwd_wgt_thin: shape not covered (B %d R %d S %d Cin %d Cout %d)" % (B, R, S, Cin, Cout))
     nbytes = (lib.sh_spiral_conv_bwd_wgt_workspace_bf16 if b16 else lib.sh_spiral_conv_bwd_wgt_workspace)(B, R, S, Cin, Cout)
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
-    check(lib.sh_spiral_conv_bwd_wgt_thin(ptr(dpre_ext), dsv, dsb, ptr(x), dtype_id(x), xsv, xsb, ptr(table_t), ptr(ws), nbytes, B, R, R, S,
-                                          Cin, Cout, dtype_id(x), stream_ptr()), "sh_spiral_conv_bwd_wgt_thin")
+    check(lib.sh_spiral_conv_bwd_wgt_thin(ptr(dpre_ext), dsv, dsb, ptr(x), dtype_id(x), xsv, xsb, ptr(table_t), ptr(ws), nbytes,
+                                          *_thin_dx_args(dx, weight, B, Cin, act_prev, zero_prev), B, R, R, S, Cin, Cout, dtype_id(x),
+                                          stream_ptr()), "sh_spiral_conv_bwd_wgt_thin")
     dW = torch.empty((Cout, S * Cin), dtype=torch.float32, device=x.device)
     db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
     args = [_c_ptr_array([ws]), _c_ptr_array([dW]), _c_ptr_array([db])] + [_c_int_array([v]) for v in (B, R, S, Cin, Cout)]

@@ -619,10 +619,13 @@ class Stack:
                 # pre-summed rows: same order as sh_stack_backward
                 thin = (want_in and side is None and not presum_side and cur_layout == "vm" and inp_layout == "vm"
                         and st.R == st.n_in and ops.wgrad_thin_ok(B, st.n_in, st.S, st.cin, st.cout, cur.dtype))
+                thin_dx = thin and g_layout == "vm" and (ep["yprev"] is None or ep["yprev"] is inp)
                 if thin:
                     presum()
-                    job = ops.spiral_conv_bwd_wgt_thin_deferred(cur, inp, st.dev["table_t"], st.R, st.S, st.cin, st.cout,
-                                                                want_bias=need_bias[st.param])
+                    job = ops.spiral_conv_bwd_wgt_thin_deferred(
+                        cur, inp, st.dev["table_t"], st.R, st.S, st.cin, st.cout, want_bias=need_bias[st.param],
+                        weight=weights[st.param], dx=g_in if thin_dx else None,
+                        act_prev=ep["act_prev"] if ep["yprev"] is not None else 0, zero_prev=ep["zero_row"])
                 else:
                     if side is not None:
                         side.wait_stream(main)                 # dpre_i (and input_i) are complete on main
@@ -637,6 +640,7 @@ class Stack:
                         main.wait_stream(ps)
                     elif not thin:
                         presum()
+                if want_in and not (thin and thin_dx):
                     ops.spiral_conv_bwd_data(cur, cur_layout, st.dev["table_t"], wts[i], g_in, g_layout,
                                              ep["yprev"], ep["yp_layout"], ep["act_prev"], ep["zero_row"],
                                              st.n_in, st.S, st.cin, st.cout)

@@ -73,6 +73,42 @@ def test_thin_wgrad_matches_the_ordinary_form(B, R, S, path):
     assert float((db - dbg).abs().max()) <= (2.0 ** -7 * np.sqrt(R * B) if path == "bf16" else tol * float(dbg.abs().max())) + 1e-4
 
 
+@pytest.mark.parametrize("B,R,S", [(64, 301, 10), (32, 97, 9), (96, 55, 7)])
+@pytest.mark.parametrize("path", ["f32", "bf16"])
+@pytest.mark.parametrize("act", ["elu", "identity"])
+def test_thin_launch_also_gives_the_input_gradient(B, R, S, path, act):
+    """dx of the same launch = backward-data over the transposed table times act'(x), dummy row forced to zero; the
+    weight gradient of that launch is the one of the launch without dx, bit for bit."""
+    torch.manual_seed(7)
+    table = rand_table(R, S, 8)
+    tt = mesh_ops.transpose_table_dense(table, R, none_row=R - 1, skip_row=-1)
+    x = torch.randn(R, B, 16)
+    x[-1] = 0
+    W = torch.randn(3, S * 16) / np.sqrt(S * 16)
+    dpre = torch.randn(R, B, 3)
+    dpre[-1] = 0
+    ext = torch.from_numpy(emulate.extend_dpre(dpre.double().numpy(), tt)).float()
+    a = ops.act_id(act)
+    if path == "bf16":
+        x = bf(x)
+        ref = emulate.conv_bwd_data(bf(ext).double().numpy(), tt.table_t, bf(W).double().numpy(), 16)
+        tol = 2.0 ** -8
+    else:
+        ref = emulate.conv_bwd_data(ext.double().numpy(), tt.table_t, W.double().numpy(), 16)
+        tol = 2e-6 * np.sqrt(3 * S)
+    ref = ref * emulate.DACT[a](x.double().numpy())
+    ref[R - 1] = 0
+    dt = torch.bfloat16 if path == "bf16" else torch.float32
+    xd, td = x.to(dev(), dt), torch.from_numpy(tt.table_t).to(dev())
+    dx = torch.full((R + 3, B, 16), float("nan"), dtype=dt, device=dev())
+    dW, db = ops.spiral_conv_bwd_wgt_thin(ext.to(dev()), xd, td, R, S, 16, 3, weight=W.to(dev()), dx=dx, act_prev=a, zero_prev=R - 1)
+    err = float((dx[:R].float().cpu().double() - torch.from_numpy(ref)).abs().max())
+    assert err <= tol * float(np.abs(ref).max()) + 1e-6
+    assert torch.isnan(dx[R:].float()).all()                             # rows behind the real ones are not touched
+    dW0, db0 = ops.spiral_conv_bwd_wgt_thin(ext.to(dev()), xd, td, R, S, 16, 3)
+    assert torch.equal(dW, dW0) and torch.equal(db, db0)
+
+
 def test_thin_wgrad_rejects_what_it_does_not_cover():
     x = torch.zeros((10, 16, 16), device=dev())
     g = torch.zeros((10, 16, 3), device=dev())
