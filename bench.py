@@ -153,9 +153,16 @@ def parse_tag(name, shape):
 
 
 def lib_sha16():
+    """Identity of the kernel-library build: SHA-256 over the kernel sources (csrc/*.hip, *.h, Makefile, in name order) - what
+    the library is compiled from.  (The bytes of the .so itself are not reproducible across checkouts; a profile taken on
+    these sources stays valid wherever they are rebuilt.)"""
+    import glob
     import hashlib
-    from semantichuman_amd import _lib
-    return hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16]
+    d = os.path.join(ROOT, "semantichuman_amd", "csrc")
+    hsh = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")) + [os.path.join(d, "Makefile")]):
+        hsh.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
+    return hsh.hexdigest()[:16]
 
 
 def measured_traffic(kernel, dtype):

@@ -6,7 +6,7 @@ MI355X_MICROARCH.md 'HBM / rocprofv3 PMC slots' prescribes) of `python3 tools/la
     rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/pmc_write -o write --output-format csv -- python3 tools/layer_report.py
     python3 tools/pmc_traffic.py gpurun_out/pmc_fetch/fetch_counter_collection.csv gpurun_out/pmc_write/write_counter_collection.csv profiles/r02_pmc_traffic_f32
 (layer_report.py takes `64 tests/golden/template6890.npz bf16` for the bf16 path -> profiles/r02_pmc_traffic_bf16).  Run it ON THE
-BOX that took the passes: the result is stamped with the hash of the kernel library it was measured on ("_meta"), and
+BOX that took the passes: the result is stamped with the hash of the kernel sources the library was built from ("_meta"), and
 bench.py only quotes it as `roofline.traffic` while that hash matches the library it runs.
 
 Units / corrections (same guide): both counters are in KiB; on gfx950 FETCH_SIZE tallies the 128-byte requests of wide
@@ -53,8 +53,9 @@ def main():
     for n, (c, fb, wb) in sorted(agg.items(), key=lambda kv: -(kv[1][1] + kv[1][2])):
         res[n] = {"launches_profiled": c, "fetch_bytes_per_launch": fb / c, "write_bytes_per_launch": wb / max(1, cnt_w[n]),
                   "hbm_bytes_per_launch": fb / c + wb / max(1, cnt_w[n])}
-    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "semantichuman_amd", "lib", "libsh_kernels.so")
-    res["_meta"] = {"lib_sha16": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16] if os.path.exists(lib) else None,
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench                                           # one definition of the build identity (hash of the kernel sources)
+    res["_meta"] = {"lib_sha16": bench.lib_sha16(),
                     "corrections": "FETCH_SIZE x 2 (gfx950 tallies 128-byte requests at 64 bytes), WRITE_SIZE exact; KiB units"}
     json.dump(res, open(out + ".json", "w"), indent=1)
     with open(out + ".txt", "w") as f:
