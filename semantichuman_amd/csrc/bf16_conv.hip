@@ -99,11 +99,18 @@ __global__ __launch_bounds__(1024) void conv_bf16_kernel(const BCParams p) {
     int tv[RT], tvn[RT];
     load_table(t, tv);                                     // first table line: in flight under the weight copy
     {
-        const int total = p.nks * NT * 64;
-        for (int i = tid; i < total; i += (int)blockDim.x) {
-            const int f = i >> 6, n = f % NT, ks = f / NT;
-            Wl[i] = p.wfrag[((long)ks * p.nt_tot + slice * NT + n) * 64 + (i & 63)];
+        // weight fragments -> LDS by LDS-DMA: one 1-KiB fragment (k-step, channel tile) per wave instruction, all of a wave's
+        // instructions in flight at once, no register round trip (the load -> ds_write loop this replaces cost ~7 us of
+        // every launch of a 128-KiB layer)
+        typedef __attribute__((address_space(3))) char* lptr_t;
+        const unsigned wl_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_t)smem);
+        const int nfrag = p.nks * NT;
+        for (int f = __builtin_amdgcn_readfirstlane(wave); f < nfrag; f += nw) {
+            const int n = f % NT, ks = f / NT;
+            const char* src = reinterpret_cast<const char*>(p.wfrag + ((long)ks * p.nt_tot + slice * NT + n) * 64 + lane);
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(__builtin_amdgcn_readfirstlane(wl_lds + (unsigned)f * 1024u)) : "memory", "m0");
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
     for (; t < t_end; t += stride) {
