@@ -26,9 +26,14 @@
 
 namespace {
 
-// gathered channels % 32 == 0 | == 16 | == 3 (fp32 triples) | % 64 == 0 with a ring slot of TWO k-steps = a full 128-byte line per
-// row, both halves requested back to back (experiment, SH_BC_C64=1: one k-step touches 16 rows x 64 B; requesting the halves
-// together changed nothing measurable, so half-line requests are not what bounds the wide-channel layers)
+// gathered channels % 32 == 0 | == 16 | == 3 (fp32 triples) | % 64 == 0 in the FULL-LINE form (BC_C64):
+// with 128- or 256-byte rows a k-step of the C32 form touches 16 rows x 64 bytes - sixteen half lines per load instruction -
+// and those layers gathered at half the bytes/us of the 64-byte-row layers (where an instruction is 1 KiB contiguous).  Here a
+// load instruction covers EIGHT rows x one whole 128-byte line (64 channels): lane (i, kb) fetches piece kb + 4 (i & 1) of row
+// i >> 1.  For the MFMA the two lanes of a row pose as two logical rows holding the lower / upper 32 channels; one product with
+// the lower-half weight fragments (right for the even logical rows) and one with the upper-half fragments (right for the odd
+// ones) go to two accumulators whose valid halves are added across the lane pair in the epilogue.  Twice the MFMAs (the
+// matrix pipes idle ~90 % of these launches), half as many, twice as efficient load instructions.
 enum { BC_C32 = 0, BC_C16 = 1, BC_C3F = 2, BC_C64 = 3 };
 
 struct BCParams {
@@ -46,11 +51,11 @@ struct BCParams {
 struct __attribute__((packed, aligned(4))) bc_f3 { float a, b, c; };
 
 constexpr int bc_depth(int NT, int RT, int MODE) {
-    const int per = RT * (MODE == BC_C3F ? 6 : MODE == BC_C64 ? 8 : 4);        // registers of one ring slot
-    const int room = 88 - NT * RT * 4 - RT * 4;            // minus accumulators and the converted operands
+    const int per = RT * (MODE == BC_C3F ? 6 : 4);         // registers of one ring slot
+    const int room = 88 - (MODE == BC_C64 ? 2 : 1) * NT * RT * 4 - RT * 4;     // minus accumulators (two sets in the full-line form) and the converted operands
     const int d = room / per;
     const int cap = MODE == BC_C3F ? 4 : 8;
-    const int lo = MODE == BC_C64 ? 2 : 3;
+    const int lo = 3;
     return d < lo ? lo : d > cap ? cap : d;
 }
 
@@ -116,14 +121,17 @@ __global__ __launch_bounds__(1024) void conv_bf16_kernel(const BCParams p) {
     for (; t < t_end; t += stride) {
         load_table(t + stride, tvn);                       // next item's table line: in flight under this item's k loop
         const int bs = t / p.n_vg, vg = t - bs * p.n_vg;
-        const int b0 = bs << 4, v0 = vg * RT;
-        const int bl = b0 + r16 < p.B ? b0 + r16 : p.B - 1;            // rows past B read the last entry; never stored
-        const char* xl = p.x + (long)bl * p.x_bb + ((MODE == BC_C32 || MODE == BC_C64) ? kq * 16 : MODE == BC_C16 ? (kq & 1) * 16 : 0);
+        constexpr int TROWS = MODE == BC_C64 ? 8 : 16;      // batch entries per tile
+        const int b0 = bs * TROWS, v0 = vg * RT;
+        const int rl = MODE == BC_C64 ? r16 >> 1 : r16;     // this lane's row inside the tile
+        const int bl = b0 + rl < p.B ? b0 + rl : p.B - 1;               // rows past B read the last entry; never stored
+        const char* xl = p.x + (long)bl * p.x_bb +
+                         (MODE == BC_C32 ? kq * 16 : MODE == BC_C64 ? (kq + 4 * (r16 & 1)) * 16 : MODE == BC_C16 ? (kq & 1) * 16 : 0);
 
         // running load position (uniform): spiral position and channel offset of the next k-step to load
         int ls = 0, lc = 0;
         constexpr int KPS = MODE == BC_C64 ? 2 : 1;        // k-steps per ring slot
-        using raw_t = typename std::conditional<MODE == BC_C3F, bc_f3[2], typename std::conditional<MODE == BC_C64, bf16x8[2], bf16x8>::type>::type;
+        using raw_t = typename std::conditional<MODE == BC_C3F, bc_f3[2], bf16x8>::type;
         raw_t ring[D][RT];
         auto issue = [&](raw_t (&a)[RT]) {
             if constexpr (MODE == BC_C32) {
@@ -140,10 +148,7 @@ __global__ __launch_bounds__(1024) void conv_bf16_kernel(const BCParams p) {
 #pragma unroll
                 for (int m = 0; m < RT; ++m) {
                     const int row = __builtin_amdgcn_readlane(tv[m], s);
-                    const char* src = xl + (long)row * p.x_rb + 2 * lc;
-                    bf16x8* dst = reinterpret_cast<bf16x8*>(&a[m]);
-                    dst[0] = *reinterpret_cast<const bf16x8*>(src);
-                    dst[1] = *reinterpret_cast<const bf16x8*>(src + 64);
+                    *reinterpret_cast<bf16x8*>(&a[m]) = *reinterpret_cast<const bf16x8*>(xl + (long)row * p.x_rb + 2 * lc);
                 }
                 lc += 64;
                 if (lc >= p.Cg) { lc = 0; ++ls; }
@@ -169,11 +174,14 @@ __global__ __launch_bounds__(1024) void conv_bf16_kernel(const BCParams p) {
                 ls += 8;
             }
         };
-        f32x4 acc[RT][NT];
+        f32x4 acc[RT][NT], acc2[MODE == BC_C64 ? RT : 1][MODE == BC_C64 ? NT : 1];
 #pragma unroll
         for (int m = 0; m < RT; ++m)
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc[m][n] = zero4;
+            for (int n = 0; n < NT; ++n) {
+                acc[m][n] = zero4;
+                if constexpr (MODE == BC_C64) acc2[m][n] = zero4;
+            }
         auto compute = [&](int slot, const raw_t (&a)[RT]) {
 #pragma unroll
             for (int h = 0; h < KPS; ++h) {
@@ -185,7 +193,7 @@ __global__ __launch_bounds__(1024) void conv_bf16_kernel(const BCParams p) {
                         g[m] = (bf16x8){(__bf16)s2[0].a, (__bf16)s2[0].b, (__bf16)s2[0].c, (__bf16)0.f,
                                         (__bf16)s2[1].a, (__bf16)s2[1].b, (__bf16)s2[1].c, (__bf16)0.f};
                     } else {
-                        g[m] = reinterpret_cast<const bf16x8*>(&a[m])[h];
+                        g[m] = *reinterpret_cast<const bf16x8*>(&a[m]);      // full-line form: the same operand for both halves
                     }
                 }
                 const u32x4* wk = Wl + ((long)(slot * KPS + h) * NT) * 64 + lane;
@@ -194,7 +202,10 @@ __global__ __launch_bounds__(1024) void conv_bf16_kernel(const BCParams p) {
                     const u32x4 wraw = wk[n * 64];
                     const bf16x8 w = *reinterpret_cast<const bf16x8*>(&wraw);
 #pragma unroll
-                    for (int m = 0; m < RT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, g[m], acc[m][n], 0, 0, 0);
+                    for (int m = 0; m < RT; ++m) {
+                        if (MODE == BC_C64 && h == 1) acc2[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, g[m], acc2[m][n], 0, 0, 0);
+                        else acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, g[m], acc[m][n], 0, 0, 0);
+                    }
                 }
             }
         };
@@ -213,11 +224,20 @@ __global__ __launch_bounds__(1024) void conv_bf16_kernel(const BCParams p) {
             if (!bc_ring_steps<0, D>(ks, nslots, step)) break;
 
         // ---- epilogue: lane holds channels c0..c0+3 (c0 = 16 n + 4 kq) of row (v0 + m, b0 + r16)
-        const int b = b0 + r16;
+        const int b = b0 + rl;
+        if constexpr (MODE == BC_C64) {                    // even logical row: lower-half products; its odd neighbour: upper-half products
+#pragma unroll
+            for (int m = 0; m < RT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[m][n][j] += __shfl_xor(acc2[m][n][j], 1, 64);
+        }
+        const bool owner = MODE != BC_C64 || (r16 & 1) == 0;           // full-line form: the even lane of a pair stores the row
 #pragma unroll
         for (int m = 0; m < RT; ++m) {
             const int v = v0 + m;
-            if (v >= p.R || b >= p.B) continue;
+            if (v >= p.R || b >= p.B || !owner) continue;
             char* yrow = p.y + (long)v * p.y_rb + (long)b * p.y_bb;
             const char* yp = (BWD && p.yprev) ? p.yprev + (long)v * p.yp_rb + (long)b * p.yp_bb : nullptr;
             const bool zero = v == p.zero_row;
@@ -320,7 +340,7 @@ int launch_bc(BCParams& p, hipStream_t st) {
         attr_set = 160 * 1024;
     }
     p.n_vg = sh_cdiv(p.R, RT);
-    const long tiles = (long)p.n_vg * sh_cdiv(p.B, 16);
+    const long tiles = (long)p.n_vg * sh_cdiv(p.B, MODE == BC_C64 ? 8 : 16);
     SH_REQUIRE(tiles < (1L << 30), SH_ERR_UNSUPPORTED, "conv_bf16: %ld work items", tiles);
     p.n_tiles = (int)tiles;
     // waves per workgroup and workgroups per CU from the LDS footprint of the resident weight (<= 16 waves per CU: the
@@ -350,18 +370,21 @@ int dispatch_bc_nt(BCParams& p, hipStream_t st) {
     p.nsplit = p.nt_tot / nt;
     while (nt > 1 && (long)p.nks * nt > 128) { nt >>= 1; p.nsplit <<= 1; }
     SH_REQUIRE((long)p.nks * nt <= 150, SH_ERR_UNSUPPORTED, "conv_bf16: K = %d too long for an LDS-resident weight slice", p.nks * 32);
-    const long tiles16 = (long)p.R * sh_cdiv(p.B, 16);          // work items if every wave took ONE vertex
+    const long tiles16 = (long)p.R * sh_cdiv(p.B, MODE == BC_C64 ? 8 : 16);      // work items if every wave took ONE vertex
     const long fill = 2L * num_cus() * 16;                       // aim for >= 2 items per resident wave
     if constexpr (OUTF32 || MODE == BC_C3F) {
         SH_REQUIRE(nt == 1 && p.nsplit == 1, SH_ERR_UNSUPPORTED, "conv_bf16: a 3-channel fp32 side needs <= 16 channels on the other (%d)",
                    p.Nout);
         return launch_bc<1, (MODE == BC_C3F ? 2 : 4), MODE, BWD, OUTF32>(p, st);
     } else {
-        constexpr int R4 = MODE == BC_C64 ? 2 : 4;              // a C64 ring slot is two k-steps: 4 vertices per wave would not fit 128 VGPRs
+        constexpr int R4 = MODE == BC_C64 ? 2 : 4;              // the full-line form keeps two accumulator sets: 4 vertices per wave would not fit 128 VGPRs
         if (nt == 1) return launch_bc<1, R4, MODE, BWD, false>(p, st);
         if (nt == 2) return tiles16 / 4 >= fill ? launch_bc<2, R4, MODE, BWD, false>(p, st) : launch_bc<2, 2, MODE, BWD, false>(p, st);
         if (nt == 4) return tiles16 / 2 >= fill ? launch_bc<4, 2, MODE, BWD, false>(p, st) : launch_bc<4, 1, MODE, BWD, false>(p, st);
-        return tiles16 / 2 >= fill ? launch_bc<8, 2, MODE, BWD, false>(p, st) : launch_bc<8, 1, MODE, BWD, false>(p, st);
+        if constexpr (MODE != BC_C64) {                        // (two accumulator sets of 8 x 2 tiles would not fit the register budget)
+            if (tiles16 / 2 >= fill) return launch_bc<8, 2, MODE, BWD, false>(p, st);
+        }
+        return launch_bc<8, 1, MODE, BWD, false>(p, st);
     }
 }
 
@@ -383,12 +406,16 @@ int dispatch_bc(BCParams& p, int in_f32, int out_f32, hipStream_t st) {
         SH_REQUIRE(p.Nout <= 16, SH_ERR_UNSUPPORTED, "conv_bf16: an fp32 output has <= 16 channels (got %d)", p.Nout);
         return p.Cg == 16 ? dispatch_bc_nt<BC_C16, BWD, true>(p, st) : dispatch_bc_nt<BC_C32, BWD, true>(p, st);
     }
-    static const int c64_on = sh_env_int("SH_BC_C64", 0, 0, 1);      // measured on MI355X: no gain (21-30 us either way), off
+    static const int c64_on = sh_env_int("SH_BC_C64", 1, 0, 1);      // full-line form for 64 / 128 gathered channels
     SH_REQUIRE(p.Nout % 4 == 0 && ((reinterpret_cast<uintptr_t>(p.y) | (uintptr_t)p.y_rb | (uintptr_t)p.y_bb) & 7) == 0 &&
                (!p.yprev || ((reinterpret_cast<uintptr_t>(p.yprev) | (uintptr_t)p.yp_rb | (uintptr_t)p.yp_bb) & 7) == 0) &&
                (!p.bias || (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0),
                SH_ERR_UNSUPPORTED, "conv_bf16: bf16 output needs channels %% 4 == 0 and 8-byte aligned rows");
-    if (p.Cg % 64 == 0 && c64_on) return dispatch_bc_nt<BC_C64, BWD, false>(p, st);
+    // ... where the layer has <= 2 channel tiles per workgroup: with 4 or 8 the doubled weight-fragment reads from LDS cost more
+    // than the better loads bring (measured: 128 -> 64 and 64 -> 128 channel layers 19-26 us -> 22-27 us; 64 -> 32: 28 -> 21 us)
+    int nt_wg = p.nt_tot > 8 ? 8 : p.nt_tot;
+    while (nt_wg > 1 && (long)p.nks * nt_wg > 128) nt_wg >>= 1;
+    if (p.Cg % 64 == 0 && c64_on && nt_wg <= 2) return dispatch_bc_nt<BC_C64, BWD, false>(p, st);
     return p.Cg == 16 ? dispatch_bc_nt<BC_C16, BWD, false>(p, st) : dispatch_bc_nt<BC_C32, BWD, false>(p, st);
 }
 
