@@ -43,6 +43,8 @@ CONV_SHAPES = [
     (16, 50, 50, 9, 16, 32, "elu"), (3, 41, 20, 11, 16, 16, "relu"), (64, 70, 70, 8, 32, 64, "elu"),
     (20, 33, 33, 8, 64, 128, "elu"), (16, 40, 40, 8, 128, 64, "tanh"), (5, 64, 64, 10, 32, 32, "identity"),
     (32, 30, 30, 18, 64, 32, "leaky_relu"), (17, 45, 45, 7, 32, 16, "sigmoid"),
+    # the full-line form (64 / 128 gathered channels, <= 2 channel tiles: 8-row tiles, paired lanes) with ragged batches
+    (5, 40, 40, 8, 64, 32, "elu"), (17, 45, 45, 7, 128, 16, "relu"), (64, 33, 20, 9, 64, 16, "tanh"),
 ]
 
 
