@@ -455,6 +455,85 @@ __global__ __launch_bounds__(LTHREADS) void linear_bwd_wgt_stream_kernel(const L
         }
 }
 
+// LDS-DMA form of the weight gradient (round 2).  The streaming kernel above keeps three 2-KiB steps of loads in flight per
+// wave against 16 MFMAs (0.2 us) per step: a tile is a chain of ~5 round trips.  Here a workgroup takes one 64-row block of
+// dy and FOUR 64-column blocks of x: the whole dy tile [M <= 64][64] (shared) and each wave's x tile [M][64] go memory -> LDS
+// in one volley of global_load_lds_dwordx4 (256-byte rows, four per instruction, their 16-byte pieces XOR-swizzled by the row
+// so that the four row groups of a fragment read hit different banks), one wait, one barrier, then the same 16 x 16 MFMAs
+// per 4 reduction rows as above with both quads read from LDS.  80 KiB per workgroup: two per CU, one loading while the
+// other multiplies.  Same products in the same order as the streaming kernel: bit-identical results.
+constexpr int LWD_TILE = 16 * 1024, LWD_LDS = 5 * LWD_TILE;
+__global__ __launch_bounds__(LTHREADS) void linear_bwd_wgt_dma_kernel(const LSParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int ktiles = p.K >> 6, kgroups = (ktiles + 3) >> 2;
+    const int item = sh_xcd_remap(blockIdx.x, gridDim.x);
+    const int kg = item % kgroups, ntile = item / kgroups;
+    const int kt = kg * 4 + wave;
+    const bool active = kt < ktiles;
+    const int n0 = ntile * 64, k0 = (active ? kt : 0) * 64;
+    const int la = lane & 15, rr = lane >> 4;
+    const int nsteps = (p.M + 3) >> 2;
+    typedef __attribute__((address_space(3))) char* lptr_t;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_t)smem);
+    auto dma16 = [](const void* gsrc, unsigned lds_dst) {
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory", "m0");
+    };
+    // instruction i of a tile: rows 4 i .. 4 i + 3; lane -> row 4 i + (lane >> 4), slot lane & 15 holds piece slot ^ ((row & 3) << 2)
+    const int piece = (lane & 15) ^ ((lane >> 4) << 2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                                     // this wave's quarter of the shared dy tile
+        const int ins = 4 * wave + i, row = 4 * ins + (lane >> 4);
+        dma16(p.a + (long)min(row, p.M - 1) * p.N + n0 + 4 * piece, lds0 + (unsigned)(ins * 1024));
+    }
+#pragma unroll
+    for (int ins = 0; ins < 16; ++ins) {                              // its own x tile
+        const int row = 4 * ins + (lane >> 4);
+        dma16(p.w + (long)min(row, p.M - 1) * p.K + k0 + 4 * piece, lds0 + (unsigned)((1 + wave) * LWD_TILE + ins * 1024));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!active) return;
+    const char* ds = smem;
+    const char* xs = smem + (1 + wave) * LWD_TILE;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool own_bias = kt == 0 && p.dbias != nullptr;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    const int roff = rr * 256 + ((la ^ (rr << 2)) << 4);               // row (4 s + rr): (row & 3) == rr
+    for (int s = 0; s < nsteps; ++s) {
+        f32x4 d4 = *reinterpret_cast<const f32x4*>(ds + s * 1024 + roff);
+        const f32x4 x4 = *reinterpret_cast<const f32x4*>(xs + s * 1024 + roff);
+        if (4 * s + rr >= p.M) d4 = (f32x4){0.f, 0.f, 0.f, 0.f};       // rows are the reduction index
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int tk = 0; tk < 4; ++tk) acc[tn][tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(d4[tn], x4[tk], acc[tn][tk], 0, 0, 0);
+        if (own_bias) bsum += d4;
+    }
+    if (own_bias) {                                                   // fixed order: steps in sequence, then the four row groups
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = bsum[j];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            bsum[j] = v;
+        }
+        if (rr == 0) *reinterpret_cast<f32x4*>(p.dbias + n0 + 4 * la) = bsum;
+    }
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            float* dst = p.out + (long)(n0 + 16 * rr + 4 * jj + tn) * p.K + k0 + 4 * la;
+            __builtin_nontemporal_store((f32x4){acc[tn][0][jj], acc[tn][1][jj], acc[tn][2][jj], acc[tn][3][jj]}, reinterpret_cast<f32x4*>(dst));
+        }
+}
+
 // plan of the streaming forms: enough items for one wave per SIMD (1024), reduction ranges multiples of 16
 struct LSPlan { bool ok; int range, nsplit, groups; };
 LSPlan plan_stream(int M, int out_cols, int red_len) {
@@ -625,7 +704,22 @@ int sh_linear_bwd_wgt(const float* dy, const float* x, float* dW, float* dbias, 
         s.a = dy; s.w = x; s.out = dW; s.M = M; s.N = N; s.K = K;
         s.dbias = (dbias && (reinterpret_cast<uintptr_t>(dbias) & 15) == 0) ? dbias : nullptr;      // fused into the tile kernel
         const int items = (N / 64) * (K / 64);
-        {
+        static const int dma_on = sh_env_int("SH_LIN_WGT_DMA", 1, 0, 1);
+        if (dma_on) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bwd_wgt_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        160 * 1024) != hipSuccess) {
+                    (void)hipGetLastError();
+                    sh_set_error("linear_bwd_wgt: cannot raise the dynamic LDS limit to %d bytes", LWD_LDS);
+                    return SH_ERR_LAUNCH;
+                }
+                attr_set = true;
+            }
+            const int wgs = (N / 64) * sh_cdiv(K / 64, 4);
+            ShProfScope ps(st, "linear_bwd_wgt_dma_kernel|M=%d N=%d K=%d", M, N, K);
+            SH_LAUNCH_PS(ps, linear_bwd_wgt_dma_kernel, dim3(wgs), dim3(LTHREADS), LWD_LDS, st, s);
+        } else {
             ShProfScope ps(st, "linear_bwd_wgt_stream_kernel|M=%d N=%d K=%d", M, N, K);
             SH_LAUNCH_PS(ps, linear_bwd_wgt_stream_kernel, dim3(sh_cdiv(items, 4)), dim3(LTHREADS), 0, st, s);
         }
