@@ -1,0 +1,159 @@
+// Host-only stand-ins for the kernel entry points the stack sequencers (csrc/stack_exec.hip) call.  The sanitizer driver
+// hands the sequencers HOST buffers sized exactly as include/sh_kernels.h specifies; every stub reads / writes the first and
+// the last element of each operand range its real counterpart would touch, so AddressSanitizer sees any pointer the
+// sequencer derived past the end of a buffer, and logs the call for the order check.  No GPU, no launches.
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "../../include/sh_kernels.h"
+
+std::vector<std::string> g_calls;
+static void touch_r(const void* p, size_t bytes) {
+    if (!p || !bytes) return;
+    volatile char c = static_cast<const volatile char*>(p)[0];
+    c = static_cast<const volatile char*>(p)[bytes - 1];
+    (void)c;
+}
+static void touch_w(void* p, size_t bytes) {
+    if (!p || !bytes) return;
+    static_cast<volatile char*>(p)[0] = 1;
+    static_cast<volatile char*>(p)[bytes - 1] = 1;
+}
+// bytes spanned by `rows` rows of a (row stride sv, batch stride sb, C channels) tensor of element size e
+static size_t span(int64_t sv, int64_t sb, int rows, int B, int C, size_t e) {
+    return (size_t)((int64_t)(rows - 1) * sv + (int64_t)(B - 1) * sb + C) * e;
+}
+static void log(const char* fmt, int a = 0, int b = 0, int c = 0) {
+    char buf[160];
+    snprintf(buf, sizeof buf, fmt, a, b, c);
+    g_calls.push_back(buf);
+}
+
+extern "C" {
+int sh_spiral_conv_fwd(const float* x, int64_t x_sv, int64_t x_sb, const int32_t* table, const float* w, const float* bias, float* y, int64_t y_sv,
+                       int64_t y_sb, int B, int R, int S, int Cin, int Cout, int act, int zero_row, sh_stream_t) {
+    int n_in = 0;
+    for (long i = 0; i < (long)R * S; ++i) n_in = table[i] + 1 > n_in ? table[i] + 1 : n_in;
+    touch_r(x, span(x_sv, x_sb, n_in, B, Cin, 4)); touch_r(w, (size_t)Cout * S * Cin * 4); touch_r(bias, bias ? Cout * 4 : 0);
+    touch_w(y, span(y_sv, y_sb, R, B, Cout, 4));
+    log("conv_fwd R=%d Cin=%d Cout=%d", R, Cin, Cout);
+    return 0;
+}
+int sh_spiral_conv_fwd_bf16(const void* x, int xd, int64_t x_sv, int64_t x_sb, const int32_t* table, const void* wfrag, const float* bias, void* y,
+                            int yd, int64_t y_sv, int64_t y_sb, int B, int R, int S, int Cin, int Cout, int act, int zero_row, sh_stream_t) {
+    int n_in = 0;
+    for (long i = 0; i < (long)R * S; ++i) n_in = table[i] + 1 > n_in ? table[i] + 1 : n_in;
+    touch_r(x, span(x_sv, x_sb, n_in, B, Cin, xd == SH_DTYPE_BF16 ? 2 : 4)); touch_r(wfrag, sh_conv_wfrag_bytes(S, Cin, Cout));
+    touch_w(y, span(y_sv, y_sb, R, B, Cout, yd == SH_DTYPE_BF16 ? 2 : 4));
+    log("conv_fwd_bf16 R=%d Cin=%d Cout=%d", R, Cin, Cout);
+    return 0;
+}
+static int spmm_common(const char* name, const int32_t* rowptr, const int32_t* col, const float* val, const void* x, int64_t x_sv, int64_t x_sb,
+                       void* y, int64_t y_sv, int64_t y_sb, const void* yprev, int64_t yp_sv, int64_t yp_sb, int B, int rows, int C, size_t e) {
+    int cols = 0;
+    for (int i = 0; i < rowptr[rows]; ++i) cols = col[i] + 1 > cols ? col[i] + 1 : cols;
+    touch_r(val, (size_t)rowptr[rows] * 4);
+    if (cols) touch_r(x, span(x_sv, x_sb, cols, B, C, e));
+    touch_w(y, span(y_sv, y_sb, rows, B, C, e));
+    if (yprev) touch_r(yprev, span(yp_sv, yp_sb, rows, B, C, e));
+    log(name, rows, C);
+    return 0;
+}
+int sh_spmm(const int32_t* rowptr, const int32_t* col, const float* val, const float* x, int64_t x_sv, int64_t x_sb, float* y, int64_t y_sv,
+            int64_t y_sb, const float* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row, int B, int rows, int C, sh_stream_t) {
+    return spmm_common("spmm rows=%d C=%d", rowptr, col, val, x, x_sv, x_sb, y, y_sv, y_sb, yprev, yp_sv, yp_sb, B, rows, C, 4);
+}
+int sh_spmm_bf16(const int32_t* rowptr, const int32_t* col, const float* val, const void* x, int64_t x_sv, int64_t x_sb, void* y, int64_t y_sv,
+                 int64_t y_sb, const void* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row, int B, int rows, int C, sh_stream_t) {
+    return spmm_common("spmm_bf16 rows=%d C=%d", rowptr, col, val, x, x_sv, x_sb, y, y_sv, y_sb, yprev, yp_sv, yp_sb, B, rows, C, 2);
+}
+int sh_act_backward(const float* dy, int64_t dy_sv, int64_t dy_sb, const float* y, int64_t y_sv, int64_t y_sb, float* dp, int64_t dp_sv, int64_t dp_sb,
+                    int B, int R, int C, int act, int zero_row, sh_stream_t) {
+    touch_r(dy, span(dy_sv, dy_sb, R, B, C, 4)); touch_r(y, span(y_sv, y_sb, R, B, C, 4)); touch_w(dp, span(dp_sv, dp_sb, R, B, C, 4));
+    log("act_backward R=%d C=%d", R, C);
+    return 0;
+}
+int sh_act_backward_bf16(const void* dy, int64_t dy_sv, int64_t dy_sb, const void* y, int64_t y_sv, int64_t y_sb, void* dp, int64_t dp_sv, int64_t dp_sb,
+                         int B, int R, int C, int act, int zero_row, sh_stream_t) {
+    touch_r(dy, span(dy_sv, dy_sb, R, B, C, 2)); touch_r(y, span(y_sv, y_sb, R, B, C, 2)); touch_w(dp, span(dp_sv, dp_sb, R, B, C, 2));
+    log("act_backward_bf16 R=%d C=%d", R, C);
+    return 0;
+}
+size_t sh_spiral_conv_bwd_wgt_workspace(int B, int R, int S, int Cin, int Cout) { return (size_t)7 * ((size_t)Cout * S * Cin + Cout) * 4; }
+size_t sh_spiral_conv_bwd_wgt_workspace_bf16(int B, int R, int S, int Cin, int Cout) { return (size_t)5 * ((size_t)Cout * S * Cin + Cout) * 4; }
+int sh_spiral_conv_bwd_wgt(const float* dpre, int64_t dp_sv, int64_t dp_sb, const float* x, int64_t x_sv, int64_t x_sb, const int32_t* table, float* dW,
+                           float* db, void* ws, size_t ws_bytes, int B, int R, int S, int Cin, int Cout, sh_stream_t) {
+    int n_in = 0;
+    for (long i = 0; i < (long)R * S; ++i) n_in = table[i] + 1 > n_in ? table[i] + 1 : n_in;
+    touch_r(dpre, span(dp_sv, dp_sb, R, B, Cout, 4)); touch_r(x, span(x_sv, x_sb, n_in, B, Cin, 4));
+    if (ws_bytes < sh_spiral_conv_bwd_wgt_workspace(B, R, S, Cin, Cout)) return SH_ERR_WORKSPACE;
+    touch_w(ws, ws_bytes);
+    log("bwd_wgt R=%d Cin=%d Cout=%d", R, Cin, Cout);
+    return 0;
+}
+int sh_spiral_conv_bwd_wgt_bf16(const void* dpre, int dd, int64_t dp_sv, int64_t dp_sb, const void* x, int xd, int64_t x_sv, int64_t x_sb,
+                                const int32_t* table, void* ws, size_t ws_bytes, int B, int R, int S, int Cin, int Cout, sh_stream_t) {
+    int n_in = 0;
+    for (long i = 0; i < (long)R * S; ++i) n_in = table[i] + 1 > n_in ? table[i] + 1 : n_in;
+    touch_r(dpre, span(dp_sv, dp_sb, R, B, Cout, dd == SH_DTYPE_BF16 ? 2 : 4)); touch_r(x, span(x_sv, x_sb, n_in, B, Cin, xd == SH_DTYPE_BF16 ? 2 : 4));
+    if (ws_bytes < sh_spiral_conv_bwd_wgt_workspace_bf16(B, R, S, Cin, Cout)) return SH_ERR_WORKSPACE;
+    touch_w(ws, ws_bytes);
+    log("bwd_wgt_bf16 R=%d Cin=%d Cout=%d", R, Cin, Cout);
+    return 0;
+}
+int sh_spiral_conv_bwd_wgt_thin_ok(int, int, int, int, int, int) { return 0; }       // the general kernels' call sequence is the one checked
+int sh_spiral_conv_bwd_wgt_thin(const float*, int64_t, int64_t, const void*, int, int64_t, int64_t, const int32_t*, void*, size_t, const float*, void*,
+                                int64_t, int64_t, int, int, int, int, int, int, int, int, int, sh_stream_t) { return SH_ERR_UNSUPPORTED; }
+static int bwd_data_common(const char* name, const void* dpre, size_t de, int64_t dp_sv, int64_t dp_sb, const int32_t* table_t, void* dx, size_t xe,
+                           int64_t dx_sv, int64_t dx_sb, const void* yprev, int64_t yp_sv, int64_t yp_sb, int B, int n_in, int S, int Cin, int Cout) {
+    int rows = 0;
+    for (long i = 0; i < (long)n_in * S; ++i) rows = table_t[i] + 1 > rows ? table_t[i] + 1 : rows;
+    touch_r(dpre, span(dp_sv, dp_sb, rows, B, Cout, de));                 // includes the pre-summed extra rows the table points at
+    touch_w(dx, span(dx_sv, dx_sb, n_in, B, Cin, xe));
+    if (yprev) touch_r(yprev, span(yp_sv, yp_sb, n_in, B, Cin, xe));
+    log(name, n_in, Cin, Cout);
+    return 0;
+}
+int sh_spiral_conv_bwd_data(const float* dpre, int64_t dp_sv, int64_t dp_sb, const int32_t* table_t, const float* weight_t, float* dx, int64_t dx_sv,
+                            int64_t dx_sb, const float* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row, int B, int n_in, int S, int Cin,
+                            int Cout, sh_stream_t) {
+    touch_r(weight_t, (size_t)Cin * S * Cout * 4);
+    return bwd_data_common("bwd_data n_in=%d Cin=%d Cout=%d", dpre, 4, dp_sv, dp_sb, table_t, dx, 4, dx_sv, dx_sb, yprev, yp_sv, yp_sb, B, n_in, S, Cin, Cout);
+}
+int sh_spiral_conv_bwd_data_bf16(const void* dpre, int dd, int64_t dp_sv, int64_t dp_sb, const int32_t* table_t, const void* wfrag_t, void* dx, int xd,
+                                 int64_t dx_sv, int64_t dx_sb, const void* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row, int B, int n_in,
+                                 int S, int Cin, int Cout, sh_stream_t) {
+    touch_r(wfrag_t, sh_conv_wfrag_bytes(S, Cout, Cin));
+    return bwd_data_common("bwd_data_bf16 n_in=%d Cin=%d Cout=%d", dpre, dd == SH_DTYPE_BF16 ? 2 : 4, dp_sv, dp_sb, table_t, dx, xd == SH_DTYPE_BF16 ? 2 : 4,
+                           dx_sv, dx_sb, yprev, yp_sv, yp_sb, B, n_in, S, Cin, Cout);
+}
+int sh_weight_transpose_multi(int n, const float* const* w, float* const* wt, const int* S, const int* Ci, const int* Co, sh_stream_t) {
+    for (int i = 0; i < n; ++i) { touch_r(w[i], (size_t)S[i] * Ci[i] * Co[i] * 4); touch_w(wt[i], (size_t)S[i] * Ci[i] * Co[i] * 4); }
+    log("weight_transpose n=%d", n);
+    return 0;
+}
+size_t sh_conv_wfrag_bytes(int S, int Cg, int Nout) {
+    const int k = Cg == 3 ? 4 * S : S * Cg, nks = (k + 31) / 32, nt = (Nout + 15) / 16;
+    const int ntt = nt <= 1 ? 1 : nt <= 2 ? 2 : nt <= 4 ? 4 : (nt + 7) / 8 * 8;
+    return (size_t)nks * ntt * 1024;
+}
+int sh_conv_wfrag_prep_multi(int n, const float* const* w, void* const* wf, const int* S, const int* Ci, const int* Co, const int* tr, sh_stream_t) {
+    for (int i = 0; i < n; ++i) {
+        touch_r(w[i], (size_t)S[i] * Ci[i] * Co[i] * 4);
+        touch_w(wf[i], tr[i] ? sh_conv_wfrag_bytes(S[i], Co[i], Ci[i]) : sh_conv_wfrag_bytes(S[i], Ci[i], Co[i]));
+    }
+    log("wfrag_prep n=%d", n);
+    return 0;
+}
+static int reduce_common(const char* name, int n, const void* const* ws, float* const* dW, float* const* db, const int* S, const int* Ci, const int* Co) {
+    for (int i = 0; i < n; ++i) { touch_r(ws[i], 16); touch_w(dW[i], (size_t)Co[i] * S[i] * Ci[i] * 4); if (db[i]) touch_w(db[i], (size_t)Co[i] * 4); }
+    log(name, n);
+    return 0;
+}
+int sh_spiral_conv_bwd_wgt_reduce_multi(int n, const void* const* ws, float* const* dW, float* const* db, const int* B, const int* R, const int* S,
+                                        const int* Ci, const int* Co, sh_stream_t) { return reduce_common("reduce n=%d", n, ws, dW, db, S, Ci, Co); }
+int sh_spiral_conv_bwd_wgt_reduce_multi_bf16(int n, const void* const* ws, float* const* dW, float* const* db, const int* B, const int* R, const int* S,
+                                             const int* Ci, const int* Co, sh_stream_t) { return reduce_common("reduce_bf16 n=%d", n, ws, dW, db, S, Ci, Co); }
+}  // extern "C"
