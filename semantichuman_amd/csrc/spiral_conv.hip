@@ -404,14 +404,17 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_direct_kernel(const GGPa
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int pq = ((lq + 4 * ks) ^ (lane & 7)) << 2;
+            // all weight quads of the step first, then t outermost: consecutive MFMAs go to DIFFERENT accumulators (a dependent
+            // v_mfma_f32_16x16x4_f32 issues 40 cycles after its predecessor, an independent one after 32)
+            f32x4 wq[NT];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const f32x4 wq = *reinterpret_cast<const f32x4*>(Wb + n * 16 * KC + pq);
+            for (int n = 0; n < NT; ++n) wq[n] = *reinterpret_cast<const f32x4*>(Wb + n * 16 * KC + pq);
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-                    for (int m = 0; m < RT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[t], ra[m][ks][t], acc[m][n], 0, 0, 0);
-            }
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int m = 0; m < RT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[n][t], ra[m][ks][t], acc[m][n], 0, 0, 0);
         }
     };
 
