@@ -230,6 +230,11 @@ def self_launch(n, argv):
     torch.distributed.run environment, wait, and return the first non-zero exit status.  Called BEFORE anything in this
     process initialises the GPU (children are started with subprocess, never exec'd from a process that touched HIP)."""
     import subprocess
+    if os.environ.get("SH_BENCH_DRYRUN", "0") == "0" and os.environ.get("SH_BENCH_BACKEND", "nccl") == "nccl":
+        have = torch.cuda.device_count()                       # counts devices without initialising the GPU in this process
+        if have < n:
+            print("bench.py: --gpus %d but this node has %d visible GPU(s)" % (n, have), file=sys.stderr)
+            return 2
     env = dict(os.environ)
     env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on this pool (RCCL needs it)
