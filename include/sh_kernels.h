@@ -58,6 +58,18 @@ enum sh_act {
 SH_API int sh_version(void);
 SH_API const char* sh_last_error(void);
 
+/* Arithmetic form of the fp32 path's matrix products (SpiralConv forward / backward-data).  The reference computes them
+ * with fp32 FMAs (models.py:45, aten::addmm).
+ *   SH_MMA_EXACT   v_mfma_f32_16x16x4_f32: an exact fp32 FMA chain.
+ *   SH_MMA_SPLIT3  every fp32 operand split EXACTLY into three bf16 terms (8+8+8 significand bits), the six leading
+ *                  partial products on v_mfma_f32_16x16x32_bf16 with fp32 accumulation; dropped terms < 2^-24 |w||x|,
+ *                  i.e. fp32-level error (the parity tolerances in tests/ are the same for both), 2.7x less matrix-pipe time.
+ * Process-wide, read at launch time (a captured hipGraph keeps the form it was captured with).  Default: environment
+ * SH_F32_MMA=exact|split3. */
+enum sh_mma_mode { SH_MMA_EXACT = 0, SH_MMA_SPLIT3 = 1 };
+SH_API int sh_set_f32_mma_mode(int mode);
+SH_API int sh_get_f32_mma_mode(void);
+
 /* Optional per-kernel timing with HIP events attached to the kernel dispatch itself (begin / end of
  * the kernel's execution, what rocprofv3 --kernel-trace reports; minor helper kernels are bracketed
  * by event records on the stream instead).  Used by bench.py for the roofline figures; off by

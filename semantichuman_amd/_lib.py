@@ -20,6 +20,8 @@ _P, _I, _L = c_void_p, c_int, c_int64
 SIGNATURES = {
     "sh_version": (c_int, []),
     "sh_last_error": (c_char_p, []),
+    "sh_set_f32_mma_mode": (c_int, [_I]),
+    "sh_get_f32_mma_mode": (c_int, []),
     "sh_clock_probe": (c_int, [_P, _I, _I, _P]),
     "sh_profile_enable": (c_int, [_I]),
     "sh_profile_count": (c_int, []),
@@ -166,6 +168,19 @@ def profile_records():
 def profile_records_by_kernel():
     """[(kernel name without the '|shape' tag, shape tag, milliseconds)]."""
     return [(n.split("|")[0], n.split("|")[1] if "|" in n else "", ms) for n, ms in profile_records()]
+
+
+MMA_MODES = {"exact": 0, "split3": 1}
+
+
+def set_f32_mma_mode(mode: str):
+    """Arithmetic form of the fp32 path's matrix products: "exact" (fp32 MFMA) or "split3" (exact bf16x3 operand split,
+    six bf16 MFMAs per product, fp32 accumulation; include/sh_kernels.h).  Process-wide, read at launch time."""
+    check(load().sh_set_f32_mma_mode(MMA_MODES[mode]), "sh_set_f32_mma_mode")
+
+
+def get_f32_mma_mode() -> str:
+    return {v: k for k, v in MMA_MODES.items()}[load().sh_get_f32_mma_mode()]
 
 
 def ptr(t):

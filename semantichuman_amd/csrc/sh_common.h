@@ -97,5 +97,7 @@ static inline int sh_ilog2_floor(int v) {
     return l;
 }
 static inline int sh_cdiv(int a, int b) { return (a + b - 1) / b; }
+// arithmetic form of the fp32 matrix products (sh_set_f32_mma_mode / SH_F32_MMA)
+int sh_f32_mma_mode();
 // tuning knob from the environment (read once by the caller through a function-local static)
 int sh_env_int(const char* name, int dflt, int lo, int hi);

@@ -98,6 +98,29 @@ int sh_clock_probe(unsigned long long* out, int n_workgroups, int iters, sh_stre
     SH_CHECK_LAUNCH("sh_clock_probe");
     return SH_OK;
 }
+// ---- arithmetic form of the fp32 path's matrix products (process-wide; read at launch time, so a captured hipGraph keeps
+// the form it was captured with).  Default from the environment: SH_F32_MMA=exact|split3 (or 0|1).
+}
+namespace {
+int mma_mode_default() {
+    const char* v = getenv("SH_F32_MMA");
+    if (!v || !*v) return SH_MMA_EXACT;
+    if (v[0] == 'e' || v[0] == '0') return SH_MMA_EXACT;
+    return SH_MMA_SPLIT3;
+}
+int g_mma_mode = -1;
+}
+int sh_f32_mma_mode() {
+    if (g_mma_mode < 0) g_mma_mode = mma_mode_default();
+    return g_mma_mode;
+}
+extern "C" {
+int sh_set_f32_mma_mode(int mode) {
+    SH_REQUIRE(mode == SH_MMA_EXACT || mode == SH_MMA_SPLIT3, SH_ERR_INVALID_ARG, "sh_set_f32_mma_mode: unknown mode %d", mode);
+    g_mma_mode = mode;
+    return SH_OK;
+}
+int sh_get_f32_mma_mode(void) { return sh_f32_mma_mode(); }
 int sh_version(void) { return 100; }   // major*10000 + minor*100 + patch
 const char* sh_last_error(void) { return g_err; }
 }

@@ -22,7 +22,7 @@
 // The MFMA sums K in the order (q, t): k = 16*ks + 4*(lane>>4) + t, which is a fixed permutation
 // of the natural order; fp32 results therefore differ from a sequential dot product only by
 // rounding (tolerance stated in tests/), and are bitwise reproducible run to run.
-#include "sh_common.h"
+#include "sh_bf16.h"
 
 #include <type_traits>
 
@@ -488,6 +488,232 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_direct_kernel(const GGPa
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// bf16x3 form of the direct kernel (sh_set_f32_mma_mode(SH_MMA_SPLIT3); Cg % 8 == 0).  Every fp32 operand is written as an
+// EXACT sum of three bf16 numbers, x = h + m + l (h = rne_bf16(x), m = rne_bf16(x - h), l = x - h - m: 8 + 8 + 8 significand
+// bits), and a product row is evaluated as the six leading terms of (Wh + Wm + Wl)(Xh + Xm + Xl) -
+//     Wh Xh + (Wh Xm + Wm Xh) + (Wh Xl + Wl Xh + Wm Xm)
+// - on v_mfma_f32_16x16x32_bf16 with fp32 accumulation.  bf16 x bf16 products are exact in fp32; the three dropped terms are
+// below 2^-24 of |w||x|, i.e. under the rounding of the fp32 FMA chain the exact form executes (the tolerances in tests/ are
+// the same for both forms; identity weights still copy bit for bit: 1.0 = (1, 0, 0) and h + m + l sums back exactly).  Six
+// 16-cycle MFMAs cover a 32-deep k-step that takes eight 32-cycle v_mfma_f32_16x16x4_f32: 2.7x less matrix-pipe time, paid
+// for with ~44 VALU operations per 8 gathered values (the split runs in the lane that loaded them).
+// Same tiling as the direct kernel: the gathered operand stays in the registers of the lane that loaded it (lane = row r,
+// k-block kq: the 32 contiguous bytes x[row r][k0 + 8 kq .. +7]); the weight chunk is split by the staging threads and kept
+// in LDS as three planes of MFMA fragments (1 KiB per 16-channel tile and plane: slot = lane, XOR-permuted inside aligned
+// groups of 8 so that the staging writes - two channels x four k-blocks per 8 threads - are conflict-free as well).
+__device__ __forceinline__ void sh_split3(const f32x4 a, const f32x4 b, u32x4& h, u32x4& m, u32x4& l) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float x0 = i < 2 ? a[2 * i] : b[2 * i - 4], x1 = i < 2 ? a[2 * i + 1] : b[2 * i - 3];
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        const bf16x2_t hp = {(__bf16)x0, (__bf16)x1};
+        const unsigned hu = __builtin_bit_cast(unsigned, hp);
+        const float r0 = x0 - __builtin_bit_cast(float, hu << 16), r1 = x1 - __builtin_bit_cast(float, hu & 0xFFFF0000u);
+        const bf16x2_t mp = {(__bf16)r0, (__bf16)r1};
+        const unsigned mu = __builtin_bit_cast(unsigned, mp);
+        const float t0 = r0 - __builtin_bit_cast(float, mu << 16), t1 = r1 - __builtin_bit_cast(float, mu & 0xFFFF0000u);
+        const bf16x2_t lp = {(__bf16)t0, (__bf16)t1};
+        h[i] = hu; m[i] = mu; l[i] = __builtin_bit_cast(unsigned, lp);
+    }
+}
+
+template <int NT, bool BWD_EPI, int RT>
+__global__ __launch_bounds__(NTHREADS) void gather_gemm_split3_kernel(const GGParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u32x4* Wl = reinterpret_cast<u32x4*>(smem);                  // [3 buffers][3 planes][NT][64 slots]
+    int* Ts = reinterpret_cast<int*>(Wl + 3 * 3 * NT * 64);      // table tile (element offsets)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int TB = 1 << p.log2TB, TV = (64 * RT) >> p.log2TB;
+    const int item = sh_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = item / p.nsplit;
+    const int n_base = (item - tile * p.nsplit) * (NT * 16);
+    const int bt = tile / p.n_vtiles, vt = tile - bt * p.n_vtiles;
+    const int v0 = vt * TV, b0 = bt * TB;
+    const int S = p.S;
+    {
+        const int nT = TV * S;
+        const long lim = (long)p.R * S;
+        for (int i = tid; i < nT; i += NTHREADS) {
+            const long g = (long)v0 * S + i;
+            Ts[i] = g < lim ? (int)(unsigned)((long)p.table[g] * p.x_sv) : 0;
+        }
+    }
+    __syncthreads();
+
+    const int lrow = lane & 15, lq = lane >> 4;
+    int a_ts[RT];
+    long a_boff[RT];
+#pragma unroll
+    for (int m = 0; m < RT; ++m) {
+        const int row = 16 * RT * wave + 16 * m + lrow;
+        const int vl = row >> p.log2TB, bl = row & (TB - 1);
+        a_ts[m] = vl * S;
+        a_boff[m] = (b0 + bl) < p.B ? (long)(b0 + bl) * p.x_sb : 0;      // rows past B read row 0 of the slice; never stored
+    }
+    // running (k, s, channel) of this lane's 8 gathered columns for the next chunk to load
+    int k_n = 8 * lq, s_n = k_n / p.Cg, c_n = k_n - s_n * p.Cg;
+    const int adv_s = KC / p.Cg, adv_c = KC - adv_s * p.Cg;
+    auto load_a = [&](f32x4 (&ra)[RT][2]) {
+        const bool kok = k_n < p.K;                              // K tail / prefetch past the end: any valid address
+        const int s = kok ? s_n : 0, ch = kok ? c_n : 0;
+        unsigned toff[RT];
+#pragma unroll
+        for (int m = 0; m < RT; ++m) toff[m] = (unsigned)Ts[a_ts[m] + s];
+#pragma unroll
+        for (int m = 0; m < RT; ++m) {
+            const float* src = p.x + toff[m] + a_boff[m] + ch;
+            ra[m][0] = *reinterpret_cast<const f32x4*>(src);
+            ra[m][1] = *reinterpret_cast<const f32x4*>(src + 4);
+        }
+        k_n += KC; c_n += adv_c; s_n += adv_s;
+        const bool wrap = c_n >= p.Cg;
+        c_n = wrap ? c_n - p.Cg : c_n;
+        s_n = wrap ? s_n + 1 : s_n;
+    };
+
+    // weight chunk staging: piece pid = tid + 256 i -> weight row pid >> 2, k-block pid & 3 (8 columns, 32 bytes)
+    constexpr int PIECES = NT * 64;
+    constexpr int WP = PIECES >= NTHREADS ? PIECES / NTHREADS : 1;
+    const bool w_thread = PIECES >= NTHREADS || tid < PIECES;
+    long w_off[WP];
+    int w_slot[WP];
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+        const int pid = tid + NTHREADS * i, n = pid >> 2, kp = pid & 3;
+        w_off[i] = (n_base + n) < p.Nout ? (long)(n_base + n) * p.Kw + 8 * kp : 8 * kp;
+        w_slot[i] = (n >> 4) * 64 + (((n & 15) + 16 * kp) ^ (kp << 1));
+    }
+    int kw_n = 8 * (tid & 3);
+    auto load_w = [&](f32x4 (&rw)[WP][2], unsigned& mask) {
+        const bool kok = kw_n < p.K;
+        mask = kok ? 1u : 0u;
+        const int kc = kok ? kw_n - 8 * (tid & 3) : 0;
+#pragma unroll
+        for (int i = 0; i < WP; ++i) {
+            rw[i][0] = *reinterpret_cast<const f32x4*>(p.w + w_off[i] + kc);
+            rw[i][1] = *reinterpret_cast<const f32x4*>(p.w + w_off[i] + kc + 4);
+        }
+        kw_n += KC;
+    };
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto store_w = [&](int buf, const f32x4 (&rw)[WP][2], unsigned mask) {
+        if (w_thread) {
+            u32x4* Wb = Wl + buf * 3 * NT * 64;
+#pragma unroll
+            for (int i = 0; i < WP; ++i) {
+                u32x4 h, m, l;
+                sh_split3(mask ? rw[i][0] : zero4, mask ? rw[i][1] : zero4, h, m, l);
+                Wb[w_slot[i]] = h;
+                Wb[NT * 64 + w_slot[i]] = m;
+                Wb[2 * NT * 64 + w_slot[i]] = l;
+            }
+        }
+    };
+
+    f32x4 acc[RT][NT];
+#pragma unroll
+    for (int m = 0; m < RT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = zero4;
+    const int rslot = lane ^ ((lane >> 4) << 1);
+    auto compute = [&](int buf, const f32x4 (&ra)[RT][2]) {
+        bf16x8 xh[RT], xm[RT], xl[RT];
+#pragma unroll
+        for (int m = 0; m < RT; ++m) {
+            u32x4 h, mm, l;
+            sh_split3(ra[m][0], ra[m][1], h, mm, l);
+            xh[m] = __builtin_bit_cast(bf16x8, h); xm[m] = __builtin_bit_cast(bf16x8, mm); xl[m] = __builtin_bit_cast(bf16x8, l);
+        }
+        const u32x4* Wb = Wl + buf * 3 * NT * 64 + rslot;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const bf16x8 wh = __builtin_bit_cast(bf16x8, Wb[n * 64]);
+            const bf16x8 wm = __builtin_bit_cast(bf16x8, Wb[(NT + n) * 64]);
+            const bf16x8 wl = __builtin_bit_cast(bf16x8, Wb[(2 * NT + n) * 64]);
+#pragma unroll
+            for (int m = 0; m < RT; ++m) {                       // smallest terms first
+                f32x4 c = acc[m][n];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[m], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[m], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm[m], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh[m], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm[m], c, 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[m], c, 0, 0, 0);
+            }
+        }
+    };
+
+    f32x4 ra[3][RT][2], rw[3][WP][2];
+    unsigned mw[3];
+    load_a(ra[0]); load_w(rw[0], mw[0]);                 // chunk 0
+    store_w(0, rw[0], mw[0]);
+    __syncthreads();
+    load_a(ra[1]); load_w(rw[1], mw[1]);                 // chunk 1
+    auto step = [&](auto J) {
+        constexpr int j = decltype(J)::value;
+        load_a(ra[(j + 2) % 3]); load_w(rw[(j + 2) % 3], mw[(j + 2) % 3]);               // chunk c+2
+        __builtin_amdgcn_sched_barrier(0);               // keep the prefetch loads AHEAD of the MFMA phase
+        compute(j, ra[j]);
+        store_w((j + 1) % 3, rw[(j + 1) % 3], mw[(j + 1) % 3]);                           // chunk c+1
+        __syncthreads();
+    };
+    for (int c = 0; c < p.nchunks; c += 3) {
+        step(std::integral_constant<int, 0>{});
+        if (c + 1 >= p.nchunks) break;
+        step(std::integral_constant<int, 1>{});
+        if (c + 2 >= p.nchunks) break;
+        step(std::integral_constant<int, 2>{});
+    }
+
+    // ---- epilogue (identical to gather_gemm_kernel): lane holds channels n0..n0+3 of tile row 16*RT*wave + 16*m + lrow
+#pragma unroll
+    for (int m = 0; m < RT; ++m) {
+        const int row = 16 * RT * wave + 16 * m + lrow;
+        const int vl = row >> p.log2TB, bl = row & (TB - 1);
+        const int v = v0 + vl, b = b0 + bl;
+        if (v >= p.R || b >= p.B) continue;
+        float* yrow = p.y + (long)v * p.y_sv + (long)b * p.y_sb;
+        const float* yp = (BWD_EPI && p.yprev) ? p.yprev + (long)v * p.yp_sv + (long)b * p.yp_sb : nullptr;
+        const bool zero = v == p.zero_row;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int n0 = n_base + n * 16 + lq * 4;
+            if (n0 >= p.Nout) continue;
+            f32x4 a = acc[m][n];
+            if (!BWD_EPI) {
+                if (p.bias) a += *reinterpret_cast<const f32x4*>(p.bias + n0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[j] = sh_act_fwd(a[j], p.act);
+            } else if (yp) {
+                const f32x4 yv = *reinterpret_cast<const f32x4*>(yp + n0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[j] *= sh_act_grad_from_out(yv[j], p.act);
+            }
+            if (zero) a = (f32x4){0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(yrow + n0) = a;
+        }
+    }
+}
+
+template <int NT, bool BWD_EPI>
+int launch_s3(const GGParams& p_in, int rt, hipStream_t st) {
+    GGParams p = p_in;
+    const int tb = 1 << p.log2TB;
+    if (tb > 64 * rt) rt = 2;
+    const int TV = (64 * rt) >> p.log2TB;
+    p.n_vtiles = sh_cdiv(p.R, TV);
+    const int nblocks = p.n_vtiles * p.n_btiles * p.nsplit;
+    const size_t smem = (size_t)(3 * 3 * NT * 64) * 16 + (size_t)(TV * p.S) * sizeof(int);
+    ShProfScope ps(st, "gather_gemm_split3_kernel<%d, %s, %d>|R=%d B=%d K=%d N=%d grid=%d", NT, BWD_EPI ? "true" : "false", rt, p.R,
+                   p.B, p.K, p.Nout, nblocks);
+    if (rt == 1) SH_LAUNCH_PS(ps, (gather_gemm_split3_kernel<NT, BWD_EPI, 1>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
+    else SH_LAUNCH_PS(ps, (gather_gemm_split3_kernel<NT, BWD_EPI, 2>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
+    SH_CHECK_LAUNCH("gather_gemm_split3");
+    return SH_OK;
+}
+
 template <int NT, bool BWD_EPI>
 int launch_ggd(const GGParams& p_in, int nblocks128 /* workgroups if the tiles had 128 rows */, hipStream_t st) {
     // 16-row tiles per wave.  Measured on MI355X (B = 64): one tile per wave (64-row workgroups, twice as many of them)
@@ -556,6 +782,22 @@ int dispatch_gg(GGParams& p, hipStream_t st) {
                 (reinterpret_cast<uintptr_t>(p.y) % 16 == 0) &&
                 (!p.bias || reinterpret_cast<uintptr_t>(p.bias) % 16 == 0) &&
                 (!p.yprev || ((p.yp_sv % 4 == 0) && (p.yp_sb % 4 == 0) && reinterpret_cast<uintptr_t>(p.yprev) % 16 == 0));
+    // bf16x3 form (sh_set_f32_mma_mode): up to four channel tiles per workgroup, the rest split over workgroups
+    if (sh_f32_mma_mode() == SH_MMA_SPLIT3 && vec4 && p.vec_out && !c3 && p.Cg % 8 == 0) {
+        static const int s3_nt = sh_env_int("SH_S3_NT", 4, 1, 8), s3_rt = sh_env_int("SH_S3_RT", 0, 0, 2);
+        static const int s3_rt2_at = sh_env_int("SH_S3_RT2_AT", 2048, 1, 1 << 30);
+        int ntw = nt;
+        p.nsplit = 1;
+        while (ntw > s3_nt) { ntw >>= 1; p.nsplit <<= 1; }
+        const long wg64 = (long)sh_cdiv(p.R, 64 >> (p.log2TB < 6 ? p.log2TB : 6)) * p.n_btiles * p.nsplit;      // workgroups of 64 rows
+        const int rt = s3_rt ? s3_rt : (wg64 >= s3_rt2_at ? 2 : 1);
+        switch (ntw) {
+            case 1: return launch_s3<1, BWD_EPI>(p, rt, st);
+            case 2: return launch_s3<2, BWD_EPI>(p, rt, st);
+            case 4: return launch_s3<4, BWD_EPI>(p, rt, st);
+            default: return launch_s3<8, BWD_EPI>(p, rt, st);
+        }
+    }
     // too few row tiles to fill 256 CUs x ~3 workgroups: split the output channels over workgroups
     static const int fill_target = sh_env_int("SH_GG_FILL", 768, 1, 1 << 20);
     static const int direct_on = sh_env_int("SH_GG_DIRECT", 1, 0, 1);
