@@ -35,75 +35,58 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA dense p
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
 
 
-def conv_launch_table(model, B):
-    """Algorithmic FLOPs / bytes per launch of every conv kernel instance, keyed by the kernel
-    name the library's profiler reports (DESIGN.md 'Roofline accounting')."""
+def f32_work_table(model, B):
+    """Algorithmic FLOPs / fused-ideal bytes of every conv-family launch of one fp32 training step, keyed by what the
+    library's profiler tags the launch with - (pass, rows, K, output channels) - not by kernel name, so the pricing follows
+    the launches whichever instantiation the dispatch picks (DESIGN.md 'Roofline accounting'):
+        ("fwd", R, S*Cin, Cout)   ("bwd", n_in, S*Cout, Cin)   ("wgt", R, S*Cin, Cout)   ("wgt+bwd", R, S*Cin, Cout)
+    3-channel inputs run over zero-padded quads (K tagged 4*S); both spellings are keys of the same entry."""
     from semantichuman_amd import _lib
     out = {}
-
-    def add(name, flops, nbytes):
-        e = out.setdefault(name, {"flops": 0.0, "bytes": 0.0, "launches": 0})
-        e["flops"] += flops; e["bytes"] += nbytes; e["launches"] += 1
-
-    def nt(c):
-        t = (c + 15) // 16
-        return 1 if t <= 1 else 2 if t <= 2 else 4 if t <= 4 else 8
     first = True
-    tb16 = "true" if B >= 16 else "false"          # batch-slice width of the tiles (SH_GG_TB default 16)
-    tb = 16 if B >= 16 else 1 << max(0, (B - 1).bit_length())
-
-    def nt_split(rows, nout, cg):
-        """Output-channel tiles per workgroup after the few-tiles split of dispatch_gg() (csrc/spiral_conv.hip)."""
-        t, blocks, split = nt(nout), -(-rows // (128 // tb)) * -(-B // tb), 1
-        direct = cg % 4 == 0
-        while t > 2 and blocks * split < 768:
-            t //= 2; split *= 2
-        if t == 2 and blocks * split * (2 if direct else 1) < 768:
-            t, split = 1, split * 2
-        if t == 8 and direct:
-            t, split = 4, split * 2
-        return t, blocks * split
-    def gg_name(t, blocks128, cg, bwd):
-        """dispatch_gg(): two channel tiles with 16-byte gathers run the direct (LDS-free gather) form; 3-channel
-        gathered rows with one channel tile run the padded-quad (dwordx3) mode of the staged kernel."""
-        if cg == 3 and t == 1:
-            return "gather_gemm_kernel<1, true, %s, %s, true>" % (bwd, tb16)
-        vec4 = "true" if cg % 4 == 0 else "false"
-        if t in (2, 4) and vec4 == "true":
-            return "gather_gemm_direct_kernel<%d, %s, %d>" % (t, bwd, 1 if blocks128 <= 1024 else 2)
-        return "gather_gemm_kernel<%d, %s, %s, %s, false>" % (t, vec4, bwd, tb16)
-
     for stack in (model._enc_stack, model._dec_stack):
         for st in stack.steps:
             if st.kind != "conv":
                 continue
             K = st.S * st.cin
             fl = 2.0 * B * st.R * K * st.cout
-            vec = "true" if st.cin % 4 == 0 else "false"
-            # fwd: read each needed input row once + weights, write output
+            # each needed input row read once + weights, output written once
             byt = 4.0 * (B * st.n_in * st.cin + B * st.R * st.cout + st.cout * K)
-            add(gg_name(*nt_split(st.R, st.cout, st.cin), cg=st.cin, bwd="false"), fl, byt)
+            e = {"flops": fl, "bytes": byt}
+            out[("fwd", st.R, K, st.cout)] = e
+            if st.cin == 3:
+                out[("fwd", st.R, 4 * st.S, st.cout)] = e
             not_first = not (first and stack is model._enc_stack)
             thin = not_first and st.R == st.n_in and bool(_lib.load().sh_spiral_conv_bwd_wgt_thin_ok(B, st.n_in, st.S, st.cin, st.cout, 0))
             if not_first and not thin:
-                # backward-data = the same kernel over the transposed table; algorithmic FLOPs are
-                # those of the R*S real (row, position) pairs, not of the padded n_in*S table
-                add(gg_name(*nt_split(st.n_in, st.cin, st.cout), cg=st.cout, bwd="true"), fl, byt)
-            if thin:
-                # the 16 -> 3 channel layer: role-swapped weight gradient AND backward-data in one launch (csrc/wgrad_thin.hip)
-                add("wgrad_thin_kernel<f32>", 2 * fl, 2 * byt)
-            elif st.cin % 4 == 0 or st.cin == 3:       # same choices as plan_wgrad() in csrc/spiral_conv.hip
-                cot = nt(st.cout)
-                add("wgrad_stream_kernel<%d, %d, %d, %s, %s>" % (cot, 1 if B <= 4 else 4, 3 if cot <= 2 else 2,
-                                                                 "true" if B % (4 if B <= 4 else 16) == 0 else "false",
-                                                                 "true" if st.cin == 3 else "false"), fl, byt)
+                # backward-data = the same kernels over the transposed table; algorithmic FLOPs are those of the R*S real
+                # (row, position) pairs, not of the padded n_in*S table
+                out[("bwd", st.n_in, st.S * st.cout, st.cin)] = e
+            if thin:     # the 16 -> 3 channel layer: role-swapped weight gradient AND backward-data in one launch (csrc/wgrad_thin.hip)
+                out[("wgt+bwd", st.R, K, st.cout)] = {"flops": 2 * fl, "bytes": 2 * byt}
             else:
-                cp = nt(st.cout) * 16
-                cost1, cost2 = -(-K // 64) * (64 + cp), -(-K // 128) * (128 + cp)
-                ctw = 1 if (nt(st.cout) == 8 or cost1 <= cost2) else 2
-                add("wgrad_kernel<%d, %d, %s>" % (nt(st.cout), ctw, vec), fl, byt)
+                out[("wgt", st.R, K, st.cout)] = e
             first = False
     return out
+
+
+def parse_tag_f32(name, shape):
+    """Key into f32_work_table() of one profiler record (kernel name, shape tag), or None for other kernels."""
+    fam = name.split("<")[0]
+    targs = [t.strip() for t in name.split("<")[1].rstrip(">").split(",")] if "<" in name else []
+    f = dict(kv.split("=") for kv in shape.split() if "=" in kv)
+    try:
+        if fam == "gather_gemm_kernel":
+            return ("bwd" if targs[2] == "true" else "fwd", int(f["R"]), int(f["K"]), int(f["N"]))
+        if fam.startswith("gather_gemm_"):                 # direct / split3 / coalesced forms: <NT, BWD, ...>
+            return ("bwd" if targs[1] == "true" else "fwd", int(f["R"]), int(f["K"]), int(f["N"]))
+        if fam in ("wgrad_stream_kernel", "wgrad_kernel") or fam.startswith("wgrad_split"):
+            return ("wgt", int(f["R"]), int(f["K"]), int(f["N"]))
+        if fam == "wgrad_thin_kernel":
+            return ("wgt+bwd" if f.get("dx") == "1" else "wgt", int(f["R"]), int(f["S"]) * int(f["Cin"]), int(f["N"]))
+    except (KeyError, ValueError, IndexError):
+        return None
+    return None
 
 
 def bf16_work_table(model, B):
@@ -153,35 +136,45 @@ def parse_tag(name, shape):
 
 
 def lib_sha16():
-    """Identity of the kernel-library build: SHA-256 over the kernel sources (csrc/*.hip, *.h, Makefile, in name order) - what
-    the library is compiled from.  (The bytes of the .so itself are not reproducible across checkouts; a profile taken on
-    these sources stays valid wherever they are rebuilt.)"""
+    """Identity of the kernel SOURCES: SHA-256 over csrc/*.hip, csrc/*.h (each group in name order) and the Makefile - the
+    bytes csrc/Makefile hashes into the library as sh_build_id().  (The bytes of the .so itself are not reproducible
+    across checkouts; a profile taken on these sources stays valid wherever they are rebuilt.)"""
     import glob
     import hashlib
     d = os.path.join(ROOT, "semantichuman_amd", "csrc")
     hsh = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")) + [os.path.join(d, "Makefile")]):
-        hsh.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
+    for f in sorted(glob.glob(os.path.join(d, "*.hip"))) + sorted(glob.glob(os.path.join(d, "*.h"))) + [os.path.join(d, "Makefile")]:
+        hsh.update(open(f, "rb").read())
     return hsh.hexdigest()[:16]
 
 
-def measured_traffic(kernel, dtype):
+def workload_tag(verts, B, dtype, mma="exact"):
+    """Name of a measured workload: what a PMC profile must have been taken on to be quoted for a run."""
+    return "%dv_b%d_%s%s" % (verts, B, dtype, "" if (dtype != "f32" or mma == "exact") else "_" + mma)
+
+
+def measured_traffic(kernel, workload):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE
-    in separate passes, gfx950 corrections applied) - quoted only while the profile was taken on THIS build of the kernel
-    library (hash stamp); a stale profile yields (None, reason) instead of a silently wrong number."""
-    for name in ("r02_pmc_traffic_%s.json" % dtype,):
-        path = os.path.join(ROOT, "profiles", name)
-        try:
-            pmc = json.load(open(path))
-        except (OSError, ValueError):
-            return None, "no PMC profile (%s)" % name
-        meta = pmc.get("_meta", {})
-        if meta.get("lib_sha16") != lib_sha16():
-            return None, "PMC profile %s was taken on another build of the kernel library (%s != %s)" % (name, meta.get("lib_sha16"), lib_sha16())
-        if kernel not in pmc:
-            return None, "kernel not in %s" % name
-        return pmc[kernel]["hbm_bytes_per_launch"], "bytes/launch, rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE (profiles/%s, same library build)" % name
-    return None, "no PMC profile"
+    in separate passes, gfx950 corrections applied) - quoted only while the profile was taken on THIS workload (template,
+    batch, dtype, arithmetic form), on THIS build of the kernel library (sh_build_id() of the loaded .so) and with the same
+    SH_* switches; anything else yields (None, reason) instead of a silently wrong number."""
+    from semantichuman_amd import _lib
+    name = "r03_pmc_traffic_%s.json" % workload
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+        pmc = json.load(open(path))
+    except (OSError, ValueError):
+        return None, "no PMC profile for this workload (%s)" % name
+    meta = pmc.get("_meta", {})
+    if meta.get("workload") != workload:
+        return None, "PMC profile %s is stamped for workload %r, not %r" % (name, meta.get("workload"), workload)
+    if meta.get("lib_sha16") != _lib.build_id():
+        return None, "PMC profile %s was taken on another build of the kernel library (%s != %s)" % (name, meta.get("lib_sha16"), _lib.build_id())
+    if meta.get("env", {}) != _lib.env_overrides():
+        return None, "PMC profile %s was taken with other SH_* switches (%s)" % (name, meta.get("env"))
+    if kernel not in pmc:
+        return None, "kernel not in %s" % name
+    return pmc[kernel]["hbm_bytes_per_launch"], "bytes/launch, rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE (profiles/%s: same workload, library build and switches)" % name
 
 
 def step_work(model, B, dtype):
@@ -218,11 +211,278 @@ def step_work(model, B, dtype):
     return flops, byt
 
 
+def replayed_training(sh, h, B, dtype, dev, steps, warmup, n_data=None, seed=100):
+    """One more training configuration measured the way the headline is: model on hierarchy `h`, batch B, kernels in
+    `dtype`; forward + loss + backward + Adam captured into one hipGraph; `steps` timed replays (batch copy-in included)
+    after `warmup`.  Returns (result dict, model, init_state, data) - used by the `secondary` block."""
+    from semantichuman_amd import synthetic
+    torch.manual_seed(2)
+    model = sh.SpiralAutoencoder(FE, FD, 256, h.sizes, h.spiral_sizes, h.spirals, h.D, h.U, dev)
+    if dtype == "bf16":
+        model.set_compute_dtype(torch.bfloat16)
+    init_state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    optim = sh.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-5)
+    ft = sh.FaceTables(h.faces, h.sizes[0] + 1, dev)
+    n_data = n_data or 4 * B
+    data = torch.from_numpy(synthetic.synth_batch(h.verts, n_data, seed=seed)).to(dev)
+    xin = torch.empty((B, h.sizes[0] + 1, 3), dtype=torch.float32, device=dev)
+    unit = torch.ones((), dtype=torch.float32, device=dev)
+
+    def one_step():
+        optim.zero_grad(set_to_none=True)
+        x_hat, _ = model(xin)
+        loss, _ = sh.recon_loss(x_hat, xin, ft, 1e-2)
+        loss.backward(unit)
+        optim.step()
+
+    xin.copy_(data[:B])
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            one_step()
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        one_step()
+    model.load_state_dict(init_state)
+    for st in optim.state.values():
+        for v in st.values():
+            if torch.is_tensor(v):
+                v.zero_()
+
+    def step(i):
+        o = (i * B) % n_data
+        xin.copy_(data[o:o + B])
+        graph.replay()
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    fl, by = step_work(model, B, dtype)
+    res = {"ms_per_step": 1e3 * dt, "meshes_per_s": B / dt, "steps": steps, "warmup": warmup, "batch": B, "dtype": dtype,
+           "vertices": int(h.sizes[0]), "spiral_sizes": [int(v) for v in h.spiral_sizes[:-1]], "launch": "hipGraph replay",
+           "whole_step": {"flops": fl, "hbm_bytes_ideal": by, "tflops": fl / dt / 1e12, "gbps": by / dt / 1e9,
+                          "frac_mfma": fl / dt / 1e12 / (2500.0 if dtype == "bf16" else PEAK_F32_MFMA_TFLOPS),
+                          "frac_hbm": by / dt / 1e9 / PEAK_HBM_GBS}}
+    del graph
+    return res, model, init_state, data, ft
+
+
+def secondary_block(sh, h, B, dev, init_state, data, test, ft, cpu_l2_mm, args):
+    """BASELINE configs 3 (per-GPU shard), 4, 5 and the semantic iteration, each measured after the headline's timed region:
+    20 replayed steps (graph replay, batch copy-in included) after 5 warm-up; failures are reported, not fatal."""
+    from semantichuman_amd import _lib
+    from semantichuman_amd.hierarchy import load_hierarchy
+    out = {}
+    steps, warm = 20, 5
+
+    def leg(name, fn):
+        try:
+            t0 = time.perf_counter()
+            out[name] = fn()
+            out[name]["wall_s"] = round(time.perf_counter() - t0, 2)
+        except Exception as e:      # noqa: BLE001
+            out[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
+    def bf16_leg():
+        res, model, init16, d16, ft16 = replayed_training(sh, h, B, "bf16", dev, steps, warm)
+        # roofline of its dominant kernel against HBM: per-launch HIP events of 3 eagerly launched steps
+        opt = sh.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-5)
+        x = d16[:B]
+        _lib.profile_enable(True)
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            loss, _ = sh.recon_loss(model(x)[0], x, ft16, 1e-2)
+            loss.backward()
+            opt.step()
+        torch.cuda.synchronize()
+        recs = _lib.profile_records_by_kernel()
+        _lib.profile_enable(False)
+        rf = roofline_bf16(recs, model, B, 3, h.sizes[0])
+        res["roofline"] = rf["roofline"]
+        res["hip_kernel_ms_per_step"] = rf["hip_kernel_ms_per_step"]
+        del model, opt
+        if cpu_l2_mm is not None:
+            margs = (FE, FD, 256, h.sizes, h.spiral_sizes, h.spirals, h.D, h.U)
+            l2 = hip_trajectory_l2(sh, margs, init_state, "bf16", data[:B], test, ft, 1 + args.cpu_iters, dev)
+            res["matched_l2"] = {"steps": 1 + args.cpu_iters, "batch": B, "hip_mm": l2, "cpu_oracle_mm": cpu_l2_mm,
+                                 "rel_diff": abs(l2 - cpu_l2_mm) / cpu_l2_mm,
+                                 "note": "same trajectory as the headline's matched_l2, bf16 kernels vs the fp32 CPU oracle"}
+        res["config"] = "BASELINE configs[2] per-GPU shard: batch %d, bf16 kernels, fp32 master weights / gradients / Adam" % B
+        return res
+
+    def config4_leg():
+        h4 = load_hierarchy(os.path.join(ROOT, "tests", "golden", "template27554.npz"))
+        res, model, _, _, _ = replayed_training(sh, h4, 32, "f32", dev, steps, warm, n_data=64)
+        del model
+        res["config"] = "BASELINE configs[3]: 27 554 vertices, spiral length 18, batch 32, fp32"
+        return res
+
+    def decode_leg():
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_decode
+        r = bench_decode.run(latents=20 * 1024, batch=1024, dev=dev)
+        r["config"] = "BASELINE configs[4] on a bounded sample: 20 batches of 1024 random latents (the full run is tools/bench_decode.py: 100k)"
+        return r
+
+    def semantic_leg():
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_semantic
+        r = bench_semantic.run(batch=16, steps=steps, graph=True, dev=dev, warmup=5)
+        r["config"] = "semantic training iteration (SURVEY row f1): 3 passes x 16 meshes, all part losses, backward, Adam"
+        return r
+
+    leg("bf16_step", bf16_leg)
+    leg("config4_27k", config4_leg)
+    leg("decode_b1024", decode_leg)
+    leg("semantic_iteration", semantic_leg)
+    return out
+
+
+def hip_trajectory_l2(sh, model_args, init_state, dtype, xg, test, ft, n_steps, dev):
+    """Held-out per-vertex L2 (mm) after `n_steps` training steps on the batch `xg` from `init_state` (Adam from zero
+    moments) on the HIP path - the trajectory the CPU oracle runs for `cpu_baseline`."""
+    m2 = sh.SpiralAutoencoder(*model_args, dev)
+    if dtype == "bf16":
+        m2.set_compute_dtype(torch.bfloat16)
+    m2.load_state_dict(init_state)
+    o2 = sh.optim.Adam(m2.parameters(), lr=1e-3, weight_decay=5e-5)
+    for _ in range(n_steps):
+        o2.zero_grad(set_to_none=True)
+        l2loss, _ = sh.recon_loss(m2(xg)[0], xg, ft, 1e-2)
+        l2loss.backward()
+        o2.step()
+    with torch.no_grad():
+        return float(sh.vertex_l2_mm(m2(test)[0], test).item())
+
+
+def roofline_bf16(recs, model, B, nprof, verts):
+    """`roofline` / `kernel_families` / `kernel_breakdown` of a bf16 run from the library's per-launch HIP-event records of
+    `nprof` eagerly launched steps."""
+    from semantichuman_amd import _lib
+    result = {}
+    work = bf16_work_table(model, B)
+    agg = {}
+    for name, shape, ms in recs:
+        a = agg.setdefault(name, {"n": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "matched": 0})
+        a["n"] += 1; a["ms"] += ms
+        key = parse_tag(name, shape)
+        if key in work:
+            a["flops"] += work[key][0]; a["bytes"] += work[key][1]; a["matched"] += 1
+    kernels = []
+    for name, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+        e = {"kernel": name, "launches_per_step": a["n"] / nprof, "avg_ms": a["ms"] / a["n"], "ms_per_step": a["ms"] / nprof}
+        if a["matched"] == a["n"] and a["n"]:
+            e["gbps"] = a["bytes"] / (a["ms"] * 1e-3) / 1e9
+            e["tflops"] = a["flops"] / (a["ms"] * 1e-3) / 1e12
+        kernels.append(e)
+    fam = {}
+    for k in kernels:
+        f = fam.setdefault(k["kernel"].split("<")[0].split("|")[0], 0.0)
+        fam[k["kernel"].split("<")[0].split("|")[0]] = f + k["ms_per_step"]
+    conv = [k for k in kernels if "gbps" in k]
+    dom = conv[0] if conv else kernels[0]
+    a = agg[dom["kernel"]]
+    # bf16: ridge of the chip ~ 2.5 PF / 8 TB/s = 300 FLOP/B, these layers have 30-250 FLOP/B -> HBM roof
+    traffic, traffic_note = measured_traffic(dom["kernel"], workload_tag(verts, B, "bf16"))
+    result["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom.get("gbps"), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                          "frac": (dom["gbps"] / PEAK_HBM_GBS) if "gbps" in dom else None, "traffic": traffic, "traffic_unit": traffic_note,
+                          "avg_launch_ms": dom["avg_ms"], "launches_per_step": dom["launches_per_step"],
+                          "algorithmic_bytes_per_launch": a["bytes"] / a["n"] if a["n"] else None,
+                          "flops_per_launch": a["flops"] / a["n"] if a["n"] else None,
+                          "mfma_tflops": dom.get("tflops"), "mfma_peak_tflops": 2500.0}
+    result["kernel_families"] = {n: {"ms_per_step": v} for n, v in sorted(fam.items(), key=lambda kv: -kv[1])[:10]}
+    result["kernel_breakdown"] = kernels[:10]
+    result["hip_kernel_ms_per_step"] = sum(k["ms_per_step"] for k in kernels)
+    return result
+
+
+def roofline_f32(recs, model, B, nprof, verts):
+    """The same for the fp32 path (MFMA roof)."""
+    from semantichuman_amd import _lib
+    result = {}
+    work = f32_work_table(model, B)
+    agg = {}
+    for name, shape, ms in recs:
+        a = agg.setdefault(name, {"n": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "matched": 0})
+        a["n"] += 1; a["ms"] += ms
+        key = parse_tag_f32(name, shape)
+        if key in work:
+            a["flops"] += work[key]["flops"]; a["bytes"] += work[key]["bytes"]; a["matched"] += 1
+    kernels = []
+    for name, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+        e = {"kernel": name, "launches_per_step": a["n"] / nprof, "avg_ms": a["ms"] / a["n"], "ms_per_step": a["ms"] / nprof}
+        if a["matched"] == a["n"] and a["n"]:
+            e["tflops"] = a["flops"] / (a["ms"] * 1e-3) / 1e12
+        kernels.append(e)
+    # The roofline is quoted for the single most expensive kernel instantiation of the step that does matrix work (the
+    # fused gather + MFMA conv kernels, forward / backward-data / weight gradient), under the exact name rocprofv3
+    # prints (profiles/); achieved = algorithmic FLOPs of its launches / their measured duration.
+    conv = [k for k in kernels if "tflops" in k]
+    dom = conv[0] if conv else kernels[0]
+    fam = {}
+    for k in kernels:
+        f = fam.setdefault(k["kernel"].split("<")[0].split("|")[0], [0.0, 0.0])
+        f[0] += k["ms_per_step"]
+        f[1] += agg[k["kernel"]]["flops"] / nprof
+    # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+    # collected separately; tools/pmc_traffic.py) - measured on the same workload, not in this run
+    mma = _lib.get_f32_mma_mode()
+    traffic, traffic_note = measured_traffic(dom["kernel"], workload_tag(verts, B, "f32", mma))
+    if "tflops" in dom:
+        a = agg[dom["kernel"]]
+        result["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
+                              "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                              "traffic_unit": traffic_note,
+                              "avg_launch_ms": dom["avg_ms"], "launches_per_step": dom["launches_per_step"],
+                              "flops_per_launch": a["flops"] / a["n"], "algorithmic_bytes_per_launch": a["bytes"] / a["n"],
+                              "f32_mma": mma}
+    else:
+        result["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                              "frac": None, "traffic": None, "avg_launch_ms": dom["avg_ms"]}
+    result["kernel_families"] = {n: {"ms_per_step": v[0], "tflops": (v[1] / (v[0] * 1e-3) / 1e12) if v[1] else None}
+                                 for n, v in sorted(fam.items(), key=lambda kv: -kv[1][0])[:8]}
+    result["kernel_breakdown"] = kernels[:8]
+    result["hip_kernel_ms_per_step"] = sum(k["ms_per_step"] for k in kernels)
+    return result
+
+
 def _free_port():
     import socket
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
+
+
+def visible_gpus():
+    """Number of GPUs a rank process of this job can open, WITHOUT touching the HIP runtime (the launcher parent must stay
+    GPU-free: it spawns the ranks): KFD topology nodes with SIMDs (/sys/class/kfd/kfd/topology/nodes/*/properties,
+    simd_count > 0; CPU nodes have 0), narrowed by HIP_/ROCR_/CUDA_VISIBLE_DEVICES when set.  None when sysfs has no KFD
+    topology (then the rank processes fail with their own message)."""
+    import glob
+    n = 0
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    for f in nodes:
+        try:
+            props = dict(l.split(None, 1) for l in open(f).read().splitlines() if " " in l)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0").strip() or 0) > 0:
+            n += 1
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
 
 
 def self_launch(n, argv):
@@ -231,8 +491,8 @@ def self_launch(n, argv):
     process initialises the GPU (children are started with subprocess, never exec'd from a process that touched HIP)."""
     import subprocess
     if os.environ.get("SH_BENCH_DRYRUN", "0") == "0" and os.environ.get("SH_BENCH_BACKEND", "nccl") == "nccl":
-        have = torch.cuda.device_count()                       # counts devices without initialising the GPU in this process
-        if have < n:
+        have = visible_gpus()                                  # sysfs / environment only: no HIP call in this process
+        if have is not None and have < n:
             print("bench.py: --gpus %d but this node has %d visible GPU(s)" % (n, have), file=sys.stderr)
             return 2
     env = dict(os.environ)
@@ -296,6 +556,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE: 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` block (the other BASELINE configurations, "
+                    "each timed as 20 replayed steps after the headline's timed region)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured hipGraph")
     ap.add_argument("--adam", choices=["hip", "torch"], default="hip", help="library Adam kernel, or torch's fused capturable Adam")
     ap.add_argument("--adam-overlap", action="store_true", help="update the big parameters on a side stream underneath backward (measured: no gain, the GPU is already saturated)")
@@ -385,20 +647,47 @@ def main():
         loss.backward(unit)
         last["loss"] = loss.detach()
 
-    use_graph = (not args.no_graph) and world == 1 and not force_reducer
+    def one_step():
+        fwd_bwd()
+        if reducer:
+            reducer.finish()
+        optim.step()
+
+    # One hipGraph holds the whole step - forward, backward, the RCCL all-reduces (launched from the gradient hooks in the
+    # middle of backward, on the process group's own stream: the capture forks to it and joins in finish()) and Adam - so
+    # the multi-rank step is replayed, not host-paced.  torch's NCCL process group is capturable once the communicator
+    # exists (init_process_group(device_id=...) creates it eagerly; the warm-up steps below run every collective once).
+    use_graph = not args.no_graph
     graph = None
+    graph_note = None
     if use_graph:
-        # capture forward+backward+Adam once, replay per step: removes ~100 host launches/step
         xin.copy_(data[:B])
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            for _ in range(3):                    # warm allocator, Adam state
-                fwd_bwd(); optim.step()
+            for _ in range(3):                    # warm allocator, Adam state, communicator
+                one_step()
         torch.cuda.current_stream().wait_stream(s)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            fwd_bwd(); optim.step()
+        torch.cuda.synchronize()
+        if reducer and world > 1:
+            dist.barrier()
+        ok = 1
+        try:
+            graph = torch.cuda.CUDAGraph()
+            # thread_local: the process group's watchdog thread may query events of the warm-up collectives meanwhile
+            with torch.cuda.graph(graph, capture_error_mode="thread_local" if reducer else "global"):
+                one_step()
+        except Exception as e:                    # noqa: BLE001 - any capture failure means: run eagerly, and say why
+            ok, graph = 0, None
+            graph_note = "hipGraph capture failed (%s: %s); eager launches" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else "")
+            print("bench.py[rank %d]: %s" % (rank, graph_note), file=sys.stderr)
+            torch.cuda.synchronize()
+            optim.zero_grad(set_to_none=True)
+        if world > 1:                             # every rank replays, or none does
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0 and graph is not None:
+                graph, graph_note = None, "hipGraph capture failed on another rank; eager launches"
         # capture must not change what is measured: restore the initial weights / optimizer
         model.load_state_dict(init_state)
         for st in optim.state.values():
@@ -412,10 +701,7 @@ def main():
         if graph is not None:
             graph.replay()
         else:
-            fwd_bwd()
-            if reducer:
-                reducer.finish()
-            optim.step()
+            one_step()
 
     for i in range(args.warmup):
         step(i)
@@ -453,7 +739,8 @@ def main():
                                % ("box_sphere(42,42,20) 6890-vertex template" if h.sizes[0] == 6890 else "%d-vertex template" % h.sizes[0],
                                   h.sizes, h.spiral_sizes[:-1], sum(p.numel() for p in model.parameters()) / 1e6),
                    "global_batch": world * B, "per_gpu_batch": B, "parallelism": "dp%d" % world,
-                   "launch": "hipGraph replay" if graph is not None else "eager",
+                   "launch": ("hipGraph replay" + (" (RCCL all-reduces inside the graph)" if reducer else "")) if graph is not None
+                             else (graph_note or "eager"),
                    **({"gradient_messages": "%.1f MB %s all-reduce per step" % (
                        sum(b.numel * (2 if (b.inplace and args.grad_comm == "bf16") else 4) for b in reducer.buckets) / 1e6,
                        "bf16 (large) + fp32" if args.grad_comm == "bf16" else "fp32")} if reducer else {})},
@@ -487,87 +774,12 @@ def main():
             optim.step()
         torch.cuda.synchronize()
         _stack.OVERLAP_WGRAD = overlap_was
-    if rank == 0 and not args.no_roofline and args.dtype == "bf16":
+    if rank == 0 and not args.no_roofline:
         recs = _lib.profile_records_by_kernel()
         _lib.profile_enable(False)
-        work = bf16_work_table(model, B)
-        agg = {}
-        for name, shape, ms in recs:
-            a = agg.setdefault(name, {"n": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "matched": 0})
-            a["n"] += 1; a["ms"] += ms
-            key = parse_tag(name, shape)
-            if key in work:
-                a["flops"] += work[key][0]; a["bytes"] += work[key][1]; a["matched"] += 1
-        kernels = []
-        for name, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
-            e = {"kernel": name, "launches_per_step": a["n"] / nprof, "avg_ms": a["ms"] / a["n"], "ms_per_step": a["ms"] / nprof}
-            if a["matched"] == a["n"] and a["n"]:
-                e["gbps"] = a["bytes"] / (a["ms"] * 1e-3) / 1e9
-                e["tflops"] = a["flops"] / (a["ms"] * 1e-3) / 1e12
-            kernels.append(e)
-        fam = {}
-        for k in kernels:
-            f = fam.setdefault(k["kernel"].split("<")[0].split("|")[0], 0.0)
-            fam[k["kernel"].split("<")[0].split("|")[0]] = f + k["ms_per_step"]
-        conv = [k for k in kernels if "gbps" in k]
-        dom = conv[0] if conv else kernels[0]
-        a = agg[dom["kernel"]]
-        # bf16: ridge of the chip ~ 2.5 PF / 8 TB/s = 300 FLOP/B, these layers have 30-250 FLOP/B -> HBM roof
-        traffic, traffic_note = measured_traffic(dom["kernel"], "bf16")
-        result["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom.get("gbps"), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                              "frac": (dom["gbps"] / PEAK_HBM_GBS) if "gbps" in dom else None, "traffic": traffic, "traffic_unit": traffic_note,
-                              "avg_launch_ms": dom["avg_ms"], "launches_per_step": dom["launches_per_step"],
-                              "algorithmic_bytes_per_launch": a["bytes"] / a["n"] if a["n"] else None,
-                              "flops_per_launch": a["flops"] / a["n"] if a["n"] else None,
-                              "mfma_tflops": dom.get("tflops"), "mfma_peak_tflops": 2500.0}
-        result["kernel_families"] = {n: {"ms_per_step": v} for n, v in sorted(fam.items(), key=lambda kv: -kv[1])[:10]}
-        result["kernel_breakdown"] = kernels[:10]
-        result["hip_kernel_ms_per_step"] = sum(k["ms_per_step"] for k in kernels)
-    elif rank == 0 and not args.no_roofline:
-        recs = _lib.profile_records_by_kernel()
-        _lib.profile_enable(False)
-        agg = {}
-        for name, _shape, ms in recs:
-            a = agg.setdefault(name, [0, 0.0])
-            a[0] += 1; a[1] += ms
-        table = conv_launch_table(model, B)
-        kernels = []
-        for name, (cnt, tot) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-            e = {"kernel": name, "launches_per_step": cnt / nprof, "avg_ms": tot / cnt, "ms_per_step": tot / nprof}
-            if name in table and table[name]["launches"] == cnt / nprof:
-                e["tflops"] = table[name]["flops"] / (tot / nprof * 1e-3) / 1e12
-            kernels.append(e)
-        # The dominant kernel of the step is the fused gather+MFMA conv kernel: `gather_gemm_kernel` and its
-        # direct form `gather_gemm_direct_kernel` (forward and backward-data) take the largest share of the
-        # step as a family; the roofline is
-        # quoted for its single most expensive instantiation, under the exact name rocprofv3 prints
-        # (profiles/), achieved = algorithmic FLOPs of its launches / their measured duration.
-        conv = [k for k in kernels if "tflops" in k and k["kernel"].startswith("gather_gemm_")]
-        dom = conv[0] if conv else kernels[0]
-        fam = {}
-        for k in kernels:
-            f = fam.setdefault(k["kernel"].split("<")[0].split("|")[0], [0.0, 0.0])
-            f[0] += k["ms_per_step"]
-            if k["kernel"] in table:
-                f[1] += table[k["kernel"]]["flops"]
-        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
-        # collected separately; tools/pmc_traffic.py) - measured on the same workload, not in this run
-        traffic, traffic_note = measured_traffic(dom["kernel"], "f32")
-        if "tflops" in dom:
-            result["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
-                                  "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                                  "traffic_unit": traffic_note,
-                                  "avg_launch_ms": dom["avg_ms"], "launches_per_step": dom["launches_per_step"],
-                                  "flops_per_launch": table[dom["kernel"]]["flops"] / table[dom["kernel"]]["launches"],
-                                  "algorithmic_bytes_per_launch": table[dom["kernel"]]["bytes"] / table[dom["kernel"]]["launches"]}
-        else:
-            result["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                  "frac": None, "traffic": None, "avg_launch_ms": dom["avg_ms"]}
-        result["kernel_families"] = {n: {"ms_per_step": v[0], "tflops": (v[1] / (v[0] * 1e-3) / 1e12) if v[1] else None}
-                                     for n, v in sorted(fam.items(), key=lambda kv: -kv[1][0])[:8]}
-        result["kernel_breakdown"] = kernels[:8]
-        result["hip_kernel_ms_per_step"] = sum(k["ms_per_step"] for k in kernels)
+        result.update((roofline_bf16 if args.dtype == "bf16" else roofline_f32)(recs, model, B, nprof, h.sizes[0]))
 
+    cpu_l2_ref = {}
     # ---- CPU baseline: the oracle (reference formulation) on this box's host cores, rank 0, N=1
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import ref_cpu
@@ -605,24 +817,13 @@ def main():
         # moments), held-out per-vertex L2 (test_funcs.py:46-49) of both
         with torch.no_grad():
             l2_cpu = float(ref_cpu.eval_metrics(om(test.cpu())[0], test.cpu())[1])
-        m2 = sh.SpiralAutoencoder(FE, FD, 256, h.sizes, h.spiral_sizes, h.spirals, h.D, h.U, dev)
-        if args.dtype == "bf16":
-            m2.set_compute_dtype(torch.bfloat16)
-        m2.load_state_dict(init_state)
-        o2 = sh.optim.Adam(m2.parameters(), lr=1e-3, weight_decay=5e-5)
-        xg = data[:B]
-        for _ in range(1 + args.cpu_iters):
-            o2.zero_grad(set_to_none=True)
-            l2loss, _ = sh.recon_loss(m2(xg)[0], xg, ft, 1e-2)
-            l2loss.backward()
-            o2.step()
-        with torch.no_grad():
-            l2_hip = float(sh.vertex_l2_mm(m2(test)[0], test).item())
+        cpu_l2_ref["mm"] = l2_cpu
+        margs = (FE, FD, 256, h.sizes, h.spiral_sizes, h.spirals, h.D, h.U)
+        l2_hip = hip_trajectory_l2(sh, margs, init_state, args.dtype, data[:B], test, ft, 1 + args.cpu_iters, dev)
         result["matched_l2"] = {"steps": 1 + args.cpu_iters, "batch": B, "hip_mm": l2_hip, "cpu_oracle_mm": l2_cpu,
                                 "rel_diff": abs(l2_hip - l2_cpu) / l2_cpu,
                                 "note": "held-out per-vertex L2 after the same training steps from the same weights on the same batch: "
                                         "HIP path (%s kernels) vs the fp32 CPU oracle" % args.dtype}
-        del m2, o2
         # ---- the two thread counts SURVEY 8d asks for beside the calibrated one, on a bounded sample (batch 4, one timed step)
         for label, nt, nb, warm in (("one_thread", 1, 4, 1), ("all_cores", ncpu, 2, 0)):    # all 256 threads: ~10 s per mesh, no warm-up
             xs4 = xc[:nb]
@@ -637,7 +838,14 @@ def main():
                                              "sample": "1 training step at batch %d after %d warm-up" % (nb, warm)}
         torch.set_num_threads(ncores)
 
+    # ---- the other BASELINE configurations, measured in the same run (each a few hundred ms of GPU time): what README /
+    # DESIGN quote for them is traceable to this line
+    if rank == 0 and world == 1 and not args.no_secondary and h.sizes[0] == 6890 and args.dtype == "f32":
+        result["secondary"] = secondary_block(sh, h, B, dev, init_state, data, test, ft, cpu_l2_ref.get("mm"), args)
+
     if rank == 0:
+        result["build"] = {"lib_build_id": _lib.build_id(), "source_sha16": lib_sha16(), "f32_mma": _lib.get_f32_mma_mode(),
+                           "env": _lib.env_overrides()}
         print(json.dumps(result))
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -57,6 +57,9 @@ enum sh_act {
 
 SH_API int sh_version(void);
 SH_API const char* sh_last_error(void);
+/* 16 hex digits: SHA-256 over the kernel sources this library was compiled from (csrc/Makefile BUILD_ID).  bench.py quotes
+ * a committed PMC profile only for the build it was taken on. */
+SH_API const char* sh_build_id(void);
 
 /* Arithmetic form of the fp32 path's matrix products (SpiralConv forward / backward-data).  The reference computes them
  * with fp32 FMAs (models.py:45, aten::addmm).

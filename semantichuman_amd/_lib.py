@@ -20,6 +20,7 @@ _P, _I, _L = c_void_p, c_int, c_int64
 SIGNATURES = {
     "sh_version": (c_int, []),
     "sh_last_error": (c_char_p, []),
+    "sh_build_id": (c_char_p, []),
     "sh_set_f32_mma_mode": (c_int, [_I]),
     "sh_get_f32_mma_mode": (c_int, []),
     "sh_clock_probe": (c_int, [_P, _I, _I, _P]),
@@ -168,6 +169,16 @@ def profile_records():
 def profile_records_by_kernel():
     """[(kernel name without the '|shape' tag, shape tag, milliseconds)]."""
     return [(n.split("|")[0], n.split("|")[1] if "|" in n else "", ms) for n, ms in profile_records()]
+
+
+def build_id() -> str:
+    """Hash of the kernel sources the LOADED library was compiled from (sh_build_id)."""
+    return load().sh_build_id().decode()
+
+
+def env_overrides() -> dict:
+    """The SH_* tuning / ablation switches set in this process's environment (they select kernels, never results)."""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("SH_") and not k.startswith(("SH_BENCH_", "SH_KERNEL_LIB"))}
 
 
 MMA_MODES = {"exact": 0, "split3": 1}

@@ -121,6 +121,10 @@ int sh_set_f32_mma_mode(int mode) {
     return SH_OK;
 }
 int sh_get_f32_mma_mode(void) { return sh_f32_mma_mode(); }
+#ifndef SH_BUILD_ID
+#define SH_BUILD_ID "unknown"
+#endif
+const char* sh_build_id(void) { return SH_BUILD_ID; }
 int sh_version(void) { return 100; }   // major*10000 + minor*100 + patch
 const char* sh_last_error(void) { return g_err; }
 }

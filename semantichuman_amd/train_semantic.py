@@ -192,6 +192,7 @@ def semantic_losses(model, ctx, tx, tx_interp, tx_exc, epoch, measure=None, inte
         lat_in = latent * full[:, :, None]
     rec = model.decode(lat_in, latent_kps, dummy)
     tx_hat, tx_zpart = rec[:B0], latent[:B0]
+    ctx.last_tx_hat = tx_hat.detach()                          # reconstruction of the training batch (save_recons, :459-470)
     o0 = B0
     if do_interp:
         rec_interp, o0 = rec[o0:o0 + Bi], o0 + Bi
@@ -266,6 +267,13 @@ def train_autoencoder_dataloader_nonormal(dataloader_train, dataloader_val, devi
     opts = options or SemanticTrainOptions()
     ctx = SemanticContext(opts, shapedata, J_regressor, vert_part_index_dict, partname_list, device)
     loss_fn = _as_loss(loss_fn)
+    import torch.distributed as dist
+    # data-parallel (the reference is single-process): every rank iterates its own shard of each loader, the gradient
+    # all-reduce is the reducer's; epoch losses are summed over ranks, rank 0 logs / writes checkpoints and samples
+    world = dist.get_world_size() if (reducer is not None and dist.is_initialized()) else 1
+    rank = dist.get_rank() if world > 1 else 0
+    if rank != 0:
+        writer, verbose = None, False
     total_steps = (start_epoch - 1) * len(dataloader_train)
     eval_freq = len(dataloader_train)
     cyc = None
@@ -275,6 +283,9 @@ def train_autoencoder_dataloader_nonormal(dataloader_train, dataloader_val, devi
         if cyc is None:
             cyc = _Cycler(dataloader_interp)
         tloss = torch.zeros((), device=device)
+        n_seen, n_val = 0, 0
+        tx = tx_hat = None
+        tx_idx = [0]
         for b, sample in enumerate(dataloader_train):
             optim.zero_grad()
             tx = sample["verts"].to(device)
@@ -285,12 +296,14 @@ def train_autoencoder_dataloader_nonormal(dataloader_train, dataloader_val, devi
                                           None if inp_i is None else inp_i["verts"].to(device),
                                           None if inp_e is None else inp_e["verts"].to(device), epoch, measure,
                                           None if inp_i is None or "measure" not in inp_i else inp_i["measure"].to(device), loss_fn)
+            tx_hat = getattr(ctx, "last_tx_hat", None)
             if reducer is not None:
                 reducer.prepare()
             loss.backward()
             if reducer is not None:
                 reducer.finish()
             optim.step()
+            n_seen += tx.shape[0]
             tloss += tx.shape[0] * loss.detach()
             if writer and total_steps % eval_freq == 0:
                 writer.add_scalar("loss/loss/data_loss", loss.item(), total_steps)
@@ -302,14 +315,27 @@ def train_autoencoder_dataloader_nonormal(dataloader_train, dataloader_val, devi
         vloss = torch.zeros((), device=device)
         with torch.no_grad():
             for sample in dataloader_val:
-                tx = sample["verts"].to(device)
-                kps = ctx.joints(tx)
-                tx_hat_val = model(tx, kps[:, ctx.kps_keep_t])[0]
-                vloss += tx.shape[0] * loss_fn(tx[:, :-1, :], tx_hat_val[:, :-1, :])
+                txv = sample["verts"].to(device)
+                if "idx" in sample:
+                    tx_idx = sample["idx"]
+                kps = ctx.joints(txv)
+                tx_hat_val = model(txv, kps[:, ctx.kps_keep_t])[0]
+                n_val += txv.shape[0]
+                vloss += txv.shape[0] * loss_fn(txv[:, :-1, :], tx_hat_val[:, :-1, :])
         if scheduler:
             scheduler.step()
-        epoch_tloss = float(tloss) / float(len(dataloader_train.dataset))
-        epoch_vloss = float(vloss) / float(len(dataloader_val.dataset)) if len(dataloader_val.dataset) > 0 else None
+        if world > 1:
+            # sums of losses and of sample counts over all ranks: one tiny collective per epoch
+            t = torch.stack([tloss.double(), vloss.double(), torch.tensor(float(n_seen), device=device, dtype=torch.float64),
+                             torch.tensor(float(n_val), device=device, dtype=torch.float64)])
+            dist.all_reduce(t)
+            epoch_tloss = float(t[0]) / max(1.0, float(t[2]))
+            tot_val = float(t[3])
+            vloss = t[1]
+        else:
+            epoch_tloss = float(tloss) / float(len(dataloader_train.dataset))
+            tot_val = float(len(dataloader_val.dataset))
+        epoch_vloss = float(vloss) / tot_val if tot_val > 0 else None
         if writer:
             writer.add_scalar("avg_epoch_train_loss", epoch_tloss, epoch)
             if epoch_vloss is not None:
@@ -318,7 +344,16 @@ def train_autoencoder_dataloader_nonormal(dataloader_train, dataloader_val, devi
             print("epoch {0} | tr {1} | val {2}".format(epoch, epoch_tloss, epoch_vloss))
         history.append((epoch, epoch_tloss, epoch_vloss))
         if epoch % opts.ck_frequency == 0 and metadata_dir is not None:
-            save_checkpoint(os.path.join(metadata_dir, checkpoint_path + "%s.pth.tar" % epoch), epoch, model, optim, scheduler)
+            if rank == 0:
+                save_checkpoint(os.path.join(metadata_dir, checkpoint_path + "%s.pth.tar" % epoch), epoch, model, optim, scheduler)
+            if world > 1:
+                dist.barrier()            # nobody runs ahead of (or reads) a checkpoint that is still being written
+        if save_recons and epoch % 50 == 0 and rank == 0 and samples_dir is not None and tx is not None and tx_hat is not None:
+            # reference :459-470: first mesh of the epoch's LAST training batch, ground truth and reconstruction, both under
+            # the sample index of the last validation batch's first mesh
+            ind = [int(tx_idx[0])]
+            shapedata.save_meshes(os.path.join(samples_dir, "epoch{0}_GT".format(epoch)), tx[0:1, 0:-1, :].detach().cpu().numpy(), ind)
+            shapedata.save_meshes(os.path.join(samples_dir, "epoch{0}_rec".format(epoch)), tx_hat[0:1, 0:-1, :].detach().cpu().numpy(), ind)
     if verbose:
         print("~FIN~")
     return history

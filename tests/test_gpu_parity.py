@@ -509,9 +509,10 @@ def test_c_abi_error_contract():
 
 @pytest.mark.parametrize("cfg", [("template6890.npz", 64), ("template6890.npz", 48), ("template27554.npz", 32)])
 def test_bench_launch_table_matches_the_library(golden_dir, cfg):
-    """bench.py prices the roofline with a table of (kernel instantiation -> algorithmic FLOPs) that mirrors the
-    library's dispatch rules; here the names and launch counts the library's profiler reports for one training step
-    are checked against that table, so a dispatch change cannot silently detach the roofline from the kernels."""
+    """bench.py prices the roofline with a table (pass, rows, K, channels) -> algorithmic FLOPs built from the model's
+    layers; here every conv-family launch the library's profiler reports for one training step must find its entry, and
+    every entry must be hit by exactly one launch, so a dispatch change cannot silently detach the roofline from the
+    kernels - in both arithmetic forms of the fp32 products."""
     import bench
     from semantichuman_amd import _lib, synthetic
     name, B = cfg
@@ -523,19 +524,27 @@ def test_bench_launch_table_matches_the_library(golden_dir, cfg):
     def step():
         m.zero_grad(set_to_none=True)
         sh.l1_loss(x, m(x)[0]).backward()
-    step()
-    torch.cuda.synchronize()
-    _lib.profile_enable(True)
-    step()
-    torch.cuda.synchronize()
-    recs = _lib.profile_records_by_kernel()
-    _lib.profile_enable(False)
-    seen = {}
-    for kname, _shape, _ms in recs:
-        if kname.startswith(("gather_gemm", "wgrad")):
-            seen[kname] = seen.get(kname, 0) + 1
-    table = bench.conv_launch_table(m, B)
-    assert seen == {k: v["launches"] for k, v in table.items()}
+    was = _lib.get_f32_mma_mode()
+    try:
+        for mode in ("exact", "split3"):
+            _lib.set_f32_mma_mode(mode)
+            step()
+            torch.cuda.synchronize()
+            _lib.profile_enable(True)
+            step()
+            torch.cuda.synchronize()
+            recs = _lib.profile_records_by_kernel()
+            _lib.profile_enable(False)
+            table = bench.f32_work_table(m, B)
+            hit = {}
+            for kname, shape, _ms in recs:
+                if kname.startswith(("gather_gemm", "wgrad")):
+                    key = bench.parse_tag_f32(kname, shape)
+                    assert key in table, (mode, kname, shape)
+                    hit[id(table[key])] = hit.get(id(table[key]), 0) + 1
+            assert hit == {id(v): 1 for v in table.values()}, mode
+    finally:
+        _lib.set_f32_mma_mode(was)
 
 
 @pytest.mark.gpu

@@ -19,33 +19,38 @@ FE = [[3, 16, 32, 64, 128], [[], [], [], [], []]]
 FD = [[128, 64, 32, 32, 16], [[], [], [], [], 3]]
 
 
+def run(latents=100000, batch=1024, dev=None, template=None):
+    """The measurement as a function (bench.py's `secondary` block calls it with fewer latents)."""
+    dev = dev or torch.device("cuda:0")
+    h = load_hierarchy(template or os.path.join(ROOT, "tests", "golden", "template6890.npz"))
+    torch.manual_seed(2)
+    m = sh.SpiralAutoencoder(FE, FD, 256, h.sizes, h.spiral_sizes, h.spirals, h.D, h.U, dev)
+    z = torch.randn(latents, 256, generator=torch.Generator().manual_seed(0)).to(dev)
+    with torch.no_grad():
+        for _ in range(3):
+            m.decode(z[:batch])
+        torch.cuda.synchronize()
+        lat = []
+        t0 = time.perf_counter()
+        for o in range(0, latents, batch):
+            t1 = time.perf_counter()
+            out = m.decode(z[o:o + batch])
+            torch.cuda.synchronize()
+            lat.append((time.perf_counter() - t1, out.shape[0]))
+        total = time.perf_counter() - t0
+    full = sorted(t for t, n in lat if n == batch)
+    p50 = full[len(full) // 2]
+    return {"metric": "decode of random latents, %d vertices" % h.sizes[0], "latents": latents, "batch": batch,
+            "batches": len(lat), "p50_batch_ms": 1e3 * p50, "per_mesh_latency_us": 1e6 * p50 / batch,
+            "meshes_per_s": latents / total, "dtype": "f32", "data": "synthetic"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--latents", type=int, default=100000)
     ap.add_argument("--batch", type=int, default=1024)
     a = ap.parse_args()
-    dev = torch.device("cuda:0")
-    h = load_hierarchy(os.path.join(ROOT, "tests", "golden", "template6890.npz"))
-    torch.manual_seed(2)
-    m = sh.SpiralAutoencoder(FE, FD, 256, h.sizes, h.spiral_sizes, h.spirals, h.D, h.U, dev)
-    z = torch.randn(a.latents, 256, generator=torch.Generator().manual_seed(0)).to(dev)
-    with torch.no_grad():
-        for _ in range(3):
-            m.decode(z[:a.batch])
-        torch.cuda.synchronize()
-        lat = []
-        t0 = time.perf_counter()
-        for o in range(0, a.latents, a.batch):
-            t1 = time.perf_counter()
-            out = m.decode(z[o:o + a.batch])
-            torch.cuda.synchronize()
-            lat.append((time.perf_counter() - t1, out.shape[0]))
-        total = time.perf_counter() - t0
-    full = sorted(t for t, n in lat if n == a.batch)
-    p50 = full[len(full) // 2]
-    print(json.dumps({"metric": "decode of random latents, 6890 vertices", "latents": a.latents, "batch": a.batch,
-                      "batches": len(lat), "p50_batch_ms": 1e3 * p50, "per_mesh_latency_us": 1e6 * p50 / a.batch,
-                      "meshes_per_s": a.latents / total, "dtype": "f32", "data": "synthetic"}))
+    print(json.dumps(run(a.latents, a.batch)))
 
 
 if __name__ == "__main__":

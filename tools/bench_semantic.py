@@ -33,13 +33,10 @@ def voronoi_parts(v, k):
     return [np.sort(np.nonzero(owner == j)[0]) for j in range(k)]
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--batch", type=int, default=16)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--graph", action="store_true", help="capture the iteration into a hipGraph and replay it")
-    a = ap.parse_args()
-    dev = torch.device("cuda:0")
+def run(batch=16, steps=50, graph=False, dev=None, warmup=10):
+    """The measurement as a function (bench.py's `secondary` block calls it with graph=True)."""
+    a = SimpleNamespace(batch=batch, steps=steps, graph=graph)
+    dev = dev or torch.device("cuda:0")
     h = load_hierarchy(os.path.join(ROOT, "tests", "golden", "template6890.npz"))
     vi = h.verts / np.asarray((0.25, 0.15, 0.9))
     fine = dict(zip(C.PART_LIST, voronoi_parts(vi, 17)))
@@ -66,7 +63,7 @@ def main():
         total.backward()
         opt.step()
         return total
-    for _ in range(10):                              # also lets the caching allocator grow to its steady-state pool
+    for _ in range(warmup):                          # also lets the caching allocator grow to its steady-state pool
         step()
     torch.cuda.synchronize()
     if a.graph:                                      # fixed edit factor / exchange kind: nothing host-side varies per replay
@@ -75,23 +72,32 @@ def main():
         with torch.cuda.stream(sidestream):
             step()
         torch.cuda.current_stream().wait_stream(sidestream)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
             loss = step()
-        run = graph.replay
+        runner = g.replay
     else:
-        run = step
+        runner = step
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        out = run()
+        out = runner()
         loss = out if out is not None else loss
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
-    print(json.dumps({"metric": "semantic training iteration (3 passes), 6890 vertices", "batch_per_pass": B, "steps": a.steps,
-                      "launch": "hipGraph replay" if a.graph else "eager", "ms_per_iteration": 1e3 * dt, "meshes_per_s": 3 * B / dt, "loss": float(loss.detach()), "dtype": "f32",
-                      "data": "synthetic (Voronoi parts, synthetic joint regressor)",
-                      "parts": {n: int(len(p)) for n, p in list(fine.items())[:4]}}))
+    return {"metric": "semantic training iteration (3 passes), 6890 vertices", "batch_per_pass": B, "steps": a.steps,
+            "launch": "hipGraph replay" if a.graph else "eager", "ms_per_iteration": 1e3 * dt, "meshes_per_s": 3 * B / dt,
+            "loss": float(loss.detach()), "dtype": "f32", "data": "synthetic (Voronoi parts, synthetic joint regressor)",
+            "parts": {n: int(len(p)) for n, p in list(fine.items())[:4]}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--graph", action="store_true", help="capture the iteration into a hipGraph and replay it")
+    a = ap.parse_args()
+    print(json.dumps(run(a.batch, a.steps, a.graph)))
 
 
 if __name__ == "__main__":
