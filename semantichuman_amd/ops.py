@@ -496,11 +496,15 @@ def spiral_conv_bwd_wgt_thin(dpre_ext, x, table_t, R, S, Cin, Cout, want_bias=Tr
     return dW, db
 
 
-def cast_bf16(src):
-    """fp32 HIP tensor -> bf16 copy (one streaming kernel)."""
+def cast_bf16(src, out=None):
+    """fp32 HIP tensor -> bf16 copy (one streaming kernel); `out`: an existing bf16 tensor of the same shape to refresh
+    in place (its address may be baked into a captured hipGraph)."""
     if not (src.is_cuda and src.dtype == torch.float32 and src.is_contiguous()):
         raise RuntimeError("cast_bf16 needs a contiguous fp32 HIP tensor; there is no CPU path")
-    dst = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
+    if out is not None and not (out.is_cuda and out.dtype == torch.bfloat16 and out.is_contiguous() and out.shape == src.shape
+                                and out.device == src.device):
+        raise RuntimeError("cast_bf16: `out` must be a contiguous bf16 HIP tensor of the source's shape and device")
+    dst = out if out is not None else torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
     if src.numel():
         check(_lib.load().sh_cast_f32_to_bf16(ptr(src), ptr(dst), src.numel(), stream_ptr()), "sh_cast_f32_to_bf16")
     return dst

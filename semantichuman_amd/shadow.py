@@ -4,7 +4,8 @@ The large dense layers read their weight as bf16 (28 MB instead of 56.6 MB per p
 `nn.Parameter` (same `state_dict`, same optimizer state).  A shadow is valid while the master has not changed:
 
   * in-place changes made through torch (load_state_dict, torch.optim, .copy_) bump the tensor's `_version` - the next
-    `get()` re-converts with one streaming kernel (sh_cast_f32_to_bf16);
+    `get()` re-converts with one streaming kernel (sh_cast_f32_to_bf16) INTO THE SAME bf16 tensor: the copy keeps its
+    address for as long as the parameter keeps its shape and device (a captured hipGraph may hold that address);
   * `semantichuman_amd.optim.Adam` updates the master through the library's kernel (raw pointer: no version bump) and
     rewrites the registered shadow IN THE SAME KERNEL (sh_adam_step_bf16) - it looks the shadow up here on every step,
     so a shadow that exists is always kept current by that optimizer.
@@ -32,12 +33,17 @@ def get(param: torch.Tensor) -> torch.Tensor:
     """The bf16 copy of `param`, converting if it is missing or stale."""
     ent = _entry(param)
     key = (param._version, param.data_ptr())
-    if ent is None or ent[2] != key or ent[1].device != param.device or ent[1].shape != param.shape:
-        sh = ops.cast_bf16(param.detach().contiguous())
-        pid = id(param)
-        _REG[pid] = [weakref.ref(param, lambda _r, pid=pid: _REG.pop(pid, None)), sh, key]
-        return sh
-    return ent[1]
+    if ent is not None and ent[1].device == param.device and ent[1].shape == param.shape:
+        if ent[2] != key:
+            # stale (load_state_dict, an in-place torch update): refresh IN PLACE - a captured hipGraph has this copy's address
+            # baked into the latent-FC kernels' and sh_adam_step_bf16's arguments, so the copy must never move while it lives
+            ops.cast_bf16(param.detach().contiguous(), out=ent[1])
+            ent[2] = key
+        return ent[1]
+    sh = ops.cast_bf16(param.detach().contiguous())             # first use, or the parameter changed device / shape
+    pid = id(param)
+    _REG[pid] = [weakref.ref(param, lambda _r, pid=pid: _REG.pop(pid, None)), sh, key]
+    return sh
 
 
 def lookup(param: torch.Tensor):

@@ -46,11 +46,33 @@ def save_checkpoint(path, epoch, model, optim, scheduler):
                 "scheduler_state_dict": scheduler.state_dict() if scheduler else None}, path)
 
 
+def _numpy_scalars_allowed():
+    """Context that lets torch.load(weights_only=True) rebuild numpy scalars and dtypes (plain data)."""
+    import contextlib
+    sg = getattr(torch.serialization, "safe_globals", None)
+    if sg is None:
+        return contextlib.nullcontext()
+    allowed = [np.dtype]
+    try:
+        from numpy._core.multiarray import scalar as _np_scalar
+    except ImportError:                                        # numpy 1.x
+        from numpy.core.multiarray import scalar as _np_scalar
+    allowed.append(_np_scalar)
+    allowed += [type(np.dtype(t)) for t in (np.float32, np.float64, np.int32, np.int64, np.bool_)]
+    return sg(allowed)
+
+
 def load_checkpoint(path, model, optim=None, scheduler=None, finetune=False, map_location="cpu", trust_pickle=False):
     """main.py:277-292: returns the epoch to start from."""
+    import pickle
     try:                      # the saved layout is tensors + plain Python containers: no pickled code needed
-        ck = torch.load(path, map_location=map_location, weights_only=True)
-    except Exception as e:    # noqa: BLE001 - torch raises pickle.UnpicklingError / RuntimeError depending on the version
+        with _numpy_scalars_allowed():     # reference-written optimizer / scheduler state may hold numpy scalars (data, no code)
+            ck = torch.load(path, map_location=map_location, weights_only=True)
+    except (pickle.UnpicklingError, RuntimeError) as e:
+        # only the weights_only refusal is handled here (torch raises pickle.UnpicklingError, older versions a RuntimeError
+        # that names weights_only); a missing / unreadable / corrupt file or an out-of-memory error propagates unchanged
+        if isinstance(e, RuntimeError) and "weights_only" not in str(e) and "Unsupported" not in str(e):
+            raise
         if not trust_pickle:
             raise RuntimeError("load_checkpoint: %s does not load with weights_only=True (%s); pass trust_pickle=True only "
                                "for a checkpoint you wrote yourself - unpickling executes code" % (path, e)) from e
