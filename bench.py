@@ -55,17 +55,23 @@ def f32_work_table(model, B):
             e = {"flops": fl, "bytes": byt}
             out[("fwd", st.R, K, st.cout)] = e
             if st.cin == 3:
-                out[("fwd", st.R, 4 * st.S, st.cout)] = e
+                out[("fwd", st.R, 4 * st.S, st.cout)] = e          # the same entry under its second spelling
             not_first = not (first and stack is model._enc_stack)
             thin = not_first and st.R == st.n_in and bool(_lib.load().sh_spiral_conv_bwd_wgt_thin_ok(B, st.n_in, st.S, st.cin, st.cout, 0))
             if not_first and not thin:
                 # backward-data = the same kernels over the transposed table; algorithmic FLOPs are those of the R*S real
                 # (row, position) pairs, not of the padded n_in*S table
-                out[("bwd", st.n_in, st.S * st.cout, st.cin)] = e
+                bw = dict(e)
+                out[("bwd", st.n_in, st.S * st.cout, st.cin)] = bw
+                if st.cout == 3:
+                    out[("bwd", st.n_in, 4 * st.S, st.cin)] = bw      # 3-channel gradient rows run over zero-padded quads
             if thin:     # the 16 -> 3 channel layer: role-swapped weight gradient AND backward-data in one launch (csrc/wgrad_thin.hip)
                 out[("wgt+bwd", st.R, K, st.cout)] = {"flops": 2 * fl, "bytes": 2 * byt}
             else:
-                out[("wgt", st.R, K, st.cout)] = e
+                w = dict(e)
+                out[("wgt", st.R, K, st.cout)] = w
+                if st.cin == 3:
+                    out[("wgt", st.R, 4 * st.S, st.cout)] = w
             first = False
     return out
 

@@ -123,6 +123,14 @@ SH_API int sh_spiral_conv_bwd_data(const float* dpre, int64_t dp_sv, int64_t dp_
                             const float* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row,
                             int B, int n_in, int S, int Cin, int Cout,
                             sh_stream_t stream);
+/* The same with one more piece of knowledge: row `dpre_zero_row` of dpre is all zero and is the row the "no source" entries
+ * of table_t point at (>= 0; -1 = unknown: identical to sh_spiral_conv_bwd_data).  With a batch slice of 16 and gathered
+ * channel counts that are multiples of 16 the kernels then skip the matrix products of (vertex, spiral position) pairs
+ * without a source - exact zeros: the result is bitwise the same; 51-59 % of the entries on down-sampling levels. */
+SH_API int sh_spiral_conv_bwd_data_z(const float* dpre, int64_t dp_sv, int64_t dp_sb, int dpre_zero_row, const int32_t* table_t,
+                                     const float* weight_t, float* dx, int64_t dx_sv, int64_t dx_sb, const float* yprev,
+                                     int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row, int B, int n_in, int S, int Cin,
+                                     int Cout, sh_stream_t stream);
 
 /* weight [Cout][S*Cin] -> weight_t [Cin][S*Cout] (see above). */
 SH_API int sh_weight_transpose(const float* weight, float* weight_t, int S, int Cin, int Cout, sh_stream_t stream);

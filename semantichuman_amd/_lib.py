@@ -29,6 +29,7 @@ SIGNATURES = {
     "sh_profile_get": (c_int, [_I, c_char_p, _I, ctypes.POINTER(c_float)]),
     "sh_spiral_conv_fwd": (c_int, [_P, _L, _L, _P, _P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sh_spiral_conv_bwd_data": (c_int, [_P, _L, _L, _P, _P, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "sh_spiral_conv_bwd_data_z": (c_int, [_P, _L, _L, _I, _P, _P, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sh_weight_transpose": (c_int, [_P, _P, _I, _I, _I, _P]),
     "sh_spiral_conv_bwd_wgt_workspace": (c_size_t, [_I, _I, _I, _I, _I]),
     "sh_spiral_conv_bwd_wgt": (c_int, [_P, _L, _L, _P, _L, _L, _P, _P, _P, _P, c_size_t, _I, _I, _I, _I, _I, _P]),

@@ -34,7 +34,14 @@ namespace {
 // the lower-half weight fragments (right for the even logical rows) and one with the upper-half fragments (right for the odd
 // ones) go to two accumulators whose valid halves are added across the lane pair in the epilogue.  Twice the MFMAs (the
 // matrix pipes idle ~90 % of these launches), half as many, twice as efficient load instructions.
-enum { BC_C32 = 0, BC_C16 = 1, BC_C3F = 2, BC_C64 = 3 };
+// BC_C32C (round 3): the C32 form with LINE-WISE loads.  In the MFMA operand layout the 16 rows of a tile sit on 16 consecutive lanes,
+// so every quad of lanes of a load instruction touches four different cache lines and the vector L1 serves the instruction as
+// 64 separate 16-byte accesses - measured (tools/exp/ta_probe.hip, rows resident in the XCD's L2): 6.8-8.7 TB/s of gathered
+// bytes chip-wide in that layout against 16.6-21.9 TB/s when four consecutive lanes read 64 contiguous bytes of ONE row.  Here
+// lane l loads piece l & 3 of row l >> 2 (16 accesses of 64 bytes per instruction) and the pieces are turned into the MFMA
+// layout - lane (r, kq) takes the piece of lane 4 r + kq - by four ds_bpermute_b32 when the k-step is multiplied (the LDS
+// crossbar, no LDS memory: all of it holds the weight).
+enum { BC_C32 = 0, BC_C16 = 1, BC_C3F = 2, BC_C64 = 3, BC_C32C = 4 };
 
 struct BCParams {
     const char* x; long x_rb, x_bb;            // byte strides of (row, batch entry)
@@ -52,7 +59,7 @@ struct __attribute__((packed, aligned(4))) bc_f3 { float a, b, c; };
 
 constexpr int bc_depth(int NT, int RT, int MODE) {
     const int per = RT * (MODE == BC_C3F ? 6 : 4);         // registers of one ring slot
-    const int room = 88 - (MODE == BC_C64 ? 2 : 1) * NT * RT * 4 - RT * 4;     // minus accumulators (two sets in the full-line form) and the converted operands
+    const int room = 88 - (MODE == BC_C64 ? 2 : 1) * NT * RT * 4 - (MODE == BC_C32C ? 3 : 1) * RT * 4;     // minus accumulators (two sets in the full-line form) and the converted / permuted operands
     const int d = room / per;
     const int cap = MODE == BC_C3F ? 4 : 8;
     const int lo = 3;
@@ -125,7 +132,9 @@ __global__ __launch_bounds__(1024) void conv_bf16_kernel(const BCParams p) {
         const int b0 = bs * TROWS, v0 = vg * RT;
         const int rl = MODE == BC_C64 ? r16 >> 1 : r16;     // this lane's row inside the tile
         const int bl = b0 + rl < p.B ? b0 + rl : p.B - 1;               // rows past B read the last entry; never stored
-        const char* xl = p.x + (long)bl * p.x_bb +
+        const int bl_co = b0 + (lane >> 2) < p.B ? b0 + (lane >> 2) : p.B - 1;      // line-wise loads: lane -> (row lane >> 2, piece lane & 3)
+        const char* xl = MODE == BC_C32C ? p.x + (long)bl_co * p.x_bb + (lane & 3) * 16
+                                         : p.x + (long)bl * p.x_bb +
                          (MODE == BC_C32 ? kq * 16 : MODE == BC_C64 ? (kq + 4 * (r16 & 1)) * 16 : MODE == BC_C16 ? (kq & 1) * 16 : 0);
 
         // running load position (uniform): spiral position and channel offset of the next k-step to load
@@ -134,7 +143,7 @@ __global__ __launch_bounds__(1024) void conv_bf16_kernel(const BCParams p) {
         using raw_t = typename std::conditional<MODE == BC_C3F, bc_f3[2], bf16x8>::type;
         raw_t ring[D][RT];
         auto issue = [&](raw_t (&a)[RT]) {
-            if constexpr (MODE == BC_C32) {
+            if constexpr (MODE == BC_C32 || MODE == BC_C32C) {
                 const int s = ls < S ? ls : S - 1;
 #pragma unroll
                 for (int m = 0; m < RT; ++m) {
@@ -192,6 +201,13 @@ __global__ __launch_bounds__(1024) void conv_bf16_kernel(const BCParams p) {
                         const bc_f3* s2 = reinterpret_cast<const bc_f3*>(&a[m]);
                         g[m] = (bf16x8){(__bf16)s2[0].a, (__bf16)s2[0].b, (__bf16)s2[0].c, (__bf16)0.f,
                                         (__bf16)s2[1].a, (__bf16)s2[1].b, (__bf16)s2[1].c, (__bf16)0.f};
+                    } else if constexpr (MODE == BC_C32C) {                  // loaded line-wise: fetch this lane's operand from lane 4 r + kq
+                        const u32x4 raw = *reinterpret_cast<const u32x4*>(&a[m]);
+                        const int src = (4 * r16 + kq) << 2;
+                        u32x4 t;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) t[j] = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)raw[j]);
+                        g[m] = *reinterpret_cast<const bf16x8*>(&t);
                     } else {
                         g[m] = *reinterpret_cast<const bf16x8*>(&a[m]);      // full-line form: the same operand for both halves
                     }
@@ -415,7 +431,9 @@ int dispatch_bc(BCParams& p, int in_f32, int out_f32, hipStream_t st) {
     // than the better loads bring (measured: 128 -> 64 and 64 -> 128 channel layers 19-26 us -> 22-27 us; 64 -> 32: 28 -> 21 us)
     int nt_wg = p.nt_tot > 8 ? 8 : p.nt_tot;
     while (nt_wg > 1 && (long)p.nks * nt_wg > 128) nt_wg >>= 1;
-    if (p.Cg % 64 == 0 && c64_on && nt_wg <= 2) return dispatch_bc_nt<BC_C64, BWD, false>(p, st);
+    static const int co_on = sh_env_int("SH_BC_CO", 1, 0, 2);          // line-wise loads (BC_C32C); 2: also instead of the full-line form
+    if (p.Cg % 64 == 0 && c64_on && nt_wg <= 2 && co_on < 2) return dispatch_bc_nt<BC_C64, BWD, false>(p, st);
+    if (p.Cg % 32 == 0 && co_on) return dispatch_bc_nt<BC_C32C, BWD, false>(p, st);
     return p.Cg == 16 ? dispatch_bc_nt<BC_C16, BWD, false>(p, st) : dispatch_bc_nt<BC_C32, BWD, false>(p, st);
 }
 

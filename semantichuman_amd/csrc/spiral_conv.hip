@@ -48,6 +48,13 @@ struct GGParams {
     int log2TB, n_btiles, n_vtiles, nchunks;
     int nsplit;         // workgroups per row tile (each owns NT*16 output channels)
     int vec_out;        // Nout % 4 == 0 and output strides 16-B aligned
+    // backward-data: row of x (= dpre) that is known to be all zero and that "no source" entries of the transposed table
+    // point at (mesh_ops.transpose_table_dense: 51-59 % of the entries of the down-sampling levels, 22-30 % of the
+    // others).  skip_on: a 16-row MFMA tile is one vertex (batch slice of 16) and a half-chunk lies inside one spiral
+    // position (gathered channels % 16 == 0), so "this tile's entry is a no-source entry" is wave-uniform and the tile's
+    // MFMAs of that half-chunk are skipped - they would add exact zeros.
+    unsigned skip_off;  // zero row * x_sv (element offset, like the entries of the LDS table tile)
+    int skip_on;
 };
 
 // 3-channel rows (the xyz input of the first encoder layer, the xyz gradient entering the last decoder layer):
@@ -200,21 +207,46 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_kernel(const GGParams p)
         for (int n = 0; n < NT; ++n) acc[m][n] = zero4;
 
     const int lrow = lane & 15, lq = lane >> 4;
+    // backward-data: skip the MFMAs of a (tile, half-chunk) whose table entry is a no-source entry (GGParams::skip_on; with a
+    // batch slice of 16 the wave's two tiles are the vertices 2 wave and 2 wave + 1 of the workgroup's eight)
+    const bool skip_on = BWD_EPI && TB16 && VEC4 && !C3 && p.skip_on;
+    int sc_k[2] = {0, 16}, sc_s[2], sc_c[2];                 // running (k, position, channel) of the half-chunks being multiplied
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) { sc_s[ks] = sc_k[ks] / p.Cg; sc_c[ks] = sc_k[ks] - sc_s[ks] * p.Cg; }
     auto compute = [&](int buf) {
         const float* Ab = As + buf * TM * KC + (32 * wave + lrow) * KC;
         const float* Wb = Ws + buf * NT * 16 * KC + lrow * KC;
 #pragma unroll
         for (int ks = 0; ks < KC / 16; ++ks) {
             const int pq = ((lq + 4 * ks) ^ (lane & 7)) << 2;
+            bool l0 = true, l1 = true;
+            if (BWD_EPI && skip_on) {
+                const int sp = sc_k[ks] < p.K ? sc_s[ks] : 0;
+                l0 = (unsigned)__builtin_amdgcn_readfirstlane(Ts[(2 * wave) * S + sp]) != p.skip_off;
+                l1 = (unsigned)__builtin_amdgcn_readfirstlane(Ts[(2 * wave + 1) * S + sp]) != p.skip_off;
+                sc_k[ks] += KC; sc_c[ks] += adv_c; sc_s[ks] += adv_s;
+                const bool wrap = sc_c[ks] >= p.Cg;
+                sc_c[ks] = wrap ? sc_c[ks] - p.Cg : sc_c[ks];
+                sc_s[ks] = wrap ? sc_s[ks] + 1 : sc_s[ks];
+                if (!(l0 || l1)) continue;
+            }
             const f32x4 g0 = *reinterpret_cast<const f32x4*>(Ab + pq);
             const f32x4 g1 = *reinterpret_cast<const f32x4*>(Ab + 16 * KC + pq);
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 const f32x4 wq = *reinterpret_cast<const f32x4*>(Wb + n * 16 * KC + pq);
+                if (!(BWD_EPI && skip_on) || (l0 && l1)) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[t], g0[t], acc[0][n], 0, 0, 0);
-                    acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[t], g1[t], acc[1][n], 0, 0, 0);
+                    for (int t = 0; t < 4; ++t) {
+                        acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[t], g0[t], acc[0][n], 0, 0, 0);
+                        acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[t], g1[t], acc[1][n], 0, 0, 0);
+                    }
+                } else if (l0) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[t], g0[t], acc[0][n], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[t], g1[t], acc[1][n], 0, 0, 0);
                 }
             }
         }
@@ -298,7 +330,8 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_kernel(const GGParams p)
 // waves, goes through LDS (triple-buffered, one barrier per chunk); gathered chunks c+1 and c+2
 // are in flight in registers while chunk c multiplies.  Same tiling, K order and epilogue as
 // gather_gemm_kernel, hence bit-identical results.
-template <int NT, bool BWD_EPI, int RT>      // RT = 16-row tiles per wave: the workgroup covers 64*RT rows
+// SKIP (backward-data, RT == 1): skip the matrix products of no-source table entries (GGParams::skip_on)
+template <int NT, bool BWD_EPI, int RT, bool SKIP = false>      // RT = 16-row tiles per wave: the workgroup covers 64*RT rows
 __global__ __launch_bounds__(NTHREADS) void gather_gemm_direct_kernel(const GGParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Ws = reinterpret_cast<float*>(smem);                 // [3][NT*16][KC]
@@ -341,7 +374,7 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_direct_kernel(const GGPa
         c_n[ks] = k_n[ks] - s_n[ks] * p.Cg;
     }
     const int adv_s = KC / p.Cg, adv_c = KC - adv_s * p.Cg;
-    auto load_a = [&](f32x4 (&ra)[RT][2]) {
+    auto load_a = [&](f32x4 (&ra)[RT][2], unsigned& live) {
         unsigned toff[RT][2];
         int ch[2];
 #pragma unroll
@@ -352,10 +385,21 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_direct_kernel(const GGPa
 #pragma unroll
             for (int m = 0; m < RT; ++m) toff[m][ks] = (unsigned)Ts[a_ts[m] + s];
         }
+        live = ~0u;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-            for (int m = 0; m < RT; ++m) ra[m][ks] = *reinterpret_cast<const f32x4*>(p.x + toff[m][ks] + a_boff[m] + ch[ks]);
+            for (int m = 0; m < RT; ++m) {
+                const float* src = p.x + toff[m][ks] + a_boff[m] + ch[ks];
+                if (SKIP) {
+                    // a no-source entry (wave-uniform, see GGParams::skip_on): every lane reads the SAME 16 bytes of the zero
+                    // row - one L1 access instead of 64 - and compute() skips the tile's MFMAs of this half-chunk
+                    const bool dead = (unsigned)__builtin_amdgcn_readfirstlane((int)toff[m][ks]) == p.skip_off;
+                    if (dead) live &= ~(1u << (2 * m + ks));
+                    src = dead ? p.x + p.skip_off : src;
+                }
+                ra[m][ks] = *reinterpret_cast<const f32x4*>(src);
+            }
             k_n[ks] += KC;
             c_n[ks] += adv_c;
             s_n[ks] += adv_s;
@@ -399,37 +443,55 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_direct_kernel(const GGPa
     for (int m = 0; m < RT; ++m)
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[m][n] = zero4;
-    auto compute = [&](int buf, const f32x4 (&ra)[RT][2]) {
+    auto compute = [&](int buf, const f32x4 (&ra)[RT][2], unsigned live) {
         const float* Wb = Ws + buf * NT * 16 * KC + lrow * KC;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int pq = ((lq + 4 * ks) ^ (lane & 7)) << 2;
+            unsigned lv = ~0u;                                   // bit m: tile m has a source in this half-chunk
+            if (SKIP) {
+                lv = 0;
+#pragma unroll
+                for (int m = 0; m < RT; ++m) lv |= ((live >> (2 * m + ks)) & 1u) << m;
+                if (lv == 0) continue;                           // scalar branch: nothing to add
+            }
             // all weight quads of the step first, then t outermost: consecutive MFMAs go to DIFFERENT accumulators (a dependent
             // v_mfma_f32_16x16x4_f32 issues 40 cycles after its predecessor, an independent one after 32)
             f32x4 wq[NT];
 #pragma unroll
             for (int n = 0; n < NT; ++n) wq[n] = *reinterpret_cast<const f32x4*>(Wb + n * 16 * KC + pq);
+            if (!SKIP || lv == (1u << RT) - 1) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int n = 0; n < NT; ++n)
+                    for (int n = 0; n < NT; ++n)
 #pragma unroll
-                    for (int m = 0; m < RT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[n][t], ra[m][ks][t], acc[m][n], 0, 0, 0);
+                        for (int m = 0; m < RT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[n][t], ra[m][ks][t], acc[m][n], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int m = 0; m < RT; ++m) {
+                    if (!((lv >> m) & 1u)) continue;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[n][t], ra[m][ks][t], acc[m][n], 0, 0, 0);
+                }
+            }
         }
     };
 
     f32x4 ra[3][RT][2], rw[3][WQ];
-    unsigned mw[3];
-    load_a(ra[0]); load_w(rw[0], mw[0]);                 // chunk 0
+    unsigned mw[3], lva[3];
+    load_a(ra[0], lva[0]); load_w(rw[0], mw[0]);         // chunk 0
     store_w(0, rw[0], mw[0]);
     __syncthreads();
-    load_a(ra[1]); load_w(rw[1], mw[1]);                 // chunk 1
+    load_a(ra[1], lva[1]); load_w(rw[1], mw[1]);         // chunk 1
     // one chunk: J = c mod 3 names the register sets / LDS buffers statically
     auto step = [&](auto J) {
         constexpr int j = decltype(J)::value;
-        load_a(ra[(j + 2) % 3]); load_w(rw[(j + 2) % 3], mw[(j + 2) % 3]);               // chunk c+2
+        load_a(ra[(j + 2) % 3], lva[(j + 2) % 3]); load_w(rw[(j + 2) % 3], mw[(j + 2) % 3]);               // chunk c+2
         __builtin_amdgcn_sched_barrier(0);               // keep the prefetch loads AHEAD of the MFMA phase
-        compute(j, ra[j]);
+        compute(j, ra[j], lva[j]);
         store_w((j + 1) % 3, rw[(j + 1) % 3], mw[(j + 1) % 3]);                           // chunk c+1
         __syncthreads();
     };
@@ -714,6 +776,225 @@ int launch_s3(const GGParams& p_in, int rt, hipStream_t st) {
     return SH_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Coalesced-gather form (round 3).  What bounds the direct kernels is not the matrix pipe but the texture-address path: the
+// MFMA operand layout puts the 16 ROWS of a tile on 16 consecutive lanes, so every quad of lanes of a wave's load
+// instruction touches four different cache lines and the instruction moves its 1 KiB at a quarter of the L1 rate
+// (tools/exp/ta_probe.hip; the bf16x3 form with 2.7x less matrix work ran no faster at the same tiling).  Here a wave
+// loads its rows LINE-WISE - lane l fetches quad l & 7 of row (l >> 3) + 8 i: eight full 128-byte lines per instruction -
+// and turns them into the MFMA layout through a wave-PRIVATE LDS tile (XOR-swizzled quads, conflict-free both ways; the
+// rows belong to this wave alone, so no workgroup barrier guards them: LDS executes a wave's accesses in order).  The
+// weight chunk is staged as before (double-buffered, one barrier per chunk).  Same tiling, K order and epilogue as the
+// staged and direct kernels, hence bit-identical results.
+template <int NT, bool BWD_EPI, int RT>
+__global__ __launch_bounds__(NTHREADS) void gather_gemm_cg_kernel(const GGParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Ws = reinterpret_cast<float*>(smem);                 // [2][NT*16][KC]
+    float* As = Ws + 2 * NT * 16 * KC;                          // [4 waves][2][16*RT][KC]
+    int* Ts = reinterpret_cast<int*>(As + 4 * 2 * 16 * RT * KC);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int TB = 1 << p.log2TB, TV = (64 * RT) >> p.log2TB;
+    const int item = sh_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = item / p.nsplit;
+    const int n_base = (item - tile * p.nsplit) * (NT * 16);
+    const int bt = tile / p.n_vtiles, vt = tile - bt * p.n_vtiles;
+    const int v0 = vt * TV, b0 = bt * TB;
+    const int S = p.S;
+    {
+        const int nT = TV * S;
+        const long lim = (long)p.R * S;
+        for (int i = tid; i < nT; i += NTHREADS) {
+            const long g = (long)v0 * S + i;
+            Ts[i] = g < lim ? (int)(unsigned)((long)p.table[g] * p.x_sv) : 0;
+        }
+    }
+    __syncthreads();
+
+    // ---- gather: lane -> quad q of rows lr0 + 8 i of this wave's 16 RT rows
+    constexpr int NL = 2 * RT;                                  // load instructions per chunk
+    const int q = lane & 7, lr0 = lane >> 3;
+    int a_ts[NL];
+    long a_boff[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const int row = 16 * RT * wave + lr0 + 8 * i;
+        const int vl = row >> p.log2TB, bl = row & (TB - 1);
+        a_ts[i] = vl * S;
+        a_boff[i] = (b0 + bl) < p.B ? (long)(b0 + bl) * p.x_sb : 0;      // rows past B read row 0 of the slice; never stored
+    }
+    float* Aw = As + wave * (2 * 16 * RT * KC);                 // this wave's two tiles
+    const int a_lds = lr0 * KC + ((q ^ (lr0 & 7)) << 2);        // (lr0 + 8 i) & 7 == lr0 & 7
+    int k_n = 4 * q, s_n = k_n / p.Cg, c_n = k_n - s_n * p.Cg;
+    const int adv_s = KC / p.Cg, adv_c = KC - adv_s * p.Cg;
+    auto load_a = [&](f32x4 (&ra)[NL]) {
+        const bool kok = k_n < p.K;                             // K tail / prefetch past the end: any valid address
+        const int s = kok ? s_n : 0, ch = kok ? c_n : 0;
+        unsigned toff[NL];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) toff[i] = (unsigned)Ts[a_ts[i] + s];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) ra[i] = *reinterpret_cast<const f32x4*>(p.x + toff[i] + a_boff[i] + ch);
+        k_n += KC; c_n += adv_c; s_n += adv_s;
+        const bool wrap = c_n >= p.Cg;
+        c_n = wrap ? c_n - p.Cg : c_n;
+        s_n = wrap ? s_n + 1 : s_n;
+    };
+    auto store_a = [&](int buf, const f32x4 (&ra)[NL]) {
+        float* Ab = Aw + buf * (16 * RT * KC) + a_lds;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) *reinterpret_cast<f32x4*>(Ab + 8 * i * KC) = ra[i];
+    };
+
+    // ---- weight chunk staging: thread -> quad q8 of rows rbase + 32 i (as in gather_gemm_kernel)
+    const int q8 = tid & 7, rbase = tid >> 3;
+    constexpr int WQ = NT >= 2 ? NT / 2 : 1;
+    const bool w_thread = (NT >= 2) || tid < 128;
+    long w_off[WQ];
+#pragma unroll
+    for (int i = 0; i < WQ; ++i) {
+        const int n = n_base + rbase + 32 * i;
+        w_off[i] = n < p.Nout ? (long)n * p.Kw : 0;
+    }
+    int kw_n = 4 * q8;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto load_w = [&](f32x4 (&rw)[WQ], unsigned& mask) {
+        const bool kok = kw_n < p.K;
+        mask = kok ? 1u : 0u;
+        const int kc = kok ? kw_n : 0;
+#pragma unroll
+        for (int i = 0; i < WQ; ++i) rw[i] = *reinterpret_cast<const f32x4*>(p.w + w_off[i] + kc);
+        kw_n += KC;
+    };
+    auto store_w = [&](int buf, const f32x4 (&rw)[WQ], unsigned mask) {
+        if (w_thread) {
+            float* Wb = Ws + buf * NT * 16 * KC;
+            const int pq = (q8 ^ (rbase & 7)) << 2;
+#pragma unroll
+            for (int i = 0; i < WQ; ++i) *reinterpret_cast<f32x4*>(Wb + (rbase + 32 * i) * KC + pq) = mask ? rw[i] : zero4;
+        }
+    };
+
+    f32x4 acc[RT][NT];
+#pragma unroll
+    for (int m = 0; m < RT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = zero4;
+    const int lrow = lane & 15, lq = lane >> 4;
+    auto compute = [&](int buf) {
+        const float* Ab = Aw + buf * (16 * RT * KC) + lrow * KC;
+        const float* Wb = Ws + buf * NT * 16 * KC + lrow * KC;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int pq = ((lq + 4 * ks) ^ (lane & 7)) << 2;
+            f32x4 g[RT], wq[NT];
+#pragma unroll
+            for (int m = 0; m < RT; ++m) g[m] = *reinterpret_cast<const f32x4*>(Ab + 16 * m * KC + pq);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) wq[n] = *reinterpret_cast<const f32x4*>(Wb + n * 16 * KC + pq);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int m = 0; m < RT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[n][t], g[m][t], acc[m][n], 0, 0, 0);
+        }
+    };
+
+    // ---- main loop: LDS holds chunk c (buffers c & 1), register sets A / B the loads of chunks c+1 and c+2
+    f32x4 raA[NL], raB[NL], rwA[WQ], rwB[WQ];
+    unsigned mA, mB;
+    load_a(raA); load_w(rwA, mA);                        // chunk 0
+    store_a(0, raA); store_w(0, rwA, mA);
+    __syncthreads();
+    load_a(raA); load_w(rwA, mA);                        // chunk 1
+    auto even = [&]() {                                  // LDS buffers 0 hold chunk c, set A chunk c+1
+        load_a(raB); load_w(rwB, mB);                    // chunk c+2
+        __builtin_amdgcn_sched_barrier(0);               // keep the prefetch loads AHEAD of the MFMA phase
+        compute(0);
+        store_a(1, raA); store_w(1, rwA, mA);            // chunk c+1 (a clamped duplicate past the end is never read)
+        __syncthreads();
+    };
+    auto odd = [&]() {                                   // LDS buffers 1 hold chunk c, set B chunk c+1
+        load_a(raA); load_w(rwA, mA);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(1);
+        store_a(0, raB); store_w(0, rwB, mB);
+        __syncthreads();
+    };
+    // four chunks per trip: hipcc drains the outstanding loads (vmcnt(0)) where the back edge joins, once per trip
+    for (int c = 0; c < p.nchunks; c += 4) {
+        even();
+        if (c + 1 >= p.nchunks) break;
+        odd();
+        if (c + 2 >= p.nchunks) break;
+        even();
+        if (c + 3 >= p.nchunks) break;
+        odd();
+    }
+
+    // ---- epilogue (identical to gather_gemm_kernel): lane holds channels n0..n0+3 of tile row 16*RT*wave + 16*m + lrow
+#pragma unroll
+    for (int m = 0; m < RT; ++m) {
+        const int row = 16 * RT * wave + 16 * m + lrow;
+        const int vl = row >> p.log2TB, bl = row & (TB - 1);
+        const int v = v0 + vl, b = b0 + bl;
+        if (v >= p.R || b >= p.B) continue;
+        float* yrow = p.y + (long)v * p.y_sv + (long)b * p.y_sb;
+        const float* yp = (BWD_EPI && p.yprev) ? p.yprev + (long)v * p.yp_sv + (long)b * p.yp_sb : nullptr;
+        const bool zero = v == p.zero_row;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int n0 = n_base + n * 16 + lq * 4;
+            if (n0 >= p.Nout) continue;
+            f32x4 a = acc[m][n];
+            if (p.vec_out) {
+                if (!BWD_EPI) {
+                    if (p.bias) a += *reinterpret_cast<const f32x4*>(p.bias + n0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[j] = sh_act_fwd(a[j], p.act);
+                } else if (yp) {
+                    const f32x4 yv = *reinterpret_cast<const f32x4*>(yp + n0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[j] *= sh_act_grad_from_out(yv[j], p.act);
+                }
+                if (zero) a = (f32x4){0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(yrow + n0) = a;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (n0 + j >= p.Nout) continue;
+                    float vv = a[j];
+                    if (!BWD_EPI) {
+                        if (p.bias) vv += p.bias[n0 + j];
+                        vv = sh_act_fwd(vv, p.act);
+                    } else if (yp) {
+                        vv *= sh_act_grad_from_out(yp[n0 + j], p.act);
+                    }
+                    yrow[n0 + j] = zero ? 0.f : vv;
+                }
+            }
+        }
+    }
+}
+
+template <int NT, bool BWD_EPI>
+int launch_cg(const GGParams& p_in, int rt, hipStream_t st) {
+    GGParams p = p_in;
+    const int tb = 1 << p.log2TB;
+    if (tb > 64 * rt) rt = 2;
+    const int TV = (64 * rt) >> p.log2TB;
+    p.n_vtiles = sh_cdiv(p.R, TV);
+    const int nblocks = p.n_vtiles * p.n_btiles * p.nsplit;
+    const size_t smem = (size_t)(2 * NT * 16 * KC + 4 * 2 * 16 * rt * KC) * sizeof(float) + (size_t)(TV * p.S) * sizeof(int);
+    ShProfScope ps(st, "gather_gemm_cg_kernel<%d, %s, %d>|R=%d B=%d K=%d N=%d grid=%d", NT, BWD_EPI ? "true" : "false", rt, p.R,
+                   p.B, p.K, p.Nout, nblocks);
+    if (rt == 1) SH_LAUNCH_PS(ps, (gather_gemm_cg_kernel<NT, BWD_EPI, 1>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
+    else SH_LAUNCH_PS(ps, (gather_gemm_cg_kernel<NT, BWD_EPI, 2>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
+    SH_CHECK_LAUNCH("gather_gemm_cg");
+    return SH_OK;
+}
+
 template <int NT, bool BWD_EPI>
 int launch_ggd(const GGParams& p_in, int nblocks128 /* workgroups if the tiles had 128 rows */, hipStream_t st) {
     // 16-row tiles per wave.  Measured on MI355X (B = 64): one tile per wave (64-row workgroups, twice as many of them)
@@ -730,7 +1011,10 @@ int launch_ggd(const GGParams& p_in, int nblocks128 /* workgroups if the tiles h
     const size_t smem = (size_t)(3 * NT * 16 * KC) * sizeof(float) + (size_t)(TV * p.S) * sizeof(int);
     ShProfScope ps(st, "gather_gemm_direct_kernel<%d, %s, %d>|R=%d B=%d K=%d N=%d grid=%d", NT, BWD_EPI ? "true" : "false", rt, p.R,
                    p.B, p.K, p.Nout, nblocks);
-    if (rt == 1) SH_LAUNCH_PS(ps, (gather_gemm_direct_kernel<NT, BWD_EPI, 1>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
+    // one tile per wave + known zero row: the form that skips no-source entries (the two-tile launches are the fine levels, where
+    // 5-22 % of the entries have no source and the extra branches cost more than they save: 58.6 -> 63.8 us measured)
+    if (rt == 1 && BWD_EPI && p.skip_on) SH_LAUNCH_PS(ps, (gather_gemm_direct_kernel<NT, BWD_EPI, 1, BWD_EPI>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
+    else if (rt == 1) SH_LAUNCH_PS(ps, (gather_gemm_direct_kernel<NT, BWD_EPI, 1>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
     else SH_LAUNCH_PS(ps, (gather_gemm_direct_kernel<NT, BWD_EPI, 2>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
     SH_CHECK_LAUNCH("gather_gemm_direct");
     return SH_OK;
@@ -761,6 +1045,8 @@ int dispatch_gg(GGParams& p, hipStream_t st) {
     int tb = 1;
     while (tb < p.B && tb < tb_pref) tb <<= 1;
     p.log2TB = sh_ilog2_floor(tb);
+    static const int skip_env = sh_env_int("SH_GG_SKIP", 1, 0, 1);
+    p.skip_on = (BWD_EPI && skip_env && p.skip_on && tb == 16 && p.Cg % 16 == 0) ? 1 : 0;
     const int TV = TM >> p.log2TB;
     p.n_btiles = sh_cdiv(p.B, tb);
     p.n_vtiles = sh_cdiv(p.R, TV);
@@ -796,6 +1082,23 @@ int dispatch_gg(GGParams& p, hipStream_t st) {
             case 2: return launch_s3<2, BWD_EPI>(p, rt, st);
             case 4: return launch_s3<4, BWD_EPI>(p, rt, st);
             default: return launch_s3<8, BWD_EPI>(p, rt, st);
+        }
+    }
+    // coalesced-gather form (exact fp32 MFMA): up to SH_CG_NT channel tiles per workgroup, the rest split over workgroups
+    static const int cg_on = sh_env_int("SH_GG_CG", 0, 0, 1);
+    if (cg_on && vec4 && !c3) {
+        static const int cg_nt = sh_env_int("SH_CG_NT", 4, 1, 8), cg_rt = sh_env_int("SH_CG_RT", 0, 0, 2);
+        static const int cg_rt2_at = sh_env_int("SH_CG_RT2_AT", 2048, 1, 1 << 30);
+        int ntw = nt;
+        p.nsplit = 1;
+        while (ntw > cg_nt) { ntw >>= 1; p.nsplit <<= 1; }
+        const long wg64 = (long)sh_cdiv(p.R, 64 >> (p.log2TB < 6 ? p.log2TB : 6)) * p.n_btiles * p.nsplit;
+        const int rt = cg_rt ? cg_rt : (wg64 >= cg_rt2_at ? 2 : 1);
+        switch (ntw) {
+            case 1: return launch_cg<1, BWD_EPI>(p, rt, st);
+            case 2: return launch_cg<2, BWD_EPI>(p, rt, st);
+            case 4: return launch_cg<4, BWD_EPI>(p, rt, st);
+            default: return launch_cg<8, BWD_EPI>(p, rt, st);
         }
     }
     // too few row tiles to fill 256 CUs x ~3 workgroups: split the output channels over workgroups
@@ -1510,6 +1813,13 @@ int sh_spiral_conv_fwd(const float* x, int64_t x_sv, int64_t x_sb, const int32_t
 int sh_spiral_conv_bwd_data(const float* dpre, int64_t dp_sv, int64_t dp_sb, const int32_t* table_t, const float* weight_t,
                             float* dx, int64_t dx_sv, int64_t dx_sb, const float* yprev, int64_t yp_sv, int64_t yp_sb,
                             int act_prev, int zero_row, int B, int n_in, int S, int Cin, int Cout, sh_stream_t stream) {
+    return sh_spiral_conv_bwd_data_z(dpre, dp_sv, dp_sb, -1, table_t, weight_t, dx, dx_sv, dx_sb, yprev, yp_sv, yp_sb, act_prev, zero_row,
+                                     B, n_in, S, Cin, Cout, stream);
+}
+
+int sh_spiral_conv_bwd_data_z(const float* dpre, int64_t dp_sv, int64_t dp_sb, int dpre_zero_row, const int32_t* table_t,
+                              const float* weight_t, float* dx, int64_t dx_sv, int64_t dx_sb, const float* yprev, int64_t yp_sv,
+                              int64_t yp_sb, int act_prev, int zero_row, int B, int n_in, int S, int Cin, int Cout, sh_stream_t stream) {
     SH_REQUIRE(dpre && table_t && weight_t && dx, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_data: null pointer");
     SH_REQUIRE(B > 0 && n_in > 0 && S > 0 && Cin > 0 && Cout > 0, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_data: non-positive size");
     SH_REQUIRE(act_prev >= SH_ACT_IDENTITY && act_prev <= SH_ACT_TANH, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_data: unknown activation %d", act_prev);
@@ -1520,6 +1830,8 @@ int sh_spiral_conv_bwd_data(const float* dpre, int64_t dp_sv, int64_t dp_sb, con
     p.yprev = yprev; p.yp_sv = yp_sv; p.yp_sb = yp_sb;
     p.B = B; p.R = n_in; p.S = S; p.Cg = Cout; p.Nout = Cin; p.K = S * Cout;
     p.act = act_prev; p.zero_row = zero_row;
+    p.skip_on = dpre_zero_row >= 0 && (long)dpre_zero_row * dp_sv < (1L << 32);
+    p.skip_off = p.skip_on ? (unsigned)((long)dpre_zero_row * dp_sv) : 0u;
     return dispatch_gg<true>(p, static_cast<hipStream_t>(stream));
 }
 

@@ -166,8 +166,10 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
                     if (rc != SH_OK) return rc;
                 }
                 if (!thin_dx) {
-                    rc = sh_spiral_conv_bwd_data(cur, cl.sv, cl.sb, s.table_t, weight_t[i], gi, gl.sv, gl.sb, yprev, yl.sv, yl.sb,
-                                                 act_prev, zero_prev, B, s.n_in, s.S, s.cin, s.cout, stream);
+                    // the "no source" entries of table_t point at this step's own dummy row of dpre (stack.py ConvStep.finalize),
+                    // which its producer forced to zero
+                    rc = sh_spiral_conv_bwd_data_z(cur, cl.sv, cl.sb, s.zero_row, s.table_t, weight_t[i], gi, gl.sv, gl.sb, yprev, yl.sv,
+                                                   yl.sb, act_prev, zero_prev, B, s.n_in, s.S, s.cin, s.cout, stream);
                     if (rc != SH_OK) return rc;
                 }
             }
