@@ -700,8 +700,19 @@ def gen_preprocess():
     the rounding noise of numpy's SVD): per level the QSlim selection and faces (mesh_sampling.qslim_decimator_transformer),
     the raw spiral lists (utils_spiral.get_spirals, 2 rings) and the shortest-path reference points.  Two meshes: 578 and
     1538 vertices."""
+    _gen_preprocess((("a", (12, 12, 6), 11), ("b", (20, 20, 9), 12)), "preprocess.npz")
+
+
+def gen_preprocess6890():
+    """The same at the BENCHMARK size: box_sphere(42, 42, 20) = 6890 vertices with the seeded 2 % jitter (tag "c"), four
+    decimation levels [6890, 3445, 1723, 862, 431] - so that the native build_hierarchy is checked bit for bit against the
+    reference's own pipeline at the size bench.py runs."""
+    _gen_preprocess((("c", (42, 42, 20), 13),), "preprocess6890.npz")
+
+
+def _gen_preprocess(cases, fname):
     arrs = {}
-    for tag, dims, seed in (("a", (12, 12, 6), 11), ("b", (20, 20, 9), 12)):
+    for tag, dims, seed in cases:
         v, f = synthetic.box_sphere(*dims)
         rs = np.random.RandomState(seed)
         e = np.linalg.norm(v[f[:, 0]] - v[f[:, 1]], axis=1).mean()
@@ -731,7 +742,7 @@ def gen_preprocess():
             arrs["%s/spiral_flat_%d" % (tag, i)] = np.asarray([x for s_ in sp for x in s_], dtype=np.int32)
             arrs["%s/spiral_len_%d" % (tag, i)] = np.asarray([len(s_) for s_ in sp], dtype=np.int32)
         print("preprocess", tag, [m.v.shape[0] for m in M], "%.1fs" % (time.time() - t0))
-    np.savez_compressed(os.path.join(GOLD, "preprocess.npz"), **arrs)
+    np.savez_compressed(os.path.join(GOLD, fname), **arrs)
 
 
 def gen_template27k():

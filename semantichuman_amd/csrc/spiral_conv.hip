@@ -580,7 +580,8 @@ __device__ __forceinline__ void sh_split3(const f32x4 a, const f32x4 b, u32x4& h
     }
 }
 
-template <int NT, bool BWD_EPI, int RT>
+// ALL9: all nine partial products (the product of the split operands is then EXACT; only the fp32 accumulation rounds)
+template <int NT, bool BWD_EPI, int RT, bool ALL9 = false>
 __global__ __launch_bounds__(NTHREADS) void gather_gemm_split3_kernel(const GGParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u32x4* Wl = reinterpret_cast<u32x4*>(smem);                  // [3 buffers][3 planes][NT][64 slots]
@@ -697,6 +698,11 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_split3_kernel(const GGPa
 #pragma unroll
             for (int m = 0; m < RT; ++m) {                       // smallest terms first
                 f32x4 c = acc[m][n];
+                if (ALL9) {
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xl[m], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xm[m], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xl[m], c, 0, 0, 0);
+                }
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[m], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[m], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm[m], c, 0, 0, 0);
@@ -770,7 +776,11 @@ int launch_s3(const GGParams& p_in, int rt, hipStream_t st) {
     const size_t smem = (size_t)(3 * 3 * NT * 64) * 16 + (size_t)(TV * p.S) * sizeof(int);
     ShProfScope ps(st, "gather_gemm_split3_kernel<%d, %s, %d>|R=%d B=%d K=%d N=%d grid=%d", NT, BWD_EPI ? "true" : "false", rt, p.R,
                    p.B, p.K, p.Nout, nblocks);
-    if (rt == 1) SH_LAUNCH_PS(ps, (gather_gemm_split3_kernel<NT, BWD_EPI, 1>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
+    static const int all9 = sh_env_int("SH_S3_ALL9", 0, 0, 1);
+    if (all9) {
+        if (rt == 1) SH_LAUNCH_PS(ps, (gather_gemm_split3_kernel<NT, BWD_EPI, 1, true>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
+        else SH_LAUNCH_PS(ps, (gather_gemm_split3_kernel<NT, BWD_EPI, 2, true>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
+    } else if (rt == 1) SH_LAUNCH_PS(ps, (gather_gemm_split3_kernel<NT, BWD_EPI, 1>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
     else SH_LAUNCH_PS(ps, (gather_gemm_split3_kernel<NT, BWD_EPI, 2>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
     SH_CHECK_LAUNCH("gather_gemm_split3");
     return SH_OK;
@@ -1069,7 +1079,8 @@ int dispatch_gg(GGParams& p, hipStream_t st) {
                 (!p.bias || reinterpret_cast<uintptr_t>(p.bias) % 16 == 0) &&
                 (!p.yprev || ((p.yp_sv % 4 == 0) && (p.yp_sb % 4 == 0) && reinterpret_cast<uintptr_t>(p.yprev) % 16 == 0));
     // bf16x3 form (sh_set_f32_mma_mode): up to four channel tiles per workgroup, the rest split over workgroups
-    if (sh_f32_mma_mode() == SH_MMA_SPLIT3 && vec4 && p.vec_out && !c3 && p.Cg % 8 == 0) {
+    static const int s3_min_nt = sh_env_int("SH_S3_MIN_NT", 4, 1, 8);      // layers with fewer channel tiles keep the exact form (no gain there)
+    if (sh_f32_mma_mode() == SH_MMA_SPLIT3 && vec4 && p.vec_out && !c3 && p.Cg % 8 == 0 && nt >= s3_min_nt) {
         static const int s3_nt = sh_env_int("SH_S3_NT", 4, 1, 8), s3_rt = sh_env_int("SH_S3_RT", 0, 0, 2);
         static const int s3_rt2_at = sh_env_int("SH_S3_RT2_AT", 2048, 1, 1 << 30);
         int ntw = nt;

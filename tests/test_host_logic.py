@@ -251,3 +251,47 @@ def test_split_identity_rows_and_folded_stack(small):
         hv = np.random.RandomState(1).randn(h.sizes[-1] + 1, 2, FD[0][0])
         outs[fold] = emulate.stack_forward(st, hv, W, Bs)[-1]
     assert np.array_equal(outs[True], outs[False])
+
+
+@pytest.mark.parametrize("act", ["identity", "relu", "elu", "leaky_relu", "sigmoid", "tanh"])
+def test_emulate_operators_equal_the_oracle(act):
+    """tests/emulate.py is a third formulation of the operators (numpy float64 over the kernels' tables) that the bf16
+    and thin-layer GPU tests compare against.  Here it is pinned, operator by operator and on the same inputs, to the oracle
+    (oracle/ref_cpu.py, itself pinned to the reference's vectors): SpiralConv forward against ref_cpu.spiral_conv, the three
+    backward formulations (transposed-table backward-data with pre-summed rows, weight gradient, role-swapped weight
+    gradient) against torch autograd of that same oracle function - float64 emulation vs the oracle's float32 at 1e-6."""
+    from semantichuman_amd import ops
+    rs = np.random.RandomState(11)
+    B, N1, S, cin, cout = 3, 41, 5, 8, 6
+    adj = rs.randint(-1, N1 - 1, size=(1, N1, S)).astype(np.int64)          # -1 = the dummy row, several readers per row
+    adj[0, :, 0] = np.arange(N1)
+    adj[0, -1, :] = -1                                                       # the dummy row's own spiral (utils_spiral.py:89)
+    x = torch.from_numpy(rs.randn(B, N1, cin).astype(np.float32)); x[:, -1] = 0
+    W = torch.from_numpy((rs.randn(cout, S * cin) * 0.3).astype(np.float32)).requires_grad_(True)
+    b = torch.from_numpy(rs.randn(cout).astype(np.float32)).requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    y = ref_cpu.spiral_conv(xr, torch.from_numpy(adj), W, b, act)            # the oracle (models.py:34-53)
+    g = torch.from_numpy(rs.randn(B, N1, cout).astype(np.float32))
+    y.backward(g)
+
+    table = mesh_ops.spirals_to_table(adj)
+    a = ops.act_id(act)
+    xv = x.permute(1, 0, 2).double().numpy()                                 # vertex-major, as the kernels see it
+    ye = emulate.conv_fwd(xv, table, W.detach().double().numpy(), b.detach().double().numpy(), a, N1 - 1)
+    yo = y.detach().permute(1, 0, 2).numpy()
+    tol = 1e-6 * max(1.0, float(np.abs(yo).max()))
+    assert np.abs(ye - yo).max() <= tol
+
+    # backward: dpre = g * act'(y) with the dummy row dead, then the three formulations
+    dpre = g.permute(1, 0, 2).double().numpy() * emulate.DACT[a](ye)
+    dpre[N1 - 1] = 0
+    tt = mesh_ops.transpose_table_dense(table, N1, none_row=N1 - 1)
+    dx = emulate.conv_bwd_data(emulate.extend_dpre(dpre, tt), tt.table_t, W.detach().double().numpy(), cin)
+    gx = xr.grad.permute(1, 0, 2).numpy()
+    assert np.abs(dx - gx).max() <= 1e-6 * max(1.0, float(np.abs(gx).max()))
+    dW, db = emulate.conv_bwd_wgt(dpre, xv, table)
+    assert np.abs(dW - W.grad.numpy()).max() <= 2e-6 * max(1.0, float(W.grad.abs().max()))
+    assert np.abs(db - b.grad.numpy()).max() <= 2e-6 * max(1.0, float(b.grad.abs().max()))
+    dW2, db2 = emulate.conv_bwd_wgt_swapped(emulate.extend_dpre(dpre, tt), xv, tt.table_t)
+    assert np.abs(dW2 - W.grad.numpy()).max() <= 2e-6 * max(1.0, float(W.grad.abs().max()))
+    assert np.abs(db2 - b.grad.numpy()).max() <= 2e-6 * max(1.0, float(b.grad.abs().max()))
