@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 FE = [[3, 16, 32, 64, 128], [[], [], [], [], []]]
 FD = [[128, 64, 32, 32, 16], [[], [], [], [], 3]]
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA dense peak
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
 
 
@@ -275,6 +276,9 @@ def replayed_training(sh, h, B, dtype, dev, steps, warmup, n_data=None, seed=100
            "whole_step": {"flops": fl, "hbm_bytes_ideal": by, "tflops": fl / dt / 1e12, "gbps": by / dt / 1e9,
                           "frac_mfma": fl / dt / 1e12 / (2500.0 if dtype == "bf16" else PEAK_F32_MFMA_TFLOPS),
                           "frac_hbm": by / dt / 1e9 / PEAK_HBM_GBS}}
+    if dtype == "f32":
+        from semantichuman_amd import _lib
+        res["f32_mma"] = _lib.get_f32_mma_mode()
     del graph
     return res, model, init_state, data, ft
 
@@ -336,6 +340,7 @@ def secondary_block(sh, h, B, dev, init_state, data, test, ft, cpu_l2_mm, args):
         import bench_decode
         r = bench_decode.run(latents=20 * 1024, batch=1024, dev=dev)
         r["config"] = "BASELINE configs[4] on a bounded sample: 20 batches of 1024 random latents (the full run is tools/bench_decode.py: 100k)"
+        r["f32_mma"] = _lib.get_f32_mma_mode()
         return r
 
     def semantic_leg():
@@ -343,8 +348,22 @@ def secondary_block(sh, h, B, dev, init_state, data, test, ft, cpu_l2_mm, args):
         import bench_semantic
         r = bench_semantic.run(batch=16, steps=steps, graph=True, dev=dev, warmup=5)
         r["config"] = "semantic training iteration (SURVEY row f1): 3 passes x 16 meshes, all part losses, backward, Adam"
+        r["f32_mma"] = _lib.get_f32_mma_mode()
         return r
 
+    def other_f32_leg():
+        other = "exact" if _lib.get_f32_mma_mode() == "split3" else "split3"
+        _lib.set_f32_mma_mode(other)
+        try:
+            res, model, _, _, _ = replayed_training(sh, h, B, "f32", dev, steps, warm)
+        finally:
+            _lib.set_f32_mma_mode("split3" if other == "exact" else "exact")
+        del model
+        res["f32_mma"] = other
+        res["config"] = "the headline's step with the other arithmetic form of the fp32 products (%s)" % other
+        return res
+
+    leg("f32_other_mma_step", other_f32_leg)
     leg("bf16_step", bf16_leg)
     leg("config4_27k", config4_leg)
     leg("decode_b1024", decode_leg)
@@ -444,8 +463,14 @@ def roofline_f32(recs, model, B, nprof, verts):
     traffic, traffic_note = measured_traffic(dom["kernel"], workload_tag(verts, B, "f32", mma))
     if "tflops" in dom:
         a = agg[dom["kernel"]]
-        result["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
-                              "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+        # a bf16x3 kernel executes six bf16 MFMA FLOPs per algorithmic fp32 FLOP: its roof is the dense bf16 MFMA peak / 6
+        is_s3 = "split3" in dom["kernel"]
+        peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if is_s3 else PEAK_F32_MFMA_TFLOPS
+        result["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": peak,
+                              "unit": "TFLOP/s", "frac": dom["tflops"] / peak, "traffic": traffic,
+                              "peak_note": ("dense bf16 MFMA peak %.0f TF / 6 partial products per fp32 product" % PEAK_BF16_MFMA_TFLOPS) if is_s3
+                                           else "fp32-input MFMA dense peak",
+                              "frac_of_f32_mfma_peak": dom["tflops"] / PEAK_F32_MFMA_TFLOPS,
                               "traffic_unit": traffic_note,
                               "avg_launch_ms": dom["avg_ms"], "launches_per_step": dom["launches_per_step"],
                               "flops_per_launch": a["flops"] / a["n"], "algorithmic_bytes_per_launch": a["bytes"] / a["n"],
@@ -572,6 +597,11 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="arithmetic of the kernels: f32 = BASELINE configs[1] (the headline), bf16 = configs[2] (bf16 activations and "
                          "working weights, fp32 accumulation, fp32 master weights / gradients / Adam)")
+    ap.add_argument("--f32-mma", choices=["split3", "exact"], default="split3",
+                    help="arithmetic form of the fp32 path's matrix products (include/sh_kernels.h sh_set_f32_mma_mode): split3 = every "
+                         "fp32 operand split exactly into three bf16 terms, six partial products on the bf16 MFMA with fp32 accumulation "
+                         "(fp32-level error: the GPU parity tests run in both forms at the same tolerances); exact = fp32 MFMA.  The "
+                         "library's own default is exact; the secondary block times the other form")
     ap.add_argument("--cpu-iters", type=int, default=8, help="timed CPU-baseline steps (8 steps at batch 64 = ~13 s of host work)")
     ap.add_argument("--template", default=os.path.join("tests", "golden", "template6890.npz"),
                     help="mesh hierarchy fixture; tests/golden/template27554.npz + --batch 32 is BASELINE config 4")
@@ -617,6 +647,7 @@ def main():
     from semantichuman_amd.hierarchy import load_hierarchy
     from semantichuman_amd.parallel import GradientAllReducer
     _lib.load()                                   # fail loudly if the HIP library is missing
+    _lib.set_f32_mma_mode(args.f32_mma)           # explicit, and reported in config.workload / build.f32_mma
 
     h = load_hierarchy(args.template if os.path.isabs(args.template) else os.path.join(ROOT, args.template))
     B = args.batch
@@ -739,7 +770,9 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": ("" if args.dtype == "f32" else "[bf16 kernels, fp32 master weights] ") +
+        "config": {"workload": (("[fp32 products as exact bf16x3 operand splits, six partial products on the bf16 MFMA, fp32 accumulate] "
+                                 if args.f32_mma == "split3" else "[fp32 MFMA] ") if args.dtype == "f32"
+                                else "[bf16 kernels, fp32 master weights] ") +
                                "plain spiral AE training step (fwd + L1 + 1e-2*edge loss + bwd + Adam), %s, levels %s, "
                                "spiral sizes %s, nz 256, %.2fM params"
                                % ("box_sphere(42,42,20) 6890-vertex template" if h.sizes[0] == 6890 else "%d-vertex template" % h.sizes[0],

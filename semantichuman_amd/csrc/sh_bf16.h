@@ -15,6 +15,25 @@ __device__ __forceinline__ bf16x4 sh_to_bf16x4(f32x4 v) {
 }
 __device__ __forceinline__ f32x4 sh_from_bf16x4(bf16x4 v) { return (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; }
 
+// EXACT split of eight fp32 numbers into three bf16 terms each, x = h + m + l (h = rne_bf16(x), m = rne_bf16(x - h),
+// l = x - h - m: 8 + 8 + 8 significand bits; both subtractions are exact in fp32), packed as MFMA operand pieces - the
+// bf16x3 form of the fp32 matrix products (include/sh_kernels.h, sh_set_f32_mma_mode).  ~44 VALU operations.
+__device__ __forceinline__ void sh_split3(const f32x4 a, const f32x4 b, u32x4& h, u32x4& m, u32x4& l) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float x0 = i < 2 ? a[2 * i] : b[2 * i - 4], x1 = i < 2 ? a[2 * i + 1] : b[2 * i - 3];
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        const bf16x2_t hp = {(__bf16)x0, (__bf16)x1};
+        const unsigned hu = __builtin_bit_cast(unsigned, hp);
+        const float r0 = x0 - __builtin_bit_cast(float, hu << 16), r1 = x1 - __builtin_bit_cast(float, hu & 0xFFFF0000u);
+        const bf16x2_t mp = {(__bf16)r0, (__bf16)r1};
+        const unsigned mu = __builtin_bit_cast(unsigned, mp);
+        const float t0 = r0 - __builtin_bit_cast(float, mu << 16), t1 = r1 - __builtin_bit_cast(float, mu & 0xFFFF0000u);
+        const bf16x2_t lp = {(__bf16)t0, (__bf16)t1};
+        h[i] = hu; m[i] = mu; l[i] = __builtin_bit_cast(unsigned, lp);
+    }
+}
+
 // Geometry of a fragment-ordered bf16 weight (the A operand of v_mfma_f32_16x16x32_bf16, one 1-KiB fragment per
 // (k-step, 16-row tile)):  frag[ks][nt][lane][j] = W'[16 nt + (lane & 15)][32 ks + 8 (lane >> 4) + j], zero outside W'.
 //   rows of W' = output channels, columns k = s * Cg + c   (Cg % 8 == 0)

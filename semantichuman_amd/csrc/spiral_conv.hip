@@ -564,22 +564,6 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_direct_kernel(const GGPa
 // k-block kq: the 32 contiguous bytes x[row r][k0 + 8 kq .. +7]); the weight chunk is split by the staging threads and kept
 // in LDS as three planes of MFMA fragments (1 KiB per 16-channel tile and plane: slot = lane, XOR-permuted inside aligned
 // groups of 8 so that the staging writes - two channels x four k-blocks per 8 threads - are conflict-free as well).
-__device__ __forceinline__ void sh_split3(const f32x4 a, const f32x4 b, u32x4& h, u32x4& m, u32x4& l) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float x0 = i < 2 ? a[2 * i] : b[2 * i - 4], x1 = i < 2 ? a[2 * i + 1] : b[2 * i - 3];
-        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-        const bf16x2_t hp = {(__bf16)x0, (__bf16)x1};
-        const unsigned hu = __builtin_bit_cast(unsigned, hp);
-        const float r0 = x0 - __builtin_bit_cast(float, hu << 16), r1 = x1 - __builtin_bit_cast(float, hu & 0xFFFF0000u);
-        const bf16x2_t mp = {(__bf16)r0, (__bf16)r1};
-        const unsigned mu = __builtin_bit_cast(unsigned, mp);
-        const float t0 = r0 - __builtin_bit_cast(float, mu << 16), t1 = r1 - __builtin_bit_cast(float, mu & 0xFFFF0000u);
-        const bf16x2_t lp = {(__bf16)t0, (__bf16)t1};
-        h[i] = hu; m[i] = mu; l[i] = __builtin_bit_cast(unsigned, lp);
-    }
-}
-
 // ALL9: all nine partial products (the product of the split operands is then EXACT; only the fp32 accumulation rounds)
 template <int NT, bool BWD_EPI, int RT, bool ALL9 = false>
 __global__ __launch_bounds__(NTHREADS) void gather_gemm_split3_kernel(const GGParams p) {

@@ -291,9 +291,21 @@ class SpiralAutoencoder_multiz_partkps(nn.Module):
         x = kps[:, self._kps_cat, :].reshape(B, -1)                         # joints of part 0 | part 1 | ...
         return grouped_linear(x, self._kps_off, self.kps_enc_list).view(B, len(self.kps_enc_list), -1)
 
+    def set_compute_dtype(self, dtype):
+        """As SpiralAutoencoder.set_compute_dtype: torch.bfloat16 runs the two SpiralConv stacks (all of the model's work but
+        a few MFLOP) on the bf16 kernels - bf16 activations and working weights, fp32 accumulation; the 3 x 17 per-part
+        `Linear` layers, parameters, gradients and every tensor at the module's interface stay fp32."""
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
+        self.compute_dtype = dtype
+        return self
+
     def encode(self, x, kps, VAE_flag=None):
         bsize = x.size(0)
-        h = run_stack(self._enc_stack, x, "bm", "bm", self.conv)            # [B, N_last+1, C]
+        if getattr(self, "compute_dtype", torch.float32) == torch.bfloat16:
+            h = run_stack_bf16(self._enc_stack, x, "bm", "bm", torch.bfloat16, self.conv).float()
+        else:
+            h = run_stack(self._enc_stack, x, "bm", "bm", self.conv)        # [B, N_last+1, C]
         feat = h.shape[2]
         hp = h[:, self._re_index, :].reshape(bsize, -1)                     # vertices of part 0 | part 1 | ...
         z = grouped_linear(hp, [o * feat for o in self._part_off], self.fc_latent_enc_list)
@@ -309,6 +321,8 @@ class SpiralAutoencoder_multiz_partkps(nn.Module):
         out = x.clone()
         out[:, self._re_index, :] = x[:, :self._re_index.shape[0], :]
         h = torch.cat([out, dummy], dim=1)
+        if getattr(self, "compute_dtype", torch.float32) == torch.bfloat16:
+            return run_stack_bf16(self._dec_stack, h.to(torch.bfloat16), "bm", "bm", torch.float32, self.dconv)
         return run_stack(self._dec_stack, h, "bm", "bm", self.dconv)
 
     def kps2skl(self, kps_tmp):

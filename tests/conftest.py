@@ -26,3 +26,25 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+# The fp32 path has two arithmetic forms of its matrix products (include/sh_kernels.h, sh_set_f32_mma_mode): the exact fp32
+# MFMA and the bf16x3 split (what bench.py's headline runs).  Every GPU parity test of the fp32 path runs in BOTH, with the
+# SAME tolerances - the condition under which the split form may be quoted as fp32 at all.
+F32_PARITY_MODULES = {"test_gpu_parity", "test_configs", "test_train_loop", "test_semantic", "test_editing", "test_wgrad_thin"}
+
+
+def pytest_generate_tests(metafunc):
+    mod = metafunc.module.__name__.split(".")[-1]
+    if mod in F32_PARITY_MODULES and metafunc.definition.get_closest_marker("gpu") is not None and "f32_mma" not in metafunc.fixturenames:
+        metafunc.fixturenames.append("f32_mma")
+        metafunc.parametrize("f32_mma", ["exact", "split3"], indirect=True)
+
+
+@pytest.fixture
+def f32_mma(request):
+    from semantichuman_amd import _lib
+    was = _lib.get_f32_mma_mode()
+    _lib.set_f32_mma_mode(request.param)
+    yield request.param
+    _lib.set_f32_mma_mode(was)

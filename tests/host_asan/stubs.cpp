@@ -122,6 +122,14 @@ int sh_spiral_conv_bwd_data(const float* dpre, int64_t dp_sv, int64_t dp_sb, con
     touch_r(weight_t, (size_t)Cin * S * Cout * 4);
     return bwd_data_common("bwd_data n_in=%d Cin=%d Cout=%d", dpre, 4, dp_sv, dp_sb, table_t, dx, 4, dx_sv, dx_sb, yprev, yp_sv, yp_sb, B, n_in, S, Cin, Cout);
 }
+int sh_spiral_conv_bwd_data_z(const float* dpre, int64_t dp_sv, int64_t dp_sb, int dpre_zero_row, const int32_t* table_t, const float* weight_t,
+                              float* dx, int64_t dx_sv, int64_t dx_sb, const float* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row,
+                              int B, int n_in, int S, int Cin, int Cout, sh_stream_t st) {
+    // the zero row the no-source entries point at is one of dpre's own rows: reading it is covered by the same range
+    if (dpre_zero_row >= 0) touch_r(dpre + (size_t)dpre_zero_row * dp_sv, (size_t)Cout * 4);
+    return sh_spiral_conv_bwd_data(dpre, dp_sv, dp_sb, table_t, weight_t, dx, dx_sv, dx_sb, yprev, yp_sv, yp_sb, act_prev, zero_row, B, n_in, S, Cin,
+                                   Cout, st);
+}
 int sh_spiral_conv_bwd_data_bf16(const void* dpre, int dd, int64_t dp_sv, int64_t dp_sb, const int32_t* table_t, const void* wfrag_t, void* dx, int xd,
                                  int64_t dx_sv, int64_t dx_sb, const void* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row, int B, int n_in,
                                  int S, int Cin, int Cout, sh_stream_t) {

@@ -121,6 +121,38 @@ def test_hip_semantic_model_matches_reference(sem):
 
 
 @pytest.mark.gpu
+def test_hip_semantic_model_bf16_matches_reference(sem):
+    """set_compute_dtype(torch.bfloat16) on the semantic model: the SpiralConv stacks on the bf16 kernels,
+    per-part layers in fp32 - outputs within 1e-2 (SURVEY 8a's bf16 bar) of the REFERENCE's fp32 vectors, gradients finite
+    and within 5e-2 of them, and the fp32 path is restored by set_compute_dtype(torch.float32)."""
+    import semantichuman_amd as sh
+    g, h, coarse, fine = sem
+    dev = torch.device("cuda:0")
+    m = sh.SpiralAutoencoder_multiz_partkps(C.KPS_INDEX_LIST, coarse, C.FILTER_SIZES_ENC, C.FILTER_SIZES_DEC, 8, 8, h.sizes,
+                                            h.spiral_sizes, h.spirals, h.D, h.U, dev)
+    m.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w0/")})
+    x, kps = torch.from_numpy(g["x"]).to(dev), torch.from_numpy(g["kps"]).to(dev)
+    x32 = m(x, kps)[0].detach()
+    m.set_compute_dtype(torch.bfloat16)
+    x_hat, z, zk = m(x, kps)
+    assert x_hat.dtype == torch.float32 and z.dtype == torch.float32
+
+    def close(a, ref, tol):
+        a = a.detach().cpu().numpy()
+        assert np.isfinite(a).all() and np.abs(a - ref).max() <= tol * np.abs(ref).max(), (np.abs(a - ref).max(), np.abs(ref).max())
+
+    close(x_hat, g["x_hat"], 1e-2); close(z, g["z"], 1e-2); close(zk, g["z_part_kps"], 1e-5)
+    assert not torch.equal(x_hat, x32)                              # it did run the other kernels
+    sh.l1_loss(x, x_hat).backward()
+    gmax = max(float(np.abs(g["grad/" + n]).max()) for n, _ in m.named_parameters())
+    for name, p in m.named_parameters():
+        d = np.abs(p.grad.cpu().numpy() - g["grad/" + name]).max()
+        assert np.isfinite(d) and d <= 5e-2 * max(float(np.abs(g["grad/" + name]).max()), 1e-2 * gmax), (name, d)
+    m.set_compute_dtype(torch.float32)
+    assert torch.equal(m(x, kps)[0].detach(), x32)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("relat", [True, False])
 def test_hip_part_pairdist_loss_matches_reference(sem, relat):
     """The kernel computes |g_i-g_j| directly; the reference uses r - 2xx' + r' in fp32, whose
