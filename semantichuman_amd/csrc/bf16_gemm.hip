@@ -130,137 +130,6 @@ __global__ __launch_bounds__(256) void tgemm_bf16_kernel(const TGParams p) {
     if (BT && p.colsum && qt == 0 && tid < 64 && p0 + tid < p.P) p.colsum[p0 + tid] = csum;
 }
 
-// ------------------------------------------------------------------------------------------
-// The same GEMM for fp32 operands in the bf16x3 form (sh_set_f32_mma_mode(SH_MMA_SPLIT3)): both operands are split EXACTLY
-// into three bf16 planes while they are staged (sh_split3) - three LDS images per operand - and every 16 x 16 x 32 product
-// is evaluated as its six leading partial products with fp32 accumulation (dropped terms < 2^-24 |a||b|).  The latent
-// layers in exact fp32 are bound by the fp32 matrix pipe (1.8 GFLOP = 11.5-13.5 us per pass at one wave per SIMD); here
-// the matrix work is 2.7x shorter and the 56.6 MB weight stream is what is left.  Single-buffered LDS (six images, 50 KB:
-// three workgroups per CU), the next stage's raw fp32 pieces wait in registers.
-template <bool TR>
-__device__ __forceinline__ void tg3_stage_load(const float* base, long ld, int i0, int ni, int r0, int r_end, int tid, f32x4 (&reg)[2][2]) {
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int id = tid + 256 * k, row = id >> 3, c8 = id & 7;
-        const int slow = (TR ? r0 : i0) + row, fast = (TR ? i0 : r0) + 8 * c8;
-        const bool ok = slow < (TR ? r_end : ni) && fast < (TR ? ni : r_end);
-        const float* s = base + (ok ? (long)slow * ld + fast : 0);
-        const f32x4 a = *reinterpret_cast<const f32x4*>(s), b = *reinterpret_cast<const f32x4*>(s + 4);
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        reg[k][0] = ok ? a : z; reg[k][1] = ok ? b : z;
-    }
-}
-template <bool TR>
-__device__ __forceinline__ void tg3_stage_store(char* img3, int tid, const f32x4 (&reg)[2][2]) {
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int id = tid + 256 * k, row = id >> 3, c8 = id & 7;
-        u32x4 h, m, l;
-        sh_split3(reg[k][0], reg[k][1], h, m, l);
-        const int off = TR ? tg_tr_piece(row, c8) : tg_nat_piece(row, c8);
-        *reinterpret_cast<u32x4*>(img3 + off) = h;
-        *reinterpret_cast<u32x4*>(img3 + TG_IMG_BYTES + off) = m;
-        *reinterpret_cast<u32x4*>(img3 + 2 * TG_IMG_BYTES + off) = l;
-    }
-}
-
-template <bool AT, bool BT, int OUT>
-__global__ __launch_bounds__(256) void tgemm_split3_kernel(const TGParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[6 * TG_IMG_BYTES];       // A: h | m | l, B: h | m | l
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int bid = blockIdx.x;
-    const int qt = bid % p.n_qt; bid /= p.n_qt;
-    const int pt = bid % p.n_pt; const int split = bid / p.n_pt;
-    const int q0 = qt * 64, p0 = pt * 64;
-    const int st0 = split * p.stages_per_split;
-    const int nst_all = (p.R + 63) >> 6;
-    const int nst = min(p.stages_per_split, nst_all - st0);
-    const int qh = wave & 1, ph = wave >> 1;
-    const float* A = static_cast<const float*>(p.a);
-    const float* Bm = static_cast<const float*>(p.b);
-    char* ia = smem;
-    char* ib = smem + 3 * TG_IMG_BYTES;
-
-    f32x4 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float csum = 0.f;
-
-    f32x4 ra[2][2], rb[2][2];
-    if (nst > 0) {
-        tg3_stage_load<AT>(A, p.a_ld, q0, p.Q, st0 * 64, p.R, tid, ra);
-        tg3_stage_load<BT>(Bm, p.b_ld, p0, p.P, st0 * 64, p.R, tid, rb);
-        tg3_stage_store<AT>(ia, tid, ra);
-        tg3_stage_store<BT>(ib, tid, rb);
-    }
-    __syncthreads();
-    for (int st = 0; st < nst; ++st) {
-        if (st + 1 < nst) {
-            tg3_stage_load<AT>(A, p.a_ld, q0, p.Q, (st0 + st + 1) * 64, p.R, tid, ra);
-            tg3_stage_load<BT>(Bm, p.b_ld, p0, p.P, (st0 + st + 1) * 64, p.R, tid, rb);
-        }
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 fa[3][2], fb[3][2];
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    fa[pl][i] = AT ? tg_tr_frag(ia + pl * TG_IMG_BYTES, 2 * qh + i, kk, lane) : tg_nat_frag(ia + pl * TG_IMG_BYTES, 2 * qh + i, kk, lane);
-                    fb[pl][i] = BT ? tg_tr_frag(ib + pl * TG_IMG_BYTES, 2 * ph + i, kk, lane) : tg_nat_frag(ib + pl * TG_IMG_BYTES, 2 * ph + i, kk, lane);
-                }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {                     // smallest terms first
-                    f32x4 c = acc[i][j];
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2][i], fb[0][j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[2][j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[1][j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[0][j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[1][j], c, 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[0][j], c, 0, 0, 0);
-                }
-        }
-        if (BT && p.colsum && qt == 0 && tid < 64) {          // column sums of B (bias gradient): thread = p index; h + m + l is the fp32 value
-            const char* col = ib + (tid >> 4) * TG_TR_BLK + (tid & 15) * 2;
-#pragma unroll 4
-            for (int r = 0; r < 64; ++r) {
-                const int o = (r >> 5) * TG_TR_KS + (r & 31) * 32;
-                const float hv = (float)*reinterpret_cast<const __bf16*>(col + o);
-                const float mv = (float)*reinterpret_cast<const __bf16*>(col + TG_IMG_BYTES + o);
-                const float lv = (float)*reinterpret_cast<const __bf16*>(col + 2 * TG_IMG_BYTES + o);
-                csum += (hv + mv) + lv;
-            }
-        }
-        __syncthreads();                                       // every wave has its fragments: the images may be overwritten
-        if (st + 1 < nst) {
-            tg3_stage_store<AT>(ia, tid, ra);
-            tg3_stage_store<BT>(ib, tid, rb);
-        }
-        __syncthreads();
-    }
-
-    // lane holds q = qb + 4 (lane >> 4) .. +3 of row p = pb + (lane & 15)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int q = q0 + 32 * qh + 16 * i + 4 * (lane >> 4), pp = p0 + 32 * ph + 16 * j + (lane & 15);
-            if (q >= p.Q || pp >= p.P) continue;
-            f32x4 v = acc[i][j];
-            if (OUT == TG_OUT_PARTIAL) {
-                *reinterpret_cast<f32x4*>(static_cast<float*>(p.out) + ((long)split * p.P + pp) * p.Q + q) = v;
-            } else {
-                if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + q);
-                *reinterpret_cast<f32x4*>(static_cast<float*>(p.out) + (long)pp * p.out_ld + q) = v;
-            }
-        }
-    if (BT && p.colsum && qt == 0 && tid < 64 && p0 + tid < p.P) p.colsum[p0 + tid] = csum;
-}
-
 // out[p][q] = sum_s slab[s][p][q] (+ bias[q]): a wave owns 64 consecutive quads... a workgroup owns 16 quads x 16 slab lanes; lane l
 // sums slabs l, l+16, ... (8 independent loads in flight), the 16 lanes are combined in a fixed order: deterministic
 template <bool OUTBF16>
@@ -343,63 +212,10 @@ int launch_tg(TGParams& p, const TGPlan& t, int out_dtype, void* ws, hipStream_t
     return SH_OK;
 }
 
-template <bool AT, bool BT>
-int launch_tg3(TGParams& p, const TGPlan& t, void* ws, hipStream_t st, const char* what) {
-    p.n_qt = t.n_qt; p.n_pt = t.n_pt; p.nsplit = t.nsplit; p.stages_per_split = t.sps;
-    const int grid = t.n_qt * t.n_pt * t.nsplit;
-    ShProfScope ps(st, "tgemm_split3_kernel<%d,%d>|%s Q=%d P=%d R=%d split=%d", (int)AT, (int)BT, what, p.Q, p.P, p.R, t.nsplit);
-    if (t.nsplit > 1) {
-        void* out = p.out; const float* bias = p.bias;
-        p.out = ws; p.bias = nullptr;
-        SH_LAUNCH_PS(ps, (tgemm_split3_kernel<AT, BT, TG_OUT_PARTIAL>), dim3(grid), dim3(256), 0, st, p);
-        const long n = (long)p.P * p.Q;
-        const int rb = (int)((n / 4 + 15) / 16);
-        hipLaunchKernelGGL(tg_reduce_kernel<false>, dim3(rb), dim3(256), 0, st, static_cast<const float*>(ws), t.nsplit, n, p.Q, bias, out);
-    } else {
-        SH_LAUNCH_PS(ps, (tgemm_split3_kernel<AT, BT, TG_OUT_F32>), dim3(grid), dim3(256), 0, st, p);
-    }
-    SH_CHECK_LAUNCH(what);
-    return SH_OK;
-}
-
 inline bool dt_ok(int d) { return d == SH_DTYPE_F32 || d == SH_DTYPE_BF16; }
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
-
-// ---- fp32 nn.Linear passes in the bf16x3 form; called by sh_linear_fwd / _bwd_data / _bwd_wgt (csrc/linear.hip) when
-// sh_set_f32_mma_mode(SH_MMA_SPLIT3) is in force and the sizes are multiples of 8 (else those keep their exact kernels)
-bool sh_linear_split3_ok(int M, int N, int K, const void* a, const void* b, const void* c) {
-    return N % 8 == 0 && K % 8 == 0 && al16(a) && al16(b) && al16(c);
-}
-size_t sh_linear_split3_workspace(int M, int N, int K) {
-    if (N % 8 || K % 8) return 0;
-    const TGPlan f = plan_tg(N, M, K), d = plan_tg(K, M, N);
-    const size_t a = f.nsplit > 1 ? (size_t)f.nsplit * M * N * 4 : 0, b = d.nsplit > 1 ? (size_t)d.nsplit * M * K * 4 : 0;
-    return (a > b ? a : b) + 16;
-}
-int sh_linear_split3_fwd(const float* x, const float* weight, const float* bias, float* y, int M, int N, int K, void* ws, size_t ws_bytes,
-                         hipStream_t st) {
-    const TGPlan t = plan_tg(N, M, K);
-    SH_REQUIRE(t.nsplit == 1 || (ws && al16(ws) && ws_bytes >= (size_t)t.nsplit * M * N * 4), SH_ERR_WORKSPACE, "sh_linear_fwd: workspace too small");
-    TGParams p{};
-    p.a = weight; p.a_ld = K; p.b = x; p.b_ld = K; p.out = y; p.out_ld = N; p.bias = bias; p.Q = N; p.P = M; p.R = K;
-    return launch_tg3<false, false>(p, t, ws, st, "linear_fwd");
-}
-int sh_linear_split3_bwd_data(const float* dy, const float* weight, float* dx, int M, int N, int K, void* ws, size_t ws_bytes, hipStream_t st) {
-    const TGPlan t = plan_tg(K, M, N);
-    SH_REQUIRE(t.nsplit == 1 || (ws && al16(ws) && ws_bytes >= (size_t)t.nsplit * M * K * 4), SH_ERR_WORKSPACE, "sh_linear_bwd_data: workspace too small");
-    TGParams p{};
-    p.a = weight; p.a_ld = K; p.b = dy; p.b_ld = N; p.out = dx; p.out_ld = K; p.Q = K; p.P = M; p.R = N;
-    return launch_tg3<true, false>(p, t, ws, st, "linear_bwd_data");
-}
-int sh_linear_split3_bwd_wgt(const float* dy, const float* x, float* dW, float* dbias, int M, int N, int K, hipStream_t st) {
-    TGPlan t = plan_tg(K, N, M);
-    t.nsplit = 1; t.sps = sh_cdiv(M, 64);                    // the batch is the reduction: never split (the output is the big side)
-    TGParams p{};
-    p.a = x; p.a_ld = K; p.b = dy; p.b_ld = N; p.out = dW; p.out_ld = K; p.colsum = dbias; p.Q = K; p.P = N; p.R = M;
-    return launch_tg3<true, true>(p, t, nullptr, st, "linear_bwd_wgt");
-}
 
 extern "C" {
 

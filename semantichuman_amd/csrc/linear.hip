@@ -635,12 +635,9 @@ int run_stream(LSParams& p, const LSPlan& pl, int cols, void* ws, size_t ws_byte
 
 }  // namespace
 
-// bf16x3 forms of the three passes (csrc/bf16_gemm.hip), taken when sh_set_f32_mma_mode(SH_MMA_SPLIT3) is in force
-bool sh_linear_split3_ok(int M, int N, int K, const void* a, const void* b, const void* c);
-size_t sh_linear_split3_workspace(int M, int N, int K);
-int sh_linear_split3_fwd(const float* x, const float* weight, const float* bias, float* y, int M, int N, int K, void* ws, size_t ws_bytes, hipStream_t st);
-int sh_linear_split3_bwd_data(const float* dy, const float* weight, float* dx, int M, int N, int K, void* ws, size_t ws_bytes, hipStream_t st);
-int sh_linear_split3_bwd_wgt(const float* dy, const float* x, float* dW, float* dbias, int M, int N, int K, hipStream_t st);
+// Measured and not kept (round 3, MI355X, batch 64, 256 x 55 296): the six latent GEMMs in the bf16x3 form of the conv kernels
+// (both fp32 operands split while staged, six bf16 MFMAs per product) took 22.8-32.7 us each against 25.5-33.5 us here - these
+// passes are not bound by the matrix pipe but by how many bytes of the 56.6 MB weight stream a CU keeps in flight.
 
 extern "C" {
 
@@ -660,15 +657,12 @@ size_t sh_linear_workspace(int M, int N, int K) {
             if (b > need) need = b;
         }
     }
-    const size_t s3 = sh_linear_split3_workspace(M, N, K);       // either arithmetic form may be selected at run time
-    return s3 > need ? s3 : need;
+    return need;
 }
 
 int sh_linear_fwd(const float* x, const float* weight, const float* bias, float* y, int M, int N, int K, void* workspace,
                   size_t workspace_bytes, sh_stream_t stream) {
     SH_REQUIRE(x && weight && y && M > 0 && N > 0 && K > 0, SH_ERR_INVALID_ARG, "sh_linear_fwd: bad argument");
-    if (sh_f32_mma_mode() == SH_MMA_SPLIT3 && sh_linear_split3_ok(M, N, K, x, weight, y) && (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0))
-        return sh_linear_split3_fwd(x, weight, bias, y, M, N, K, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
     {
         const LSPlan pl = plan_stream(M, N, K);
         if (pl.ok && aligned16(x, weight, y) && (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0)) {
@@ -688,8 +682,6 @@ int sh_linear_fwd(const float* x, const float* weight, const float* bias, float*
 int sh_linear_bwd_data(const float* dy, const float* weight, float* dx, int M, int N, int K, void* workspace,
                        size_t workspace_bytes, sh_stream_t stream) {
     SH_REQUIRE(dy && weight && dx && M > 0 && N > 0 && K > 0, SH_ERR_INVALID_ARG, "sh_linear_bwd_data: bad argument");
-    if (sh_f32_mma_mode() == SH_MMA_SPLIT3 && sh_linear_split3_ok(M, N, K, dy, weight, dx))
-        return sh_linear_split3_bwd_data(dy, weight, dx, M, N, K, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
     {
         const LSPlan pl = plan_stream(M, K, N);
         if (pl.ok && aligned16(dy, weight, dx)) {
@@ -710,7 +702,6 @@ int sh_linear_bwd_wgt(const float* dy, const float* x, float* dW, float* dbias, 
                       size_t workspace_bytes, sh_stream_t stream) {
     SH_REQUIRE(dy && x && dW && M > 0 && N > 0 && K > 0, SH_ERR_INVALID_ARG, "sh_linear_bwd_wgt: bad argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (sh_f32_mma_mode() == SH_MMA_SPLIT3 && sh_linear_split3_ok(M, N, K, dy, x, dW)) return sh_linear_split3_bwd_wgt(dy, x, dW, dbias, M, N, K, st);
     static const int stream_on = sh_env_int("SH_LIN_STREAM", 1, 0, 1);
     if (stream_on && M <= 64 && N % 64 == 0 && K % 64 == 0 && aligned16(dy, x, dW)) {
         LSParams s{};

@@ -34,6 +34,23 @@ __device__ __forceinline__ void sh_split3(const f32x4 a, const f32x4 b, u32x4& h
     }
 }
 
+// the same for one quad: four fp32 numbers -> three pieces of four bf16 (8 bytes each), ~22 VALU operations
+__device__ __forceinline__ void sh_split3_quad(const f32x4 a, u32x2& h, u32x2& m, u32x2& l) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float x0 = a[2 * i], x1 = a[2 * i + 1];
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        const bf16x2_t hp = {(__bf16)x0, (__bf16)x1};
+        const unsigned hu = __builtin_bit_cast(unsigned, hp);
+        const float r0 = x0 - __builtin_bit_cast(float, hu << 16), r1 = x1 - __builtin_bit_cast(float, hu & 0xFFFF0000u);
+        const bf16x2_t mp = {(__bf16)r0, (__bf16)r1};
+        const unsigned mu = __builtin_bit_cast(unsigned, mp);
+        const float t0 = r0 - __builtin_bit_cast(float, mu << 16), t1 = r1 - __builtin_bit_cast(float, mu & 0xFFFF0000u);
+        const bf16x2_t lp = {(__bf16)t0, (__bf16)t1};
+        h[i] = hu; m[i] = mu; l[i] = __builtin_bit_cast(unsigned, lp);
+    }
+}
+
 // Geometry of a fragment-ordered bf16 weight (the A operand of v_mfma_f32_16x16x32_bf16, one 1-KiB fragment per
 // (k-step, 16-row tile)):  frag[ks][nt][lane][j] = W'[16 nt + (lane & 15)][32 ks + 8 (lane >> 4) + j], zero outside W'.
 //   rows of W' = output channels, columns k = s * Cg + c   (Cg % 8 == 0)

@@ -770,225 +770,6 @@ int launch_s3(const GGParams& p_in, int rt, hipStream_t st) {
     return SH_OK;
 }
 
-// ------------------------------------------------------------------------------------------
-// Coalesced-gather form (round 3).  What bounds the direct kernels is not the matrix pipe but the texture-address path: the
-// MFMA operand layout puts the 16 ROWS of a tile on 16 consecutive lanes, so every quad of lanes of a wave's load
-// instruction touches four different cache lines and the instruction moves its 1 KiB at a quarter of the L1 rate
-// (tools/exp/ta_probe.hip; the bf16x3 form with 2.7x less matrix work ran no faster at the same tiling).  Here a wave
-// loads its rows LINE-WISE - lane l fetches quad l & 7 of row (l >> 3) + 8 i: eight full 128-byte lines per instruction -
-// and turns them into the MFMA layout through a wave-PRIVATE LDS tile (XOR-swizzled quads, conflict-free both ways; the
-// rows belong to this wave alone, so no workgroup barrier guards them: LDS executes a wave's accesses in order).  The
-// weight chunk is staged as before (double-buffered, one barrier per chunk).  Same tiling, K order and epilogue as the
-// staged and direct kernels, hence bit-identical results.
-template <int NT, bool BWD_EPI, int RT>
-__global__ __launch_bounds__(NTHREADS) void gather_gemm_cg_kernel(const GGParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* Ws = reinterpret_cast<float*>(smem);                 // [2][NT*16][KC]
-    float* As = Ws + 2 * NT * 16 * KC;                          // [4 waves][2][16*RT][KC]
-    int* Ts = reinterpret_cast<int*>(As + 4 * 2 * 16 * RT * KC);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int TB = 1 << p.log2TB, TV = (64 * RT) >> p.log2TB;
-    const int item = sh_xcd_remap(blockIdx.x, gridDim.x);
-    const int tile = item / p.nsplit;
-    const int n_base = (item - tile * p.nsplit) * (NT * 16);
-    const int bt = tile / p.n_vtiles, vt = tile - bt * p.n_vtiles;
-    const int v0 = vt * TV, b0 = bt * TB;
-    const int S = p.S;
-    {
-        const int nT = TV * S;
-        const long lim = (long)p.R * S;
-        for (int i = tid; i < nT; i += NTHREADS) {
-            const long g = (long)v0 * S + i;
-            Ts[i] = g < lim ? (int)(unsigned)((long)p.table[g] * p.x_sv) : 0;
-        }
-    }
-    __syncthreads();
-
-    // ---- gather: lane -> quad q of rows lr0 + 8 i of this wave's 16 RT rows
-    constexpr int NL = 2 * RT;                                  // load instructions per chunk
-    const int q = lane & 7, lr0 = lane >> 3;
-    int a_ts[NL];
-    long a_boff[NL];
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-        const int row = 16 * RT * wave + lr0 + 8 * i;
-        const int vl = row >> p.log2TB, bl = row & (TB - 1);
-        a_ts[i] = vl * S;
-        a_boff[i] = (b0 + bl) < p.B ? (long)(b0 + bl) * p.x_sb : 0;      // rows past B read row 0 of the slice; never stored
-    }
-    float* Aw = As + wave * (2 * 16 * RT * KC);                 // this wave's two tiles
-    const int a_lds = lr0 * KC + ((q ^ (lr0 & 7)) << 2);        // (lr0 + 8 i) & 7 == lr0 & 7
-    int k_n = 4 * q, s_n = k_n / p.Cg, c_n = k_n - s_n * p.Cg;
-    const int adv_s = KC / p.Cg, adv_c = KC - adv_s * p.Cg;
-    auto load_a = [&](f32x4 (&ra)[NL]) {
-        const bool kok = k_n < p.K;                             // K tail / prefetch past the end: any valid address
-        const int s = kok ? s_n : 0, ch = kok ? c_n : 0;
-        unsigned toff[NL];
-#pragma unroll
-        for (int i = 0; i < NL; ++i) toff[i] = (unsigned)Ts[a_ts[i] + s];
-#pragma unroll
-        for (int i = 0; i < NL; ++i) ra[i] = *reinterpret_cast<const f32x4*>(p.x + toff[i] + a_boff[i] + ch);
-        k_n += KC; c_n += adv_c; s_n += adv_s;
-        const bool wrap = c_n >= p.Cg;
-        c_n = wrap ? c_n - p.Cg : c_n;
-        s_n = wrap ? s_n + 1 : s_n;
-    };
-    auto store_a = [&](int buf, const f32x4 (&ra)[NL]) {
-        float* Ab = Aw + buf * (16 * RT * KC) + a_lds;
-#pragma unroll
-        for (int i = 0; i < NL; ++i) *reinterpret_cast<f32x4*>(Ab + 8 * i * KC) = ra[i];
-    };
-
-    // ---- weight chunk staging: thread -> quad q8 of rows rbase + 32 i (as in gather_gemm_kernel)
-    const int q8 = tid & 7, rbase = tid >> 3;
-    constexpr int WQ = NT >= 2 ? NT / 2 : 1;
-    const bool w_thread = (NT >= 2) || tid < 128;
-    long w_off[WQ];
-#pragma unroll
-    for (int i = 0; i < WQ; ++i) {
-        const int n = n_base + rbase + 32 * i;
-        w_off[i] = n < p.Nout ? (long)n * p.Kw : 0;
-    }
-    int kw_n = 4 * q8;
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    auto load_w = [&](f32x4 (&rw)[WQ], unsigned& mask) {
-        const bool kok = kw_n < p.K;
-        mask = kok ? 1u : 0u;
-        const int kc = kok ? kw_n : 0;
-#pragma unroll
-        for (int i = 0; i < WQ; ++i) rw[i] = *reinterpret_cast<const f32x4*>(p.w + w_off[i] + kc);
-        kw_n += KC;
-    };
-    auto store_w = [&](int buf, const f32x4 (&rw)[WQ], unsigned mask) {
-        if (w_thread) {
-            float* Wb = Ws + buf * NT * 16 * KC;
-            const int pq = (q8 ^ (rbase & 7)) << 2;
-#pragma unroll
-            for (int i = 0; i < WQ; ++i) *reinterpret_cast<f32x4*>(Wb + (rbase + 32 * i) * KC + pq) = mask ? rw[i] : zero4;
-        }
-    };
-
-    f32x4 acc[RT][NT];
-#pragma unroll
-    for (int m = 0; m < RT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n) acc[m][n] = zero4;
-    const int lrow = lane & 15, lq = lane >> 4;
-    auto compute = [&](int buf) {
-        const float* Ab = Aw + buf * (16 * RT * KC) + lrow * KC;
-        const float* Wb = Ws + buf * NT * 16 * KC + lrow * KC;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int pq = ((lq + 4 * ks) ^ (lane & 7)) << 2;
-            f32x4 g[RT], wq[NT];
-#pragma unroll
-            for (int m = 0; m < RT; ++m) g[m] = *reinterpret_cast<const f32x4*>(Ab + 16 * m * KC + pq);
-#pragma unroll
-            for (int n = 0; n < NT; ++n) wq[n] = *reinterpret_cast<const f32x4*>(Wb + n * 16 * KC + pq);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-#pragma unroll
-                    for (int m = 0; m < RT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[n][t], g[m][t], acc[m][n], 0, 0, 0);
-        }
-    };
-
-    // ---- main loop: LDS holds chunk c (buffers c & 1), register sets A / B the loads of chunks c+1 and c+2
-    f32x4 raA[NL], raB[NL], rwA[WQ], rwB[WQ];
-    unsigned mA, mB;
-    load_a(raA); load_w(rwA, mA);                        // chunk 0
-    store_a(0, raA); store_w(0, rwA, mA);
-    __syncthreads();
-    load_a(raA); load_w(rwA, mA);                        // chunk 1
-    auto even = [&]() {                                  // LDS buffers 0 hold chunk c, set A chunk c+1
-        load_a(raB); load_w(rwB, mB);                    // chunk c+2
-        __builtin_amdgcn_sched_barrier(0);               // keep the prefetch loads AHEAD of the MFMA phase
-        compute(0);
-        store_a(1, raA); store_w(1, rwA, mA);            // chunk c+1 (a clamped duplicate past the end is never read)
-        __syncthreads();
-    };
-    auto odd = [&]() {                                   // LDS buffers 1 hold chunk c, set B chunk c+1
-        load_a(raA); load_w(rwA, mA);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(1);
-        store_a(0, raB); store_w(0, rwB, mB);
-        __syncthreads();
-    };
-    // four chunks per trip: hipcc drains the outstanding loads (vmcnt(0)) where the back edge joins, once per trip
-    for (int c = 0; c < p.nchunks; c += 4) {
-        even();
-        if (c + 1 >= p.nchunks) break;
-        odd();
-        if (c + 2 >= p.nchunks) break;
-        even();
-        if (c + 3 >= p.nchunks) break;
-        odd();
-    }
-
-    // ---- epilogue (identical to gather_gemm_kernel): lane holds channels n0..n0+3 of tile row 16*RT*wave + 16*m + lrow
-#pragma unroll
-    for (int m = 0; m < RT; ++m) {
-        const int row = 16 * RT * wave + 16 * m + lrow;
-        const int vl = row >> p.log2TB, bl = row & (TB - 1);
-        const int v = v0 + vl, b = b0 + bl;
-        if (v >= p.R || b >= p.B) continue;
-        float* yrow = p.y + (long)v * p.y_sv + (long)b * p.y_sb;
-        const float* yp = (BWD_EPI && p.yprev) ? p.yprev + (long)v * p.yp_sv + (long)b * p.yp_sb : nullptr;
-        const bool zero = v == p.zero_row;
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const int n0 = n_base + n * 16 + lq * 4;
-            if (n0 >= p.Nout) continue;
-            f32x4 a = acc[m][n];
-            if (p.vec_out) {
-                if (!BWD_EPI) {
-                    if (p.bias) a += *reinterpret_cast<const f32x4*>(p.bias + n0);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) a[j] = sh_act_fwd(a[j], p.act);
-                } else if (yp) {
-                    const f32x4 yv = *reinterpret_cast<const f32x4*>(yp + n0);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) a[j] *= sh_act_grad_from_out(yv[j], p.act);
-                }
-                if (zero) a = (f32x4){0.f, 0.f, 0.f, 0.f};
-                *reinterpret_cast<f32x4*>(yrow + n0) = a;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (n0 + j >= p.Nout) continue;
-                    float vv = a[j];
-                    if (!BWD_EPI) {
-                        if (p.bias) vv += p.bias[n0 + j];
-                        vv = sh_act_fwd(vv, p.act);
-                    } else if (yp) {
-                        vv *= sh_act_grad_from_out(yp[n0 + j], p.act);
-                    }
-                    yrow[n0 + j] = zero ? 0.f : vv;
-                }
-            }
-        }
-    }
-}
-
-template <int NT, bool BWD_EPI>
-int launch_cg(const GGParams& p_in, int rt, hipStream_t st) {
-    GGParams p = p_in;
-    const int tb = 1 << p.log2TB;
-    if (tb > 64 * rt) rt = 2;
-    const int TV = (64 * rt) >> p.log2TB;
-    p.n_vtiles = sh_cdiv(p.R, TV);
-    const int nblocks = p.n_vtiles * p.n_btiles * p.nsplit;
-    const size_t smem = (size_t)(2 * NT * 16 * KC + 4 * 2 * 16 * rt * KC) * sizeof(float) + (size_t)(TV * p.S) * sizeof(int);
-    ShProfScope ps(st, "gather_gemm_cg_kernel<%d, %s, %d>|R=%d B=%d K=%d N=%d grid=%d", NT, BWD_EPI ? "true" : "false", rt, p.R,
-                   p.B, p.K, p.Nout, nblocks);
-    if (rt == 1) SH_LAUNCH_PS(ps, (gather_gemm_cg_kernel<NT, BWD_EPI, 1>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
-    else SH_LAUNCH_PS(ps, (gather_gemm_cg_kernel<NT, BWD_EPI, 2>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
-    SH_CHECK_LAUNCH("gather_gemm_cg");
-    return SH_OK;
-}
-
 template <int NT, bool BWD_EPI>
 int launch_ggd(const GGParams& p_in, int nblocks128 /* workgroups if the tiles had 128 rows */, hipStream_t st) {
     // 16-row tiles per wave.  Measured on MI355X (B = 64): one tile per wave (64-row workgroups, twice as many of them)
@@ -1077,23 +858,6 @@ int dispatch_gg(GGParams& p, hipStream_t st) {
             case 2: return launch_s3<2, BWD_EPI>(p, rt, st);
             case 4: return launch_s3<4, BWD_EPI>(p, rt, st);
             default: return launch_s3<8, BWD_EPI>(p, rt, st);
-        }
-    }
-    // coalesced-gather form (exact fp32 MFMA): up to SH_CG_NT channel tiles per workgroup, the rest split over workgroups
-    static const int cg_on = sh_env_int("SH_GG_CG", 0, 0, 1);
-    if (cg_on && vec4 && !c3) {
-        static const int cg_nt = sh_env_int("SH_CG_NT", 4, 1, 8), cg_rt = sh_env_int("SH_CG_RT", 0, 0, 2);
-        static const int cg_rt2_at = sh_env_int("SH_CG_RT2_AT", 2048, 1, 1 << 30);
-        int ntw = nt;
-        p.nsplit = 1;
-        while (ntw > cg_nt) { ntw >>= 1; p.nsplit <<= 1; }
-        const long wg64 = (long)sh_cdiv(p.R, 64 >> (p.log2TB < 6 ? p.log2TB : 6)) * p.n_btiles * p.nsplit;
-        const int rt = cg_rt ? cg_rt : (wg64 >= cg_rt2_at ? 2 : 1);
-        switch (ntw) {
-            case 1: return launch_cg<1, BWD_EPI>(p, rt, st);
-            case 2: return launch_cg<2, BWD_EPI>(p, rt, st);
-            case 4: return launch_cg<4, BWD_EPI>(p, rt, st);
-            default: return launch_cg<8, BWD_EPI>(p, rt, st);
         }
     }
     // too few row tiles to fill 256 CUs x ~3 workgroups: split the output channels over workgroups

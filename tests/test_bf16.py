@@ -435,6 +435,8 @@ def test_bf16_step_runs_the_intended_kernels():
     assert len(fam.get("wgrad_bf16_kernel", [])) == 1                      # only the fp32 3-channel input side is staged
     conv = fam.get("conv_bf16_kernel", [])
     assert len(conv) == 16                                                  # 9 forward + 7 backward-data (dec4's rides in the thin launch)
-    assert sum(1 for n, _ in conv if n.split(",")[2].strip() == "3") == 2   # full-line form on the two 64 -> 32 channel launches
+    # line-wise loads (BC_C32C, round 3) on every layer that gathers a multiple of 32 bf16 channels: 6 forward + 6 backward-data
+    assert sum(1 for n, _ in conv if n.split(",")[2].strip() == "4") == 12
+    assert sum(1 for n, _ in conv if n.split(",")[2].strip() in ("0", "3")) == 0      # no plain / full-line gathers left
     up = [t for _, t in fam.get("spmm_bf16_kernel", []) if "rows=3445 " in t or "rows=1722 " in t or "rows=861 " in t]
     assert len(up) == 3                                                     # folded up-sampling: only the blended rows
