@@ -87,7 +87,7 @@ def parse_tag_f32(name, shape):
             return ("bwd" if targs[2] == "true" else "fwd", int(f["R"]), int(f["K"]), int(f["N"]))
         if fam.startswith("gather_gemm_"):                 # direct / split3 / coalesced forms: <NT, BWD, ...>
             return ("bwd" if targs[1] == "true" else "fwd", int(f["R"]), int(f["K"]), int(f["N"]))
-        if fam in ("wgrad_stream_kernel", "wgrad_kernel") or fam.startswith("wgrad_split"):
+        if fam in ("wgrad_stream_kernel", "wgrad_kernel", "wgrad_split3_kernel"):
             return ("wgt", int(f["R"]), int(f["K"]), int(f["N"]))
         if fam == "wgrad_thin_kernel":
             return ("wgt+bwd" if f.get("dx") == "1" else "wgt", int(f["R"]), int(f["S"]) * int(f["Cin"]), int(f["N"]))
@@ -597,11 +597,11 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="arithmetic of the kernels: f32 = BASELINE configs[1] (the headline), bf16 = configs[2] (bf16 activations and "
                          "working weights, fp32 accumulation, fp32 master weights / gradients / Adam)")
-    ap.add_argument("--f32-mma", choices=["split3", "exact"], default="split3",
-                    help="arithmetic form of the fp32 path's matrix products (include/sh_kernels.h sh_set_f32_mma_mode): split3 = every "
-                         "fp32 operand split exactly into three bf16 terms, six partial products on the bf16 MFMA with fp32 accumulation "
-                         "(fp32-level error: the GPU parity tests run in both forms at the same tolerances); exact = fp32 MFMA.  The "
-                         "library's own default is exact; the secondary block times the other form")
+    ap.add_argument("--f32-mma", choices=["exact", "split3"], default="exact",
+                    help="arithmetic form of the fp32 path's matrix products (include/sh_kernels.h sh_set_f32_mma_mode): exact = fp32 "
+                         "MFMA, the reference's arithmetic and the headline; split3 = every fp32 operand split exactly into three bf16 "
+                         "terms, six partial products on the bf16 MFMA with fp32 accumulation (fp32-level error: the GPU parity tests run "
+                         "in both forms at the same tolerances).  The secondary block times the other form")
     ap.add_argument("--cpu-iters", type=int, default=8, help="timed CPU-baseline steps (8 steps at batch 64 = ~13 s of host work)")
     ap.add_argument("--template", default=os.path.join("tests", "golden", "template6890.npz"),
                     help="mesh hierarchy fixture; tests/golden/template27554.npz + --batch 32 is BASELINE config 4")

@@ -1455,9 +1455,155 @@ int launch_ws(const WSParams& p, hipStream_t st) {
     return SH_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Weight gradient in the bf16x3 form (sh_set_f32_mma_mode(SH_MMA_SPLIT3); Cin % 4 == 0, batch % 16 == 0, >= 2 output-channel
+// tiles).  Same work items, slabs and output mapping as wgrad_stream_kernel; the reduction runs in steps of 32 rows = two
+// vertices x 16 batch entries on v_mfma_f32_16x16x32_bf16: lane (a = lane & 15, kb = lane >> 4) loads the quads
+// x[nbr(v + (kb >> 1), s_a)][b0 + 8 (kb & 1) + j][c_a .. c_a+3], j = 0..7 - its eight reduction rows of the four gathered
+// columns 4a .. 4a+3 - and the matching eight rows of dpre[.][16 b + a]; column t of the eight quads, split exactly into three
+// bf16 terms (sh_split3), is the A operand of the products for the column set {4i + t}, the dpre values the B operand.  Six
+// partial products per fp32 product, fp32 accumulation: 24 COT MFMAs of 16 cycles per 32 rows against 32 COT of 32 cycles in
+// the exact form; the splits (44 VALU operations per eight values) ride in the MFMAs' issue shadow for >= 4 channel tiles.
+template <int COT>
+__global__ __launch_bounds__(NTHREADS) void wgrad_split3_kernel(const WSParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int* Tl = reinterpret_cast<int*>(smem) + wave * p.vpc * p.S;
+    const int item_raw = sh_xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
+    const bool active = item_raw < p.n_items;
+    const int item = active ? item_raw : 0;
+    const int rc = item / p.ncg, cg = item - rc * p.ncg;
+    const int bt = rc / p.nvc, vc = rc - bt * p.nvc;
+    const int b0 = bt << p.log2TB;                               // log2TB == 4: a slice of 16 batch entries
+    const int v_begin = vc * p.vpc;
+    const int nv = active ? min(p.vpc, p.R - v_begin) : 0;
+    const int S = p.S;
+    for (int i = lane; i < nv * S; i += 64) Tl[i] = p.table[(long)v_begin * S + i];
+    __syncthreads();
+    if (nv <= 0) return;
+
+    const int la = lane & 15, kb = lane >> 4;
+    const int k0 = cg * 64 + 4 * la;
+    const bool k_in = k0 < p.K;
+    const int s_l = k_in ? k0 / p.Cin : 0, c_l = k_in ? k0 - s_l * p.Cin : 0;
+    const int dv = kb >> 1;                                      // which of the step's two vertices this lane's rows belong to
+    const long xo = (long)(b0 + 8 * (kb & 1)) * p.x_sb + c_l;    // first of this lane's eight batch rows
+    const long po = (long)(b0 + 8 * (kb & 1)) * p.dp_sb;
+    const float* pb = p.dpre + (long)v_begin * p.dp_sv + po;
+    int pco[COT];
+#pragma unroll
+    for (int b = 0; b < COT; ++b) pco[b] = min(16 * b + la, p.Cout - 1);
+
+    f32x4 g4[2][8];
+    float pr[2][8][COT];
+    auto load_step = [&](int vl, f32x4 (&g)[8], float (&pp)[8][COT]) {
+        int vv = vl + dv;
+        vv = vv < nv ? vv : nv - 1;                              // past the chunk: a valid row; its dpre values are zeroed below
+        const float* gsrc = p.x + (long)Tl[vv * S + s_l] * p.x_sv + xo;
+        const float* psrc = pb + (long)vv * p.dp_sv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] = *reinterpret_cast<const f32x4*>(gsrc + (long)j * p.x_sb);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int b = 0; b < COT; ++b) pp[j][b] = psrc[(long)j * p.dp_sb + pco[b]];
+    };
+
+    f32x4 acc[4][COT];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int b = 0; b < COT; ++b) acc[t][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bs[COT];
+#pragma unroll
+    for (int b = 0; b < COT; ++b) bs[b] = 0.f;
+
+    auto mma_step = [&](int vl, const f32x4 (&g)[8], const float (&pp)[8][COT]) {
+        const bool live = vl + dv < nv;                          // the second vertex of the last, odd step does not exist
+        bf16x8 ah[4], am[4], al[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            u32x4 h, m, l;
+            sh_split3((f32x4){g[0][t], g[1][t], g[2][t], g[3][t]}, (f32x4){g[4][t], g[5][t], g[6][t], g[7][t]}, h, m, l);
+            ah[t] = __builtin_bit_cast(bf16x8, h); am[t] = __builtin_bit_cast(bf16x8, m); al[t] = __builtin_bit_cast(bf16x8, l);
+        }
+#pragma unroll
+        for (int b = 0; b < COT; ++b) {
+            float pv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pv[j] = live ? pp[j][b] : 0.f;
+            if (cg == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bs[b] += pv[j];
+            }
+            u32x4 h, m, l;
+            sh_split3((f32x4){pv[0], pv[1], pv[2], pv[3]}, (f32x4){pv[4], pv[5], pv[6], pv[7]}, h, m, l);
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, h), bm = __builtin_bit_cast(bf16x8, m), bl = __builtin_bit_cast(bf16x8, l);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {                        // smallest terms first
+                f32x4 c = acc[t][b];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[t], bh, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], bl, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[t], bm, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[t], bh, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], bm, c, 0, 0, 0);
+                acc[t][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], bh, c, 0, 0, 0);
+            }
+        }
+    };
+
+    load_step(0, g4[0], pr[0]);
+    for (int vl = 0; vl < nv; vl += 4) {
+        load_step(vl + 2, g4[1], pr[1]);
+        __builtin_amdgcn_sched_barrier(0);                       // prefetch loads stay ahead of the MFMAs
+        mma_step(vl, g4[0], pr[0]);
+        if (vl + 2 >= nv) break;                                 // wave-uniform
+        load_step(vl + 4, g4[0], pr[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_step(vl + 2, g4[1], pr[1]);
+    }
+
+    float* slab = p.slab + (long)rc * p.slab_stride;
+#pragma unroll
+    for (int b = 0; b < COT; ++b) {
+        const int co = 16 * b + la;
+        if (co >= p.Cout) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = cg * 64 + 16 * kb + 4 * j;
+            if (col < p.K)
+                *reinterpret_cast<f32x4*>(slab + (long)co * p.K + col) = (f32x4){acc[0][b][j], acc[1][b][j], acc[2][b][j], acc[3][b][j]};
+        }
+    }
+    if (cg == 0) {
+#pragma unroll
+        for (int b = 0; b < COT; ++b) {
+            float v = bs[b];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int co = 16 * b + la;
+            if (kb == 0 && co < p.Cout) p.slab[p.bias_off + (long)rc * p.Cout + co] = v;
+        }
+    }
+}
+
+template <int COT>
+int launch_ws3(const WSParams& p, hipStream_t st) {
+    const size_t smem = (size_t)4 * p.vpc * p.S * sizeof(int);
+    const int grid = sh_cdiv(p.n_items, 4);
+    ShProfScope ps(st, "wgrad_split3_kernel<%d>|R=%d B=%d K=%d N=%d grid=%d", COT, p.R, p.B, p.K, p.Cout, grid);
+    SH_LAUNCH_PS(ps, (wgrad_split3_kernel<COT>), dim3(grid), dim3(NTHREADS), smem, st, p);
+    SH_CHECK_LAUNCH("wgrad_split3");
+    return SH_OK;
+}
+
 template <int COT>
 int dispatch_ws(const WSParams& p, hipStream_t st) {
     const bool full = (p.B & ((1 << p.log2TB) - 1)) == 0;
+    static const int s3_min_cot = sh_env_int("SH_S3_WG_MIN_COT", 2, 1, 16);   // one channel tile: the splits outweigh the matrix time saved
+    // 2 and 4 channel tiles (8 would need more than the 512 registers of a one-wave-per-SIMD kernel: it keeps the exact form)
+    if ((COT == 2 || COT == 4) && sh_f32_mma_mode() == SH_MMA_SPLIT3 && COT >= s3_min_cot && full && p.log2TB == 4 && p.Cin % 4 == 0)
+        return launch_ws3<(COT == 4 ? 4 : 2)>(p, st);
     if (p.log2TB == 2) return full ? launch_ws<COT, 1, true>(p, st) : launch_ws<COT, 1, false>(p, st);
     return full ? launch_ws<COT, 4, true>(p, st) : launch_ws<COT, 4, false>(p, st);
 }
