@@ -345,15 +345,6 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_direct_kernel(const GGPa
     const int bt = tile / p.n_vtiles, vt = tile - bt * p.n_vtiles;
     const int v0 = vt * TV, b0 = bt * TB;
     const int S = p.S;
-    {
-        const int nT = TV * S;
-        const long lim = (long)p.R * S;
-        for (int i = tid; i < nT; i += NTHREADS) {
-            const long g = (long)v0 * S + i;
-            Ts[i] = g < lim ? (int)(unsigned)((long)p.table[g] * p.x_sv) : 0;
-        }
-    }
-    __syncthreads();
 
     const int lrow = lane & 15, lq = lane >> 4;
     int a_ts[RT];
@@ -482,7 +473,17 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_direct_kernel(const GGPa
 
     f32x4 ra[3][RT][2], rw[3][WQ];
     unsigned mw[3], lva[3];
-    load_a(ra[0], lva[0]); load_w(rw[0], mw[0]);         // chunk 0
+    load_w(rw[0], mw[0]);                                // chunk 0 of the weight does not need the table: in flight under its load
+    {
+        const int nT = TV * S;
+        const long lim = (long)p.R * S;
+        for (int i = tid; i < nT; i += NTHREADS) {
+            const long g = (long)v0 * S + i;
+            Ts[i] = g < lim ? (int)(unsigned)((long)p.table[g] * p.x_sv) : 0;
+        }
+    }
+    __syncthreads();
+    load_a(ra[0], lva[0]);                               // chunk 0
     store_w(0, rw[0], mw[0]);
     __syncthreads();
     load_a(ra[1], lva[1]); load_w(rw[1], mw[1]);         // chunk 1
@@ -579,15 +580,6 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_split3_kernel(const GGPa
     const int bt = tile / p.n_vtiles, vt = tile - bt * p.n_vtiles;
     const int v0 = vt * TV, b0 = bt * TB;
     const int S = p.S;
-    {
-        const int nT = TV * S;
-        const long lim = (long)p.R * S;
-        for (int i = tid; i < nT; i += NTHREADS) {
-            const long g = (long)v0 * S + i;
-            Ts[i] = g < lim ? (int)(unsigned)((long)p.table[g] * p.x_sv) : 0;
-        }
-    }
-    __syncthreads();
 
     const int lrow = lane & 15, lq = lane >> 4;
     int a_ts[RT];
@@ -699,7 +691,17 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_split3_kernel(const GGPa
 
     f32x4 ra[3][RT][2], rw[3][WP][2];
     unsigned mw[3];
-    load_a(ra[0]); load_w(rw[0], mw[0]);                 // chunk 0
+    load_w(rw[0], mw[0]);                                // chunk 0 of the weight does not need the table: in flight under its load
+    {
+        const int nT = TV * S;
+        const long lim = (long)p.R * S;
+        for (int i = tid; i < nT; i += NTHREADS) {
+            const long g = (long)v0 * S + i;
+            Ts[i] = g < lim ? (int)(unsigned)((long)p.table[g] * p.x_sv) : 0;
+        }
+    }
+    __syncthreads();
+    load_a(ra[0]);                                       // chunk 0
     store_w(0, rw[0], mw[0]);
     __syncthreads();
     load_a(ra[1]); load_w(rw[1], mw[1]);                 // chunk 1
@@ -826,8 +828,11 @@ int dispatch_gg(GGParams& p, hipStream_t st) {
     p.n_btiles = sh_cdiv(p.B, tb);
     p.n_vtiles = sh_cdiv(p.R, TV);
     p.Kw = p.K;
-    int nt = sh_cdiv(p.Nout, 16);
-    nt = nt <= 1 ? 1 : nt <= 2 ? 2 : nt <= 4 ? 4 : 8;
+    // channel tiles of 16: up to 8 per workgroup, more output channels are split over workgroups from the start (each
+    // workgroup gathers the rows again; the reference's configurations stay <= 128)
+    const int nt_all = sh_cdiv(p.Nout, 16);
+    int nt = nt_all <= 1 ? 1 : nt_all <= 2 ? 2 : nt_all <= 4 ? 4 : 8;
+    const int nsplit0 = sh_cdiv(nt_all, nt);
     // 3-channel gathered rows (built for one channel tile): dwordx3 loads, K counted in zero-padded quads
     static const int c3_on = sh_env_int("SH_GG_C3", 1, 0, 1);
     const bool c3 = c3_on && p.Cg == 3 && nt == 1 && reinterpret_cast<uintptr_t>(p.w) % 4 == 0;
@@ -835,7 +840,6 @@ int dispatch_gg(GGParams& p, hipStream_t st) {
     p.nchunks = sh_cdiv(p.K, KC);
     const long nblocks = (long)p.n_vtiles * p.n_btiles;
     SH_REQUIRE(nblocks > 0 && nblocks < (1L << 31), SH_ERR_UNSUPPORTED, "gather_gemm: grid %ld out of range", nblocks);
-    SH_REQUIRE(p.Nout <= 128, SH_ERR_UNSUPPORTED, "gather_gemm: more than 128 output channels (%d) not built", p.Nout);
     SH_REQUIRE(p.S <= 64, SH_ERR_UNSUPPORTED, "gather_gemm: spiral length %d > 64", p.S);
     const bool vec4 = (p.Cg % 4 == 0) && (p.x_sv % 4 == 0) && (p.x_sb % 4 == 0) &&
                       ((reinterpret_cast<uintptr_t>(p.x) | reinterpret_cast<uintptr_t>(p.w)) % 16 == 0);
@@ -849,7 +853,7 @@ int dispatch_gg(GGParams& p, hipStream_t st) {
         static const int s3_nt = sh_env_int("SH_S3_NT", 4, 1, 8), s3_rt = sh_env_int("SH_S3_RT", 0, 0, 2);
         static const int s3_rt2_at = sh_env_int("SH_S3_RT2_AT", 2048, 1, 1 << 30);
         int ntw = nt;
-        p.nsplit = 1;
+        p.nsplit = nsplit0;
         while (ntw > s3_nt) { ntw >>= 1; p.nsplit <<= 1; }
         const long wg64 = (long)sh_cdiv(p.R, 64 >> (p.log2TB < 6 ? p.log2TB : 6)) * p.n_btiles * p.nsplit;      // workgroups of 64 rows
         const int rt = s3_rt ? s3_rt : (wg64 >= s3_rt2_at ? 2 : 1);
@@ -863,7 +867,7 @@ int dispatch_gg(GGParams& p, hipStream_t st) {
     // too few row tiles to fill 256 CUs x ~3 workgroups: split the output channels over workgroups
     static const int fill_target = sh_env_int("SH_GG_FILL", 768, 1, 1 << 20);
     static const int direct_on = sh_env_int("SH_GG_DIRECT", 1, 0, 1);
-    p.nsplit = 1;
+    p.nsplit = nsplit0;
     while (nt > 2 && nblocks * p.nsplit < fill_target) { nt >>= 1; p.nsplit <<= 1; }
     // two channel tiles run in the direct form with 64-row workgroups (twice the count): only split them further if even
     // that does not fill the chip - one tile per workgroup is the slower staged form
@@ -1236,6 +1240,7 @@ struct WSParams {
     float* slab; long slab_stride, bias_off;
     int B, R, S, Cin, Cout, K;
     int log2TB, n_btiles, nvc, vpc, ncg, n_items;     // vpc = vertices per chunk
+    int co0;                                          // first output channel of this launch (groups of <= 128 channels)
 };
 
 // C3: Cin == 3, columns counted in zero-padded quads (k' = 4 s + c), dwordx3 gathers, scalar slab stores.
@@ -1274,7 +1279,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_stream_kernel(const WSParams p
     const float* pb = p.dpre + (long)v_begin * p.dp_sv;
     int pco[COT];
 #pragma unroll
-    for (int b = 0; b < COT; ++b) pco[b] = min(16 * b + la, p.Cout - 1);      // channels past Cout: duplicate, never stored
+    for (int b = 0; b < COT; ++b) pco[b] = min(p.co0 + 16 * b + la, p.Cout - 1);      // channels past Cout: duplicate, never stored
 
     f32x4 gr[DEPTH][NG];
     float pr[DEPTH][NG][COT];
@@ -1333,7 +1338,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_stream_kernel(const WSParams p
     float* slab = p.slab + (long)rc * p.slab_stride;
 #pragma unroll
     for (int b = 0; b < COT; ++b) {
-        const int co = 16 * b + la;
+        const int co = p.co0 + 16 * b + la;
         if (co >= p.Cout) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1355,7 +1360,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_stream_kernel(const WSParams p
             float v = bs[b];
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
-            const int co = 16 * b + la;
+            const int co = p.co0 + 16 * b + la;
             if (kq == 0 && co < p.Cout) p.slab[p.bias_off + (long)rc * p.Cout + co] = v;
         }
     }
@@ -1377,7 +1382,7 @@ WGPlan plan_wgrad(int B, int R, int S, int Cin, int Cout) {
     const int tv = TMW >> w.log2TB;
     w.n_btiles = sh_cdiv(B, tb);
     w.n_vtiles = sh_cdiv(R, tv);
-    const int cot = sh_cdiv(Cout, 16);
+    const int cot = sh_cdiv(Cout < 128 ? Cout : 128, 16);      // more than 128 output channels: launches of <= 128 (streaming form)
     w.cot = cot <= 1 ? 1 : cot <= 2 ? 2 : cot <= 4 ? 4 : 8;
     // column-group width (64 or 128 weight columns): minimise the staged work per row, i.e. column
     // groups x (gathered columns incl. the padding of the last group + the dpre channels re-read by
@@ -1492,7 +1497,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_split3_kernel(const WSParams p
     const float* pb = p.dpre + (long)v_begin * p.dp_sv + po;
     int pco[COT];
 #pragma unroll
-    for (int b = 0; b < COT; ++b) pco[b] = min(16 * b + la, p.Cout - 1);
+    for (int b = 0; b < COT; ++b) pco[b] = min(p.co0 + 16 * b + la, p.Cout - 1);
 
     f32x4 g4[2][8];
     float pr[2][8][COT];
@@ -1566,7 +1571,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_split3_kernel(const WSParams p
     float* slab = p.slab + (long)rc * p.slab_stride;
 #pragma unroll
     for (int b = 0; b < COT; ++b) {
-        const int co = 16 * b + la;
+        const int co = p.co0 + 16 * b + la;
         if (co >= p.Cout) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1581,7 +1586,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_split3_kernel(const WSParams p
             float v = bs[b];
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
-            const int co = 16 * b + la;
+            const int co = p.co0 + 16 * b + la;
             if (kb == 0 && co < p.Cout) p.slab[p.bias_off + (long)rc * p.Cout + co] = v;
         }
     }
@@ -1765,7 +1770,6 @@ int sh_spiral_conv_bwd_wgt(const float* dpre, int64_t dp_sv, int64_t dp_sb, cons
                            int R, int S, int Cin, int Cout, sh_stream_t stream) {
     SH_REQUIRE(dpre && x && table && workspace, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_wgt: null pointer");
     SH_REQUIRE(B > 0 && R > 0 && S > 0 && Cin > 0 && Cout > 0, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_wgt: non-positive size");
-    SH_REQUIRE(Cout <= 128, SH_ERR_UNSUPPORTED, "sh_spiral_conv_bwd_wgt: more than 128 output channels (%d) not built", Cout);
     SH_REQUIRE(workspace_bytes >= sh_spiral_conv_bwd_wgt_workspace(B, R, S, Cin, Cout), SH_ERR_WORKSPACE,
                "sh_spiral_conv_bwd_wgt: workspace too small");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1790,14 +1794,22 @@ int sh_spiral_conv_bwd_wgt(const float* dpre, int64_t dp_sv, int64_t dp_sb, cons
         s.B = B; s.R = R; s.S = S; s.Cin = Cin; s.Cout = Cout; s.K = p.K;
         s.log2TB = w.log2TB; s.n_btiles = w.n_btiles; s.nvc = w.nvc; s.vpc = w.vpc; s.ncg = w.ncg;
         s.n_items = w.nrc * w.ncg;
-        rc = w.cot == 1 ? dispatch_ws<1>(s, st) : w.cot == 2 ? dispatch_ws<2>(s, st) : w.cot == 4 ? dispatch_ws<4>(s, st)
-                                                                                                  : dispatch_ws<8>(s, st);
-    } else
+        rc = SH_OK;
+        for (int co0 = 0; co0 < Cout && rc == SH_OK; co0 += 128) {          // one launch per group of <= 128 output channels
+            s.co0 = co0;
+            const int tiles = sh_cdiv((Cout - co0 < 128 ? Cout - co0 : 128), 16);
+            const int cg_t = tiles <= 1 ? 1 : tiles <= 2 ? 2 : tiles <= 4 ? 4 : 8;
+            rc = cg_t == 1 ? dispatch_ws<1>(s, st) : cg_t == 2 ? dispatch_ws<2>(s, st) : cg_t == 4 ? dispatch_ws<4>(s, st) : dispatch_ws<8>(s, st);
+        }
+    } else {
+        SH_REQUIRE(Cout <= 128, SH_ERR_UNSUPPORTED,
+                   "sh_spiral_conv_bwd_wgt: more than 128 output channels (%d) need input channels that are a multiple of 4 (or 3)", Cout);
 #define SH_WG_CASE(C, T) rc = launch_wg<C, T>(p, w, vec4, st)
     if (w.ctw == 1) {
         if (w.cot == 1) SH_WG_CASE(1, 1); else if (w.cot == 2) SH_WG_CASE(2, 1); else if (w.cot == 4) SH_WG_CASE(4, 1); else SH_WG_CASE(8, 1);
     } else {
         if (w.cot == 1) SH_WG_CASE(1, 2); else if (w.cot == 2) SH_WG_CASE(2, 2); else if (w.cot == 4) SH_WG_CASE(4, 2); else SH_WG_CASE(8, 2);
+    }
     }
 #undef SH_WG_CASE
     if (rc != SH_OK) return rc;

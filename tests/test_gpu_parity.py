@@ -76,6 +76,9 @@ SHAPES = [  # (B, n_rows, S, Cin, Cout)  - ragged / odd cases on purpose
     # dispatch corners: 128 channels with >= 768 row tiles (eight channel tiles -> two direct four-tile workgroups), two
     # channel tiles at a batch that is not a multiple of 64 (stay direct, 64-row workgroups), spiral length 18 (config 4)
     (64, 1600, 4, 16, 128), (48, 1400, 5, 16, 32), (32, 3200, 18, 32, 64),
+    # more than 128 channels on either side (round 3: the output channels split over workgroups / launches, any count), and a
+    # channel count past 128 that is not a multiple of 16
+    (16, 200, 6, 16, 160), (5, 90, 4, 192, 272), (16, 300, 5, 160, 8), (3, 70, 3, 8, 132),
 ]
 
 
@@ -479,9 +482,9 @@ def test_c_abi_error_contract():
     assert b"null" in lib.sh_last_error()
     # unknown activation id
     assert lib.sh_spiral_conv_fwd(_lib.ptr(x), 4, 36, _lib.ptr(table), _lib.ptr(w), None, _lib.ptr(y), 4, 36, 2, 9, 3, 4, 4, 17, 8, st) == -1
-    # more output channels than the kernels are built for -> SH_ERR_UNSUPPORTED, message names the limit
-    assert lib.sh_spiral_conv_fwd(_lib.ptr(x), 4, 36, _lib.ptr(table), _lib.ptr(w), None, _lib.ptr(y), 4, 36, 2, 9, 3, 4, 200, 2, 8, st) == -2
-    assert b"128" in lib.sh_last_error()
+    # a spiral longer than the kernels are built for -> SH_ERR_UNSUPPORTED, message names the limit
+    assert lib.sh_spiral_conv_fwd(_lib.ptr(x), 4, 36, _lib.ptr(table), _lib.ptr(w), None, _lib.ptr(y), 4, 36, 2, 9, 65, 4, 4, 2, 8, st) == -2
+    assert b"64" in lib.sh_last_error()
     # workspace too small -> SH_ERR_WORKSPACE
     need = lib.sh_spiral_conv_bwd_wgt_workspace(2, 9, 3, 4, 4)
     assert need > 0
@@ -502,8 +505,9 @@ def test_c_abi_error_contract():
     assert lib.sh_stack_forward(1, steps, _lib.ptr(x), 1, 9, 4, 2, wp, None, outs, 1, st) == -1
     assert b"output buffer" in lib.sh_last_error()
     # the typed wrappers raise
-    with pytest.raises(RuntimeError, match="status -2"):
-        ops.spiral_conv_fwd(x, "bm", table, torch.zeros((200, 12), device=d), None, torch.zeros((2, 9, 200), device=d), "bm", 9, 3, 2, 8)
+    with pytest.raises(RuntimeError, match="status -2"):             # a spiral longer than the kernels' 64-entry table lines
+        ops.spiral_conv_fwd(x, "bm", torch.zeros((9, 65), dtype=torch.int32, device=d), torch.zeros((8, 65 * 4), device=d), None,
+                            torch.zeros((2, 9, 8), device=d), "bm", 9, 65, 2, 8)
     torch.cuda.synchronize()
 
 
