@@ -760,9 +760,9 @@ int launch_s3(const GGParams& p_in, int rt, hipStream_t st) {
     p.n_vtiles = sh_cdiv(p.R, TV);
     const int nblocks = p.n_vtiles * p.n_btiles * p.nsplit;
     const size_t smem = (size_t)(3 * 3 * NT * 64) * 16 + (size_t)(TV * p.S) * sizeof(int);
-    ShProfScope ps(st, "gather_gemm_split3_kernel<%d, %s, %d>|R=%d B=%d K=%d N=%d grid=%d", NT, BWD_EPI ? "true" : "false", rt, p.R,
-                   p.B, p.K, p.Nout, nblocks);
     static const int all9 = sh_env_int("SH_S3_ALL9", 0, 0, 1);
+    ShProfScope ps(st, "gather_gemm_split3_kernel<%d, %s, %d, %s>|R=%d B=%d K=%d N=%d grid=%d", NT, BWD_EPI ? "true" : "false", rt,
+                   all9 ? "true" : "false", p.R, p.B, p.K, p.Nout, nblocks);
     if (all9) {
         if (rt == 1) SH_LAUNCH_PS(ps, (gather_gemm_split3_kernel<NT, BWD_EPI, 1, true>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
         else SH_LAUNCH_PS(ps, (gather_gemm_split3_kernel<NT, BWD_EPI, 2, true>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
@@ -786,11 +786,12 @@ int launch_ggd(const GGParams& p_in, int nblocks128 /* workgroups if the tiles h
     p.n_vtiles = sh_cdiv(p.R, TV);
     const int nblocks = p.n_vtiles * p.n_btiles * p.nsplit;
     const size_t smem = (size_t)(3 * NT * 16 * KC) * sizeof(float) + (size_t)(TV * p.S) * sizeof(int);
-    ShProfScope ps(st, "gather_gemm_direct_kernel<%d, %s, %d>|R=%d B=%d K=%d N=%d grid=%d", NT, BWD_EPI ? "true" : "false", rt, p.R,
-                   p.B, p.K, p.Nout, nblocks);
+    const bool skip = rt == 1 && BWD_EPI && p.skip_on;
+    ShProfScope ps(st, "gather_gemm_direct_kernel<%d, %s, %d, %s>|R=%d B=%d K=%d N=%d grid=%d", NT, BWD_EPI ? "true" : "false", rt,
+                   skip ? "true" : "false", p.R, p.B, p.K, p.Nout, nblocks);
     // one tile per wave + known zero row: the form that skips no-source entries (the two-tile launches are the fine levels, where
     // 5-22 % of the entries have no source and the extra branches cost more than they save: 58.6 -> 63.8 us measured)
-    if (rt == 1 && BWD_EPI && p.skip_on) SH_LAUNCH_PS(ps, (gather_gemm_direct_kernel<NT, BWD_EPI, 1, BWD_EPI>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
+    if (skip) SH_LAUNCH_PS(ps, (gather_gemm_direct_kernel<NT, BWD_EPI, 1, BWD_EPI>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
     else if (rt == 1) SH_LAUNCH_PS(ps, (gather_gemm_direct_kernel<NT, BWD_EPI, 1>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
     else SH_LAUNCH_PS(ps, (gather_gemm_direct_kernel<NT, BWD_EPI, 2>), dim3(nblocks), dim3(NTHREADS), smem, st, p);
     SH_CHECK_LAUNCH("gather_gemm_direct");
@@ -856,7 +857,8 @@ int dispatch_gg(GGParams& p, hipStream_t st) {
         p.nsplit = nsplit0;
         while (ntw > s3_nt) { ntw >>= 1; p.nsplit <<= 1; }
         const long wg64 = (long)sh_cdiv(p.R, 64 >> (p.log2TB < 6 ? p.log2TB : 6)) * p.n_btiles * p.nsplit;      // workgroups of 64 rows
-        const int rt = s3_rt ? s3_rt : (wg64 >= s3_rt2_at ? 2 : 1);
+        // two row tiles per wave halve the weight-split work per MFMA: pays from ~1000 reduction columns on (67.7 -> 64.7, 64.2 -> 60.5 us)
+        const int rt = s3_rt ? s3_rt : ((wg64 >= s3_rt2_at || (p.K >= 1024 && wg64 >= 512)) ? 2 : 1);
         switch (ntw) {
             case 1: return launch_s3<1, BWD_EPI>(p, rt, st);
             case 2: return launch_s3<2, BWD_EPI>(p, rt, st);

@@ -298,7 +298,7 @@ int sh_spiral_conv_bwd_wgt_thin(const float* dpre_ext, int64_t dp_sv, int64_t dp
         }
         attr_set[b16] = true;
     }
-    ShProfScope ps(st, "wgrad_thin_kernel<%s>|R=%d B=%d S=%d Cin=%d N=%d grid=%d waves=%d dx=%d", b16 ? "bf16" : "f32", n_in, B, S, Cin, Cout, nslab, nw, dx ? 1 : 0);
+    ShProfScope ps(st, "wgrad_thin_kernel<%s>|R=%d B=%d S=%d Cin=%d N=%d grid=%d waves=%d dx=%d", b16 ? "true" : "false", n_in, B, S, Cin, Cout, nslab, nw, dx ? 1 : 0);
     if (b16) SH_LAUNCH_PS(ps, wgrad_thin_kernel<true>, dim3(nslab), dim3(64 * nw), smem, st, p);
     else SH_LAUNCH_PS(ps, wgrad_thin_kernel<false>, dim3(nslab), dim3(64 * nw), smem, st, p);
     SH_CHECK_LAUNCH("wgrad_thin");
