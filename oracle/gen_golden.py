@@ -207,6 +207,31 @@ def gen_small():
     print("small_ae.npz: sizes", sizes, "S", spiral_sizes, "loss", loss.item(), "L2mm", l2)
 
 
+def gen_small_random():
+    """The REFERENCE's SpiralAutoencoder on the 170-vertex hierarchy of small_ae.npz with its OWN default initialisation
+    (torch.manual_seed(7); nn.Linear's uniform init, as main.py constructs it) instead of the smooth closed-form fill:
+    weights, forward outputs, L1-loss gradients.  Random weights are what the bf16 path's 1e-2 bar is stated for:
+    on the smooth fill the rounding errors of neighbouring terms are correlated (tests/test_bf16.py:296)."""
+    v, f = synthetic.box_sphere(6, 6, 4)
+    M, D, U, Fs, sizes, spirals_np, spiral_sizes = build_hierarchy(v, f, ref_point=17)
+    tD, tU = dense_consts(D, U)
+    tS = [torch.from_numpy(s).long() for s in spirals_np]
+    dev = torch.device("cpu")
+    torch.manual_seed(7)
+    model = ref_models.SpiralAutoencoder(FILTERS_ENC, FILTERS_DEC, 16, sizes, spiral_sizes, tS, tD, tU, dev)
+    x = torch.from_numpy(synthetic.synth_batch(v, 4, seed=5))
+    arrs = {"x": x.numpy()}
+    for name, p in model.named_parameters():
+        arrs["w0/" + name] = p.detach().numpy().copy()
+    x_hat, z = model(x)
+    torch.nn.functional.l1_loss(x, x_hat).backward()
+    arrs["x_hat"], arrs["z"] = x_hat.detach().numpy(), z.detach().numpy()
+    for name, p in model.named_parameters():
+        arrs["grad_l1/" + name] = p.grad.numpy().copy()
+    np.savez_compressed(os.path.join(GOLD, "small_ae_random.npz"), **arrs)
+    print("small_ae_random.npz: |x_hat|max %.4f |z|max %.4f" % (float(x_hat.abs().max()), float(z.abs().max())))
+
+
 def gen_conv_acts():
     """reference models.SpiralConv alone: every activation, input + weight grads."""
     g = np.load(os.path.join(GOLD, "small_ae.npz"))

@@ -106,3 +106,23 @@ def test_full_size_manifest(golden_dir):
         assert s.shape == (h.sizes[l] + 1, h.spiral_sizes[l])
         assert np.all(s[-1] == -1) and np.array_equal(s[:-1, 0], np.arange(h.sizes[l]))   # col 0 = the vertex itself
     assert all(d.is_row_select() for d in h.D)
+
+
+def test_oracle_matches_reference_under_random_init(golden_dir):
+    """The oracle against the REFERENCE's output under the reference's own default initialisation (small_ae_random.npz):
+    forward bit-identical or at re-association noise, L1-loss gradients 1e-5 - the fixture the bf16 path's 1e-2 bar is
+    checked against on the GPU."""
+    g = np.load(os.path.join(golden_dir, "small_ae_random.npz"))
+    h = load_hierarchy(os.path.join(golden_dir, "small_ae.npz"))
+    S, D, U = h.dense_constants()
+    om = ref_cpu.SpiralAEOracle([[3, 16, 32, 64, 128], [[], [], [], [], []]], [[128, 64, 32, 32, 16], [[], [], [], [], 3]], 16, h.sizes,
+                                h.spiral_sizes, S, D, U)
+    om.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w0/")})
+    x = torch.from_numpy(g["x"])
+    x_hat, z = om(x)
+    assert float((x_hat.detach() - torch.from_numpy(g["x_hat"])).abs().max()) <= 1e-6 * float(np.abs(g["x_hat"]).max())
+    assert float((z.detach() - torch.from_numpy(g["z"])).abs().max()) <= 1e-6 * float(np.abs(g["z"]).max())
+    torch.nn.functional.l1_loss(x, x_hat).backward()
+    for n, p in om.named_parameters():
+        ref = g["grad_l1/" + n]
+        assert float(np.abs(p.grad.numpy() - ref).max()) <= 1e-5 * float(np.abs(ref).max()) + 1e-12, n
