@@ -177,7 +177,8 @@ def measured_traffic(kernel, workload):
         return None, "PMC profile %s is stamped for workload %r, not %r" % (name, meta.get("workload"), workload)
     if meta.get("lib_sha16") != _lib.build_id():
         return None, "PMC profile %s was taken on another build of the kernel library (%s != %s)" % (name, meta.get("lib_sha16"), _lib.build_id())
-    if meta.get("env", {}) != _lib.env_overrides():
+    strip = lambda e: {k: v for k, v in e.items() if k != "SH_F32_MMA"}      # noqa: E731 - the arithmetic form is part of the workload tag
+    if strip(meta.get("env", {})) != strip(_lib.env_overrides()):
         return None, "PMC profile %s was taken with other SH_* switches (%s)" % (name, meta.get("env"))
     if kernel not in pmc:
         return None, "kernel not in %s" % name
