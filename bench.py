@@ -698,6 +698,11 @@ def main():
     use_graph = not args.no_graph
     graph = None
     graph_note = None
+    if use_graph and reducer is not None and os.environ.get("SH_BENCH_DP_GRAPH", "1") == "0":
+        use_graph, graph_note = False, "eager (SH_BENCH_DP_GRAPH=0)"      # opt-out: a capture that fails WITH collectives inside is fatal
+    if use_graph and reducer is not None and backend != "nccl":
+        # a host-side collective (gloo: the one-GPU control-flow test) synchronises the stream: not capturable by construction
+        use_graph, graph_note = False, "eager (collectives of backend %s are host-side: not capturable)" % backend
     if use_graph:
         xin.copy_(data[:B])
         s = torch.cuda.Stream()
@@ -710,15 +715,31 @@ def main():
         if reducer and world > 1:
             dist.barrier()
         ok = 1
+        before = torch.cuda.current_stream()
+        cap_stream = torch.cuda.Stream()
         try:
             graph = torch.cuda.CUDAGraph()
             # thread_local: the process group's watchdog thread may query events of the warm-up collectives meanwhile
-            with torch.cuda.graph(graph, capture_error_mode="thread_local" if reducer else "global"):
+            with torch.cuda.graph(graph, stream=cap_stream, capture_error_mode="thread_local" if reducer else "global"):
+                if os.environ.get("SH_BENCH_TEST_CAPTURE_FAIL", "0") != "0":      # test hook: a capture that dies half way
+                    fwd_bwd()
+                    raise RuntimeError("injected capture failure (SH_BENCH_TEST_CAPTURE_FAIL)")
                 one_step()
         except Exception as e:                    # noqa: BLE001 - any capture failure means: run eagerly, and say why
-            ok, graph = 0, None
+            ok = 0
             graph_note = "hipGraph capture failed (%s: %s); eager launches" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else "")
             print("bench.py[rank %d]: %s" % (rank, graph_note), file=sys.stderr)
+            # (without collectives inside - measured with SH_BENCH_TEST_CAPTURE_FAIL=1 - the run continues eagerly; a capture that
+            # dies AFTER it recorded RCCL work takes the process down through the process group's watchdog: SH_BENCH_DP_GRAPH=0)
+            # leave the capture cleanly: end it if the context manager could not (an exception inside the body makes its
+            # __exit__ raise before it restores the stream), go back to the stream we came from, drop what was captured
+            try:
+                if torch.cuda.is_current_stream_capturing():
+                    graph.capture_end()
+            except Exception:                     # noqa: BLE001
+                pass
+            torch.cuda.set_stream(before)
+            graph = None
             torch.cuda.synchronize()
             optim.zero_grad(set_to_none=True)
         if world > 1:                             # every rank replays, or none does
