@@ -149,6 +149,17 @@ SH_API int sh_spiral_conv_bwd_wgt(const float* dpre, int64_t dp_sv, int64_t dp_s
                            int B, int R, int S, int Cin, int Cout,
                            sh_stream_t stream);
 
+/* The same launch with a rider: the LAST pre-sum level of the layer's backward-data pass (sh_stack_step.sum1 / sum2: rows
+ * R .. of the dpre buffer = sums of rows that several (vertex, position) pairs of the transposed table share) -
+ *     sum_out[r][b][:] = sum_e sum_val[e] * dpre[sum_col[e]][b][:]      r < sum_rows, strides of dpre, sh_spmm's arithmetic
+ * - computed by extra workgroups of the weight-gradient launch (both only read the first R rows of dpre) instead of a launch of
+ * its own, when a second wave of the kernel fits on a SIMD; otherwise the entry point issues sh_spmm itself, first.
+ * sum_rows == 0: exactly sh_spiral_conv_bwd_wgt. */
+SH_API int sh_spiral_conv_bwd_wgt_presum(const float* dpre, int64_t dp_sv, int64_t dp_sb, const float* x, int64_t x_sv, int64_t x_sb,
+                                         const int32_t* table, float* dW, float* dbias, void* workspace, size_t workspace_bytes,
+                                         const int32_t* sum_rowptr, const int32_t* sum_col, const float* sum_val, float* sum_out,
+                                         int sum_rows, int B, int R, int S, int Cin, int Cout, sh_stream_t stream);
+
 /* Batched forms for a whole stack of layers (one launch instead of one per layer; host arrays of
  * n_layers entries, passed by value into the kernel arguments -> graph-capturable):
  *  - sh_spiral_conv_bwd_wgt called with dW == NULL only writes its partial slabs into `workspace`;

@@ -33,6 +33,7 @@ SIGNATURES = {
     "sh_weight_transpose": (c_int, [_P, _P, _I, _I, _I, _P]),
     "sh_spiral_conv_bwd_wgt_workspace": (c_size_t, [_I, _I, _I, _I, _I]),
     "sh_spiral_conv_bwd_wgt": (c_int, [_P, _L, _L, _P, _L, _L, _P, _P, _P, _P, c_size_t, _I, _I, _I, _I, _I, _P]),
+    "sh_spiral_conv_bwd_wgt_presum": (c_int, [_P, _L, _L, _P, _L, _L, _P, _P, _P, _P, c_size_t, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "sh_spiral_conv_bwd_wgt_reduce_multi": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sh_weight_transpose_multi": (c_int, [_I, _P, _P, _P, _P, _P, _P]),
     "sh_act_backward": (c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _P]),

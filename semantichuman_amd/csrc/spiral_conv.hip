@@ -1243,15 +1243,55 @@ struct WSParams {
     int B, R, S, Cin, Cout, K;
     int log2TB, n_btiles, nvc, vpc, ncg, n_items;     // vpc = vertices per chunk
     int co0;                                          // first output channel of this launch (groups of <= 128 channels)
+    // tail job (sh_spiral_conv_bwd_wgt_presum): workgroups grid_main .. grid_main + tail_blocks - 1 of the launch fill the
+    // pre-summed rows the layer's backward-data pass reads through its transposed table - y[r] = sum_e val[e] dpre[col[e]],
+    // sh_spmm's arithmetic entry for entry - beside the weight-gradient workgroups instead of in a launch of their own
+    int grid_main, tail_blocks, tail_rows;
+    const int* tail_rowptr; const int* tail_col; const float* tail_val;
+    float* tail_y;                                    // same (row, batch) strides as dpre
 };
+
+// the tail job: one 256-element part of an output row per step, as spmm_kernel<true> (bitwise the same sums)
+__device__ __forceinline__ void ws_presum_tail(const WSParams& p) {
+    const int CW = p.Cout >> 2, per_row = p.B * CW;
+    const int parts = (per_row + 255) >> 8;
+    const long items = (long)p.tail_rows * parts;
+    for (long it = (long)blockIdx.x - p.grid_main; it < items; it += p.tail_blocks) {
+        const int r = (int)(it / parts), part = (int)(it - (long)r * parts);
+        const int e0 = p.tail_rowptr[r], e1 = p.tail_rowptr[r + 1];
+        const int j = part * 256 + threadIdx.x;
+        if (j >= per_row) continue;
+        const int b = j / CW, co = 4 * (j - b * CW);
+        const long xo = (long)b * p.dp_sb + co;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        int e = e0;
+        for (; e + 3 < e1; e += 4) {                          // 4 independent 16-B loads in flight
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(p.dpre + (long)p.tail_col[e] * p.dp_sv + xo);
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(p.dpre + (long)p.tail_col[e + 1] * p.dp_sv + xo);
+            const f32x4 x2 = *reinterpret_cast<const f32x4*>(p.dpre + (long)p.tail_col[e + 2] * p.dp_sv + xo);
+            const f32x4 x3 = *reinterpret_cast<const f32x4*>(p.dpre + (long)p.tail_col[e + 3] * p.dp_sv + xo);
+            const float w0 = p.tail_val[e], w1 = p.tail_val[e + 1], w2 = p.tail_val[e + 2], w3 = p.tail_val[e + 3];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = fmaf(w3, x3[k], fmaf(w2, x2[k], fmaf(w1, x1[k], fmaf(w0, x0[k], acc[k]))));
+        }
+        for (; e < e1; ++e) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(p.dpre + (long)p.tail_col[e] * p.dp_sv + xo);
+            const float w = p.tail_val[e];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = fmaf(w, xv[k], acc[k]);
+        }
+        *reinterpret_cast<f32x4*>(p.tail_y + (long)r * p.dp_sv + xo) = acc;
+    }
+}
 
 // C3: Cin == 3, columns counted in zero-padded quads (k' = 4 s + c), dwordx3 gathers, scalar slab stores.
 template <int COT, int NG, int DEPTH, bool FULL, bool C3 = false>
 __global__ __launch_bounds__(NTHREADS) void wgrad_stream_kernel(const WSParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x >= p.grid_main) { ws_presum_tail(p); return; }    // tail job (whole workgroups; before any barrier)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int* Tl = reinterpret_cast<int*>(smem) + wave * p.vpc * p.S;          // this wave's table lines
-    const int item_raw = sh_xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
+    const int item_raw = sh_xcd_remap(blockIdx.x, p.grid_main) * 4 + wave;
     const bool active = item_raw < p.n_items;
     const int item = active ? item_raw : 0;
     const int rc = item / p.ncg, cg = item - rc * p.ncg;
@@ -1452,10 +1492,10 @@ template <int COT, int NG, bool FULL>
 int launch_ws(const WSParams& p, hipStream_t st) {
     constexpr int DEPTH = COT <= 2 ? 3 : 2;       // vertices of loads in flight (deeper measured no faster)
     const size_t smem = (size_t)4 * p.vpc * p.S * sizeof(int);
-    const int grid = sh_cdiv(p.n_items, 4);
+    const int grid = p.grid_main + p.tail_blocks;
     const bool c3 = p.Cin == 3;
-    ShProfScope ps(st, "wgrad_stream_kernel<%d, %d, %d, %s, %s>|R=%d B=%d K=%d N=%d grid=%d", COT, NG, DEPTH, FULL ? "true" : "false",
-                   c3 ? "true" : "false", p.R, p.B, p.K, p.Cout, grid);
+    ShProfScope ps(st, "wgrad_stream_kernel<%d, %d, %d, %s, %s>|R=%d B=%d K=%d N=%d grid=%d presum=%d", COT, NG, DEPTH, FULL ? "true" : "false",
+                   c3 ? "true" : "false", p.R, p.B, p.K, p.Cout, p.grid_main, p.tail_blocks ? p.tail_rows : 0);
     if (c3) SH_LAUNCH_PS(ps, (wgrad_stream_kernel<COT, NG, DEPTH, FULL, true>), dim3(grid), dim3(NTHREADS), smem, st, p);
     else SH_LAUNCH_PS(ps, (wgrad_stream_kernel<COT, NG, DEPTH, FULL, false>), dim3(grid), dim3(NTHREADS), smem, st, p);
     SH_CHECK_LAUNCH("wgrad_stream");
@@ -1474,9 +1514,10 @@ int launch_ws(const WSParams& p, hipStream_t st) {
 template <int COT>
 __global__ __launch_bounds__(NTHREADS) void wgrad_split3_kernel(const WSParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x >= p.grid_main) { ws_presum_tail(p); return; }    // tail job (whole workgroups; before any barrier)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int* Tl = reinterpret_cast<int*>(smem) + wave * p.vpc * p.S;
-    const int item_raw = sh_xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
+    const int item_raw = sh_xcd_remap(blockIdx.x, p.grid_main) * 4 + wave;
     const bool active = item_raw < p.n_items;
     const int item = active ? item_raw : 0;
     const int rc = item / p.ncg, cg = item - rc * p.ncg;
@@ -1597,20 +1638,27 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_split3_kernel(const WSParams p
 template <int COT>
 int launch_ws3(const WSParams& p, hipStream_t st) {
     const size_t smem = (size_t)4 * p.vpc * p.S * sizeof(int);
-    const int grid = sh_cdiv(p.n_items, 4);
-    ShProfScope ps(st, "wgrad_split3_kernel<%d>|R=%d B=%d K=%d N=%d grid=%d", COT, p.R, p.B, p.K, p.Cout, grid);
+    const int grid = p.grid_main + p.tail_blocks;
+    ShProfScope ps(st, "wgrad_split3_kernel<%d>|R=%d B=%d K=%d N=%d grid=%d presum=%d", COT, p.R, p.B, p.K, p.Cout, p.grid_main,
+                   p.tail_blocks ? p.tail_rows : 0);
     SH_LAUNCH_PS(ps, (wgrad_split3_kernel<COT>), dim3(grid), dim3(NTHREADS), smem, st, p);
     SH_CHECK_LAUNCH("wgrad_split3");
     return SH_OK;
 }
 
+// does a streaming weight-gradient launch with `cot` channel tiles run in the bf16x3 form?
+// 2 and 4 channel tiles (8 would need more than the 512 registers of a one-wave-per-SIMD kernel; one tile: the splits outweigh
+// the matrix time saved)
+bool ws_uses_split3(int cot, const WSParams& p) {
+    static const int s3_min_cot = sh_env_int("SH_S3_WG_MIN_COT", 2, 1, 16);
+    const bool full = (p.B & ((1 << p.log2TB) - 1)) == 0;
+    return (cot == 2 || cot == 4) && sh_f32_mma_mode() == SH_MMA_SPLIT3 && cot >= s3_min_cot && full && p.log2TB == 4 && p.Cin % 4 == 0;
+}
+
 template <int COT>
 int dispatch_ws(const WSParams& p, hipStream_t st) {
     const bool full = (p.B & ((1 << p.log2TB) - 1)) == 0;
-    static const int s3_min_cot = sh_env_int("SH_S3_WG_MIN_COT", 2, 1, 16);   // one channel tile: the splits outweigh the matrix time saved
-    // 2 and 4 channel tiles (8 would need more than the 512 registers of a one-wave-per-SIMD kernel: it keeps the exact form)
-    if ((COT == 2 || COT == 4) && sh_f32_mma_mode() == SH_MMA_SPLIT3 && COT >= s3_min_cot && full && p.log2TB == 4 && p.Cin % 4 == 0)
-        return launch_ws3<(COT == 4 ? 4 : 2)>(p, st);
+    if ((COT == 2 || COT == 4) && ws_uses_split3(COT, p)) return launch_ws3<(COT == 4 ? 4 : 2)>(p, st);
     if (p.log2TB == 2) return full ? launch_ws<COT, 1, true>(p, st) : launch_ws<COT, 1, false>(p, st);
     return full ? launch_ws<COT, 4, true>(p, st) : launch_ws<COT, 4, false>(p, st);
 }
@@ -1770,7 +1818,17 @@ size_t sh_spiral_conv_bwd_wgt_workspace(int B, int R, int S, int Cin, int Cout) 
 int sh_spiral_conv_bwd_wgt(const float* dpre, int64_t dp_sv, int64_t dp_sb, const float* x, int64_t x_sv, int64_t x_sb,
                            const int32_t* table, float* dW, float* dbias, void* workspace, size_t workspace_bytes, int B,
                            int R, int S, int Cin, int Cout, sh_stream_t stream) {
+    return sh_spiral_conv_bwd_wgt_presum(dpre, dp_sv, dp_sb, x, x_sv, x_sb, table, dW, dbias, workspace, workspace_bytes, nullptr, nullptr,
+                                         nullptr, nullptr, 0, B, R, S, Cin, Cout, stream);
+}
+
+int sh_spiral_conv_bwd_wgt_presum(const float* dpre, int64_t dp_sv, int64_t dp_sb, const float* x, int64_t x_sv, int64_t x_sb,
+                                  const int32_t* table, float* dW, float* dbias, void* workspace, size_t workspace_bytes,
+                                  const int32_t* sum_rowptr, const int32_t* sum_col, const float* sum_val, float* sum_out, int sum_rows,
+                                  int B, int R, int S, int Cin, int Cout, sh_stream_t stream) {
     SH_REQUIRE(dpre && x && table && workspace, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_wgt: null pointer");
+    SH_REQUIRE(sum_rows == 0 || (sum_rows > 0 && sum_rowptr && sum_col && sum_val && sum_out), SH_ERR_INVALID_ARG,
+               "sh_spiral_conv_bwd_wgt_presum: incomplete pre-sum job");
     SH_REQUIRE(B > 0 && R > 0 && S > 0 && Cin > 0 && Cout > 0, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_wgt: non-positive size");
     SH_REQUIRE(workspace_bytes >= sh_spiral_conv_bwd_wgt_workspace(B, R, S, Cin, Cout), SH_ERR_WORKSPACE,
                "sh_spiral_conv_bwd_wgt: workspace too small");
@@ -1796,6 +1854,24 @@ int sh_spiral_conv_bwd_wgt(const float* dpre, int64_t dp_sv, int64_t dp_sb, cons
         s.B = B; s.R = R; s.S = S; s.Cin = Cin; s.Cout = Cout; s.K = p.K;
         s.log2TB = w.log2TB; s.n_btiles = w.n_btiles; s.nvc = w.nvc; s.vpc = w.vpc; s.ncg = w.ncg;
         s.n_items = w.nrc * w.ncg;
+        s.grid_main = sh_cdiv(s.n_items, 4);
+        // The pre-sum job rides as tail workgroups of this launch when a second wave of the kernel fits beside the first on
+        // a SIMD (exact form: up to four channel tiles; bf16x3 form: two) and the rows take 16-byte accesses; otherwise it is
+        // the launch of its own it used to be.  Measured: the seven foldable launches of a step were 58 us + their gaps.
+        static const int tail_on = sh_env_int("SH_WS_TAIL", 1, 0, 1), tail_cap = sh_env_int("SH_WS_TAIL_BLOCKS", 768, 1, 1 << 16);
+        const bool sum_vec = (Cout % 4 == 0) && (dp_sv % 4 == 0) && (dp_sb % 4 == 0) &&
+                             ((reinterpret_cast<uintptr_t>(dpre) | reinterpret_cast<uintptr_t>(sum_out)) % 16 == 0);
+        bool fold = tail_on && sum_rows > 0 && sum_vec && Cout <= 128 && !(Cin == 3) &&
+                    (ws_uses_split3(w.cot, s) ? w.cot == 2 : w.cot <= 4);
+        if (sum_rows > 0 && !fold) {
+            rc = sh_spmm(sum_rowptr, sum_col, sum_val, dpre, dp_sv, dp_sb, sum_out, dp_sv, dp_sb, nullptr, 0, 0, 0, -1, B, sum_rows, Cout, stream);
+            if (rc != SH_OK) return rc;
+        }
+        if (fold) {
+            const long items = (long)sum_rows * (((long)B * (Cout / 4) + 255) / 256);
+            s.tail_blocks = (int)(items < tail_cap ? items : tail_cap);
+            s.tail_rows = sum_rows; s.tail_rowptr = sum_rowptr; s.tail_col = sum_col; s.tail_val = sum_val; s.tail_y = sum_out;
+        }
         rc = SH_OK;
         for (int co0 = 0; co0 < Cout && rc == SH_OK; co0 += 128) {          // one launch per group of <= 128 output channels
             s.co0 = co0;
@@ -1804,6 +1880,10 @@ int sh_spiral_conv_bwd_wgt(const float* dpre, int64_t dp_sv, int64_t dp_sb, cons
             rc = cg_t == 1 ? dispatch_ws<1>(s, st) : cg_t == 2 ? dispatch_ws<2>(s, st) : cg_t == 4 ? dispatch_ws<4>(s, st) : dispatch_ws<8>(s, st);
         }
     } else {
+        if (sum_rows > 0) {
+            rc = sh_spmm(sum_rowptr, sum_col, sum_val, dpre, dp_sv, dp_sb, sum_out, dp_sv, dp_sb, nullptr, 0, 0, 0, -1, B, sum_rows, Cout, stream);
+            if (rc != SH_OK) return rc;
+        }
         SH_REQUIRE(Cout <= 128, SH_ERR_UNSUPPORTED,
                    "sh_spiral_conv_bwd_wgt: more than 128 output channels (%d) need input channels that are a multiple of 4 (or 3)", Cout);
 #define SH_WG_CASE(C, T) rc = launch_wg<C, T>(p, w, vec4, st)

@@ -133,9 +133,22 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
             // gradient buffer through the transposed table, so it runs after the pre-sum launches below
             const bool thin = want_in && s.table_t && s.R == s.n_in && il.sb == s.cin && il.sv == (long)B * s.cin && cl.sb == s.cout &&
                               cl.sv == (long)B * s.cout && sh_spiral_conv_bwd_wgt_thin_ok(B, s.n_in, s.S, s.cin, s.cout, SH_DTYPE_F32);
+            // the last pre-sum level of this layer rides in the weight-gradient launch (sh_spiral_conv_bwd_wgt_presum); an
+            // earlier level (very long lists: two levels) runs first, on its own
+            const bool ride = !thin && want_in && s.table_t && (s.n1 || s.n2);
+            float* mut0 = const_cast<float*>(cur);
+            if (ride && s.n1 && s.n2) {
+                rc = sh_spmm(s.sum1.rowptr, s.sum1.col, s.sum1.val, cur, cl.sv, cl.sb, mut0 + (long)s.R * cl.sv, cl.sv, cl.sb, nullptr, 0, 0,
+                             0, -1, B, s.n1, s.cout, stream);
+                if (rc != SH_OK) return rc;
+            }
             if (!thin) {
-                rc = sh_spiral_conv_bwd_wgt(cur, cl.sv, cl.sb, inp, il.sv, il.sb, s.table, nullptr, nullptr, workspace[i],
-                                            workspace_bytes[i], B, s.R, s.S, s.cin, s.cout, stream);
+                const sh_csr_ref& lm = s.n2 ? s.sum2 : s.sum1;
+                const int ln = ride ? (s.n2 ? s.n2 : s.n1) : 0;
+                float* lout = mut0 + (long)(s.R + (s.n2 ? s.n1 : 0)) * cl.sv;
+                rc = sh_spiral_conv_bwd_wgt_presum(cur, cl.sv, cl.sb, inp, il.sv, il.sb, s.table, nullptr, nullptr, workspace[i],
+                                                   workspace_bytes[i], ln ? lm.rowptr : nullptr, ln ? lm.col : nullptr,
+                                                   ln ? lm.val : nullptr, ln ? lout : nullptr, ln, B, s.R, s.S, s.cin, s.cout, stream);
                 if (rc != SH_OK) return rc;
             }
             job_ws[njobs] = workspace[i]; job_dW[njobs] = dW[s.param]; job_db[njobs] = dbias ? dbias[s.param] : nullptr;
@@ -145,12 +158,12 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
             if (want_in) {
                 SH_REQUIRE(s.table_t, SH_ERR_INVALID_ARG, "sh_stack_backward: step %d has no transposed table", i);
                 float* mut = const_cast<float*>(cur);          // the extra rows behind the R real ones of this step's own buffer
-                if (s.n1) {
+                if (s.n1 && !ride) {
                     rc = sh_spmm(s.sum1.rowptr, s.sum1.col, s.sum1.val, cur, cl.sv, cl.sb, mut + (long)s.R * cl.sv, cl.sv, cl.sb,
                                  nullptr, 0, 0, 0, -1, B, s.n1, s.cout, stream);
                     if (rc != SH_OK) return rc;
                 }
-                if (s.n2) {
+                if (s.n2 && !ride) {
                     rc = sh_spmm(s.sum2.rowptr, s.sum2.col, s.sum2.val, cur, cl.sv, cl.sb, mut + (long)(s.R + s.n1) * cl.sv,
                                  cl.sv, cl.sb, nullptr, 0, 0, 0, -1, B, s.n2, s.cout, stream);
                     if (rc != SH_OK) return rc;

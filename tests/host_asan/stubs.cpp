@@ -93,6 +93,14 @@ int sh_spiral_conv_bwd_wgt(const float* dpre, int64_t dp_sv, int64_t dp_sb, cons
     log("bwd_wgt R=%d Cin=%d Cout=%d", R, Cin, Cout);
     return 0;
 }
+int sh_spiral_conv_bwd_wgt_presum(const float* dpre, int64_t dp_sv, int64_t dp_sb, const float* x, int64_t x_sv, int64_t x_sb, const int32_t* table,
+                                  float* dW, float* db, void* ws, size_t ws_bytes, const int32_t* sum_rowptr, const int32_t* sum_col,
+                                  const float* sum_val, float* sum_out, int sum_rows, int B, int R, int S, int Cin, int Cout, sh_stream_t st) {
+    // the rider reads and writes exactly what the sh_spmm launch it replaces does; logged in the order the work is visible in
+    const int rc = sh_spiral_conv_bwd_wgt(dpre, dp_sv, dp_sb, x, x_sv, x_sb, table, dW, db, ws, ws_bytes, B, R, S, Cin, Cout, st);
+    if (rc != 0 || sum_rows == 0) return rc;
+    return sh_spmm(sum_rowptr, sum_col, sum_val, dpre, dp_sv, dp_sb, sum_out, dp_sv, dp_sb, nullptr, 0, 0, 0, -1, B, sum_rows, Cout, st);
+}
 int sh_spiral_conv_bwd_wgt_bf16(const void* dpre, int dd, int64_t dp_sv, int64_t dp_sb, const void* x, int xd, int64_t x_sv, int64_t x_sb,
                                 const int32_t* table, void* ws, size_t ws_bytes, int B, int R, int S, int Cin, int Cout, sh_stream_t) {
     int n_in = 0;
