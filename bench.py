@@ -85,6 +85,8 @@ def parse_tag_f32(name, shape):
     try:
         if fam == "gather_gemm_kernel":
             return ("bwd" if targs[2] == "true" else "fwd", int(f["R"]), int(f["K"]), int(f["N"]))
+        if fam == "conv_out3_linewise_kernel":             # forward of the <= 3-channel last layer on the VALU
+            return ("fwd", int(f["R"]), int(f["K"]), int(f["N"]))
         if fam.startswith("gather_gemm_"):                 # direct / split3 / coalesced forms: <NT, BWD, ...>
             return ("bwd" if targs[1] == "true" else "fwd", int(f["R"]), int(f["K"]), int(f["N"]))
         if fam in ("wgrad_stream_kernel", "wgrad_kernel", "wgrad_split3_kernel"):

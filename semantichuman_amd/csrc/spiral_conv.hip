@@ -798,6 +798,95 @@ int launch_ggd(const GGParams& p_in, int nblocks128 /* workgroups if the tiles h
     return SH_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Forward of a layer with <= 3 output channels over 16-channel rows (the autoencoder's last decoder layer, 16 -> xyz at the
+// finest level).  One 16-wide channel tile would push 13 zero columns through the matrix pipe, but that is not what the MFMA
+// kernels lose on this layer: they are bound by the vector L1, which serves a gathered operand in MFMA layout as 64 separate
+// 16-byte accesses per load instruction (6.8-8.7 TB/s measured, tools/exp/ta_probe.hip).  Here the gather is LINE-WISE: four
+// lanes read one 64-byte row, a wave's load instruction covers sixteen consecutive batch entries of one gathered vertex = 1 KiB
+// contiguous (16.6-21.9 TB/s from L2), and the arithmetic - 12 FMAs per 16-byte quad - runs on the VALU with the layer's whole
+// weight (S x 16 x 3 floats, 12 per position per lane) in registers.  No LDS, no barrier; a wave walks rows of its XCD's
+// contiguous slice (the gathered neighbourhoods stay in that XCD's L2), one 16-batch unit in flight under the one it
+// multiplies; the table entries of a row are wave-uniform scalars.  Fixed summation order: positions in sequence, the
+// lane's four channels in sequence, then the four channel groups by two butterfly steps.
+template <int S>
+__global__ __launch_bounds__(256) void conv_out3_linewise_kernel(const GGParams p) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int cq = lane & 3, bl = lane >> 2;
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int nw = (int)(gridDim.x >> 3) * 4;                          // waves per XCD (the grid is a multiple of 8)
+    const int lo = (int)((long)p.R * xcd / 8), hi = (int)((long)p.R * (xcd + 1) / 8);
+    const int wl = local * 4 + wave;
+    const int nch = (p.B + 15) >> 4;
+    // the weight: w[n][s][4 cq .. 4 cq + 3] for n < Nout (rows of w beyond Nout do not exist: read row 0, never used)
+    f32x4 w[S][3];
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int n = 0; n < 3; ++n) w[s][n] = *reinterpret_cast<const f32x4*>(p.w + (long)(n < p.Nout ? n : 0) * p.Kw + s * 16 + 4 * cq);
+    const long lane_off = 4 * cq;
+    const int nrows = lo + wl < hi ? (hi - lo - wl + nw - 1) / nw : 0;
+    const int units = nrows * nch;
+    if (units == 0) return;
+    const float bias = (p.bias && cq < p.Nout) ? p.bias[cq] : 0.f;
+    // Straight-line pipeline (no branch around a vector load, so the waits stay counted): unit u multiplies from one buffer
+    // while unit u + 1 is in flight in the other and the table line of unit u + 2 is in flight in scalar registers; units past
+    // the end repeat the last one and are not stored.
+    auto load_table = [&](int u, long (&tt)[S]) {
+        const int r = lo + wl + (min(u, units - 1) / nch) * nw;
+#pragma unroll
+        for (int s = 0; s < S; ++s) tt[s] = (long)p.table[(long)r * S + s] * p.x_sv;
+    };
+    auto issue = [&](const long (&tt)[S], int u, f32x4 (&buf)[S]) {
+        const int b = min(16 * (min(u, units - 1) % nch) + bl, p.B - 1);
+        const float* base = p.x + (long)b * p.x_sb + lane_off;
+#pragma unroll
+        for (int s = 0; s < S; ++s) buf[s] = *reinterpret_cast<const f32x4*>(base + tt[s]);
+    };
+    auto finish = [&](int u, const f32x4 (&buf)[S]) {
+        const int r = lo + wl + (u / nch) * nw, j = u % nch;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a0 = fmaf(buf[s][i], w[s][0][i], a0);
+                a1 = fmaf(buf[s][i], w[s][1][i], a1);
+                a2 = fmaf(buf[s][i], w[s][2][i], a2);
+            }
+        a0 += __shfl_xor(a0, 1, 64); a1 += __shfl_xor(a1, 1, 64); a2 += __shfl_xor(a2, 1, 64);
+        a0 += __shfl_xor(a0, 2, 64); a1 += __shfl_xor(a1, 2, 64); a2 += __shfl_xor(a2, 2, 64);
+        const int b = 16 * j + bl;
+        if (u < units && cq < p.Nout && b < p.B) {                     // lane cq stores channel cq
+            const float v = sh_act_fwd((cq == 0 ? a0 : cq == 1 ? a1 : a2) + bias, p.act);
+            p.y[(long)r * p.y_sv + (long)b * p.y_sb + cq] = r == p.zero_row ? 0.f : v;
+        }
+    };
+    f32x4 bufA[S], bufB[S];
+    long t0[S], t1[S];
+    load_table(0, t0);
+    issue(t0, 0, bufA);
+    load_table(1, t1);
+    for (int u = 0; u < units; u += 2) {
+        issue(t1, u + 1, bufB);
+        load_table(u + 2, t0);
+        finish(u, bufA);
+        issue(t0, u + 2, bufA);
+        load_table(u + 3, t1);
+        finish(u + 1, bufB);
+    }
+}
+
+template <int S>
+int launch_out3(const GGParams& p, hipStream_t st) {
+    static const int grid = 8 * sh_env_int("SH_OUT3_WG_PER_XCD", 64, 1, 1024);       // 2 workgroups per CU
+    ShProfScope ps(st, "conv_out3_linewise_kernel<%d>|R=%d B=%d K=%d N=%d grid=%d", S, p.R, p.B, p.K, p.Nout, grid);
+    SH_LAUNCH_PS(ps, conv_out3_linewise_kernel<S>, dim3(grid), dim3(256), 0, st, p);
+    SH_CHECK_LAUNCH("conv_out3_linewise");
+    return SH_OK;
+}
+
 template <int NT, bool VEC4, bool BWD_EPI, bool C3 = false>
 int launch_gg(const GGParams& p, int nblocks, hipStream_t st) {
     const int TV = TM >> p.log2TB;
@@ -848,6 +937,20 @@ int dispatch_gg(GGParams& p, hipStream_t st) {
                 (reinterpret_cast<uintptr_t>(p.y) % 16 == 0) &&
                 (!p.bias || reinterpret_cast<uintptr_t>(p.bias) % 16 == 0) &&
                 (!p.yprev || ((p.yp_sv % 4 == 0) && (p.yp_sb % 4 == 0) && reinterpret_cast<uintptr_t>(p.yprev) % 16 == 0));
+    // <= 3 output channels over 16-channel rows: the line-wise VALU kernel (both arithmetic forms: nothing for a split to win)
+    static const int out3_on = sh_env_int("SH_GG_OUT3", 1, 0, 1);
+    if (!BWD_EPI && out3_on && p.Nout <= 3 && p.Cg == 16 && vec4 && p.S >= 6 && p.S <= 12) {
+        p.Kw = p.K;
+        switch (p.S) {
+            case 6: return launch_out3<6>(p, st);
+            case 7: return launch_out3<7>(p, st);
+            case 8: return launch_out3<8>(p, st);
+            case 9: return launch_out3<9>(p, st);
+            case 10: return launch_out3<10>(p, st);
+            case 11: return launch_out3<11>(p, st);
+            default: return launch_out3<12>(p, st);
+        }
+    }
     // bf16x3 form (sh_set_f32_mma_mode): up to four channel tiles per workgroup, the rest split over workgroups
     static const int s3_min_nt = sh_env_int("SH_S3_MIN_NT", 4, 1, 8);      // layers with fewer channel tiles keep the exact form (no gain there)
     if (sh_f32_mma_mode() == SH_MMA_SPLIT3 && vec4 && p.vec_out && !c3 && p.Cg % 8 == 0 && nt >= s3_min_nt) {

@@ -79,6 +79,8 @@ SHAPES = [  # (B, n_rows, S, Cin, Cout)  - ragged / odd cases on purpose
     # more than 128 channels on either side (round 3: the output channels split over workgroups / launches, any count), and a
     # channel count past 128 that is not a multiple of 16
     (16, 200, 6, 16, 160), (5, 90, 4, 192, 272), (16, 300, 5, 160, 8), (3, 70, 3, 8, 132),
+    # <= 3 output channels over 16-channel rows: the line-wise VALU forward (spiral lengths 6..12), full / ragged batch slices
+    (64, 500, 10, 16, 3), (20, 130, 12, 16, 2), (7, 90, 6, 16, 1), (33, 64, 13, 16, 3),
 ]
 
 
@@ -542,7 +544,7 @@ def test_bench_launch_table_matches_the_library(golden_dir, cfg):
             table = bench.f32_work_table(m, B)
             hit = {}
             for kname, shape, _ms in recs:
-                if kname.startswith(("gather_gemm", "wgrad")):
+                if kname.startswith(("gather_gemm", "wgrad", "conv_out3")):
                     key = bench.parse_tag_f32(kname, shape)
                     assert key in table, (mode, kname, shape)
                     hit[id(table[key])] = hit.get(id(table[key]), 0) + 1

@@ -41,7 +41,7 @@ def main():
     fetch, write, out = read(sys.argv[1], "FETCH_SIZE"), read(sys.argv[2], "WRITE_SIZE"), sys.argv[3]
     workload = sys.argv[4] if len(sys.argv) > 4 else None       # bench.workload_tag(...) of the profiled run, e.g. 6890v_b64_f32
     ours = lambda n: any(k in n for k in ("gather_gemm", "wgrad", "spmm", "skinny", "linear_", "adam", "slab_reduce", "split_reduce",  # noqa: E731
-                                          "conv_bf16", "tgemm", "tg_reduce", "wfrag"))
+                                          "conv_bf16", "conv_out3", "tgemm", "tg_reduce", "wfrag"))
     agg = defaultdict(lambda: [0, 0.0, 0.0])
     for (_, n, _, v) in fetch:
         if ours(n):
