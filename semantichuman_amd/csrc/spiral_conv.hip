@@ -809,6 +809,8 @@ int launch_ggd(const GGParams& p_in, int nblocks128 /* workgroups if the tiles h
 // contiguous slice (the gathered neighbourhoods stay in that XCD's L2), one 16-batch unit in flight under the one it
 // multiplies; the table entries of a row are wave-uniform scalars.  Fixed summation order: positions in sequence, the
 // lane's four channels in sequence, then the four channel groups by two butterfly steps.
+// (The mirror case - first encoder layer, 3-channel rows -> 16 channels, lane = (batch entry, channel quad) - measured no
+// gain in this form: 20.3 vs 18.6 us, its 12-byte rows are scattered over the batch-major input; not kept.)
 template <int S>
 __global__ __launch_bounds__(256) void conv_out3_linewise_kernel(const GGParams p) {
     const int lane = threadIdx.x & 63;

@@ -81,6 +81,7 @@ SHAPES = [  # (B, n_rows, S, Cin, Cout)  - ragged / odd cases on purpose
     (16, 200, 6, 16, 160), (5, 90, 4, 192, 272), (16, 300, 5, 160, 8), (3, 70, 3, 8, 132),
     # <= 3 output channels over 16-channel rows: the line-wise VALU forward (spiral lengths 6..12), full / ragged batch slices
     (64, 500, 10, 16, 3), (20, 130, 12, 16, 2), (7, 90, 6, 16, 1), (33, 64, 13, 16, 3),
+    (64, 400, 10, 3, 16), (9, 77, 7, 3, 16),
 ]
 
 
