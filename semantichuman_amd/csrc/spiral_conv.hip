@@ -829,25 +829,30 @@ __global__ __launch_bounds__(256) void conv_out3_linewise_kernel(const GGParams 
         for (int n = 0; n < 3; ++n) w[s][n] = *reinterpret_cast<const f32x4*>(p.w + (long)(n < p.Nout ? n : 0) * p.Kw + s * 16 + 4 * cq);
     const long lane_off = 4 * cq;
     const int nrows = lo + wl < hi ? (hi - lo - wl + nw - 1) / nw : 0;
-    const int units = nrows * nch;
+    // unit = (batch slice of 64, row, 16-batch chunk of the slice), slice-major: a large batch is walked in slices so that the
+    // rows an XCD gathers from stay inside its 4 MiB L2 (861 rows x 4 KiB per slice at 6890 vertices)
+    const int cps = nch < 4 ? nch : 4, per_slice = nrows * cps;
+    const int units = ((nch + cps - 1) / cps) * per_slice;
     if (units == 0) return;
+    auto unit_row = [&](int u) { return lo + wl + ((u % per_slice) / cps) * nw; };
+    auto unit_chunk = [&](int u) { return (u / per_slice) * cps + (u % per_slice) % cps; };      // may be >= nch in the last slice: not stored
     const float bias = (p.bias && cq < p.Nout) ? p.bias[cq] : 0.f;
     // Straight-line pipeline (no branch around a vector load, so the waits stay counted): unit u multiplies from one buffer
     // while unit u + 1 is in flight in the other and the table line of unit u + 2 is in flight in scalar registers; units past
     // the end repeat the last one and are not stored.
     auto load_table = [&](int u, long (&tt)[S]) {
-        const int r = lo + wl + (min(u, units - 1) / nch) * nw;
+        const int r = unit_row(min(u, units - 1));
 #pragma unroll
         for (int s = 0; s < S; ++s) tt[s] = (long)p.table[(long)r * S + s] * p.x_sv;
     };
     auto issue = [&](const long (&tt)[S], int u, f32x4 (&buf)[S]) {
-        const int b = min(16 * (min(u, units - 1) % nch) + bl, p.B - 1);
+        const int b = min(16 * unit_chunk(min(u, units - 1)) + bl, p.B - 1);
         const float* base = p.x + (long)b * p.x_sb + lane_off;
 #pragma unroll
         for (int s = 0; s < S; ++s) buf[s] = *reinterpret_cast<const f32x4*>(base + tt[s]);
     };
     auto finish = [&](int u, const f32x4 (&buf)[S]) {
-        const int r = lo + wl + (u / nch) * nw, j = u % nch;
+        const int r = unit_row(u), j = unit_chunk(u);
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll
         for (int s = 0; s < S; ++s)

@@ -4,24 +4,6 @@ O=gpurun_out/r03final; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 timeout 1500 python -m pytest tests -q -m gpu > $O/tests_all.txt 2>&1
 grep -n "passed\|failed\|FAILED" $O/tests_all.txt | tail -12
-timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_f32.json 2>$O/bench_f32.err
-timeout 600 python bench.py --steps 20 --warmup 5 --dtype bf16 > $O/bench_bf16.json 2>$O/bench_bf16.err
-timeout 600 python bench.py --steps 20 --warmup 5 --f32-mma split3 --no-secondary > $O/bench_f32_split3.json 2>$O/bench_f32_split3.err
-SH_BENCH_FORCE_REDUCER=1 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-roofline > $O/bench_reducer_graph_f32.json 2>$O/bench_reducer_graph_f32.err
-SH_BENCH_FORCE_REDUCER=1 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-roofline --dtype bf16 > $O/bench_reducer_graph_bf16.json 2>$O/bench_reducer_graph_bf16.err
-timeout 300 python tools/layer_report.py 64 > $O/layer_report_f32.txt 2>/dev/null
-SH_F32_MMA=split3 timeout 300 python tools/layer_report.py 64 > $O/layer_report_f32_split3.txt 2>/dev/null
-timeout 300 python tools/layer_report.py 64 tests/golden/template6890.npz bf16 > $O/layer_report_bf16.txt 2>/dev/null
-timeout 300 python tools/layer_report.py 32 tests/golden/template27554.npz f32 > $O/layer_report_config4_f32.txt 2>/dev/null
-timeout 600 python tools/bench_decode.py > $O/decode_config5.json 2>/dev/null
-# rocprofv3 kernel statistics of the bench command itself
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_f32 -o f32 --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $O/bench_f32_rocprof_run.json 2>$O/prof_f32.err
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_bf16 -o bf16 --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --dtype bf16 > $O/bench_bf16_rocprof_run.json 2>$O/prof_bf16.err
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_s3 -o s3 --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --f32-mma split3 > $O/bench_f32_split3_rocprof_run.json 2>$O/prof_s3.err
-cp $(find $O/prof_f32 -name "*kernel_stats.csv" | head -1) $O/rocprof_kernel_stats_f32.csv 2>/dev/null
-cp $(find $O/prof_bf16 -name "*kernel_stats.csv" | head -1) $O/rocprof_kernel_stats_bf16.csv 2>/dev/null
-cp $(find $O/prof_s3 -name "*kernel_stats.csv" | head -1) $O/rocprof_kernel_stats_f32_split3.csv 2>/dev/null
-rm -rf $O/prof_f32 $O/prof_bf16 $O/prof_s3
 # PMC traffic: FETCH_SIZE and WRITE_SIZE in separate passes, per workload
 pmc() {  # tag, env assignment or "-", layer_report args...
   tag=$1; envs=$2; shift 2
@@ -39,6 +21,29 @@ pmc 6890v_b64_f32 - 64
 pmc 6890v_b64_f32_split3 SH_F32_MMA=split3 64
 pmc 6890v_b64_bf16 - 64 tests/golden/template6890.npz bf16
 pmc 27554v_b32_f32 - 32 tests/golden/template27554.npz f32
+# the bench lines below quote these profiles (same build, same box): put them where bench.py looks
+for w in 6890v_b64_f32 6890v_b64_f32_split3 6890v_b64_bf16 27554v_b32_f32; do
+  cp $O/pmc_traffic_$w.json profiles/r03_pmc_traffic_$w.json; cp $O/pmc_traffic_$w.txt profiles/r03_pmc_traffic_$w.txt
+done
+timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_f32.json 2>$O/bench_f32.err
+timeout 600 python bench.py --steps 20 --warmup 5 --dtype bf16 > $O/bench_bf16.json 2>$O/bench_bf16.err
+timeout 600 python bench.py --steps 20 --warmup 5 --f32-mma split3 --no-secondary > $O/bench_f32_split3.json 2>$O/bench_f32_split3.err
+SH_BENCH_FORCE_REDUCER=1 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-roofline > $O/bench_reducer_graph_f32.json 2>$O/bench_reducer_graph_f32.err
+SH_BENCH_FORCE_REDUCER=1 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-roofline --dtype bf16 > $O/bench_reducer_graph_bf16.json 2>$O/bench_reducer_graph_bf16.err
+timeout 300 python tools/layer_report.py 64 > $O/layer_report_f32.txt 2>/dev/null
+SH_F32_MMA=split3 timeout 300 python tools/layer_report.py 64 > $O/layer_report_f32_split3.txt 2>/dev/null
+timeout 300 python tools/layer_report.py 64 tests/golden/template6890.npz bf16 > $O/layer_report_bf16.txt 2>/dev/null
+timeout 300 python tools/layer_report.py 32 tests/golden/template27554.npz f32 > $O/layer_report_config4_f32.txt 2>/dev/null
+timeout 600 python tools/bench_decode.py > $O/decode_config5.json 2>/dev/null
+timeout 300 python tools/layer_report_decode.py > $O/layer_report_decode.txt 2>/dev/null
+# rocprofv3 kernel statistics of the bench command itself
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_f32 -o f32 --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $O/bench_f32_rocprof_run.json 2>$O/prof_f32.err
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_bf16 -o bf16 --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --dtype bf16 > $O/bench_bf16_rocprof_run.json 2>$O/prof_bf16.err
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_s3 -o s3 --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --f32-mma split3 > $O/bench_f32_split3_rocprof_run.json 2>$O/prof_s3.err
+cp $(find $O/prof_f32 -name "*kernel_stats.csv" | head -1) $O/rocprof_kernel_stats_f32.csv 2>/dev/null
+cp $(find $O/prof_bf16 -name "*kernel_stats.csv" | head -1) $O/rocprof_kernel_stats_bf16.csv 2>/dev/null
+cp $(find $O/prof_s3 -name "*kernel_stats.csv" | head -1) $O/rocprof_kernel_stats_f32_split3.csv 2>/dev/null
+rm -rf $O/prof_f32 $O/prof_bf16 $O/prof_s3
 ls -la $O | head -60
 python - <<'PY'
 import json,glob
