@@ -423,6 +423,21 @@ SH_API int sh_part_volume_loss_bwd(const float* x_rec, int64_t x_bs, const int32
                                    const float* gscale, float* grad, sh_stream_t stream);
 SH_API int sh_zpart_reg(const float* z, const float* measure, const int32_t* part_idx, const int32_t* measure_idx, int B, int P,
                         int L, int M, int n, int relat, float* loss, float* dz, const float* gscale, sh_stream_t stream);
+/*  - joints <-> bones (utils_SH.py:26-84; inputs of the loop, no gradient).  sh_kps2skl: kps [B][J][3], bone k = joint i0[k] -
+ *    (joint i1[k] + joint i2[k]) / 2 (i2 == i1 for two-joint bones), n = |bone|; mode 0: out [B][n_bones][4] = (bone / n, n),
+ *    1: (bone, n), 2: [..][3] = bone (the pair loss's bone directions, :449-452), 3: [..][1] = n.  sh_skl2kps: skl
+ *    [B][n_bones][4] (mode 0: direction * length; 1: first three) or [..][3] (mode 2); joints rebuilt in list order, joint
+ *    tail[k] = joint head[k] - bone k with unassigned joints at the origin (n_joints <= 64), out [B][n_keep][3] = joints keep[].
+ *    Operation for operation the arithmetic of the tensor-op forms (same bits).
+ *  - sh_weighted_sum: out[0] = w0 t0 + w1 t1 + ... summed in sequence (terms: HOST array of n <= 16 DEVICE scalars, weights:
+ *    HOST floats; a weight of exactly 1 leaves its term unscaled) when out != NULL; grads[i] = gscale[0] * w_i when grads !=
+ *    NULL - the loop's `loss = loss + w * term` chain and its backward as one launch each. */
+SH_API int sh_kps2skl(const float* kps, int B, int J, const int32_t* i0, const int32_t* i1, const int32_t* i2, int n_bones, int mode,
+                      float* out, sh_stream_t stream);
+SH_API int sh_skl2kps(const float* skl, int B, int n_bones, int mode, const int32_t* head, const int32_t* tail, int n_joints,
+                      const int32_t* keep, int n_keep, float* out, sh_stream_t stream);
+SH_API int sh_weighted_sum(int n, const float* const* terms, const float* weights, float* out, const float* gscale, float* grads,
+                           sh_stream_t stream);
 
 /* =============================================================================================
  * bf16 compute path (BASELINE.json configs[2]: "batch=512 bf16, DDP 8x"; the reference itself is fp32-only,

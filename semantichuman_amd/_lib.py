@@ -72,6 +72,9 @@ SIGNATURES = {
     "sh_part_volume_loss_fwd": (c_int, [_P, _P, _L, _P, _P, _P, _I, _I, _P, _P, _P]),
     "sh_part_volume_loss_bwd": (c_int, [_P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "sh_zpart_reg": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "sh_kps2skl": (c_int, [_P, _I, _I, _P, _P, _P, _I, _I, _P, _P]),
+    "sh_skl2kps": (c_int, [_P, _I, _I, _I, _P, _P, _I, _P, _I, _P, _P]),
+    "sh_weighted_sum": (c_int, [_I, _P, _P, _P, _P, _P, _P]),
     # bf16 compute path
     "sh_conv_wfrag_bytes": (c_size_t, [_I, _I, _I]),
     "sh_conv_wfrag_prep_multi": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P]),

@@ -3,6 +3,8 @@
 //   joint regression + joint L1     kps = J x[:, :-1] (train_funcs.py:131,161,230,296,336), F.l1_loss(kps[:, keep], target) (:231,:342)
 //   part volume ratio               cal_volloss (train_funcs.py:56-71) averaged over the batch (:323-330)
 //   latent-norm regulariser         zpartreg (train_funcs.py:145-152)
+//   joints <-> bones                kps2skl / skl2kps (utils_SH.py:26-84), bone directions of the pair loss (:449-452)
+//   the weighted sum of the terms   `loss = loss + w * term` (train_funcs.py:141-389)
 //
 // Each is a forward launch pair (partial results, fixed-order final reduction) and ONE backward launch; no atomics, so the
 // gradients are bitwise reproducible.  They are launch-bound (a few hundred KB each): what they buy is launches - the
@@ -167,9 +169,108 @@ __global__ __launch_bounds__(256) void zpart_kernel(const float* __restrict__ z,
     }
 }
 
+// ---- skeleton bookkeeping of the loop (utils_SH.py:26-84, :449-452) ------------------------------------------------------
+// joints -> bones: vec = joint a - (joint b + joint c) / 2 (c == b for two-joint bones: (b + b) / 2 == b exactly), n = |vec|;
+// mode 0: (vec / n, n)  1: (vec, n)  2: vec  3: n.  One thread per (batch entry, bone); the arithmetic of the tensor-op form,
+// operation for operation (no contraction), so the results are the same bits.
+__global__ __launch_bounds__(256) void kps2skl_kernel(const float* __restrict__ kps, int J, const int* __restrict__ i0, const int* __restrict__ i1,
+                                                      const int* __restrict__ i2, int B, int nb, int mode, float* __restrict__ out) {
+#pragma clang fp contract(off)
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= B * nb) return;
+    const int b = t / nb, k = t - b * nb;
+    const float* kb = kps + (long)b * J * 3;
+    float v[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = kb[3 * i0[k] + c] - (kb[3 * i1[k] + c] + kb[3 * i2[k] + c]) / 2.f;
+    const float n = sqrtf((v[0] * v[0] + v[2] * v[2]) + v[1] * v[1]);      // the order torch.sum reduces a 3-element row in (measured)
+    const int w = mode == 0 || mode == 1 ? 4 : mode == 2 ? 3 : 1;
+    float* o = out + (long)t * w;
+    if (mode == 0) { o[0] = v[0] / n; o[1] = v[1] / n; o[2] = v[2] / n; o[3] = n; }
+    else if (mode == 1) { o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = n; }
+    else if (mode == 2) { o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; }
+    else o[0] = n;
+}
+
+// bones -> joints, from the root outwards in list order: joint tail[k] = joint head[k] - bone k, joints not assigned yet are the
+// origin (utils_SH.py:77-83); then the kept joints are gathered.  One thread per batch entry (the chain is sequential).
+// mode 0: bone = skl[:3] * skl[3]   1: skl[:3] of 4   2: skl[:3] of 3
+constexpr int SKL_MAX_J = 64;
+__global__ __launch_bounds__(64) void skl2kps_kernel(const float* __restrict__ skl, const int* __restrict__ head, const int* __restrict__ tail,
+                                                     int B, int nb, int n_j, int mode, const int* __restrict__ keep, int n_keep,
+                                                     float* __restrict__ out) {
+#pragma clang fp contract(off)
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    float kp[SKL_MAX_J][3];
+    for (int j = 0; j < n_j; ++j) kp[j][0] = kp[j][1] = kp[j][2] = 0.f;
+    const int w = mode == 2 ? 3 : 4;
+    const float* sb = skl + (long)b * nb * w;
+    for (int k = 0; k < nb; ++k) {
+        const float m = mode == 0 ? sb[k * w + 3] : 1.f;
+        const int h = head[k], tl = tail[k];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float bone = mode == 0 ? sb[k * w + c] * m : sb[k * w + c];
+            kp[tl][c] = kp[h][c] - bone;
+        }
+    }
+    float* o = out + (long)b * n_keep * 3;
+    for (int m = 0; m < n_keep; ++m) { o[3 * m] = kp[keep[m]][0]; o[3 * m + 1] = kp[keep[m]][1]; o[3 * m + 2] = kp[keep[m]][2]; }
+}
+
+// total = t0 * w0 (w0 == 1: t0 itself) + w1 * t1 + ... in sequence - the loop's `loss = loss + w * term` chain as one launch;
+// backward: grads[i] = gscale * w_i
+constexpr int WS_MAX = 16;
+struct WSumArgs { const float* t[WS_MAX]; float w[WS_MAX]; int n; };
+__global__ void weighted_sum_kernel(const WSumArgs a, float* __restrict__ out) {
+#pragma clang fp contract(off)
+    float s = a.w[0] == 1.f ? a.t[0][0] : a.w[0] * a.t[0][0];
+    for (int i = 1; i < a.n; ++i) s = s + a.w[i] * a.t[i][0];
+    out[0] = s;
+}
+__global__ void weighted_sum_bwd_kernel(const WSumArgs a, const float* __restrict__ gscale, float* __restrict__ grads) {
+    const int i = threadIdx.x;
+    if (i < a.n) grads[i] = a.w[i] == 1.f ? gscale[0] : gscale[0] * a.w[i];
+}
+
 }  // namespace
 
 extern "C" {
+
+int sh_kps2skl(const float* kps, int B, int J, const int32_t* i0, const int32_t* i1, const int32_t* i2, int n_bones, int mode, float* out,
+               sh_stream_t stream) {
+    SH_REQUIRE(kps && i0 && i1 && i2 && out && B > 0 && J > 0 && n_bones > 0, SH_ERR_INVALID_ARG, "sh_kps2skl: bad argument");
+    SH_REQUIRE(mode >= 0 && mode <= 3, SH_ERR_INVALID_ARG, "sh_kps2skl: unknown mode %d", mode);
+    hipLaunchKernelGGL(kps2skl_kernel, dim3((unsigned)sh_cdiv(B * n_bones, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), kps, J, i0, i1, i2,
+                       B, n_bones, mode, out);
+    SH_CHECK_LAUNCH("kps2skl");
+    return SH_OK;
+}
+
+int sh_skl2kps(const float* skl, int B, int n_bones, int mode, const int32_t* head, const int32_t* tail, int n_joints, const int32_t* keep,
+               int n_keep, float* out, sh_stream_t stream) {
+    SH_REQUIRE(skl && head && tail && keep && out && B > 0 && n_bones > 0 && n_keep > 0, SH_ERR_INVALID_ARG, "sh_skl2kps: bad argument");
+    SH_REQUIRE(mode >= 0 && mode <= 2, SH_ERR_INVALID_ARG, "sh_skl2kps: unknown mode %d", mode);
+    SH_REQUIRE(n_joints > 0 && n_joints <= SKL_MAX_J, SH_ERR_UNSUPPORTED, "sh_skl2kps: %d joints (at most %d)", n_joints, SKL_MAX_J);
+    hipLaunchKernelGGL(skl2kps_kernel, dim3((unsigned)sh_cdiv(B, 64)), dim3(64), 0, static_cast<hipStream_t>(stream), skl, head, tail, B, n_bones,
+                       n_joints, mode, keep, n_keep, out);
+    SH_CHECK_LAUNCH("skl2kps");
+    return SH_OK;
+}
+
+int sh_weighted_sum(int n, const float* const* terms, const float* weights, float* out, const float* gscale, float* grads, sh_stream_t stream) {
+    SH_REQUIRE(n > 0 && n <= WS_MAX && weights, SH_ERR_INVALID_ARG, "sh_weighted_sum: 1..%d terms", WS_MAX);
+    SH_REQUIRE((terms && out) || (gscale && grads), SH_ERR_INVALID_ARG, "sh_weighted_sum: nothing to do");
+    WSumArgs a{};
+    a.n = n;
+    for (int i = 0; i < n; ++i) { a.w[i] = weights[i]; a.t[i] = terms ? terms[i] : nullptr; SH_REQUIRE(!out || a.t[i], SH_ERR_INVALID_ARG, "sh_weighted_sum: null term %d", i); }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (out) hipLaunchKernelGGL(weighted_sum_kernel, dim3(1), dim3(1), 0, st, a, out);
+    if (grads) hipLaunchKernelGGL(weighted_sum_bwd_kernel, dim3(1), dim3(64), 0, st, a, gscale, grads);
+    SH_CHECK_LAUNCH("weighted_sum");
+    return SH_OK;
+}
 
 int sh_joint_regress(const float* x, int64_t x_bs, const float* J, int B, int N, int K, float* kps, sh_stream_t stream) {
     SH_REQUIRE(x && J && kps && B > 0 && N > 0 && K > 0, SH_ERR_INVALID_ARG, "sh_joint_regress: bad argument");

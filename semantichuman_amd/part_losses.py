@@ -110,10 +110,41 @@ def _bone_index(skl_list, device):
     return hit[1]
 
 
+_BONE_I32_CACHE = {}
+_SKL_MODES = {"ori_m": 0, "kps_ori_m": 0, "vec_m": 1, "vec": 2, "m": 3}
+
+
+def _bone_i32(skl_list, device):
+    """(head, tail, second tail or tail again) of a bone list as int32 device tensors for the kernels."""
+    key = (id(skl_list), len(skl_list), str(device))
+    hit = _BONE_I32_CACHE.get(key)
+    if hit is None or hit[0] is not skl_list:
+        idx = [torch.tensor(v, dtype=torch.int32, device=device) for v in
+               ([b[0] for b in skl_list], [b[1] for b in skl_list], [b[2] if len(b) == 3 else b[1] for b in skl_list])]
+        hit = (skl_list, idx)
+        _BONE_I32_CACHE[key] = hit
+    return hit[1]
+
+
+def _kernel_ok(t):
+    """The skeleton kernels serve what the loops hand them: contiguous fp32 HIP tensors that carry no gradient."""
+    return t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and not t.requires_grad
+
+
+def _kps2skl_kernel(kps, skl_list, mode):
+    B, J = kps.shape[0], kps.shape[1]
+    i0, i1, i2 = _bone_i32(skl_list, kps.device)
+    out = torch.empty((B, len(skl_list), (4, 4, 3, 1)[mode]), dtype=torch.float32, device=kps.device)
+    check(_lib.load().sh_kps2skl(ptr(kps), B, J, ptr(i0), ptr(i1), ptr(i2), len(skl_list), mode, ptr(out), stream_ptr()), "sh_kps2skl")
+    return out
+
+
 def bone_directions(kps, skl_list=None):
     """[B, P, 3] bone vector of each part from the FULL joint set (utils_SH.py:449-452):
     joint a - joint b, or joint a - mean(joint b, joint c)."""
     skl_list = constants.SKL_LIST if skl_list is None else skl_list
+    if _kernel_ok(kps):
+        return _kps2skl_kernel(kps, skl_list, 2)                        # one launch instead of five
     i0, i1, i2 = _bone_index(skl_list, kps.device)
     return kps[:, i0, :] - (kps[:, i1, :] + kps[:, i2, :]) / 2          # two-joint bones have i2 == i1: (a + a) / 2 == a exactly
 
@@ -323,11 +354,17 @@ def zpart_regulariser(z_part, measure, part_idx, measure_idx, relat=True):
 def kps2skl(kps_tmp, skl_mode="ori_m", newskl_list=None):
     """utils_SH.py:26-69."""
     skl_list = constants.NEWSKL_LIST if newskl_list is None else newskl_list
+    if skl_mode not in _SKL_MODES:
+        raise NotImplementedError(skl_mode)
     if kps_tmp.shape[1] == len(skl_list) + 4:
+        if _kernel_ok(kps_tmp):
+            return _kps2skl_kernel(kps_tmp, skl_list, _SKL_MODES[skl_mode])     # one launch instead of twelve, the same bits
         kps = kps_tmp.clone()
     else:
         kps = torch.zeros((kps_tmp.shape[0], len(skl_list) + 4, 3), device=kps_tmp.device)
         kps[:, index_tensor(constants.kps_keep(skl_list), kps_tmp.device), :] = kps_tmp
+    if _kernel_ok(kps):
+        return _kps2skl_kernel(kps, skl_list, _SKL_MODES[skl_mode])
     i0, i1, i2 = _bone_index(skl_list, kps.device)
     vec = kps[:, i0, :] - (kps[:, i1, :] + kps[:, i2, :]) / 2            # [B, n_bones, 3]; i2 == i1 for two-joint bones
     n = torch.sqrt(torch.sum(vec ** 2, dim=2, keepdim=True))
@@ -370,6 +407,14 @@ def skl2kps(skl, skl_mode="ori_m", newskl_list=None):
     """utils_SH.py:71-84: rebuild joints from the root outwards (joint b[1] = joint b[0] - bone), one tree level at a
     time - the same subtraction per joint as the reference's bone-by-bone loop."""
     skl_list = constants.NEWSKL_LIST if newskl_list is None else newskl_list
+    if skl_mode in ("ori_m", "kps_ori_m", "vec_m", "vec") and _kernel_ok(skl) and len(skl_list) + 4 <= 64:
+        # the reference's bone-by-bone loop as ONE launch (a thread per batch entry walks the list) instead of five per tree level
+        head, tail, _ = _bone_i32(skl_list, skl.device)
+        keep = _i32(constants.kps_keep(skl_list), skl.device)
+        out = torch.empty((skl.shape[0], keep.shape[0], 3), dtype=torch.float32, device=skl.device)
+        check(_lib.load().sh_skl2kps(ptr(skl), skl.shape[0], len(skl_list), {"ori_m": 0, "kps_ori_m": 0, "vec_m": 1, "vec": 2}[skl_mode],
+                                     ptr(head), ptr(tail), len(skl_list) + 4, ptr(keep), keep.shape[0], ptr(out), stream_ptr()), "sh_skl2kps")
+        return out
     if skl_mode == "vec":
         bone = skl
     elif skl_mode == "vec_m":

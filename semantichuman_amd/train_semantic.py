@@ -129,6 +129,67 @@ def _full_scale(ctx, part_index, a, B):
     return s
 
 
+class _WeightedSum(torch.autograd.Function):
+    """total = t0 (* w0) + w1 * t1 + ... in sequence - the loop's `loss = loss + w * term` chain - as ONE launch forward and
+    one backward (sh_weighted_sum) instead of a multiply, an add and a MulBackward per term.  Same arithmetic, same bits."""
+
+    @staticmethod
+    def forward(ctx, weights, *terms):
+        import ctypes
+        from . import _lib
+        n = len(terms)
+        arr = (ctypes.c_void_p * n)(*[t.data_ptr() for t in terms])
+        w = (ctypes.c_float * n)(*weights)
+        out = torch.empty((), dtype=torch.float32, device=terms[0].device)
+        _lib.check(_lib.load().sh_weighted_sum(n, arr, w, _lib.ptr(out), None, None, _lib.stream_ptr()), "sh_weighted_sum")
+        ctx.weights = tuple(weights)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes
+        from . import _lib
+        n = len(ctx.weights)
+        w = (ctypes.c_float * n)(*ctx.weights)
+        grads = torch.empty((n,), dtype=torch.float32, device=g.device)
+        _lib.check(_lib.load().sh_weighted_sum(n, None, w, None, _lib.ptr(g.contiguous()), _lib.ptr(grads), _lib.stream_ptr()), "sh_weighted_sum")
+        return (None,) + tuple(grads[i] for i in range(n))
+
+
+def weighted_sum(pairs):
+    """pairs: [(weight, scalar loss tensor)], the first weight 1 - summed in list order."""
+    ts = [t for _, t in pairs]
+    if len(pairs) > 1 and len(pairs) <= 16 and all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 0 for t in ts):
+        return _WeightedSum.apply(tuple(float(w) for w, _ in pairs), *ts)
+    loss = ts[0] if pairs[0][0] == 1 else pairs[0][0] * ts[0]
+    for w, t in pairs[1:]:
+        loss = loss + w * t
+    return loss
+
+
+class _SplitRows(torch.autograd.Function):
+    """x[:n0], x[n0:n0+n1], ... as views; backward = one concatenation of the pieces' gradients (instead of a zero-filled
+    full-size tensor, a copy and an add per piece)."""
+
+    @staticmethod
+    def forward(ctx, x, *sizes):
+        ctx.sizes, ctx.meta = sizes, (x.shape, x.dtype, x.device)
+        outs, o = [], 0
+        for n in sizes:
+            outs.append(x.narrow(0, o, n))
+            o += n
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        shape, dtype, dev = ctx.meta
+        parts = [g if g is not None else torch.zeros((n,) + tuple(shape[1:]), dtype=dtype, device=dev) for g, n in zip(gs, ctx.sizes)]
+        rest = shape[0] - sum(ctx.sizes)
+        if rest:
+            parts.append(torch.zeros((rest,) + tuple(shape[1:]), dtype=dtype, device=dev))
+        return (torch.cat(parts, dim=0),) + (None,) * len(ctx.sizes)
+
+
 def semantic_losses(model, ctx, tx, tx_interp, tx_exc, epoch, measure=None, interp_measure=None, loss_fn=None,
                     draw_factor=None, exc_choice=None):
     """All loss terms of one iteration (reference :129-389).  Returns (total, dict of terms).
@@ -191,35 +252,36 @@ def semantic_losses(model, ctx, tx, tx_interp, tx_exc, epoch, measure=None, inte
         full[B0:B0 + Bi] = scale
         lat_in = latent * full[:, :, None]
     rec = model.decode(lat_in, latent_kps, dummy)
-    tx_hat, tx_zpart = rec[:B0], latent[:B0]
+    tx_zpart = latent[:B0]
+    pieces = _SplitRows.apply(rec, *([B0] + ([Bi] if do_interp else []) + ([Be] if do_exc else [])))
+    tx_hat = pieces[0]
     ctx.last_tx_hat = tx_hat.detach()                          # reconstruction of the training batch (save_recons, :459-470)
-    o0 = B0
     if do_interp:
-        rec_interp, o0 = rec[o0:o0 + Bi], o0 + Bi
+        rec_interp = pieces[1]
     if do_exc:
-        rec_exc = rec[o0:o0 + Be]
+        rec_exc = pieces[-1]
 
     terms["rec_loss"] = loss_fn(tx, tx_hat)
-    loss = terms["rec_loss"]
+    weighted = [(1.0, terms["rec_loss"])]                      # `loss = loss + w * term`, summed in this order at the end
     if epoch > o.edgereg_epoch and o.edgereg_w > 0:
         if ctx.face_tables is None:
             ctx.face_tables = losses.FaceTables(ctx.f_np, tx.shape[1], ctx.device)
         terms["edgereg_loss"] = losses.edge_ratio_loss(tx_hat, tx, ctx.face_tables)
-        loss = loss + o.edgereg_w * terms["edgereg_loss"]
+        weighted.append((o.edgereg_w, terms["edgereg_loss"]))
     if epoch > o.zpartreg_epoch and o.zpartreg_w > 0 and measure is not None:
         terms["zpartreg_loss"] = part_losses.zpart_regulariser_fused(tx_zpart, measure, ctx.part_index_in_allpart,
                                                                      ctx.part_index_in_measure, o.relat_flag)
-        loss = loss + o.zpartreg_w * terms["zpartreg_loss"]
+        weighted.append((o.zpartreg_w, terms["zpartreg_loss"]))
 
     if do_interp:
         if o.interp_kps_w > 0:
             terms["interp_kps_loss"] = part_losses.joint_l1_loss(rec_interp, new_kps_i, ctx.J, ctx.kps_keep_i32)
-            loss = loss + o.interp_kps_w * terms["interp_kps_loss"]
+            weighted.append((o.interp_kps_w, terms["interp_kps_loss"]))
         if o.interp_euc_w > 0:
             terms["interp_euc_loss"] = part_losses.part_pairdist_loss(rec_interp, tx_interp, kps_i, ctx.tables, scale=scale,
                                                                       w_mode=o.w_mode, w_threshold=o.w_threshold,
                                                                       relat=o.relat_flag, skl_list=o.skl_list)
-            loss = loss + o.interp_euc_w * terms["interp_euc_loss"]
+            weighted.append((o.interp_euc_w, terms["interp_euc_loss"]))
 
     if do_exc:
         if epoch > o.vol_epoch and o.vol_w > 0 and exc_kind == "ori":
@@ -227,16 +289,16 @@ def semantic_losses(model, ctx, tx, tx_interp, tx_exc, epoch, measure=None, inte
                 ctx.part_faces = part_losses.PartFaceTables(ctx.f_np, ctx.fpi.cpu().numpy(), ctx.part_index_in_allpart, rec_exc.shape[1],
                                                             ctx.device)
             terms["vol_loss"] = part_losses.part_volume_loss_fused(rec_exc, tx_exc, ctx.part_faces)
-            loss = loss + o.vol_w * terms["vol_loss"]
+            weighted.append((o.vol_w, terms["vol_loss"]))
         if o.exc_kps_w > 0:
             terms["exc_kps_loss"] = part_losses.joint_l1_loss(rec_exc, new_kps_e, ctx.J, ctx.kps_keep_i32)
-            loss = loss + o.exc_kps_w * terms["exc_kps_loss"]
+            weighted.append((o.exc_kps_w, terms["exc_kps_loss"]))
         if o.exc_euc_w > 0:
             terms["exc_euc_loss"] = part_losses.part_pairdist_loss(rec_exc, tx_exc, kps_e, ctx.tables, scale=None, w_mode=o.w_mode,
                                                                    w_threshold=o.w_threshold, relat=o.relat_flag,
                                                                    skl_list=o.skl_list)
-            loss = loss + o.exc_euc_w * terms["exc_euc_loss"]
-    return loss, terms
+            weighted.append((o.exc_euc_w, terms["exc_euc_loss"]))
+    return weighted_sum(weighted), terms
 
 
 class _Cycler:

@@ -397,3 +397,102 @@ def test_hip_small_semantic_losses_as_kernels(sem):
         assert float((z1.grad - z2.grad).abs().max()) <= 1e-6 * float(z2.grad.abs().max()) + 1e-9
     a2 = pl.joint_l1_loss(rec.clone().requires_grad_(True), target, J, keep)
     assert torch.equal(a2.detach(), l1.detach())
+
+
+@pytest.mark.gpu
+def test_skeleton_kernels_equal_the_tensor_op_forms_bitwise():
+    """sh_kps2skl / sh_skl2kps / the pair loss's bone directions (one launch each) against the tensor-op forms of the same
+    functions (which the CPU tests pin to the reference, utils_SH.py:26-84): the same bits, every mode; and
+    sh_weighted_sum against the `loss = loss + w * term` chain, value and gradients."""
+    from semantichuman_amd import part_losses as pl
+    from semantichuman_amd import train_semantic as ts
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    n_j = len(C.NEWSKL_LIST) + 4
+    kps = (torch.randn(16, n_j, 3, generator=g) * 0.3).to(dev)
+    kps_g = kps.clone().requires_grad_(True)                      # a tensor that carries a gradient takes the tensor-op path
+    for mode in ("ori_m", "vec_m", "vec", "m"):
+        a, b = pl.kps2skl(kps, mode), pl.kps2skl(kps_g, mode).detach()
+        assert a.shape == b.shape and torch.equal(a, b), mode
+    skl = pl.kps2skl(kps, "ori_m")
+    for mode, s in (("ori_m", skl), ("vec_m", pl.kps2skl(kps, "vec_m")), ("vec", pl.kps2skl(kps, "vec"))):
+        a, b = pl.skl2kps(s, mode), pl.skl2kps(s.clone().requires_grad_(True), mode).detach()
+        assert a.shape == b.shape and torch.equal(a, b), mode
+    full = (torch.randn(5, 40, 3, generator=g)).to(dev)
+    assert torch.equal(pl.bone_directions(full), pl.bone_directions(full.clone().requires_grad_(True)).detach())
+    # weighted sum
+    vals = [torch.tensor(v, device=dev, requires_grad=True) for v in (0.731, 12.5, 3e-4, 0.0421, 7.7)]
+    ws = (1.0, 1e-2, 1e-2, 1.0, 0.37)
+    tot = ts.weighted_sum(list(zip(ws, vals)))
+    ref_vals = [v.detach().clone().requires_grad_(True) for v in vals]
+    ref = ref_vals[0]
+    for w, v in zip(ws[1:], ref_vals[1:]):
+        ref = ref + w * v
+    assert torch.equal(tot.detach(), ref.detach())
+    (tot * 3.0).backward()
+    (ref * 3.0).backward()
+    for v, r in zip(vals, ref_vals):
+        assert torch.equal(v.grad, r.grad)
+
+
+@pytest.mark.gpu
+def test_semantic_losses_fused_bookkeeping_is_bitwise_the_tensor_op_form():
+    """One iteration's losses with the round-3 launch savings (skeleton kernels, sh_weighted_sum, one-concatenation split of
+    the decoded batch) against the same iteration with every one of them switched back to tensor ops: the total, every term
+    and every parameter gradient bit for bit."""
+    import sys
+    from types import SimpleNamespace
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import bench_semantic as bs
+    import semantichuman_amd as sh
+    from semantichuman_amd import part_losses as pl, synthetic, train_semantic as ts
+    dev = torch.device("cuda:0")
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    h = load_hierarchy(os.path.join(golden, "template6890.npz"))
+    vi = h.verts / np.asarray((0.25, 0.15, 0.9))
+    fine = dict(zip(C.PART_LIST, bs.voronoi_parts(vi, 17)))
+    idx = np.arange(h.sizes[0])
+    for d in h.D:
+        idx = idx[np.asarray(d.col[:-1])]
+    coarse = dict(zip(C.PART_LIST, bs.voronoi_parts(vi[idx], 17)))
+    J = np.abs(synthetic.closed_form_fill((35, h.sizes[0]), 1.0, 0.618, 0.3)) ** 8
+    J = (J / J.sum(1, keepdims=True)).astype(np.float32)
+    torch.manual_seed(2)
+    m = sh.SpiralAutoencoder_multiz_partkps(C.KPS_INDEX_LIST, coarse, C.FILTER_SIZES_ENC, C.FILTER_SIZES_DEC, 8, 8, h.sizes,
+                                            h.spiral_sizes, h.spirals, h.D, h.U, dev)
+    ctx = ts.SemanticContext(ts.SemanticTrainOptions(), SimpleNamespace(reference_mesh=SimpleNamespace(f=h.faces)), J, fine,
+                             C.PART_LIST, dev)
+    B = 4
+    tx, txi, txe = (torch.from_numpy(synthetic.synth_batch(h.verts, B, seed=s)).to(dev) for s in (1, 2, 3))
+    measure = torch.ones((B, 32), device=dev)
+
+    def run():
+        m.zero_grad(set_to_none=True)
+        total, terms = ts.semantic_losses(m, ctx, tx, txi, txe, epoch=1, measure=measure, draw_factor=1.1, exc_choice="ori")
+        total.backward()
+        return total.detach().clone(), {k: v.detach().clone() for k, v in terms.items()}, [p.grad.clone() for p in m.parameters()]
+    fused = run()
+    saved = pl._kernel_ok, ts.weighted_sum, ts._SplitRows.apply
+
+    def plain_sum(pairs):
+        loss = pairs[0][1]
+        for w, t in pairs[1:]:
+            loss = loss + w * t
+        return loss
+
+    def plain_split(x, *sizes):
+        outs, o = [], 0
+        for n in sizes:
+            outs.append(x[o:o + n]); o += n
+        return tuple(outs)
+    try:
+        pl._kernel_ok = lambda t: False
+        ts.weighted_sum = plain_sum
+        ts._SplitRows.apply = staticmethod(plain_split)
+        plain = run()
+    finally:
+        pl._kernel_ok, ts.weighted_sum = saved[0], saved[1]
+        ts._SplitRows.apply = saved[2]
+    assert torch.equal(fused[0], plain[0])
+    assert fused[1].keys() == plain[1].keys() and all(torch.equal(fused[1][k], plain[1][k]) for k in fused[1])
+    assert len(fused[2]) == len(plain[2]) and all(torch.equal(a, b) for a, b in zip(fused[2], plain[2]))
