@@ -10,7 +10,7 @@
 
 namespace {
 
-constexpr int AT = 24;          // tensors per launch (kernel-argument table)
+constexpr int AT = 60;          // tensors per launch (kernel-argument table: 3.6 KiB of the 4 KiB a launch may carry)
 constexpr int ACH = 4096;       // elements per workgroup
 constexpr int ANT = 256;
 

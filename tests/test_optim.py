@@ -6,7 +6,7 @@ import torch
 
 import semantichuman_amd as sh
 
-SHAPES = [(7,), (33, 5), (4096,), (4097,), (3, 16, 30), (128, 1024), (1,)] + [(11 + i,) for i in range(22)]   # > 24 tensors: two launches
+SHAPES = [(7,), (33, 5), (4096,), (4097,), (3, 16, 30), (128, 1024), (1,)] + [(11 + i,) for i in range(60)]   # > 60 tensors: two launches
 
 
 def make(dev, seed=0):
