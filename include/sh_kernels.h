@@ -346,6 +346,19 @@ SH_API int sh_part_pairdist_loss_bwd(const float* x_rec, const float* x_gt, cons
                               const int32_t* flags, const float* w_part, int B, int N1, int P, int T, int max_part,
                               int w_mode, float w_threshold, int relat, const float* part_cnt, const float* gscale,
                               float* grad, sh_stream_t stream);
+/* The forward pass that also leaves the backward pass's row sums: grad_raw [B][N1][3] (rows of part vertices written, the
+ * rest untouched) = pairdist's gradient without the factor 2 gscale w_p / count_p, which only exists once the counts are
+ * complete; sh_part_pairdist_loss_bwd_scale applies it (grad: cleared, then the part vertices' rows written;
+ * n_part_verts = part_ptr[P]) - the same bits as sh_part_pairdist_loss_bwd, without its second sweep over the pairs.
+ * grad_raw == NULL: exactly sh_part_pairdist_loss_fwd. */
+SH_API int sh_part_pairdist_loss_fwd_grad(const float* x_rec, const float* x_gt, const float* bone, const float* scale,
+                                   const int32_t* part_ptr, const int32_t* part_vert, const int32_t* tile_ptr, const int32_t* flags,
+                                   const float* w_part, int B, int N1, int P, int T, int max_part, int w_mode, float w_threshold,
+                                   int relat, float* loss, float* part_sum, float* part_cnt, float* grad_raw, void* workspace,
+                                   size_t workspace_bytes, sh_stream_t stream);
+SH_API int sh_part_pairdist_loss_bwd_scale(const float* grad_raw, const int32_t* part_ptr, const int32_t* part_vert,
+                                   const float* w_part, const float* part_cnt, const float* gscale, int B, int N1, int P,
+                                   int n_part_verts, float* grad, sh_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Body measurements (utils_SH.py:86-98 cal_length, :144-161 measure_body_quick; numpy twins

@@ -61,6 +61,8 @@ SIGNATURES = {
     "sh_part_pairdist_tile_rows": (c_int, []),
     "sh_part_pairdist_loss_fwd": (c_int, [_P] * 9 + [_I] * 6 + [c_float, _I, _P, _P, _P, _P, c_size_t, _P]),
     "sh_part_pairdist_loss_bwd": (c_int, [_P] * 9 + [_I] * 6 + [c_float, _I, _P, _P, _P, _P]),
+    "sh_part_pairdist_loss_fwd_grad": (c_int, [_P] * 9 + [_I] * 6 + [c_float, _I, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "sh_part_pairdist_loss_bwd_scale": (c_int, [_P] * 6 + [_I] * 4 + [_P, _P]),
     "sh_measure_girth": (c_int, [_P, _L, _P, _P, _P, _P, _I, _I, _P, _P]),
     "sh_bone_length": (c_int, [_P, _P, _I, _I, _I, _P, _P]),
     "sh_dataset_normalize": (c_int, [_P, _P, _I, _I, _I, ctypes.c_uint, _P, _P, _P, _P, _P, _P]),

@@ -53,8 +53,15 @@ __device__ __forceinline__ int find_part(const int* tile_ptr, int P, int t) {
     return p;
 }
 
-// forward: partial[(b*T + t)*2 + {0,1}] = (sum of terms, number of kept pairs) of the block's rows
-__global__ __launch_bounds__(PNT) void pairdist_fwd_kernel(const PLParams q, float* __restrict__ partial) {
+// forward: partial[(b*T + t)*2 + {0,1}] = (sum of terms, number of kept pairs) of the block's rows.
+// GRAD: the sweep also leaves the backward pass's row sums  graw[b][v][:] = sum_j coef_ij (r_i - r_j) / |r_i - r_j|  - everything
+// the gradient needs except the factor 2 gscale w_p / count_p, which exists only once every row of the part is done: the
+// backward pass is then one scaling launch instead of a second sweep over the 44.6 M pairs (acosf, two square roots and
+// three divisions each).  The sums are formed exactly as pairdist_bwd_kernel forms them (same expressions, same order), so
+// scale(graw) is that kernel's output bit for bit.
+// (One kernel whether graw is wanted or not: two instantiations summed the loss to different last bits.)
+__global__ __launch_bounds__(PNT) void pairdist_fwd_kernel(const PLParams q, float* __restrict__ partial, float* __restrict__ graw) {
+    constexpr bool GRAD = true;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.x / q.T, t = blockIdx.x - b * q.T;
     const int p = find_part(q.tile_ptr, q.P, t);
@@ -73,6 +80,7 @@ __global__ __launch_bounds__(PNT) void pairdist_fwd_kernel(const PLParams q, flo
     const bool all_one = q.flags[p] & 1;
     const int i = (t - q.tile_ptr[p]) * PT + (threadIdx.x / JS), seg = threadIdx.x % JS;
     float s = 0.f, cnt = 0.f;
+    float ax = 0.f, ay = 0.f, az = 0.f;
     if (i < n) {
         const float gx = G[3 * i], gy = G[3 * i + 1], gz = G[3 * i + 2];
         const float rx = R[3 * i], ry = R[3 * i + 1], rz = R[3 * i + 2];
@@ -85,8 +93,25 @@ __global__ __launch_bounds__(PNT) void pairdist_fwd_kernel(const PLParams q, flo
             if (w * De == 0.f) continue;
             const float ux = rx - R[3 * j], uy = ry - R[3 * j + 1], uz = rz - R[3 * j + 2];
             const float Dr = sqrtf(ux * ux + uy * uy + uz * uz);
-            s += q.relat ? fabsf(w * Dr / De - w) : fabsf(w * Dr - w * De);
+            const float e = q.relat ? (w * Dr / De - w) : (w * Dr - w * De);      // one evaluation for the term and its sign
+            s += fabsf(e);
             cnt += 1.f;
+            if (GRAD) {                                              // pairdist_bwd_kernel's statements
+                if (Dr == 0.f) continue;
+                const float sg = e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f);
+                const float c = sg * (q.relat ? w / De : w) / Dr;
+                ax += c * ux; ay += c * uy; az += c * uz;
+            }
+        }
+    }
+    if (GRAD) {
+#pragma unroll
+        for (int m = 1; m < JS; m <<= 1) {                           // the row's JS partial sums (adjacent lanes), fixed order
+            ax += __shfl_xor(ax, m, 64); ay += __shfl_xor(ay, m, 64); az += __shfl_xor(az, m, 64);
+        }
+        if (graw != nullptr && i < n && seg == 0) {
+            const long o = ((long)b * q.N1 + q.part_vert[v0 + i]) * 3;
+            graw[o] = ax; graw[o + 1] = ay; graw[o + 2] = az;
         }
     }
     __shared__ float red[2][PNT / 64];
@@ -180,6 +205,24 @@ __global__ __launch_bounds__(PNT) void pairdist_bwd_kernel(const PLParams q, con
     grad[o] = norm * ax; grad[o + 1] = norm * ay; grad[o + 2] = norm * az;
 }
 
+// backward from the forward pass's row sums: grad[b][v][:] = (2 gscale w_p / count_p) * graw[b][v][:] for the vertices of part p
+// (rows outside every part stay zero: the caller cleared grad)
+__global__ __launch_bounds__(256) void pairdist_scale_kernel(const float* __restrict__ graw, const int* __restrict__ part_ptr,
+                                                            const int* __restrict__ part_vert, const float* __restrict__ w_part,
+                                                            const float* __restrict__ part_cnt, const float* __restrict__ gscale, int B,
+                                                            int N1, int P, float* __restrict__ grad) {
+    const int nv = part_ptr[P];
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)B * nv) return;
+    const int b = (int)(t / nv), k = (int)(t - (long)b * nv);
+    int p = 0;
+    while (p + 1 < P && part_ptr[p + 1] <= k) ++p;
+    const float cnt = part_cnt[p];
+    const float norm = cnt > 0.f ? 2.f * gscale[0] * w_part[p] / cnt : 0.f;
+    const long o = ((long)b * N1 + part_vert[k]) * 3;
+    grad[o] = norm * graw[o]; grad[o + 1] = norm * graw[o + 1]; grad[o + 2] = norm * graw[o + 2];
+}
+
 int fill(PLParams& q, const float* x_rec, const float* x_gt, const float* bone, const float* scale, const int32_t* part_ptr,
          const int32_t* part_vert, const int32_t* tile_ptr, const int32_t* flags, const float* w_part, int B, int N1, int P,
          int T, int w_mode, float thr, int relat) {
@@ -203,6 +246,15 @@ int sh_part_pairdist_loss_fwd(const float* x_rec, const float* x_gt, const float
                               const int32_t* part_vert, const int32_t* tile_ptr, const int32_t* flags, const float* w_part, int B,
                               int N1, int P, int T, int max_part, int w_mode, float w_threshold, int relat, float* loss,
                               float* part_sum, float* part_cnt, void* workspace, size_t workspace_bytes, sh_stream_t stream) {
+    return sh_part_pairdist_loss_fwd_grad(x_rec, x_gt, bone, scale, part_ptr, part_vert, tile_ptr, flags, w_part, B, N1, P, T, max_part, w_mode,
+                                          w_threshold, relat, loss, part_sum, part_cnt, nullptr, workspace, workspace_bytes, stream);
+}
+
+int sh_part_pairdist_loss_fwd_grad(const float* x_rec, const float* x_gt, const float* bone, const float* scale, const int32_t* part_ptr,
+                                   const int32_t* part_vert, const int32_t* tile_ptr, const int32_t* flags, const float* w_part, int B,
+                                   int N1, int P, int T, int max_part, int w_mode, float w_threshold, int relat, float* loss,
+                                   float* part_sum, float* part_cnt, float* grad_raw, void* workspace, size_t workspace_bytes,
+                                   sh_stream_t stream) {
     PLParams q{};
     const int rc = fill(q, x_rec, x_gt, bone, scale, part_ptr, part_vert, tile_ptr, flags, w_part, B, N1, P, T, w_mode, w_threshold, relat);
     if (rc != SH_OK) return rc;
@@ -212,8 +264,8 @@ int sh_part_pairdist_loss_fwd(const float* x_rec, const float* x_gt, const float
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* partial = static_cast<float*>(workspace);
     {
-        ShProfScope ps(st, "pairdist_fwd_kernel|B=%d T=%d", B, T);
-        hipLaunchKernelGGL(pairdist_fwd_kernel, dim3((unsigned)(B * T)), dim3(PNT), (size_t)max_part * 24, st, q, partial);
+        ShProfScope ps(st, "pairdist_fwd_kernel|B=%d T=%d grad=%d", B, T, grad_raw ? 1 : 0);
+        hipLaunchKernelGGL(pairdist_fwd_kernel, dim3((unsigned)(B * T)), dim3(PNT), (size_t)max_part * 24, st, q, partial, grad_raw);
     }
     hipLaunchKernelGGL(pairdist_final_kernel, dim3(1), dim3(64), 0, st, partial, tile_ptr, w_part, B, P, T, part_sum, part_cnt, loss);
     SH_CHECK_LAUNCH("part_pairdist_loss_fwd");
@@ -238,6 +290,23 @@ int sh_part_pairdist_loss_bwd(const float* x_rec, const float* x_gt, const float
         hipLaunchKernelGGL(pairdist_bwd_kernel, dim3((unsigned)(B * T)), dim3(PNT), (size_t)max_part * 24, st, q, part_cnt, gscale, grad);
     }
     SH_CHECK_LAUNCH("part_pairdist_loss_bwd");
+    return SH_OK;
+}
+
+int sh_part_pairdist_loss_bwd_scale(const float* grad_raw, const int32_t* part_ptr, const int32_t* part_vert, const float* w_part,
+                                    const float* part_cnt, const float* gscale, int B, int N1, int P, int n_part_verts, float* grad,
+                                    sh_stream_t stream) {
+    SH_REQUIRE(grad_raw && part_ptr && part_vert && w_part && part_cnt && gscale && grad && B > 0 && N1 > 0 && P > 0 && n_part_verts > 0,
+               SH_ERR_INVALID_ARG, "sh_part_pairdist_loss_bwd_scale: bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(grad, 0, (size_t)B * N1 * 3 * sizeof(float), st) != hipSuccess) {
+        sh_set_error("sh_part_pairdist_loss_bwd_scale: memset failed");
+        return SH_ERR_LAUNCH;
+    }
+    const long n = (long)B * n_part_verts;
+    hipLaunchKernelGGL(pairdist_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, grad_raw, part_ptr, part_vert, w_part, part_cnt,
+                       gscale, B, N1, P, grad);
+    SH_CHECK_LAUNCH("part_pairdist_loss_bwd_scale");
     return SH_OK;
 }
 

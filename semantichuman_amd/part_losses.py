@@ -56,16 +56,32 @@ class _PairDist(torch.autograd.Function):
         psum = torch.empty(tb.P, dtype=torch.float32, device=dev)
         pcnt = torch.empty(tb.P, dtype=torch.float32, device=dev)
         ws = torch.empty(B * tb.T * 2, dtype=torch.float32, device=dev)
-        check(_lib.load().sh_part_pairdist_loss_fwd(ptr(x_rec), ptr(x_gt), ptr(bone), ptr(scale), ptr(tb.part_ptr), ptr(tb.part_vert),
-                                                    ptr(tb.tile_ptr), ptr(tb.flags), ptr(tb.w_part), B, N1, tb.P, tb.T, tb.max_part,
-                                                    w_mode, thr, int(relat), ptr(loss), ptr(psum), ptr(pcnt), ptr(ws), ws.numel() * 4,
-                                                    stream_ptr()), "sh_part_pairdist_loss_fwd")
+        # when the reconstruction carries a gradient the same sweep leaves the backward pass's row sums (everything but the
+        # factor 2 g w_p / count_p): backward is then one scaling launch, not a second sweep over the pairs - the same bits
+        graw = torch.empty_like(x_rec) if ctx.needs_input_grad[0] else None
+        check(_lib.load().sh_part_pairdist_loss_fwd_grad(ptr(x_rec), ptr(x_gt), ptr(bone), ptr(scale), ptr(tb.part_ptr), ptr(tb.part_vert),
+                                                         ptr(tb.tile_ptr), ptr(tb.flags), ptr(tb.w_part), B, N1, tb.P, tb.T, tb.max_part,
+                                                         w_mode, thr, int(relat), ptr(loss), ptr(psum), ptr(pcnt), ptr(graw), ptr(ws),
+                                                         ws.numel() * 4, stream_ptr()), "sh_part_pairdist_loss_fwd_grad")
+        if graw is not None:
+            ctx.save_for_backward(graw, pcnt)
+            ctx.args = (tb, None)
+            return loss
         ctx.save_for_backward(x_rec, x_gt, bone, pcnt) if scale is None else ctx.save_for_backward(x_rec, x_gt, bone, pcnt, scale)
         ctx.args = (tb, w_mode, thr, relat, scale is not None)
         return loss
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.args[1] is None:                                     # the forward pass left the row sums
+            tb = ctx.args[0]
+            graw, pcnt = ctx.saved_tensors
+            B, N1, _ = graw.shape
+            grad = torch.empty_like(graw)
+            check(_lib.load().sh_part_pairdist_loss_bwd_scale(ptr(graw), ptr(tb.part_ptr), ptr(tb.part_vert), ptr(tb.w_part), ptr(pcnt),
+                                                              ptr(g.contiguous()), B, N1, tb.P, int(tb.part_vert.numel()), ptr(grad),
+                                                              stream_ptr()), "sh_part_pairdist_loss_bwd_scale")
+            return grad, None, None, None, None, None, None, None
         tb, w_mode, thr, relat, has_scale = ctx.args
         saved = ctx.saved_tensors
         x_rec, x_gt, bone, pcnt = saved[:4]

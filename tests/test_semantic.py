@@ -187,6 +187,25 @@ def test_hip_part_pairdist_loss_matches_reference(sem, relat):
                                         list(fine.values()), C.SKL_LIST, LEAF, None, mode, 0.8, relat)
         assert lm.item() == pytest.approx(float(lo), rel=1e-4), mode
     assert torch.equal(pl.part_pairdist_loss(rec.detach(), x, kf, tb, relat=relat), pl.part_pairdist_loss(rec.detach(), x, kf, tb, relat=relat))
+    # the gradient above came from the forward sweep's row sums + one scaling launch; the stand-alone backward sweep
+    # (sh_part_pairdist_loss_bwd) must give the same bits
+    from semantichuman_amd._lib import check, load, ptr, stream_ptr
+    sc = scale_of(g).to(dev).contiguous()
+    bone = pl.bone_directions(kf)
+    B, N1 = rec.shape[0], rec.shape[1]
+    loss2, psum, pcnt = (torch.empty(s, device=dev) for s in ((), (tb.P,), (tb.P,)))
+    ws = torch.empty(B * tb.T * 2, device=dev)
+    rd = rec.detach().contiguous()
+    check(load().sh_part_pairdist_loss_fwd(ptr(rd), ptr(x), ptr(bone), ptr(sc), ptr(tb.part_ptr), ptr(tb.part_vert), ptr(tb.tile_ptr),
+                                           ptr(tb.flags), ptr(tb.w_part), B, N1, tb.P, tb.T, tb.max_part, 3, 0.8, int(relat), ptr(loss2),
+                                           ptr(psum), ptr(pcnt), ptr(ws), ws.numel() * 4, stream_ptr()), "fwd")
+    grad2 = torch.empty_like(rd)
+    one = torch.ones((), device=dev)
+    check(load().sh_part_pairdist_loss_bwd(ptr(rd), ptr(x), ptr(bone), ptr(sc), ptr(tb.part_ptr), ptr(tb.part_vert), ptr(tb.tile_ptr),
+                                           ptr(tb.flags), ptr(tb.w_part), B, N1, tb.P, tb.T, tb.max_part, 3, 0.8, int(relat), ptr(pcnt),
+                                           ptr(one), ptr(grad2), stream_ptr()), "bwd")
+    assert torch.equal(grad2, rec.grad), float((grad2 - rec.grad).abs().max())
+    assert torch.equal(loss2, l.detach()), (float(loss2), float(l))
 
 
 # ------------------------------------------------------------------------------------------ semantic loop
