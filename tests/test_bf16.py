@@ -375,6 +375,56 @@ def test_adam_keeps_bf16_working_copies_current():
     assert torch.equal(shadow.lookup(m.fc_latent_enc.weight), m.fc_latent_enc.weight.detach().to(torch.bfloat16))
 
 
+def test_captured_bf16_step_survives_load_state_dict():
+    """A hipGraph of the bf16 step has the bf16 working copies' addresses baked in (the latent FCs read them, Adam rewrites
+    them).  load_state_dict makes the copies stale; the next eager use must refresh them IN PLACE, so that a replay of the
+    old graph reads current weights: replay from a restored state == the first replay from that state, bit for bit."""
+    from semantichuman_amd import shadow
+    p = os.path.join(GOLDEN, "small_ae.npz")
+    g, h = np.load(p), load_hierarchy(p)
+    m, _ = _models(h, g, 16)
+    x = torch.from_numpy(g["x"]).to(dev())
+    opt = sh.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-5)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        sh.l1_loss(x, m(x)[0]).backward()
+        opt.step()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    torch.cuda.synchronize()
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    opt0 = {id(q): {k: v.detach().clone() for k, v in opt.state[q].items()} for q in m.parameters()}
+    addr = {n: shadow.lookup(w).data_ptr() for n, w in (("enc", m.fc_latent_enc.weight), ("dec", m.fc_latent_dec.weight))}
+    graph.replay()
+    torch.cuda.synchronize()
+    first = [q.detach().clone() for q in m.parameters()]
+    assert not torch.equal(first[0], list(sd0.values())[0])          # the replay did train
+    # back to the captured state through torch: parameters by load_state_dict (in-place copies: version bump -> stale copies),
+    # optimizer state tensor by tensor
+    m.load_state_dict(sd0)
+    for q in m.parameters():
+        for k, v in opt.state[q].items():
+            v.copy_(opt0[id(q)][k])
+    assert shadow.lookup(m.fc_latent_enc.weight) is None             # stale until the next use ...
+    with torch.no_grad():
+        m(x)                                                          # ... which refreshes them where they are
+    for n, w in (("enc", m.fc_latent_enc.weight), ("dec", m.fc_latent_dec.weight)):
+        assert shadow.lookup(w) is not None and shadow.lookup(w).data_ptr() == addr[n], n
+    graph.replay()
+    torch.cuda.synchronize()
+    for a, q in zip(first, m.parameters()):
+        assert torch.equal(a, q.detach())
+
+
 def test_matched_l2_bf16_vs_fp32_training():
     """Config 3's acceptance: 'matched L2' on the trained metric.  30 training steps (batch 16, L1 + 1e-2 edge loss, Adam)
     from the same weights on the same batches, bf16 path vs fp32 path; held-out per-vertex L2 within 5 %.
