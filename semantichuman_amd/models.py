@@ -16,6 +16,8 @@ There is no CPU execution path: calling forward on CPU tensors raises.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -116,7 +118,9 @@ def conv_layout(filters_enc, filters_dec, spiral_sizes, activation):
     return enc, dec
 
 
-def build_encoder_stack(enc_layout, tables, Ds, sizes) -> Stack:
+def build_encoder_stack(enc_layout, tables, Ds, sizes, out_order=None) -> Stack:
+    """out_order: row order of the stack's OUTPUT (a permutation of the last level's rows, dummy row included) - a conv's output
+    row r is defined by row r of its gather table alone, so permuting the output is permuting the last table's rows: free."""
     steps = []
     levels = len(Ds)
     for lvl in range(levels):
@@ -130,12 +134,24 @@ def build_encoder_stack(enc_layout, tables, Ds, sizes) -> Stack:
             steps.append(ConvStep(param=j, table=table, n_in=sizes[lvl] + 1, cin=cin, cout=cout, act=ops.act_id(act)))
         if not fuse or not convs:
             steps.append(SpmmStep(D))
+    if out_order is not None:
+        if not isinstance(steps[-1], ConvStep):
+            raise ValueError("build_encoder_stack: an output row order needs a conv as the last step")
+        steps[-1].table = np.ascontiguousarray(steps[-1].table[np.asarray(out_order, dtype=np.int64)])
     return Stack(steps, input_dummy_dead=False)
 
 
-def build_decoder_stack(dec_layout, tables, Us, sizes) -> Stack:
+def build_decoder_stack(dec_layout, tables, Us, sizes, in_position=None) -> Stack:
+    """in_position: where each vertex of the coarsest level (dummy included) sits in the stack's INPUT - the first up-sampling
+    reads its columns through it (entries keep their order, so every sum keeps its order): an input in another row order costs
+    nothing."""
     steps = []
     levels = len(Us)
+    if in_position is not None:
+        u = Us[levels - 1]
+        pos = np.asarray(in_position, dtype=np.int32)
+        Us = list(Us)
+        Us[levels - 1] = CSR(u.rows, u.cols, u.rowptr, pos[u.col].astype(np.int32), u.val)
     for lvl in range(levels - 1, -1, -1):
         steps.append(SpmmStep(Us[lvl]))
         for j, (cin, S, cout, act, l) in enumerate(dec_layout):
@@ -257,12 +273,28 @@ class SpiralAutoencoder_multiz_partkps(nn.Module):
         self.dconv = nn.ModuleList([SpiralConv(c, S, o, activation=a, device=device) for (c, S, o, a, _) in dec_layout])
 
         tables = [_as_table(spirals[l]) for l in range(levels)]
-        self._enc_stack = build_encoder_stack(enc_layout, tables, [_as_csr(D[l]) for l in range(levels)], sizes)
+        # The per-part layers see the coarsest level's rows part by part (models.py:229-236) and give them back that way
+        # (:262-272).  When the parts are a partition of that level - the reference's segmentation is - the two stacks work in
+        # that row order directly: the encoder's last table has its rows permuted, the decoder's first up-sampling reads its
+        # columns through the inverse; the gather before the encoders' layers and the scatter behind the decoders' disappear
+        # (with their backward passes), and every value is the same bits.
+        n_last = sizes[-1]
+        re = np.concatenate(parts).astype(np.int64)
+        Ds, Us = [_as_csr(D[l]) for l in range(levels)], [_as_csr(U[l]) for l in range(levels)]
+        self._parts_folded = (os.environ.get("SH_FOLD_PARTS", "1") != "0" and re.size == n_last
+                              and np.array_equal(np.sort(re), np.arange(n_last)) and Ds[-1].is_row_select()
+                              and any(l[4] == levels - 1 for l in enc_layout))
+        out_order = in_position = None
+        if self._parts_folded:
+            out_order = np.concatenate([re, [n_last]])
+            in_position = np.empty(n_last + 1, dtype=np.int64)
+            in_position[out_order] = np.arange(n_last + 1)
+        self._enc_stack = build_encoder_stack(enc_layout, tables, Ds, sizes, out_order=out_order)
         # decode(z, z_part_kps, dummy): the dummy row comes from the caller (the encoder's masked row,
         # or demo.py:74's tensor) - treat its gradient as live
-        self._dec_stack = build_decoder_stack(dec_layout, tables, [_as_csr(U[l]) for l in range(levels)], sizes)
+        self._dec_stack = build_decoder_stack(dec_layout, tables, Us, sizes, in_position=in_position)
         self._part_index = [torch.from_numpy(v.astype(np.int64)) for v in parts]
-        self._re_index = torch.from_numpy(np.concatenate(parts).astype(np.int64))
+        self._re_index = torch.from_numpy(re)
         self._part_off = [int(o) for o in np.cumsum([0] + [len(v) for v in parts[:-1]])]        # first row of each part
         self._kps_cat = torch.from_numpy(np.concatenate([np.asarray(k, dtype=np.int64) for k in kps_index_list]))
         self._kps_off = [int(3 * o) for o in np.cumsum([0] + [len(k) for k in kps_index_list[:-1]])]
@@ -307,7 +339,10 @@ class SpiralAutoencoder_multiz_partkps(nn.Module):
         else:
             h = run_stack(self._enc_stack, x, "bm", "bm", self.conv)        # [B, N_last+1, C]
         feat = h.shape[2]
-        hp = h[:, self._re_index, :].reshape(bsize, -1)                     # vertices of part 0 | part 1 | ...
+        if self._parts_folded:
+            hp = h.reshape(bsize, -1)                                       # already part 0 | part 1 | ... | dummy row (no group reads it)
+        else:
+            hp = h[:, self._re_index, :].reshape(bsize, -1)                 # vertices of part 0 | part 1 | ...
         z = grouped_linear(hp, [o * feat for o in self._part_off], self.fc_latent_enc_list)
         return z.view(bsize, len(self.fc_latent_enc_list), -1), self.kps_encode(kps), h[:, -1:, :]
 
@@ -317,10 +352,13 @@ class SpiralAutoencoder_multiz_partkps(nn.Module):
         width = zin.shape[2]
         x = grouped_linear(zin.reshape(bsize, -1), [k * width for k in range(zin.shape[1])], self.fc_latent_dec_list)
         x = x.view(bsize, self.sizes[-1], -1)
-        # models.py:270-272: rows are produced part by part, scatter them back to vertex order
-        out = x.clone()
-        out[:, self._re_index, :] = x[:, :self._re_index.shape[0], :]
-        h = torch.cat([out, dummy], dim=1)
+        if self._parts_folded:
+            h = torch.cat([x, dummy], dim=1)                                # the decoder stack reads the rows where the parts left them
+        else:
+            # models.py:270-272: rows are produced part by part, scatter them back to vertex order
+            out = x.clone()
+            out[:, self._re_index, :] = x[:, :self._re_index.shape[0], :]
+            h = torch.cat([out, dummy], dim=1)
         if getattr(self, "compute_dtype", torch.float32) == torch.bfloat16:
             return run_stack_bf16(self._dec_stack, h.to(torch.bfloat16), "bm", "bm", torch.float32, self.dconv)
         return run_stack(self._dec_stack, h, "bm", "bm", self.dconv)

@@ -352,6 +352,7 @@ def test_hip_semantic_loop_matches_the_reference_loop(golden_dir, tmp_path):
     # the same log: tags, steps, values
     assert [r[0] for r in rows] == [str(t) for t in g["tags"]]
     assert [r[2] for r in rows] == [int(s) for s in g["steps"]]
+    worst = (0.0, None)
     for (tag, val, step), ref in zip(rows, g["values"]):
         tol = 1e-4 if step == 0 and not tag.startswith("avg") else 1e-3
         if tag.endswith("_euc_loss"):
@@ -359,6 +360,8 @@ def test_hip_semantic_loop_matches_the_reference_loop(golden_dir, tmp_path):
             # cancellation noise of ~1e-4 relative per distance, and pairs next to the angle threshold can change sides
             tol *= 5
         assert val == pytest.approx(float(ref), rel=tol, abs=1e-7), (tag, step, val, float(ref))
+        worst = max(worst, (abs(val - float(ref)) / max(tol * abs(float(ref)), 1e-7), (tag, step)))
+    print("semantic loop: worst deviation / tolerance = %.3f at %s" % worst)
     assert opt.param_groups[0]["lr"] == pytest.approx(float(g["lr_final"]), rel=1e-12)
     ck = torch.load(tmp_path / "checkpoint2.pth.tar", map_location="cpu", weights_only=True)
     assert sorted(ck) == [str(k) for k in g["ckpt_keys"]]
@@ -515,3 +518,43 @@ def test_semantic_losses_fused_bookkeeping_is_bitwise_the_tensor_op_form():
     assert torch.equal(fused[0], plain[0])
     assert fused[1].keys() == plain[1].keys() and all(torch.equal(fused[1][k], plain[1][k]) for k in fused[1])
     assert len(fused[2]) == len(plain[2]) and all(torch.equal(a, b) for a, b in zip(fused[2], plain[2]))
+
+
+@pytest.mark.gpu
+def test_part_order_folded_into_the_stacks_is_the_gather_scatter_form():
+    """The two stacks of the semantic model work in part order when the parts partition the coarsest level (the encoder's
+    last table has its rows permuted, the decoder's first up-sampling reads its columns through the inverse) instead of a
+    gather before and a scatter behind the per-part layers: latents and reconstruction are the same bits; gradients agree
+    to rounding (the last encoder layer's weight gradient sums its rows in the new order)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import bench_semantic as bs
+    import semantichuman_amd as sh
+    from semantichuman_amd import synthetic
+    dev = torch.device("cuda:0")
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    h = load_hierarchy(os.path.join(golden, "template6890.npz"))
+    vi = h.verts / np.asarray((0.25, 0.15, 0.9))
+    idx = np.arange(h.sizes[0])
+    for d in h.D:
+        idx = idx[np.asarray(d.col[:-1])]
+    coarse = dict(zip(C.PART_LIST, bs.voronoi_parts(vi[idx], 17)))
+    x = torch.from_numpy(synthetic.synth_batch(h.verts, 4, seed=7)).to(dev)
+    kps = torch.randn(4, len(C.NEWSKL_LIST) + 4 - 3, 3, generator=torch.Generator().manual_seed(3)).to(dev)
+    outs = {}
+    for fold in ("1", "0"):
+        os.environ["SH_FOLD_PARTS"] = fold
+        try:
+            torch.manual_seed(2)
+            m = sh.SpiralAutoencoder_multiz_partkps(C.KPS_INDEX_LIST, coarse, C.FILTER_SIZES_ENC, C.FILTER_SIZES_DEC, 8, 8, h.sizes,
+                                                    h.spiral_sizes, h.spirals, h.D, h.U, dev)
+        finally:
+            os.environ.pop("SH_FOLD_PARTS", None)
+        assert m._parts_folded == (fold == "1")
+        z, zk, dummy = m.encode(x, kps)
+        rec = m.decode(z, zk, dummy)
+        (rec.square().mean() + z.square().mean()).backward()
+        outs[fold] = (z.detach().clone(), rec.detach().clone(), [p.grad.clone() for p in m.parameters()])
+    assert torch.equal(outs["1"][0], outs["0"][0]) and torch.equal(outs["1"][1], outs["0"][1])
+    for a, b in zip(outs["1"][2], outs["0"][2]):
+        assert float((a - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), 1e-6)
