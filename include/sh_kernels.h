@@ -177,6 +177,13 @@ SH_API int sh_act_backward(const float* dy, int64_t dy_sv, int64_t dy_sb,
                     const float* y, int64_t y_sv, int64_t y_sb,
                     float* dpre, int64_t dp_sv, int64_t dp_sb,
                     int B, int R, int C, int act, int zero_row, sh_stream_t stream);
+/* The same launch with the weight transposes of a stack's backward pass (sh_weight_transpose_multi's arguments) as extra
+ * workgroups: both are a few microseconds of work, a launch boundary costs ~3 us whatever follows it.  n_layers == 0:
+ * exactly sh_act_backward. */
+SH_API int sh_act_backward_tr(const float* dy, int64_t dy_sv, int64_t dy_sb, const float* y, int64_t y_sv, int64_t y_sb,
+                       float* dpre, int64_t dp_sv, int64_t dp_sb, int B, int R, int C, int act, int zero_row, int n_layers,
+                       const float* const* weight, float* const* weight_t, const int* S, const int* Cin, const int* Cout,
+                       sh_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Sparse mesh re-sampling.  Replaces the dense aten::bmm of models.py:127 (D) and :148 (U), and

@@ -1319,12 +1319,12 @@ __global__ __launch_bounds__(1024) void slab_reduce_multi_kernel(const MultiRedu
 struct MultiTranspose {
     const float* w[MR_MAX]; float* wt[MR_MAX]; int S[MR_MAX]; int Cin[MR_MAX]; int Cout[MR_MAX]; int block0[MR_MAX]; int nd;
 };
-__global__ __launch_bounds__(256) void weight_transpose_multi_kernel(const MultiTranspose m) {
+__device__ __forceinline__ void weight_transpose_block(const MultiTranspose& m, int blk) {
     int d = 0;
-    while (d + 1 < m.nd && m.block0[d + 1] <= (int)blockIdx.x) ++d;
+    while (d + 1 < m.nd && m.block0[d + 1] <= blk) ++d;
     const int S = m.S[d], Cin = m.Cin[d], Cout = m.Cout[d];
     const long n = (long)S * Cin * Cout;
-    const long i = (long)(blockIdx.x - m.block0[d]) * 256 + threadIdx.x;
+    const long i = (long)(blk - m.block0[d]) * 256 + threadIdx.x;
     if (i >= n) return;
     const int co = (int)(i % Cout);
     const long t = i / Cout;
@@ -1332,6 +1332,7 @@ __global__ __launch_bounds__(256) void weight_transpose_multi_kernel(const Multi
     const int ci = (int)(t / S);
     m.wt[d][i] = m.w[d][(long)co * S * Cin + (long)s * Cin + ci];      // wt[ci][s*Cout + co] = w[co][s*Cin + ci]
 }
+__global__ __launch_bounds__(256) void weight_transpose_multi_kernel(const MultiTranspose m) { weight_transpose_block(m, (int)blockIdx.x); }
 
 // ------------------------------------------------------------------------------------------
 // weight gradient, streaming form (Cin % 4 == 0).  The staged kernel above moves the gathered
@@ -1801,17 +1802,21 @@ __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __re
     wt[i] = w[(long)co * S * Cin + (long)s * Cin + ci];
 }
 
+// The weight transposes of a stack's backward pass ride in the launch that opens it (sh_act_backward_tr): workgroups
+// grid_main .. of the activation-backward launch are weight_transpose_multi_kernel's workgroups - two launches of a few
+// microseconds each become one (a launch boundary costs ~3 us whatever the kernel does).  tr.nd == 0: no rider.
 // one workgroup per row (vertex), 32-bit index arithmetic, 16-byte accesses when the channel count allows
 template <bool VEC4>
 __global__ void act_backward_kernel(const float* __restrict__ dy, long dy_sv, long dy_sb,
                                     const float* __restrict__ y, long y_sv, long y_sb,
                                     float* __restrict__ dp, long dp_sv, long dp_sb,
-                                    int B, int R, int C, int act, int zero_row) {
+                                    int B, int R, int C, int act, int zero_row, int grid_main, const MultiTranspose tr) {
+    if ((int)blockIdx.x >= grid_main) { weight_transpose_block(tr, (int)blockIdx.x - grid_main); return; }
     const int cq = VEC4 ? C >> 2 : C;                 // elements (or quads) per (row, batch) entry
     const int per_row = B * cq;
     const int parts = (per_row + 255) >> 8;           // work item = 256-element part of a row (coarse levels: few long rows)
     const long items = (long)R * parts;
-    for (long it = blockIdx.x; it < items; it += gridDim.x) {
+    for (long it = blockIdx.x; it < items; it += grid_main) {
         const int r = (int)(it / parts), part = (int)(it - (long)r * parts);
         const bool zero = r == zero_row;
         const float* dyr = dy + (long)r * dy_sv;
@@ -1840,7 +1845,9 @@ __global__ void act_backward_kernel(const float* __restrict__ dy, long dy_sv, lo
 // TV * C contiguous floats, turns the tile in LDS and writes TV contiguous B * C rows.
 constexpr int AB_TV = 16;
 __global__ __launch_bounds__(256) void act_backward_turn_kernel(const float* __restrict__ dy, const float* __restrict__ y, long src_sb,
-                                                                float* __restrict__ dp, int B, int R, int C, int act, int zero_row) {
+                                                                float* __restrict__ dp, int B, int R, int C, int act, int zero_row,
+                                                                int grid_main, const MultiTranspose tr) {
+    if ((int)blockIdx.x >= grid_main) { weight_transpose_block(tr, (int)blockIdx.x - grid_main); return; }
     extern __shared__ float tile[];                    // [TV][B * C + 1]
     const int r0 = blockIdx.x * AB_TV, tv = min(AB_TV, R - r0);
     const int seg = tv * C, pitch = B * C + 1;
@@ -2075,7 +2082,24 @@ int sh_weight_transpose_multi(int n_layers, const float* const* weight, float* c
 
 int sh_act_backward(const float* dy, int64_t dy_sv, int64_t dy_sb, const float* y, int64_t y_sv, int64_t y_sb, float* dpre,
                     int64_t dp_sv, int64_t dp_sb, int B, int R, int C, int act, int zero_row, sh_stream_t stream) {
+    return sh_act_backward_tr(dy, dy_sv, dy_sb, y, y_sv, y_sb, dpre, dp_sv, dp_sb, B, R, C, act, zero_row, 0, nullptr, nullptr, nullptr, nullptr,
+                              nullptr, stream);
+}
+
+int sh_act_backward_tr(const float* dy, int64_t dy_sv, int64_t dy_sb, const float* y, int64_t y_sv, int64_t y_sb, float* dpre,
+                       int64_t dp_sv, int64_t dp_sb, int B, int R, int C, int act, int zero_row, int n_layers, const float* const* weight,
+                       float* const* weight_t, const int* S, const int* Cin, const int* Cout, sh_stream_t stream) {
     SH_REQUIRE(dy && y && dpre && B > 0 && R > 0 && C > 0, SH_ERR_INVALID_ARG, "sh_act_backward: bad argument");
+    SH_REQUIRE(n_layers >= 0 && n_layers <= MR_MAX && (n_layers == 0 || (weight && weight_t && S && Cin && Cout)), SH_ERR_INVALID_ARG,
+               "sh_act_backward_tr: bad transpose list (at most %d layers)", MR_MAX);
+    MultiTranspose tr{};
+    int tr_blocks = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        SH_REQUIRE(weight[i] && weight_t[i] && S[i] > 0 && Cin[i] > 0 && Cout[i] > 0, SH_ERR_INVALID_ARG, "sh_act_backward_tr: bad layer %d", i);
+        tr.w[i] = weight[i]; tr.wt[i] = weight_t[i]; tr.S[i] = S[i]; tr.Cin[i] = Cin[i]; tr.Cout[i] = Cout[i]; tr.block0[i] = tr_blocks;
+        tr_blocks += (int)(((long)S[i] * Cin[i] * Cout[i] + 255) / 256);
+    }
+    tr.nd = n_layers;
     SH_REQUIRE(act >= SH_ACT_IDENTITY && act <= SH_ACT_TANH, SH_ERR_INVALID_ARG, "sh_act_backward: unknown activation %d", act);
     const bool vec = (C % 4 == 0) && ((dy_sv | dy_sb | y_sv | y_sb | dp_sv | dp_sb) % 4 == 0) &&
                      ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dpre)) % 16 == 0);
@@ -2086,17 +2110,18 @@ int sh_act_backward(const float* dy, int64_t dy_sv, int64_t dy_sb, const float* 
     const bool turn = C <= 8 && dy_sv == C && y_sv == C && dy_sb == y_sb && dy_sb >= (int64_t)R * C && dp_sb == C && dp_sv == (int64_t)B * C &&
                       (size_t)AB_TV * ((size_t)B * C + 1) * sizeof(float) <= 64 * 1024;
     if (turn) {
-        hipLaunchKernelGGL(act_backward_turn_kernel, dim3((R + AB_TV - 1) / AB_TV), dim3(256), (size_t)AB_TV * ((size_t)B * C + 1) * sizeof(float), st,
-                           dy, y, (long)dy_sb, dpre, B, R, C, act, zero_row);
+        const int gm = (R + AB_TV - 1) / AB_TV;
+        hipLaunchKernelGGL(act_backward_turn_kernel, dim3(gm + tr_blocks), dim3(256), (size_t)AB_TV * ((size_t)B * C + 1) * sizeof(float), st,
+                           dy, y, (long)dy_sb, dpre, B, R, C, act, zero_row, gm, tr);
         SH_CHECK_LAUNCH("act_backward");
         return SH_OK;
     }
     if (vec)
-        hipLaunchKernelGGL(act_backward_kernel<true>, dim3(blocks), dim3(256), 0, st, dy, dy_sv, dy_sb, y, y_sv, y_sb, dpre, dp_sv, dp_sb,
-                           B, R, C, act, zero_row);
+        hipLaunchKernelGGL(act_backward_kernel<true>, dim3(blocks + tr_blocks), dim3(256), 0, st, dy, dy_sv, dy_sb, y, y_sv, y_sb, dpre, dp_sv, dp_sb,
+                           B, R, C, act, zero_row, blocks, tr);
     else
-        hipLaunchKernelGGL(act_backward_kernel<false>, dim3(blocks), dim3(256), 0, st, dy, dy_sv, dy_sb, y, y_sv, y_sb, dpre, dp_sv, dp_sb,
-                           B, R, C, act, zero_row);
+        hipLaunchKernelGGL(act_backward_kernel<false>, dim3(blocks + tr_blocks), dim3(256), 0, st, dy, dy_sv, dy_sb, y, y_sv, y_sb, dpre, dp_sv, dp_sb,
+                           B, R, C, act, zero_row, blocks, tr);
     SH_CHECK_LAUNCH("act_backward");
     return SH_OK;
 }

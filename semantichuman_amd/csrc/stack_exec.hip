@@ -81,21 +81,22 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
         int c = c0;
         for (int i = 0; i < n_steps; ++i) { cin_of[i] = c; if (steps[i].kind == 0) c = steps[i].cout; }
     }
-    // all weight transposes of the stack in one launch
-    {
-        const float* w[32]; float* wt[32]; int S[32], Ci[32], Co[32];
-        int n = 0;
-        for (int i = 0; i < n_steps; ++i) {
-            if (steps[i].kind != 0 || !(i > 0 || need_x_grad)) continue;
-            SH_REQUIRE(weight_t && weight_t[i], SH_ERR_INVALID_ARG, "sh_stack_backward: no weight_t buffer for step %d", i);
-            SH_REQUIRE(n < 32, SH_ERR_UNSUPPORTED, "sh_stack_backward: more than 32 conv steps");
-            w[n] = weights[steps[i].param]; wt[n] = weight_t[i]; S[n] = steps[i].S; Ci[n] = steps[i].cin; Co[n] = steps[i].cout;
-            ++n;
-        }
-        if (n) {
-            rc = sh_weight_transpose_multi(n, w, wt, S, Ci, Co, stream);
-            if (rc != SH_OK) return rc;
-        }
+    // all weight transposes of the stack: workgroups of the launch that opens the pass (the last step's activation backward),
+    // or a launch of their own when the pass opens with a re-sampling step
+    const float* tr_w[32]; float* tr_wt[32]; int tr_S[32], tr_Ci[32], tr_Co[32];
+    int n_tr = 0;
+    for (int i = 0; i < n_steps; ++i) {
+        if (steps[i].kind != 0 || !(i > 0 || need_x_grad)) continue;
+        SH_REQUIRE(weight_t && weight_t[i], SH_ERR_INVALID_ARG, "sh_stack_backward: no weight_t buffer for step %d", i);
+        SH_REQUIRE(n_tr < 32, SH_ERR_UNSUPPORTED, "sh_stack_backward: more than 32 conv steps");
+        tr_w[n_tr] = weights[steps[i].param]; tr_wt[n_tr] = weight_t[i]; tr_S[n_tr] = steps[i].S; tr_Ci[n_tr] = steps[i].cin; tr_Co[n_tr] = steps[i].cout;
+        ++n_tr;
+    }
+    static const int tr_ride = sh_env_int("SH_TR_RIDE", 1, 0, 1);
+    if (n_tr && !(tr_ride && steps[last].kind == 0)) {
+        rc = sh_weight_transpose_multi(n_tr, tr_w, tr_wt, tr_S, tr_Ci, tr_Co, stream);
+        if (rc != SH_OK) return rc;
+        n_tr = 0;
     }
     // gradient entering the last step
     const float* cur; Lay cl;
@@ -104,8 +105,8 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
         if (s.kind == 0) {
             SH_REQUIRE(dpre_last, SH_ERR_INVALID_ARG, "sh_stack_backward: no dpre_last buffer");
             const Lay ol = lay(out_layout, s.R, B, s.cout), dl = lay(0, 0, B, s.cout);
-            rc = sh_act_backward(g, ol.sv, ol.sb, acts[last], ol.sv, ol.sb, dpre_last, dl.sv, dl.sb, B, s.R, s.cout, s.act,
-                                 s.zero_row, stream);
+            rc = sh_act_backward_tr(g, ol.sv, ol.sb, acts[last], ol.sv, ol.sb, dpre_last, dl.sv, dl.sb, B, s.R, s.cout, s.act, s.zero_row, n_tr,
+                                    tr_w, tr_wt, tr_S, tr_Ci, tr_Co, stream);
             if (rc != SH_OK) return rc;
             cur = dpre_last; cl = dl;
         } else {

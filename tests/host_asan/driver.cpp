@@ -14,6 +14,7 @@
 
 extern std::vector<std::string> g_calls;
 void sh_set_error(const char* fmt, ...) { (void)fmt; }
+int sh_env_int(const char*, int dflt, int, int) { return dflt; }      // the sequencers' switches at their defaults
 
 struct Csr { std::vector<int32_t> rp, col; std::vector<float> val; sh_csr_ref ref() const { return {rp.data(), col.data(), val.data()}; } };
 static Csr make_csr(int rows, int cols, int per_row) {

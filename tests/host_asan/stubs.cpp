@@ -75,6 +75,14 @@ int sh_act_backward(const float* dy, int64_t dy_sv, int64_t dy_sb, const float* 
     log("act_backward R=%d C=%d", R, C);
     return 0;
 }
+int sh_act_backward_tr(const float* dy, int64_t dy_sv, int64_t dy_sb, const float* y, int64_t y_sv, int64_t y_sb, float* dp, int64_t dp_sv, int64_t dp_sb,
+                       int B, int R, int C, int act, int zero_row, int n, const float* const* w, float* const* wt, const int* S, const int* Ci,
+                       const int* Co, sh_stream_t) {
+    for (int i = 0; i < n; ++i) { touch_r(w[i], (size_t)S[i] * Ci[i] * Co[i] * 4); touch_w(wt[i], (size_t)S[i] * Ci[i] * Co[i] * 4); }
+    touch_r(dy, span(dy_sv, dy_sb, R, B, C, 4)); touch_r(y, span(y_sv, y_sb, R, B, C, 4)); touch_w(dp, span(dp_sv, dp_sb, R, B, C, 4));
+    log("act_backward R=%d C=%d transposes=%d", R, C, n);
+    return 0;
+}
 int sh_act_backward_bf16(const void* dy, int64_t dy_sv, int64_t dy_sb, const void* y, int64_t y_sv, int64_t y_sb, void* dp, int64_t dp_sv, int64_t dp_sb,
                          int B, int R, int C, int act, int zero_row, sh_stream_t) {
     touch_r(dy, span(dy_sv, dy_sb, R, B, C, 2)); touch_r(y, span(y_sv, y_sb, R, B, C, 2)); touch_w(dp, span(dp_sv, dp_sb, R, B, C, 2));
