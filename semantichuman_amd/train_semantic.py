@@ -204,12 +204,17 @@ def semantic_losses(model, ctx, tx, tx_interp, tx_exc, epoch, measure=None, inte
     do_interp = epoch > o.interp_epoch and tx_interp is not None
     do_exc = epoch > o.exc_epoch and tx_exc is not None
     B0 = tx.shape[0]
-    kps_GT = ctx.joints(tx)
-    xs, ks = [tx], [kps_GT[:, ctx.kps_keep_t]]
+    # one pass of the network over [reconstruction | interpolation | exchange] (below) - and ONE joint regression over the
+    # same concatenation instead of one per input (the regression is per batch entry: the same bits)
+    xs = [tx] + ([tx_interp] if do_interp else []) + ([tx_exc] if do_exc else [])
+    X = torch.cat(xs, dim=0) if len(xs) > 1 else tx
+    kps_all = ctx.joints(X)
+    kps_GT = kps_all[:B0]
+    ks = [kps_GT[:, ctx.kps_keep_t]]
 
     if do_interp:
         Bi = tx_interp.shape[0]
-        kps_i = ctx.joints(tx_interp)
+        kps_i = kps_all[B0:B0 + Bi]
         if o.editskl_flag:
             n = len(ctx.skl_keep) if o.edit_mode == "rand" else 1
             f = torch.rand(n).to(ctx.device) * o.factor[0] + o.factor[1]
@@ -220,11 +225,11 @@ def semantic_losses(model, ctx, tx, tx_interp, tx_exc, epoch, measure=None, inte
             new_kps_i = kps_i[:, ctx.kps_keep_t]
         part_index, a = _edit_scales(ctx, o, Bi, epoch, interp_measure, draw_factor)
         scale = _full_scale(ctx, part_index, a, Bi)
-        xs.append(tx_interp); ks.append(new_kps_i)
+        ks.append(new_kps_i)
 
     if do_exc:
         Be = tx_exc.shape[0]
-        kps_e = ctx.joints(tx_exc)
+        kps_e = kps_all[X.shape[0] - Be:]
         mode = o.exc_mode
         if mode == "ori_or_m":
             pick = (np.random.rand(1) > 0.5) if exc_choice is None else (exc_choice == "ori")
@@ -240,10 +245,8 @@ def semantic_losses(model, ctx, tx, tx_interp, tx_exc, epoch, measure=None, inte
                 skl[:, ctx.skl_keep_t, 3] = torch.flip(skl[:, ctx.skl_keep_t, 3], dims=[0])
             new_kps_e = part_losses.skl2kps(skl, "ori_m", o.newskl_list)
             exc_kind = mode
-        xs.append(tx_exc); ks.append(new_kps_e)
+        ks.append(new_kps_e)
 
-    # one pass of the network over [reconstruction | interpolation | exchange]
-    X = torch.cat(xs, dim=0) if len(xs) > 1 else tx
     K = torch.cat(ks, dim=0) if len(ks) > 1 else ks[0]
     latent, latent_kps, dummy = model.encode(X, K)
     lat_in = latent
