@@ -295,3 +295,29 @@ def test_emulate_operators_equal_the_oracle(act):
     dW2, db2 = emulate.conv_bwd_wgt_swapped(emulate.extend_dpre(dpre, tt), xv, tt.table_t)
     assert np.abs(dW2 - W.grad.numpy()).max() <= 2e-6 * max(1.0, float(W.grad.abs().max()))
     assert np.abs(db2 - b.grad.numpy()).max() <= 2e-6 * max(1.0, float(b.grad.abs().max()))
+
+
+def test_semantic_loop_bookkeeping_helpers_on_cpu():
+    """train_semantic.weighted_sum (tensor-op fallback off the GPU) is the `loss = loss + w * term` chain, and _SplitRows
+    is row slicing whose backward is one concatenation: values and gradients as the plain forms."""
+    from semantichuman_amd import train_semantic as ts
+    vals = [torch.tensor(v, requires_grad=True) for v in (0.731, 12.5, 3e-4)]
+    ref_vals = [v.detach().clone().requires_grad_(True) for v in vals]
+    ws = (1.0, 1e-2, 0.37)
+    tot = ts.weighted_sum(list(zip(ws, vals)))
+    ref = ref_vals[0] + ws[1] * ref_vals[1]
+    ref = ref + ws[2] * ref_vals[2]
+    assert torch.equal(tot.detach(), ref.detach())
+    tot.backward(); ref.backward()
+    assert all(torch.equal(a.grad, b.grad) for a, b in zip(vals, ref_vals))
+    x = torch.randn(7, 5, 3, requires_grad=True)
+    xr = x.detach().clone().requires_grad_(True)
+    a, b, c = ts._SplitRows.apply(x, 2, 4, 1)
+    assert torch.equal(a, xr[:2]) and torch.equal(b, xr[2:6]) and torch.equal(c, xr[6:])
+    (a.sum() * 2.0 + (b * b).sum()).backward()                    # the last piece gets no gradient: zeros in the concatenation
+    (xr[:2].sum() * 2.0 + (xr[2:6] * xr[2:6]).sum()).backward()
+    assert torch.equal(x.grad, xr.grad)
+    y = torch.randn(6, 4, requires_grad=True)                      # rows beyond the listed pieces: zero gradient
+    (p,) = ts._SplitRows.apply(y, 4)
+    p.sum().backward()
+    assert torch.equal(y.grad[:4], torch.ones(4, 4)) and torch.equal(y.grad[4:], torch.zeros(2, 4))
