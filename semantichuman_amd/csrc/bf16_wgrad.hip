@@ -340,7 +340,10 @@ BWPlan plan_bw(int B, int R, int S, int Cin, int Cout) {
     w.n_qg = sh_cdiv(K, 16 * w.qt);
     w.n_pt = sh_cdiv(Cout, 16 * w.pt);
     w.n_stages = rows / 32;
-    static const int wave_target = sh_env_int("SH_BW_WAVES", 2048, 64, 1 << 16);
+    // 1024 waves = 256 workgroups = ONE round of the chip (a workgroup's 160 KiB of LDS fills a CU): 2048 left a second round
+    // of 240 workgroups behind the first 256 (6890 vertices, batch 64: the five launches 37.5 / 26.0 / 21.2 / 26.1 / 19.6 ->
+    // 33.1 / 21.5 / 17.0 / 22.0 / 15.4 us, step 0.965 -> 0.945 ms; 768 and 1280 are both slower)
+    static const int wave_target = sh_env_int("SH_BW_WAVES", 1024, 64, 1 << 16);
     static const int slab_mb = sh_env_int("SH_BW_SLAB_MB", 32, 1, 4096);
     const long tiles = (long)w.n_qg * w.n_pt;
     long ns = wave_target / tiles;
