@@ -488,6 +488,37 @@ def roofline_f32(recs, model, B, nprof, verts):
     return result
 
 
+def collective_block(reducer, world, rank, dev, backend):
+    """World size, the device every rank runs on, and what the step's gradient messages cost when nothing else runs: each
+    message size of the reducer all-reduced 5 times (after 2 warm-ups) between HIP events; bus bandwidth by the ring
+    formula 2 (n - 1) / n x bytes / time.  Every rank calls this (collectives inside)."""
+    ids = [None] * dist.get_world_size()
+    dist.all_gather_object(ids, {"rank": rank, "device": torch.cuda.current_device(), "name": torch.cuda.get_device_name(),
+                                 "pid": os.getpid()})
+    msgs = []
+    for b in reducer.buckets:
+        nbytes = b.numel * (2 if (b.inplace and reducer.large_dtype is not None and reducer.large_dtype.itemsize == 2) else 4)
+        buf = torch.zeros(nbytes // 4, dtype=torch.float32, device=dev)
+        for _ in range(2):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dist.all_reduce(buf)
+        e1.record()
+        torch.cuda.synchronize()
+        t = torch.tensor([e0.elapsed_time(e1) / 5.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms = float(t.item())
+        n = dist.get_world_size()
+        msgs.append({"bytes": nbytes, "ms": ms, "alg_gbps": nbytes / ms / 1e6, "bus_gbps": 2.0 * (n - 1) / n * nbytes / ms / 1e6})
+        del buf
+    return {"world_size": dist.get_world_size(), "backend": backend, "ranks": ids, "messages": msgs,
+            "averaging": "ncclAvg in the collective" if reducer.avg else "sum of pre-scaled gradients",
+            "overlap": "large messages launched from gradient hooks" if reducer.overlap else "after backward"}
+
+
 def _free_port():
     import socket
     with socket.socket() as s:
@@ -556,6 +587,135 @@ def self_launch(n, argv):
     return rc
 
 
+# ---- N > 1: every rank runs under a GPU-free supervisor that can start the rank's work again in a more conservative mode
+# ("order of fallbacks").  The multi-rank step is one hipGraph with the RCCL all-reduces inside; a capture
+# or replay that fails with collectives recorded cannot be survived by the process (the process group's watchdog aborts
+# it), and under torch.distributed.run a dead rank ends the job.  So the process the launcher started never touches the
+# GPU: it starts the real rank as a CHILD (subprocess: never an exec from a GPU process), and when an attempt fails on any
+# rank, all supervisors start FRESH children for the next attempt on a fresh rendezvous port.
+ATTEMPTS = (
+    ("graph", {}),                                                           # the step as one hipGraph, RCCL inside
+    ("eager", {"SH_BENCH_DP_GRAPH": "0"}),                                   # the same step, launched eagerly
+    ("eager-safe", {"SH_BENCH_DP_GRAPH": "0", "SH_BENCH_DP_SAFE": "1"}),     # + lazy communicator, no stream priority, all-reduce
+)                                                                            #   (sum of pre-scaled gradients) after backward
+
+
+def _touch(path, text=""):
+    tmp = path + ".tmp%d" % os.getpid()
+    with open(tmp, "w") as f:
+        f.write(text)
+    os.replace(tmp, path)                                  # atomic: a reader never sees a half-written file
+
+
+def supervise_rank(argv):
+    """The launcher's rank process (RANK / WORLD_SIZE set, SH_BENCH_ATTEMPT not): runs the attempts of ATTEMPTS in order
+    until one succeeds on rank 0; returns the exit status.  Coordination between the supervisors of one node is a
+    directory of marker files (one node by contract: `--nnodes=1`):
+        attempt<k>.port      rank 0's fresh rendezvous port for attempt k > 0
+        attempt<k>.rankfail.<r>   rank r's child exited non-zero
+        attempt<k>.ok / .failed   rank 0's verdict (it owns the JSON line); everybody waits for it
+    Rank 0's child writes the JSON line to a pipe; it is forwarded only when the attempt is the one that counts."""
+    import subprocess
+    import tempfile
+    import threading
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ["WORLD_SIZE"])
+    port0 = os.environ.get("MASTER_PORT", "29500")
+    job = os.path.join(tempfile.gettempdir(), "sh_bench_%s_%d_%s" % (port0, os.getppid(), os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")))
+    os.makedirs(job, exist_ok=True)
+    timeout = float(os.environ.get("SH_BENCH_ATTEMPT_TIMEOUT", "900"))
+    grace = float(os.environ.get("SH_BENCH_FAIL_GRACE", "20"))
+    attempts = [a for a in ATTEMPTS if not (a[0] == "graph" and os.environ.get("SH_BENCH_DP_GRAPH", "1") == "0")]
+    history, rc = [], 1
+
+    def wait_for(paths, limit):
+        t0 = time.time()
+        while time.time() - t0 < limit:
+            for q in paths:
+                if os.path.exists(q):
+                    return q
+            time.sleep(0.05)
+        return None
+
+    for k, (name, extra) in enumerate(attempts):
+        base = os.path.join(job, "attempt%d" % k)
+        env = dict(os.environ, SH_BENCH_ATTEMPT=str(k), SH_BENCH_ATTEMPT_NAME=name, SH_BENCH_ATTEMPT_HISTORY="; ".join(history), **extra)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if k > 0:                                           # fresh rendezvous: the first one's store holds the dead attempt's keys
+            if rank == 0:
+                _touch(base + ".port", str(_free_port()))
+            if not wait_for([base + ".port"], 120):
+                print("bench.py[supervisor %d]: no rendezvous port for attempt %d" % (rank, k), file=sys.stderr)
+                return rc
+            env["MASTER_PORT"] = open(base + ".port").read().strip()
+            env.pop("TORCHELASTIC_USE_AGENT_STORE", None)   # rank 0's child hosts the store itself
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                             stdout=subprocess.PIPE if rank == 0 else None, text=True if rank == 0 else None)
+        lines = []
+        reader = None
+        if rank == 0:
+            reader = threading.Thread(target=lambda: lines.extend(p.stdout), daemon=True)
+            reader.start()
+        t0, first_fail, killed = time.time(), None, None
+        while p.poll() is None:
+            if os.path.exists(base + ".failed"):
+                killed = "attempt declared failed by rank 0"
+            elif time.time() - t0 > timeout:
+                killed = "no result after %.0f s" % timeout
+            elif rank == 0:
+                if first_fail is None and any(f.startswith("attempt%d.rankfail." % k) for f in os.listdir(job)):
+                    first_fail = time.time()
+                if first_fail is not None and time.time() - first_fail > grace:
+                    killed = "another rank failed"           # the survivors are blocked in a collective
+            if killed:
+                p.terminate()
+                try:
+                    p.wait(10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+                break
+            time.sleep(0.05)
+        st = p.returncode
+        if reader:
+            reader.join(5)
+        if rank == 0:
+            ok = st == 0 and not killed and any(l.startswith("{") for l in lines)
+            _touch(base + (".ok" if ok else ".failed"), killed or "rc=%s" % st)
+        else:
+            if st != 0 and not killed:
+                _touch(base + ".rankfail.%d" % rank, "rc=%s" % st)
+            verdict = wait_for([base + ".ok", base + ".failed"], timeout + grace + 30)
+            ok = verdict is not None and verdict.endswith(".ok")
+            if verdict is None:
+                print("bench.py[supervisor %d]: no verdict from rank 0 for attempt %d" % (rank, k), file=sys.stderr)
+                return st or 1
+        if ok:
+            if rank == 0:
+                sys.stdout.write("".join(lines))
+                sys.stdout.flush()
+            return 0
+        rc = st if st not in (0, None) else 1
+        history.append("%s: %s" % (name, killed or "rc=%s" % st))
+        print("bench.py[supervisor %d]: attempt %d (%s) failed: %s" % (rank, k, name, history[-1]), file=sys.stderr)
+    return rc
+
+
+def attempt_note():
+    """What config.launch says about the supervisor's attempts (empty for the first one)."""
+    h = os.environ.get("SH_BENCH_ATTEMPT_HISTORY", "")
+    return " [attempt %s '%s' after failed: %s]" % (os.environ.get("SH_BENCH_ATTEMPT"), os.environ.get("SH_BENCH_ATTEMPT_NAME"), h) if h else ""
+
+
+def injected_rank_failure(rank):
+    """Test hook: SH_BENCH_TEST_RANK_FAIL='<attempt>:<rank>' makes that rank of that attempt exit with status 7 right after
+    the rendezvous (tests/test_bench_launch.py proves the retry with it)."""
+    spec = os.environ.get("SH_BENCH_TEST_RANK_FAIL")
+    if spec and spec in ("%s:%d" % (os.environ.get("SH_BENCH_ATTEMPT", "0"), rank), "*:%d" % rank):
+        print("bench.py[rank %d]: injected failure (SH_BENCH_TEST_RANK_FAIL=%s)" % (rank, spec), file=sys.stderr)
+        sys.stdout.flush()
+        os._exit(7)
+
+
 def dry_run(args, world, rank):
     """SH_BENCH_DRYRUN=1: the launch / rendezvous / timing / reporting skeleton of this script over gloo with no GPU work
     (the CPU container has no device): rendezvous, warm-up, K barrier-bracketed empty steps, MAX over ranks, one JSON
@@ -563,6 +723,7 @@ def dry_run(args, world, rank):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")
+        injected_rank_failure(rank)
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -577,7 +738,8 @@ def dry_run(args, world, rank):
     if rank == 0:
         print(json.dumps({"metric": "training meshes/sec at 6890 verts, batch=%d" % args.batch, "value": None, "unit": "meshes/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(1, args.steps),
-                          "dry_run": True, "config": {"global_batch": world * args.batch, "parallelism": "dp%d" % world}}))
+                          "dry_run": True, "config": {"global_batch": world * args.batch, "parallelism": "dp%d" % world,
+                                                     "launch": "dry run (%s)" % os.environ.get("SH_BENCH_ATTEMPT_NAME", "single process") + attempt_note()}}))
     if dist.is_initialized():
         dist.destroy_process_group()
 
@@ -615,6 +777,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+    if world > 1 and "SH_BENCH_ATTEMPT" not in os.environ and os.environ.get("SH_BENCH_SUPERVISE", "1") != "0":
+        sys.exit(supervise_rank(sys.argv[1:]))     # this process stays GPU-free; the rank's work runs in children
     if os.environ.get("SH_BENCH_DRYRUN", "0") != "0":
         if args.gpus != world:
             sys.exit(2)
@@ -626,6 +794,9 @@ def main():
     # SH_BENCH_FORCE_REDUCER=1: run the data-parallel control flow (hooks, buckets, RCCL calls, eager launches) in a world
     # of ONE rank - what the multi-GPU path costs on the host side, measurable on a 1-GPU box
     force_reducer = os.environ.get("SH_BENCH_FORCE_REDUCER", "0") != "0"
+    # SH_BENCH_DP_SAFE=1 (the supervisor's last attempt): the most conservative data-parallel configuration - communicator
+    # created lazily, no stream priority, one blocking all-reduce pass (sum of pre-scaled gradients) after backward
+    safe = os.environ.get("SH_BENCH_DP_SAFE", "0") != "0"
     if force_reducer and world == 1:
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
@@ -633,15 +804,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # the all-reduce kernels share the chip with backward kernels that are sized to fill every CU: give the
         # collectives' stream dispatch priority so their few workgroups are placed as soon as a slot frees
-        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        if not safe:
+            os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
+        if backend == "nccl" and not safe:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))     # communicator created here, eagerly
         else:
-            dist.init_process_group(backend)
-    if args.gpus != world:
-        if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world), file=sys.stderr)
-        sys.exit(2)
+            torch.cuda.set_device(dev_index)
+            dist.init_process_group(backend)                                               # safe mode: created by the first collective
+        injected_rank_failure(rank)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
 
@@ -666,7 +836,8 @@ def main():
     else:
         optim = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-5, capturable=True, fused=True)
     ft = sh.FaceTables(h.faces, h.sizes[0] + 1, dev)
-    reducer = GradientAllReducer(model, bucket_cap_mb=64.0, force_collectives=force_reducer,
+    reducer = GradientAllReducer(model, bucket_cap_mb=64.0, force_collectives=force_reducer, overlap=not safe,
+                                 average_in_collective=not safe,
                                  large_message_dtype=torch.bfloat16 if args.grad_comm == "bf16" else None) \
         if (world > 1 or force_reducer) else None
 
@@ -802,8 +973,8 @@ def main():
                                % ("box_sphere(42,42,20) 6890-vertex template" if h.sizes[0] == 6890 else "%d-vertex template" % h.sizes[0],
                                   h.sizes, h.spiral_sizes[:-1], sum(p.numel() for p in model.parameters()) / 1e6),
                    "global_batch": world * B, "per_gpu_batch": B, "parallelism": "dp%d" % world,
-                   "launch": ("hipGraph replay" + (" (RCCL all-reduces inside the graph)" if reducer else "")) if graph is not None
-                             else (graph_note or "eager"),
+                   "launch": (("hipGraph replay" + (" (RCCL all-reduces inside the graph)" if reducer else "")) if graph is not None
+                              else (graph_note or "eager")) + (" safe mode (SH_BENCH_DP_SAFE)" if safe and reducer else "") + attempt_note(),
                    **({"gradient_messages": "%.1f MB %s all-reduce per step" % (
                        sum(b.numel * (2 if (b.inplace and args.grad_comm == "bf16") else 4) for b in reducer.buckets) / 1e6,
                        "bf16 (large) + fp32" if args.grad_comm == "bf16" else "fp32")} if reducer else {})},
@@ -817,6 +988,11 @@ def main():
                             "frac_mfma": fl_step / (elapsed / args.steps) / 1e12 / (2500.0 if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS),
                             "frac_hbm": by_step / (elapsed / args.steps) / 1e9 / PEAK_HBM_GBS,
                             "note": "algorithmic FLOPs and fused-ideal bytes of one step (SURVEY 8d) / measured ms_per_step, per GPU"}
+
+    # ---- the data-parallel job as RCCL saw it: ranks, devices, and the gradient messages timed alone (HIP events on this
+    # rank's stream around blocking all-reduces of the step's own message sizes, MAX over ranks)
+    if reducer is not None and dist.is_initialized():
+        result["collective"] = collective_block(reducer, world, rank, dev, backend)
 
     # ---- roofline of the dominant kernel: HIP events recorded by the library around every launch
     if not args.no_roofline:

@@ -49,18 +49,20 @@ class GradientAllReducer:
     """Bucketed, overlapped gradient averaging for a replicated nn.Module."""
 
     def __init__(self, module: torch.nn.Module, process_group=None, bucket_cap_mb: float = 64.0, overlap: bool = True,
-                 inplace_min_mb: float = 16.0, force_collectives: bool = False, large_message_dtype=None):
+                 inplace_min_mb: float = 16.0, force_collectives: bool = False, large_message_dtype=None,
+                 average_in_collective: bool = True):
         """force_collectives: issue the collectives even in a world of one rank (exercises the RCCL path on a 1-GPU box).
         large_message_dtype: e.g. torch.bfloat16 - the large in-place gradients travel in that type (half the xGMI
         bytes: 57 MB instead of 114 MB for the plain autoencoder) and are converted back into the
-        fp32 gradient after the collective.  Off by default: fp32 training exchanges fp32 gradients."""
+        fp32 gradient after the collective.  Off by default: fp32 training exchanges fp32 gradients.
+        average_in_collective=False: never use ncclAvg (sum of pre-scaled gradients; bench.py's safe mode)."""
         self.large_dtype = large_message_dtype
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (force_collectives and dist.is_initialized())
         self.overlap = overlap
         # RCCL averages in the collective (ncclAvg): no pre-scaling pass.  gloo (CPU tests) only sums.
-        self.avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
+        self.avg = average_in_collective and dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         params = [p for p in module.parameters() if p.requires_grad]
         if self.avg and self.active and params:
             try:                                               # every rank builds its reducer: a collective probe is safe

@@ -47,3 +47,44 @@ def test_failing_rank_propagates_exit_status():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
                        timeout=120)
     assert r.returncode == 2
+
+
+def _retry_env(spec, **kw):
+    return dict(_env(), SH_BENCH_TEST_RANK_FAIL=spec, SH_BENCH_FAIL_GRACE="1", SH_BENCH_ATTEMPT_TIMEOUT="120", **kw)
+
+
+def test_failed_attempt_is_retried_with_fresh_children():
+    """A rank that dies in the first attempt (the hipGraph-with-RCCL mode on a real node) must not end the job: every rank's
+    GPU-free supervisor starts a FRESH child for the next, more conservative mode on a fresh rendezvous port; rank 0 prints
+    exactly one JSON line - the successful attempt's - and says in config.launch what happened before."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0"],
+                       env=_retry_env("0:1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    res = _one_json_line(r.stdout)
+    assert res["n_gpus"] == 2
+    assert "attempt 1 'eager'" in res["config"]["launch"] and "graph: " in res["config"]["launch"], res["config"]["launch"]
+    assert "attempt 0 (graph) failed" in r.stderr
+
+
+def test_retry_under_torch_distributed_run_rank0_failure():
+    """The same under the driver's launcher, with rank 0 (which owns the JSON line) the one that dies: the next mode
+    (eager) produces the line, torch.distributed.run sees exit status 0 from every rank."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = _retry_env("0:0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                        "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    res = _one_json_line(r.stdout)
+    assert "attempt 1 'eager'" in res["config"]["launch"]
+
+
+def test_all_attempts_failing_gives_a_nonzero_status():
+    env = dict(_retry_env("0:1"), SH_BENCH_DP_GRAPH="0")     # attempts: eager (index 0, fails), eager-safe (index 1)
+    env["SH_BENCH_TEST_RANK_FAIL"] = "*:1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
