@@ -145,14 +145,15 @@ def parse_tag(name, shape):
 
 
 def lib_sha16():
-    """Identity of the kernel SOURCES: SHA-256 over csrc/*.hip, csrc/*.h (each group in name order) and the Makefile - the
+    """Identity of the kernel SOURCES: SHA-256 over csrc/*.hip, csrc/*.h, include/*.h (each group in name order) and the Makefile - the
     bytes csrc/Makefile hashes into the library as sh_build_id().  (The bytes of the .so itself are not reproducible
     across checkouts; a profile taken on these sources stays valid wherever they are rebuilt.)"""
     import glob
     import hashlib
     d = os.path.join(ROOT, "semantichuman_amd", "csrc")
     hsh = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(d, "*.hip"))) + sorted(glob.glob(os.path.join(d, "*.h"))) + [os.path.join(d, "Makefile")]:
+    for f in sorted(glob.glob(os.path.join(d, "*.hip"))) + sorted(glob.glob(os.path.join(d, "*.h"))) + \
+            sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))) + [os.path.join(d, "Makefile")]:
         hsh.update(open(f, "rb").read())
     return hsh.hexdigest()[:16]
 

@@ -61,17 +61,20 @@ SH_API const char* sh_last_error(void);
  * a committed PMC profile only for the build it was taken on. */
 SH_API const char* sh_build_id(void);
 
-/* Arithmetic form of the fp32 path's matrix products (SpiralConv forward / backward-data).  The reference computes them
- * with fp32 FMAs (models.py:45, aten::addmm).
- *   SH_MMA_EXACT   v_mfma_f32_16x16x4_f32: an exact fp32 FMA chain.
- *   SH_MMA_SPLIT3  every fp32 operand split EXACTLY into three bf16 terms (8+8+8 significand bits), the six leading
- *                  partial products on v_mfma_f32_16x16x32_bf16 with fp32 accumulation; dropped terms < 2^-24 |w||x|,
- *                  i.e. fp32-level error (the parity tolerances in tests/ are the same for both), 2.7x less matrix-pipe time.
- * Process-wide, read at launch time (a captured hipGraph keeps the form it was captured with).  Default: environment
- * SH_F32_MMA=exact|split3. */
-enum sh_mma_mode { SH_MMA_EXACT = 0, SH_MMA_SPLIT3 = 1 };
-SH_API int sh_set_f32_mma_mode(int mode);
-SH_API int sh_get_f32_mma_mode(void);
+/* Arithmetic form of the fp32 path's matrix products (SpiralConv forward / backward-data / weight gradient).  The
+ * reference computes them with fp32 FMAs (models.py:45, aten::addmm).
+ *   SH_MMA_EXACT    v_mfma_f32_16x16x4_f32: an exact fp32 FMA chain.
+ *   SH_MMA_SPLIT3   every fp32 operand split EXACTLY into three bf16 terms (8+8+8 significand bits), the six leading
+ *                   partial products on v_mfma_f32_16x16x32_bf16 with fp32 accumulation; dropped terms < 2^-24 |w||x|,
+ *                   i.e. fp32-level error (the parity tolerances in tests/ are the same for all forms); the split is done
+ *                   by every consumer on what it gathered.
+ *   SH_MMA_PLANES3  the same arithmetic with the split done ONCE, by the producer of a tensor, into three bf16 planes that
+ *                   the consumers gather (the ..._p3 entry points at the end of this header; sh_stack_forward /
+ *                   sh_stack_backward run them wherever the plane buffers they are given allow, and the SPLIT3 kernels
+ *                   elsewhere).  On the per-layer fp32 entry points it selects the SPLIT3 kernels.
+ * `mma_mode` is an ARGUMENT of every entry point whose kernel choice depends on it: there is no process-wide setting (a
+ * forward pass and the backward pass of another node may run concurrently on different threads in different forms). */
+enum sh_mma_mode { SH_MMA_EXACT = 0, SH_MMA_SPLIT3 = 1, SH_MMA_PLANES3 = 2 };
 
 /* Optional per-kernel timing with HIP events attached to the kernel dispatch itself (begin / end of
  * the kernel's execution, what rocprofv3 --kernel-trace reports; minor helper kernels are bracketed
@@ -99,7 +102,7 @@ SH_API int sh_profile_get(int i, char* name, int name_len, float* ms);
 SH_API int sh_spiral_conv_fwd(const float* x, int64_t x_sv, int64_t x_sb,
                        const int32_t* table, const float* weight, const float* bias,
                        float* y, int64_t y_sv, int64_t y_sb,
-                       int B, int R, int S, int Cin, int Cout, int act, int zero_row,
+                       int B, int R, int S, int Cin, int Cout, int act, int zero_row, int mma_mode,
                        sh_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -121,7 +124,7 @@ SH_API int sh_spiral_conv_bwd_data(const float* dpre, int64_t dp_sv, int64_t dp_
                             const int32_t* table_t, const float* weight_t,
                             float* dx, int64_t dx_sv, int64_t dx_sb,
                             const float* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row,
-                            int B, int n_in, int S, int Cin, int Cout,
+                            int B, int n_in, int S, int Cin, int Cout, int mma_mode,
                             sh_stream_t stream);
 /* The same with one more piece of knowledge: row `dpre_zero_row` of dpre is all zero and is the row the "no source" entries
  * of table_t point at (>= 0; -1 = unknown: identical to sh_spiral_conv_bwd_data).  With a batch slice of 16 and gathered
@@ -130,7 +133,7 @@ SH_API int sh_spiral_conv_bwd_data(const float* dpre, int64_t dp_sv, int64_t dp_
 SH_API int sh_spiral_conv_bwd_data_z(const float* dpre, int64_t dp_sv, int64_t dp_sb, int dpre_zero_row, const int32_t* table_t,
                                      const float* weight_t, float* dx, int64_t dx_sv, int64_t dx_sb, const float* yprev,
                                      int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row, int B, int n_in, int S, int Cin,
-                                     int Cout, sh_stream_t stream);
+                                     int Cout, int mma_mode, sh_stream_t stream);
 
 /* weight [Cout][S*Cin] -> weight_t [Cin][S*Cout] (see above). */
 SH_API int sh_weight_transpose(const float* weight, float* weight_t, int S, int Cin, int Cout, sh_stream_t stream);
@@ -146,7 +149,7 @@ SH_API size_t sh_spiral_conv_bwd_wgt_workspace(int B, int R, int S, int Cin, int
 SH_API int sh_spiral_conv_bwd_wgt(const float* dpre, int64_t dp_sv, int64_t dp_sb,
                            const float* x, int64_t x_sv, int64_t x_sb, const int32_t* table,
                            float* dW, float* dbias, void* workspace, size_t workspace_bytes,
-                           int B, int R, int S, int Cin, int Cout,
+                           int B, int R, int S, int Cin, int Cout, int mma_mode,
                            sh_stream_t stream);
 
 /* The same launch with a rider: the LAST pre-sum level of the layer's backward-data pass (sh_stack_step.sum1 / sum2: rows
@@ -158,7 +161,7 @@ SH_API int sh_spiral_conv_bwd_wgt(const float* dpre, int64_t dp_sv, int64_t dp_s
 SH_API int sh_spiral_conv_bwd_wgt_presum(const float* dpre, int64_t dp_sv, int64_t dp_sb, const float* x, int64_t x_sv, int64_t x_sb,
                                          const int32_t* table, float* dW, float* dbias, void* workspace, size_t workspace_bytes,
                                          const int32_t* sum_rowptr, const int32_t* sum_col, const float* sum_val, float* sum_out,
-                                         int sum_rows, int B, int R, int S, int Cin, int Cout, sh_stream_t stream);
+                                         int sum_rows, int B, int R, int S, int Cin, int Cout, int mma_mode, sh_stream_t stream);
 
 /* Batched forms for a whole stack of layers (one launch instead of one per layer; host arrays of
  * n_layers entries, passed by value into the kernel arguments -> graph-capturable):
@@ -232,9 +235,14 @@ typedef struct sh_stack_step {
 
 /* outs[i]: output of step i, vertex-major, except outs[n_steps-1] which has layout out_layout.
  * x: [rows0] rows of c0 channels in layout x_layout. */
+/* Three-plane form (mma_mode == SH_MMA_PLANES3; ignored otherwise, may be NULL): planes[i] = buffer for the plane image of
+ * outs[i] (sh_p3_bytes of the buffer's rows - a step that appends shares its predecessor's buffer AND image - or NULL: the
+ * step that gathers it keeps the SPLIT3 kernels); wfrag3[i] = three-plane weight fragments of conv step i, forward operand
+ * (sh_conv_wfrag3_prep_multi, transpose 0), already converted from the CURRENT weights.  A conv step whose input has an
+ * image and whose shape sh_spiral_conv_p3_ok() takes runs sh_spiral_conv_fwd_p3; images are written by their producers. */
 SH_API int sh_stack_forward(int n_steps, const sh_stack_step* steps, const float* x, int x_layout, int rows0, int c0, int B,
                             const float* const* weights, const float* const* biases, float* const* outs, int out_layout,
-                            sh_stream_t stream);
+                            int mma_mode, void* const* planes, const void* const* wfrag3, sh_stream_t stream);
 
 /* acts[i]: what sh_stack_forward wrote to outs[i].  g: gradient w.r.t. the stack output (out_layout).
  * gin[i]: gradient w.r.t. the INPUT of step i - for i >= 1 vertex-major with (n1 + n2 of step i-1, if that is a
@@ -242,11 +250,16 @@ SH_API int sh_stack_forward(int n_steps, const sh_stack_step* steps, const float
  * non-adjacent steps may alias (gin[i] is dead once gin[i-1] has been produced).  dpre_last: as gin[] for the
  * output of the last step when that is a conv ([R + n1 + n2][B][cout]), else unused.  Per conv step i:
  * weight_t[i] ([cin][S*cout], needed when i > 0 or need_x_grad), workspace[i] / workspace_bytes[i]
- * (>= sh_spiral_conv_bwd_wgt_workspace); per parameter index: dW[p], dbias[p] (may be NULL). */
+ * (>= sh_spiral_conv_bwd_wgt_workspace); per parameter index: dW[p], dbias[p] (may be NULL).
+ * Three-plane form (SH_MMA_PLANES3; otherwise ignored, may be NULL): gin_planes[i] / dpre_last_planes = buffers for the plane
+ * images of gin[i] / dpre_last (all rows, the pre-summed ones included; NULL = that conv step's backward-data pass keeps the
+ * SPLIT3 kernels), wfrag3_t[i] = fragments of conv step i's backward-data operand (transpose 1); weight_t[i] may be NULL for
+ * a step that runs sh_spiral_conv_bwd_data_p3. */
 SH_API int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, int x_layout, int rows0, int c0, int B,
                              const float* const* acts, const float* g, int out_layout, const float* const* weights,
                              float* const* gin, float* dpre_last, float* const* weight_t, void* const* workspace,
                              const size_t* workspace_bytes, float* const* dW, float* const* dbias, int need_x_grad,
+                             int mma_mode, void* const* gin_planes, void* dpre_last_planes, const void* const* wfrag3_t,
                              sh_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -564,6 +577,36 @@ SH_API int sh_stack_backward_bf16(int n_steps, const sh_stack_step* steps, const
                                   void* const* wfrag_t, int wfrag_ready, void* const* workspace,
                                   const size_t* workspace_bytes, float* const* dW, float* const* dbias, int need_x_grad,
                                   sh_stream_t stream);
+
+/* =============================================================================================
+ * Three-plane form of the fp32 path's matrix products (round 4).  Same operators, same fp32 tensors at every interface
+ * as the fp32 entry points above (models.py:34-53 and its autograd); what changes is where the exact bf16x3 operand
+ * split of SH_MMA_SPLIT3 happens: the PRODUCER of an activation / gradient writes, beside the fp32 tensor, its three
+ * bf16 planes v = h + m + l (exact) once, and the conv kernels gather the planes and only multiply (six - or with
+ * SH_P3_NP=9 all nine - partial products on v_mfma_f32_16x16x32_bf16, fp32 accumulation).
+ *
+ * Plane image of a tensor [rows][B][C], B % 16 == 0, C == 16 or C % 32 == 0 (sh_p3_bytes(rows, B, C) bytes, 0 =
+ * unsupported shape; 16-byte aligned): fragment-major - the B-operand order of the matrix instruction, so a wave's gather
+ * is one contiguous 1-KiB access (layout in csrc/p3_conv.hip).  sh_to_p3 converts rows of an fp32 tensor (strides as
+ * everywhere: element (r, b, c) at x + r*sv + b*sb + c); the conv entry points can also write the image of their output
+ * (yp / dxp != NULL; then Cout resp. Cin must be 16 or a multiple of 32) next to - or instead of (y / dx == NULL) - the
+ * fp32 tensor.  Weights: sh_conv_wfrag3_prep_multi = sh_conv_wfrag_prep_multi with three planes per fragment
+ * (sh_conv_wfrag3_bytes).  sh_spiral_conv_p3_ok(B, S, Cg, Nout): 1 when the kernels take a layer with Cg gathered and
+ * Nout produced channels (its three-plane weight must fit LDS); otherwise the caller keeps the exact kernels. */
+SH_API size_t sh_p3_bytes(int rows, int B, int C);
+SH_API int sh_to_p3(const float* x, int64_t x_sv, int64_t x_sb, void* planes, int B, int rows, int C, sh_stream_t stream);
+SH_API size_t sh_conv_wfrag3_bytes(int S, int Cg, int Nout);
+SH_API int sh_conv_wfrag3_prep_multi(int n_layers, const float* const* weight, void* const* wfrag3, const int* S, const int* Cin,
+                                     const int* Cout, const int* transpose, sh_stream_t stream);
+SH_API int sh_spiral_conv_p3_ok(int B, int S, int Cg, int Nout);
+/* sh_spiral_conv_fwd with x given as its plane image xp ([n_in] rows) */
+SH_API int sh_spiral_conv_fwd_p3(const void* xp, const int32_t* table, const void* wfrag3, const float* bias, float* y, int64_t y_sv,
+                                 int64_t y_sb, void* yp, int B, int R, int S, int Cin, int Cout, int act, int zero_row,
+                                 sh_stream_t stream);
+/* sh_spiral_conv_bwd_data with dpre given as its plane image dprep (all rows table_t refers to, pre-summed rows included) */
+SH_API int sh_spiral_conv_bwd_data_p3(const void* dprep, const int32_t* table_t, const void* wfrag3_t, float* dx, int64_t dx_sv,
+                                      int64_t dx_sb, void* dxp, const float* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev,
+                                      int zero_row, int B, int n_in, int S, int Cin, int Cout, sh_stream_t stream);
 
 #ifdef __cplusplus
 }

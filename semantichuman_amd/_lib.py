@@ -21,26 +21,24 @@ SIGNATURES = {
     "sh_version": (c_int, []),
     "sh_last_error": (c_char_p, []),
     "sh_build_id": (c_char_p, []),
-    "sh_set_f32_mma_mode": (c_int, [_I]),
-    "sh_get_f32_mma_mode": (c_int, []),
     "sh_clock_probe": (c_int, [_P, _I, _I, _P]),
     "sh_profile_enable": (c_int, [_I]),
     "sh_profile_count": (c_int, []),
     "sh_profile_get": (c_int, [_I, c_char_p, _I, ctypes.POINTER(c_float)]),
-    "sh_spiral_conv_fwd": (c_int, [_P, _L, _L, _P, _P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "sh_spiral_conv_bwd_data": (c_int, [_P, _L, _L, _P, _P, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "sh_spiral_conv_bwd_data_z": (c_int, [_P, _L, _L, _I, _P, _P, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "sh_spiral_conv_fwd": (c_int, [_P, _L, _L, _P, _P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "sh_spiral_conv_bwd_data": (c_int, [_P, _L, _L, _P, _P, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "sh_spiral_conv_bwd_data_z": (c_int, [_P, _L, _L, _I, _P, _P, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sh_weight_transpose": (c_int, [_P, _P, _I, _I, _I, _P]),
     "sh_spiral_conv_bwd_wgt_workspace": (c_size_t, [_I, _I, _I, _I, _I]),
-    "sh_spiral_conv_bwd_wgt": (c_int, [_P, _L, _L, _P, _L, _L, _P, _P, _P, _P, c_size_t, _I, _I, _I, _I, _I, _P]),
-    "sh_spiral_conv_bwd_wgt_presum": (c_int, [_P, _L, _L, _P, _L, _L, _P, _P, _P, _P, c_size_t, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "sh_spiral_conv_bwd_wgt": (c_int, [_P, _L, _L, _P, _L, _L, _P, _P, _P, _P, c_size_t, _I, _I, _I, _I, _I, _I, _P]),
+    "sh_spiral_conv_bwd_wgt_presum": (c_int, [_P, _L, _L, _P, _L, _L, _P, _P, _P, _P, c_size_t, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sh_spiral_conv_bwd_wgt_reduce_multi": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sh_weight_transpose_multi": (c_int, [_I, _P, _P, _P, _P, _P, _P]),
     "sh_act_backward": (c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _P]),
     "sh_act_backward_tr": (c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "sh_spmm": (c_int, [_P, _P, _P, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _P]),
-    "sh_stack_forward": (c_int, [_I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
-    "sh_stack_backward": (c_int, [_I, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "sh_stack_forward": (c_int, [_I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "sh_stack_backward": (c_int, [_I, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "sh_linear_workspace": (c_size_t, [_I, _I, _I]),
     "sh_linear_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, c_size_t, _P]),
     "sh_linear_bwd_data": (c_int, [_P, _P, _P, _I, _I, _I, _P, c_size_t, _P]),
@@ -96,6 +94,14 @@ SIGNATURES = {
     "sh_adam_step_bf16": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P] + [ctypes.c_double] * 4 + [_P]),
     "sh_stack_forward_bf16": (c_int, [_I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _P]),
     "sh_stack_backward_bf16": (c_int, [_I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _P]),
+    # three-plane form of the fp32 path
+    "sh_p3_bytes": (c_size_t, [_I, _I, _I]),
+    "sh_to_p3": (c_int, [_P, _L, _L, _P, _I, _I, _I, _P]),
+    "sh_conv_wfrag3_bytes": (c_size_t, [_I, _I, _I]),
+    "sh_conv_wfrag3_prep_multi": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P]),
+    "sh_spiral_conv_p3_ok": (c_int, [_I, _I, _I, _I]),
+    "sh_spiral_conv_fwd_p3": (c_int, [_P, _P, _P, _P, _P, _L, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "sh_spiral_conv_bwd_data_p3": (c_int, [_P, _P, _P, _P, _L, _L, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _P]),
 }
 DTYPE_IDS = {"float32": 0, "bfloat16": 1}
 
@@ -189,17 +195,37 @@ def env_overrides() -> dict:
     return {k: v for k, v in sorted(os.environ.items()) if k.startswith("SH_") and not k.startswith(("SH_BENCH_", "SH_KERNEL_LIB"))}
 
 
-MMA_MODES = {"exact": 0, "split3": 1}
+MMA_MODES = {"exact": 0, "split3": 1, "planes3": 2}
+
+
+def _mma_default() -> str:
+    v = os.environ.get("SH_F32_MMA", "exact").strip().lower()
+    if v in MMA_MODES:
+        return v
+    return {"0": "exact", "1": "split3", "2": "planes3"}.get(v, "exact")
+
+
+_mma_mode = _mma_default()
 
 
 def set_f32_mma_mode(mode: str):
-    """Arithmetic form of the fp32 path's matrix products: "exact" (fp32 MFMA) or "split3" (exact bf16x3 operand split,
-    six bf16 MFMAs per product, fp32 accumulation; include/sh_kernels.h).  Process-wide, read at launch time."""
-    check(load().sh_set_f32_mma_mode(MMA_MODES[mode]), "sh_set_f32_mma_mode")
+    """Arithmetic form of the fp32 path's matrix products for the calls that follow (include/sh_kernels.h enum sh_mma_mode):
+    "exact" (fp32 MFMA), "split3" (exact bf16x3 operand split by every consumer, six bf16 MFMAs per product, fp32
+    accumulation) or "planes3" (the same arithmetic, the split written once by the producer as three bf16 planes).  A
+    Python-side default only: the library has no mode of its own, every call names its form, and an autograd node keeps the
+    form its forward pass ran in for its backward pass."""
+    global _mma_mode
+    if mode not in MMA_MODES:
+        raise ValueError("f32 mma mode must be one of %s" % sorted(MMA_MODES))
+    _mma_mode = mode
 
 
 def get_f32_mma_mode() -> str:
-    return {v: k for k, v in MMA_MODES.items()}[load().sh_get_f32_mma_mode()]
+    return _mma_mode
+
+
+def mma_id(mode: str | None = None) -> int:
+    return MMA_MODES[_mma_mode if mode is None else mode]
 
 
 def ptr(t):

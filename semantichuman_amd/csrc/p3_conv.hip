@@ -1,0 +1,475 @@
+// Spiral convolution of the fp32 path in the THREE-PLANE form (SH_MMA_PLANES3) on CDNA4 (gfx950).
+//
+//   forward        y[r,b,:]  = act( sum_s x[table[r,s],b,:] . W_s^T + bias )       (reference models.py:40-51)
+//   backward-data  dx[u,b,:] = sum_s dpre[table_t[u,s],b,:] . W_s                   (autograd of :42,:45)
+//
+// Arithmetic: every fp32 operand is an EXACT sum of three bf16 numbers, v = h + m + l (8 + 8 + 8 significand bits,
+// sh_split3), and a product row is the six leading (or all nine) terms of (Wh + Wm + Wl)(Xh + Xm + Xl) on
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulation - the arithmetic of the bf16x3 kernels of spiral_conv.hip (fp32-level
+// error; tests/test_p3.py gates it against a float64 evaluation next to the exact fp32 MFMA form).  What differs is WHERE
+// the split happens: there every consumer splits what it gathered (~5.5 VALU operations per gathered element, S-fold per
+// activation, which is what bounds those kernels); here the PRODUCER of an activation or gradient writes the three planes
+// once, beside the fp32 tensor the element-wise consumers keep using, and the consumers only load and multiply.
+//
+// Plane image of a tensor [rows][B][C] (B % 16 == 0; C % 32 == 0 or C == 16): FRAGMENT-MAJOR, i.e. stored in exactly the
+// order the matrix instruction wants its B operand, one 1-KiB fragment per (row, 16 batch entries, 32 channels, plane):
+//     C % 32 == 0:  byte ((row * nbg + bg) * C/32 + cg) * 3072 + plane * 1024 + lane * 16,   lane = kb * 16 + (b & 15)
+//                   holds the 8 bf16 of channels cg * 32 + kb * 8 .. + 7 of batch entry bg * 16 + (b & 15)
+//     C == 16:      byte (row * nbg + bg) * 1536 + plane * 512 + (kb2 * 16 + (b & 15)) * 16,  kb2 = channel / 8
+//                   (a k-step of 32 covers two spiral positions: lanes 0-31 read one neighbour, lanes 32-63 the next)
+// so a wave's gather instruction is ONE contiguous 1-KiB (or two 512-byte) access with lane l at base + 16 l - the
+// vector L1 serves it as eight full lines instead of 64 separate 16-byte accesses (6.8-8.7 TB/s of gathered
+// bytes in the MFMA operand layout of a row-major tensor against 16.6-21.9 TB/s line-wise) - and nothing is permuted,
+// converted or staged between the load and the MFMA.
+//
+// Kernel structure = the bf16 path's gather stream (bf16_conv.hip): the layer's weight (three planes of fragments) sits in
+// LDS for the lifetime of the persistent workgroup, a WAVE owns items of RT vertices x 16 batch entries, D k-steps of loads
+// in flight, no barrier in the loop, table line of a vertex in one VGPR across the wave (v_readlane -> scalar row base).
+#include "sh_bf16.h"
+
+#include <type_traits>
+
+namespace {
+
+struct P3Params {
+    const char* xp; long x_vb, x_bgb;          // plane image of the gathered tensor: bytes per row / per 16-batch group
+    const int* table;                          // [R][S]
+    const u32x4* wfrag;                        // [nks][nt_tot][3][64] 16-byte fragment pieces
+    const float* bias;
+    float* y; long y_sv, y_sb;                 // fp32 output, element strides of (row, batch entry); may be NULL
+    char* yp; long yp_vb, yp_bgb;              // plane image of the output; may be NULL
+    const float* yprev; long yv_sv, yv_sb;     // fp32 output of the layer that produced x (backward epilogue)
+    int B, R, S, Cg, Nout, nks, nt_tot, ncg;
+    int act, zero_row;
+    int n_vg, n_tiles, nsplit;
+};
+
+constexpr int p3_depth(int NT, int RT) {
+    const int d = (88 - NT * RT * 4 - 12) / (RT * 12);
+    return d < 2 ? 2 : d > 4 ? 4 : d;
+}
+
+template <int J, int D, class F>
+__device__ __forceinline__ bool p3_ring_steps(int ks, int nks, F&& f) {
+    f(std::integral_constant<int, J>{}, ks + J);
+    if constexpr (J + 1 < D) {
+        if (ks + J + 1 >= nks) return false;
+        return p3_ring_steps<J + 1, D>(ks, nks, f);
+    } else {
+        return true;
+    }
+}
+
+template <int NT, int RT, bool C16, bool BWD, int NP>
+__global__ __launch_bounds__(1024) void conv_p3_kernel(const P3Params p) {
+    constexpr int D = p3_depth(NT, RT);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const u32x4* Wl = reinterpret_cast<const u32x4*>(smem);       // [nks][NT][3][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+    const int nwg_x = ((int)gridDim.x - xcd + 7) >> 3;
+    const int slice = li % p.nsplit, lj = li / p.nsplit;
+    const int ngrp = nwg_x / p.nsplit;
+    const int q8 = p.n_tiles >> 3, r8 = p.n_tiles & 7;
+    const int t_begin = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int t_end = t_begin + (xcd < r8 ? q8 + 1 : q8);
+    const int stride = ngrp * nw;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int S = p.S, sl = lane < S ? lane : S - 1;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    auto load_table = [&](int t, int (&tv)[RT]) {
+        const int tt = t < t_end ? t : (t_end > 0 ? t_end - 1 : 0);
+        const int vg = tt % p.n_vg;
+#pragma unroll
+        for (int m = 0; m < RT; ++m) {
+            const int v = vg * RT + m < p.R ? vg * RT + m : p.R - 1;
+            tv[m] = p.table[(long)v * S + sl];
+        }
+    };
+
+    int t = t_begin + lj * nw + wave;
+    int tv[RT], tvn[RT];
+    load_table(t, tv);
+    {
+        // weight fragments (three planes) -> LDS by LDS-DMA, one 1-KiB fragment per wave instruction
+        typedef __attribute__((address_space(3))) char* lptr_t;
+        const unsigned wl_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_t)smem);
+        const int nfrag = p.nks * NT * 3;
+        for (int f = __builtin_amdgcn_readfirstlane(wave); f < nfrag; f += nw) {
+            const int pl = f % 3, n = (f / 3) % NT, ks = f / (3 * NT);
+            const char* src = reinterpret_cast<const char*>(p.wfrag + (((long)ks * p.nt_tot + slice * NT + n) * 3 + pl) * 64 + lane);
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(__builtin_amdgcn_readfirstlane(wl_lds + (unsigned)f * 1024u)) : "memory", "m0");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    constexpr int PB = C16 ? 512 : 1024;                   // bytes between the planes of a fragment
+    for (; t < t_end; t += stride) {
+        load_table(t + stride, tvn);
+        const int bs = t / p.n_vg, vg = t - bs * p.n_vg;
+        const int v0 = vg * RT;
+        const char* xl = p.xp + (long)bs * p.x_bgb + (C16 ? ((kq & 1) * 16 + r16) * 16 : lane * 16);
+
+        int ls = 0, lc = 0;                                // running load position (uniform)
+        u32x4 ring[D][RT][3];
+        auto issue = [&](u32x4 (&a)[RT][3]) {
+            if constexpr (!C16) {
+                const int s = ls < S ? ls : S - 1;
+#pragma unroll
+                for (int m = 0; m < RT; ++m) {
+                    const int row = __builtin_amdgcn_readlane(tv[m], s);
+                    const char* src = xl + (long)row * p.x_vb + (long)lc * 3072;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) a[m][pl] = *reinterpret_cast<const u32x4*>(src + pl * PB);
+                }
+                if (++lc >= p.ncg) { lc = 0; ++ls; }
+            } else {
+                const int s0 = ls < S ? ls : S - 1, s1 = ls + 1 < S ? ls + 1 : S - 1;
+#pragma unroll
+                for (int m = 0; m < RT; ++m) {
+                    const int r0 = __builtin_amdgcn_readlane(tv[m], s0), r1 = __builtin_amdgcn_readlane(tv[m], s1);
+                    const int row = (kq & 2) ? r1 : r0;
+                    const char* src = xl + (long)row * p.x_vb;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) a[m][pl] = *reinterpret_cast<const u32x4*>(src + pl * PB);
+                }
+                ls += 2;
+            }
+        };
+        f32x4 acc[RT][NT];
+#pragma unroll
+        for (int m = 0; m < RT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = zero4;
+        auto compute = [&](int ks, const u32x4 (&a)[RT][3]) {
+            const u32x4* wk = Wl + ((long)ks * NT) * 192 + lane;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const u32x4 r0 = wk[n * 192], r1 = wk[n * 192 + 64], r2 = wk[n * 192 + 128];
+                const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&r0), wm = *reinterpret_cast<const bf16x8*>(&r1),
+                             wl = *reinterpret_cast<const bf16x8*>(&r2);
+#pragma unroll
+                for (int m = 0; m < RT; ++m) {
+                    const bf16x8 xh = *reinterpret_cast<const bf16x8*>(&a[m][0]), xm = *reinterpret_cast<const bf16x8*>(&a[m][1]),
+                                 xl2 = *reinterpret_cast<const bf16x8*>(&a[m][2]);
+                    f32x4 c = acc[m][n];
+                    if constexpr (NP == 9) {
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xl2, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xm, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xl2, c, 0, 0, 0);
+                    }
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl2, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, c, 0, 0, 0);
+                    acc[m][n] = c;
+                }
+            }
+        };
+
+#pragma unroll
+        for (int d = 0; d < D - 1; ++d) issue(ring[d]);
+        auto step = [&](auto J, int ks) {
+            constexpr int j = decltype(J)::value;
+            issue(ring[(j + D - 1) % D]);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(ks, ring[j]);
+        };
+        for (int ks = 0; ks < p.nks; ks += D)
+            if (!p3_ring_steps<0, D>(ks, p.nks, step)) break;
+
+        // ---- epilogue: lane holds channels c0..c0+3 (c0 = 16 n + 4 kq) of row (v0 + m, bs * 16 + r16)
+        const int b = bs * 16 + r16;
+#pragma unroll
+        for (int m = 0; m < RT; ++m) {
+            const int v = v0 + m;
+            if (v >= p.R || b >= p.B) continue;
+            const bool zero = v == p.zero_row;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int c0 = (slice * NT + n) * 16 + kq * 4;
+                if (c0 >= p.Nout) continue;
+                f32x4 a = acc[m][n];
+                if (!BWD) {
+                    if (p.bias) a += *reinterpret_cast<const f32x4*>(p.bias + c0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[j] = sh_act_fwd(a[j], p.act);
+                } else if (p.yprev) {
+                    const f32x4 yv = *reinterpret_cast<const f32x4*>(p.yprev + (long)v * p.yv_sv + (long)b * p.yv_sb + c0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[j] *= sh_act_grad_from_out(yv[j], p.act);
+                }
+                if (zero) a = zero4;
+                if (p.y) *reinterpret_cast<f32x4*>(p.y + (long)v * p.y_sv + (long)b * p.y_sb + c0) = a;
+                if (p.yp) {
+                    u32x2 h, mm, l;
+                    sh_split3_quad(a, h, mm, l);
+                    const bool o16 = p.Nout == 16;
+                    char* dst = p.yp + (long)v * p.yp_vb + (long)bs * p.yp_bgb +
+                                (o16 ? ((c0 >> 3) * 16 + r16) * 16 : (c0 >> 5) * 3072 + (((c0 & 31) >> 3) * 16 + r16) * 16) + (kq & 1) * 8;
+                    const int opb = o16 ? 512 : 1024;
+                    *reinterpret_cast<u32x2*>(dst) = h;
+                    *reinterpret_cast<u32x2*>(dst + opb) = mm;
+                    *reinterpret_cast<u32x2*>(dst + 2 * opb) = l;
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < RT; ++m) tv[m] = tvn[m];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// fp32 tensor [rows][B][C] (element strides sv, sb; channels contiguous) -> its plane image.  One 16-byte piece of each
+// plane per thread.
+struct ToP3Args { const float* x; long sv, sb; char* out; int nbg, C; long total; };
+__global__ __launch_bounds__(256) void to_p3_kernel(const ToP3Args a) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= a.total) return;
+    int l, kb, cbase; long blk; char* d; int pb;
+    if (a.C == 16) {
+        l = (int)(q & 31); blk = q >> 5; kb = l >> 4; cbase = kb * 8;
+        d = a.out + blk * 1536 + l * 16; pb = 512;
+    } else {
+        l = (int)(q & 63); const long f = q >> 6; const int ncg = a.C >> 5;
+        blk = f / ncg; const int cg = (int)(f - blk * ncg); kb = l >> 4; cbase = cg * 32 + kb * 8;
+        d = a.out + f * 3072 + l * 16; pb = 1024;
+    }
+    const long v = blk / a.nbg; const int bg = (int)(blk - v * a.nbg), r = l & 15;
+    const float* s = a.x + v * a.sv + (long)(bg * 16 + r) * a.sb + cbase;
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(s), hi = *reinterpret_cast<const f32x4*>(s + 4);
+    u32x4 h, m, lw;
+    sh_split3(lo, hi, h, m, lw);
+    *reinterpret_cast<u32x4*>(d) = h;
+    *reinterpret_cast<u32x4*>(d + pb) = m;
+    *reinterpret_cast<u32x4*>(d + 2 * pb) = lw;
+}
+
+// fp32 master weight -> three planes of fragment-ordered bf16 (one launch for all layers; geometry of sh_frag_geom):
+//   frag3[ks][nt][plane][lane][j] = plane of W'[16 nt + (lane & 15)][32 ks + 8 (lane >> 4) + j]
+constexpr int WF3_MAX = 24;
+struct WFrag3Args {
+    const float* w[WF3_MAX]; u32x4* out[WF3_MAX];
+    int S[WF3_MAX], Cin[WF3_MAX], Cout[WF3_MAX], tr[WF3_MAX], nks[WF3_MAX], nt_tot[WF3_MAX], block0[WF3_MAX + 1];
+    int nd;
+};
+__global__ __launch_bounds__(256) void wfrag3_prep_kernel(const WFrag3Args a) {
+    int d = 0;
+    while (d + 1 < a.nd && a.block0[d + 1] <= (int)blockIdx.x) ++d;
+    const long i = (long)((int)blockIdx.x - a.block0[d]) * 256 + threadIdx.x;
+    const long total = (long)a.nks[d] * a.nt_tot[d] * 64;
+    if (i >= total) return;
+    const int lane = (int)(i & 63), f = (int)(i >> 6), nt = f % a.nt_tot[d], ks = f / a.nt_tot[d];
+    const int S = a.S[d], Cin = a.Cin[d], Cout = a.Cout[d], tr = a.tr[d];
+    const int Cg = tr ? Cout : Cin, Nout = tr ? Cin : Cout;
+    const int row = nt * 16 + (lane & 15), k0 = 32 * ks + 8 * (lane >> 4);
+    const float* w = a.w[d];
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = k0 + j;
+        const int s = k / Cg, c = k - s * Cg;
+        v[j] = 0.f;
+        if (row < Nout && s < S) {
+            const int co = tr ? c : row, ci = tr ? row : c;
+            v[j] = w[(long)co * S * Cin + (long)s * Cin + ci];
+        }
+    }
+    u32x4 h, m, l;
+    sh_split3((f32x4){v[0], v[1], v[2], v[3]}, (f32x4){v[4], v[5], v[6], v[7]}, h, m, l);
+    u32x4* o = a.out[d] + (long)f * 192 + lane;
+    o[0] = h; o[64] = m; o[128] = l;
+}
+
+int p3_num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+// channel tiles per workgroup and output-channel slices for an LDS-resident three-plane weight (<= 150 KiB)
+struct P3Geom { int nks, nt_tot, nt, nsplit; };
+inline P3Geom p3_geom(int S, int Cg, int Nout) {
+    const ShFragGeom g = sh_frag_geom(S, Cg, Nout);
+    P3Geom r{g.nks, g.nt_tot, g.nt_tot > 8 ? 8 : g.nt_tot, 1};
+    r.nsplit = g.nt_tot / r.nt;
+    while (r.nt > 1 && (long)g.nks * r.nt * 3 > 150) { r.nt >>= 1; r.nsplit <<= 1; }
+    return r;
+}
+inline bool p3_shape_ok(int B, int S, int Cg, int Nout) {
+    if (B <= 0 || B % 16 || S <= 0 || S > 64 || Nout % 4) return false;
+    if (!(Cg == 16 || (Cg > 0 && Cg % 32 == 0))) return false;
+    const P3Geom g = p3_geom(S, Cg, Nout);
+    static const int max_split = sh_env_int("SH_P3_MAX_SPLIT", 1, 1, 8);      // output-channel slices re-gather the input
+    return (long)g.nks * g.nt * 3 <= 150 && g.nsplit <= max_split;
+}
+
+template <int NT, int RT, bool C16, bool BWD, int NP>
+int launch_p3(P3Params& p, hipStream_t st) {
+    auto kern = conv_p3_kernel<NT, RT, C16, BWD, NP>;
+    const size_t smem = (size_t)p.nks * NT * 3072;
+    static size_t attr_set = 0;
+    if (smem > 65536 && smem > attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            (void)hipGetLastError();
+            sh_set_error("conv_p3: cannot raise the dynamic LDS limit to %zu bytes", smem);
+            return SH_ERR_LAUNCH;
+        }
+        attr_set = 160 * 1024;
+    }
+    p.n_vg = sh_cdiv(p.R, RT);
+    const long tiles = (long)p.n_vg * (p.B / 16);
+    SH_REQUIRE(tiles < (1L << 30), SH_ERR_UNSUPPORTED, "conv_p3: %ld work items", tiles);
+    p.n_tiles = (int)tiles;
+    const int per_cu = smem <= 36 * 1024 ? 4 : smem <= 76 * 1024 ? 2 : 1;
+    int nw = 16 / per_cu;
+    while (nw > 4 && (long)p3_num_cus() * per_cu * (nw >> 1) >= tiles * p.nsplit) nw >>= 1;
+    long groups = (tiles + nw - 1) / nw;
+    const long cap = (long)p3_num_cus() * per_cu / p.nsplit;
+    if (groups > cap) groups = cap;
+    if (groups < 8) groups = 8;
+    groups = (groups + 7) / 8 * 8;
+    const int grid = (int)groups * p.nsplit;
+    ShProfScope ps(st, "conv_p3_kernel<%d, %d, %s, %s, %d>|R=%d B=%d K=%d N=%d grid=%dx%d", NT, RT, C16 ? "true" : "false",
+                   BWD ? "true" : "false", NP, p.R, p.B, p.S * p.Cg, p.Nout, grid, nw * 64);
+    SH_LAUNCH_PS(ps, kern, dim3(grid), dim3(nw * 64), smem, st, p);
+    SH_CHECK_LAUNCH("conv_p3");
+    return SH_OK;
+}
+
+template <bool C16, bool BWD, int NP>
+int dispatch_p3_nt(P3Params& p, int nt, hipStream_t st) {
+    const long tiles16 = (long)p.R * (p.B / 16);
+    const long fill = 2L * p3_num_cus() * 16;
+    static const int rt_force = sh_env_int("SH_P3_RT", 0, 0, 2);
+    const bool two = rt_force ? rt_force == 2 : tiles16 / 2 >= fill;
+    if (nt == 1) return two ? launch_p3<1, 2, C16, BWD, NP>(p, st) : launch_p3<1, 1, C16, BWD, NP>(p, st);
+    if (nt == 2) return two ? launch_p3<2, 2, C16, BWD, NP>(p, st) : launch_p3<2, 1, C16, BWD, NP>(p, st);
+    if constexpr (!C16) {
+        if (nt == 4) return two ? launch_p3<4, 2, C16, BWD, NP>(p, st) : launch_p3<4, 1, C16, BWD, NP>(p, st);
+        if (nt == 8) return launch_p3<8, 1, C16, BWD, NP>(p, st);
+    }
+    sh_set_error("conv_p3: %d channel tiles per workgroup with %d gathered channels is not built", nt, p.Cg);
+    return SH_ERR_UNSUPPORTED;
+}
+
+template <bool BWD>
+int dispatch_p3(P3Params& p, hipStream_t st) {
+    SH_REQUIRE(p3_shape_ok(p.B, p.S, p.Cg, p.Nout), SH_ERR_UNSUPPORTED,
+               "conv_p3: B=%d S=%d gathered channels=%d output channels=%d is outside the three-plane kernels (sh_spiral_conv_p3_ok)",
+               p.B, p.S, p.Cg, p.Nout);
+    const P3Geom g = p3_geom(p.S, p.Cg, p.Nout);
+    p.nks = g.nks; p.nt_tot = g.nt_tot; p.nsplit = g.nsplit; p.ncg = p.Cg / 32;
+    const int nbg = p.B / 16;
+    p.x_bgb = p.Cg == 16 ? 1536 : (long)p.ncg * 3072;
+    p.x_vb = p.x_bgb * nbg;
+    if (p.yp) {
+        SH_REQUIRE(p.Nout == 16 || p.Nout % 32 == 0, SH_ERR_UNSUPPORTED, "conv_p3: a plane image has 16 or a multiple of 32 channels (%d)", p.Nout);
+        p.yp_bgb = p.Nout == 16 ? 1536 : (long)(p.Nout / 32) * 3072;
+        p.yp_vb = p.yp_bgb * nbg;
+    }
+    SH_REQUIRE(p.y || p.yp, SH_ERR_INVALID_ARG, "conv_p3: no output");
+    SH_REQUIRE(((reinterpret_cast<uintptr_t>(p.xp) | reinterpret_cast<uintptr_t>(p.yp) | reinterpret_cast<uintptr_t>(p.y) |
+                 reinterpret_cast<uintptr_t>(p.yprev) | reinterpret_cast<uintptr_t>(p.bias)) & 15) == 0 &&
+               ((p.y_sv | p.y_sb | p.yv_sv | p.yv_sb) & 3) == 0, SH_ERR_INVALID_ARG, "conv_p3: tensors must be 16-byte aligned with strides %% 4 == 0");
+    static const int np = sh_env_int("SH_P3_NP", 6, 6, 9);
+    if (p.Cg == 16) return np == 9 ? dispatch_p3_nt<true, BWD, 9>(p, g.nt, st) : dispatch_p3_nt<true, BWD, 6>(p, g.nt, st);
+    return np == 9 ? dispatch_p3_nt<false, BWD, 9>(p, g.nt, st) : dispatch_p3_nt<false, BWD, 6>(p, g.nt, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t sh_p3_bytes(int rows, int B, int C) {
+    if (rows <= 0 || B <= 0 || B % 16 || !(C == 16 || (C > 0 && C % 32 == 0))) return 0;
+    return (size_t)rows * (B / 16) * (C == 16 ? 1536 : (size_t)(C / 32) * 3072);
+}
+
+int sh_to_p3(const float* x, int64_t x_sv, int64_t x_sb, void* planes, int B, int rows, int C, sh_stream_t stream) {
+    SH_REQUIRE(x && planes && rows > 0, SH_ERR_INVALID_ARG, "sh_to_p3: null pointer or no rows");
+    SH_REQUIRE(sh_p3_bytes(rows, B, C) > 0, SH_ERR_UNSUPPORTED, "sh_to_p3: B=%d C=%d has no plane image (B %% 16 == 0; C == 16 or C %% 32 == 0)", B, C);
+    SH_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(planes)) & 15) == 0 && ((x_sv | x_sb) & 3) == 0,
+               SH_ERR_INVALID_ARG, "sh_to_p3: tensors must be 16-byte aligned with strides %% 4 == 0");
+    ToP3Args a{x, (long)x_sv, (long)x_sb, static_cast<char*>(planes), B / 16, C, (long)rows * (B / 16) * (C == 16 ? 32 : (C / 32) * 64)};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long blocks = (a.total + 255) / 256;
+    SH_REQUIRE(blocks < (1L << 31), SH_ERR_UNSUPPORTED, "sh_to_p3: tensor too large");
+    ShProfScope ps(st, "to_p3_kernel|rows=%d B=%d C=%d", rows, B, C);
+    SH_LAUNCH_PS(ps, to_p3_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    SH_CHECK_LAUNCH("to_p3");
+    return SH_OK;
+}
+
+size_t sh_conv_wfrag3_bytes(int S, int Cg, int Nout) {
+    if (S <= 0 || Cg <= 0 || Nout <= 0) return 0;
+    const ShFragGeom g = sh_frag_geom(S, Cg, Nout);
+    return (size_t)g.nks * g.nt_tot * 3072;
+}
+
+int sh_conv_wfrag3_prep_multi(int n_layers, const float* const* weight, void* const* wfrag3, const int* S, const int* Cin,
+                              const int* Cout, const int* transpose, sh_stream_t stream) {
+    SH_REQUIRE(n_layers > 0 && weight && wfrag3 && S && Cin && Cout && transpose, SH_ERR_INVALID_ARG, "sh_conv_wfrag3_prep_multi: bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int l0 = 0; l0 < n_layers; l0 += WF3_MAX) {
+        WFrag3Args a{};
+        a.nd = n_layers - l0 < WF3_MAX ? n_layers - l0 : WF3_MAX;
+        int blocks = 0;
+        for (int i = 0; i < a.nd; ++i) {
+            const int k = l0 + i;
+            SH_REQUIRE(weight[k] && wfrag3[k] && S[k] > 0 && Cin[k] > 0 && Cout[k] > 0, SH_ERR_INVALID_ARG,
+                       "sh_conv_wfrag3_prep_multi: bad layer %d", k);
+            SH_REQUIRE((reinterpret_cast<uintptr_t>(wfrag3[k]) & 15) == 0, SH_ERR_INVALID_ARG, "sh_conv_wfrag3_prep_multi: wfrag3 %d misaligned", k);
+            const int Cg = transpose[k] ? Cout[k] : Cin[k];
+            SH_REQUIRE(Cg % 8 == 0, SH_ERR_UNSUPPORTED, "sh_conv_wfrag3_prep_multi: %d gathered channels", Cg);
+            const ShFragGeom g = transpose[k] ? sh_frag_geom(S[k], Cout[k], Cin[k]) : sh_frag_geom(S[k], Cin[k], Cout[k]);
+            a.w[i] = weight[k]; a.out[i] = static_cast<u32x4*>(wfrag3[k]);
+            a.S[i] = S[k]; a.Cin[i] = Cin[k]; a.Cout[i] = Cout[k]; a.tr[i] = transpose[k] ? 1 : 0; a.nks[i] = g.nks; a.nt_tot[i] = g.nt_tot;
+            a.block0[i] = blocks;
+            blocks += (g.nks * g.nt_tot * 64 + 255) / 256;
+        }
+        a.block0[a.nd] = blocks;
+        ShProfScope ps(st, "wfrag3_prep_kernel|layers=%d", a.nd);
+        SH_LAUNCH_PS(ps, wfrag3_prep_kernel, dim3(blocks), dim3(256), 0, st, a);
+        SH_CHECK_LAUNCH("wfrag3_prep");
+    }
+    return SH_OK;
+}
+
+int sh_spiral_conv_p3_ok(int B, int S, int Cg, int Nout) { return p3_shape_ok(B, S, Cg, Nout) ? 1 : 0; }
+
+int sh_spiral_conv_fwd_p3(const void* xp, const int32_t* table, const void* wfrag3, const float* bias, float* y, int64_t y_sv,
+                          int64_t y_sb, void* yp, int B, int R, int S, int Cin, int Cout, int act, int zero_row, sh_stream_t stream) {
+    SH_REQUIRE(xp && table && wfrag3, SH_ERR_INVALID_ARG, "sh_spiral_conv_fwd_p3: null pointer");
+    SH_REQUIRE(B > 0 && R > 0 && S > 0 && Cin > 0 && Cout > 0, SH_ERR_INVALID_ARG, "sh_spiral_conv_fwd_p3: non-positive size");
+    SH_REQUIRE(act >= SH_ACT_IDENTITY && act <= SH_ACT_TANH, SH_ERR_INVALID_ARG, "sh_spiral_conv_fwd_p3: unknown activation %d", act);
+    P3Params p{};
+    p.xp = static_cast<const char*>(xp); p.table = table; p.wfrag = static_cast<const u32x4*>(wfrag3); p.bias = bias;
+    p.y = y; p.y_sv = y_sv; p.y_sb = y_sb; p.yp = static_cast<char*>(yp);
+    p.B = B; p.R = R; p.S = S; p.Cg = Cin; p.Nout = Cout; p.act = act; p.zero_row = zero_row;
+    return dispatch_p3<false>(p, static_cast<hipStream_t>(stream));
+}
+
+int sh_spiral_conv_bwd_data_p3(const void* dprep, const int32_t* table_t, const void* wfrag3_t, float* dx, int64_t dx_sv, int64_t dx_sb,
+                               void* dxp, const float* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row, int B, int n_in,
+                               int S, int Cin, int Cout, sh_stream_t stream) {
+    SH_REQUIRE(dprep && table_t && wfrag3_t, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_data_p3: null pointer");
+    SH_REQUIRE(B > 0 && n_in > 0 && S > 0 && Cin > 0 && Cout > 0, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_data_p3: non-positive size");
+    SH_REQUIRE(act_prev >= SH_ACT_IDENTITY && act_prev <= SH_ACT_TANH, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_data_p3: unknown activation");
+    P3Params p{};
+    p.xp = static_cast<const char*>(dprep); p.table = table_t; p.wfrag = static_cast<const u32x4*>(wfrag3_t); p.bias = nullptr;
+    p.y = dx; p.y_sv = dx_sv; p.y_sb = dx_sb; p.yp = static_cast<char*>(dxp);
+    p.yprev = yprev; p.yv_sv = yp_sv; p.yv_sb = yp_sb;
+    p.B = B; p.R = n_in; p.S = S; p.Cg = Cout; p.Nout = Cin; p.act = act_prev; p.zero_row = zero_row;
+    return dispatch_p3<true>(p, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -97,7 +97,16 @@ static inline int sh_ilog2_floor(int v) {
     return l;
 }
 static inline int sh_cdiv(int a, int b) { return (a + b - 1) / b; }
-// arithmetic form of the fp32 matrix products (sh_set_f32_mma_mode / SH_F32_MMA)
+// Arithmetic form of the fp32 matrix products (enum sh_mma_mode).  It is an ARGUMENT of every entry point whose kernel choice
+// depends on it; the entry point pins it for the duration of the call on the calling thread (ShMmaScope) and the dispatch
+// code reads it back with sh_f32_mma_mode().  No process-wide state: a forward pass on one thread and the backward pass of
+// another node on autograd's thread each run in the form their own call names.
 int sh_f32_mma_mode();
+bool sh_mma_mode_valid(int mode);
+struct ShMmaScope {
+    int was;
+    explicit ShMmaScope(int mode);
+    ~ShMmaScope();
+};
 // tuning knob from the environment (read once by the caller through a function-local static)
 int sh_env_int(const char* name, int dflt, int lo, int hi);

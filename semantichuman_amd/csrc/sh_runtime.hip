@@ -98,29 +98,16 @@ int sh_clock_probe(unsigned long long* out, int n_workgroups, int iters, sh_stre
     SH_CHECK_LAUNCH("sh_clock_probe");
     return SH_OK;
 }
-// ---- arithmetic form of the fp32 path's matrix products (process-wide; read at launch time, so a captured hipGraph keeps
-// the form it was captured with).  Default from the environment: SH_F32_MMA=exact|split3 (or 0|1).
+// ---- arithmetic form of the fp32 path's matrix products: per call, pinned on the calling thread by the entry point
 }
 namespace {
-int mma_mode_default() {
-    const char* v = getenv("SH_F32_MMA");
-    if (!v || !*v) return SH_MMA_EXACT;
-    if (v[0] == 'e' || v[0] == '0') return SH_MMA_EXACT;
-    return SH_MMA_SPLIT3;
+thread_local int tl_mma_mode = SH_MMA_EXACT;
 }
-int g_mma_mode = -1;
-}
-int sh_f32_mma_mode() {
-    if (g_mma_mode < 0) g_mma_mode = mma_mode_default();
-    return g_mma_mode;
-}
+int sh_f32_mma_mode() { return tl_mma_mode; }
+bool sh_mma_mode_valid(int mode) { return mode == SH_MMA_EXACT || mode == SH_MMA_SPLIT3 || mode == SH_MMA_PLANES3; }
+ShMmaScope::ShMmaScope(int mode) : was(tl_mma_mode) { tl_mma_mode = mode; }
+ShMmaScope::~ShMmaScope() { tl_mma_mode = was; }
 extern "C" {
-int sh_set_f32_mma_mode(int mode) {
-    SH_REQUIRE(mode == SH_MMA_EXACT || mode == SH_MMA_SPLIT3, SH_ERR_INVALID_ARG, "sh_set_f32_mma_mode: unknown mode %d", mode);
-    g_mma_mode = mode;
-    return SH_OK;
-}
-int sh_get_f32_mma_mode(void) { return sh_f32_mma_mode(); }
 #ifndef SH_BUILD_ID
 #define SH_BUILD_ID "unknown"
 #endif

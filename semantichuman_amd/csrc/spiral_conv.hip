@@ -960,7 +960,7 @@ int dispatch_gg(GGParams& p, hipStream_t st) {
     }
     // bf16x3 form (sh_set_f32_mma_mode): up to four channel tiles per workgroup, the rest split over workgroups
     static const int s3_min_nt = sh_env_int("SH_S3_MIN_NT", 4, 1, 8);      // layers with fewer channel tiles keep the exact form (no gain there)
-    if (sh_f32_mma_mode() == SH_MMA_SPLIT3 && vec4 && p.vec_out && !c3 && p.Cg % 8 == 0 && nt >= s3_min_nt) {
+    if (sh_f32_mma_mode() != SH_MMA_EXACT && vec4 && p.vec_out && !c3 && p.Cg % 8 == 0 && nt >= s3_min_nt) {
         static const int s3_nt = sh_env_int("SH_S3_NT", 4, 1, 8), s3_rt = sh_env_int("SH_S3_RT", 0, 0, 2);
         static const int s3_rt2_at = sh_env_int("SH_S3_RT2_AT", 2048, 1, 1 << 30);
         int ntw = nt;
@@ -1763,7 +1763,7 @@ int launch_ws3(const WSParams& p, hipStream_t st) {
 bool ws_uses_split3(int cot, const WSParams& p) {
     static const int s3_min_cot = sh_env_int("SH_S3_WG_MIN_COT", 2, 1, 16);
     const bool full = (p.B & ((1 << p.log2TB) - 1)) == 0;
-    return (cot == 2 || cot == 4) && sh_f32_mma_mode() == SH_MMA_SPLIT3 && cot >= s3_min_cot && full && p.log2TB == 4 && p.Cin % 4 == 0;
+    return (cot == 2 || cot == 4) && sh_f32_mma_mode() != SH_MMA_EXACT && cot >= s3_min_cot && full && p.log2TB == 4 && p.Cin % 4 == 0;
 }
 
 template <int COT>
@@ -1872,8 +1872,10 @@ extern "C" {
 
 int sh_spiral_conv_fwd(const float* x, int64_t x_sv, int64_t x_sb, const int32_t* table, const float* weight,
                        const float* bias, float* y, int64_t y_sv, int64_t y_sb, int B, int R, int S, int Cin,
-                       int Cout, int act, int zero_row, sh_stream_t stream) {
+                       int Cout, int act, int zero_row, int mma_mode, sh_stream_t stream) {
     SH_REQUIRE(x && table && weight && y, SH_ERR_INVALID_ARG, "sh_spiral_conv_fwd: null pointer");
+    SH_REQUIRE(sh_mma_mode_valid(mma_mode), SH_ERR_INVALID_ARG, "sh_spiral_conv_fwd: unknown mma_mode %d", mma_mode);
+    ShMmaScope mma_scope(mma_mode);
     SH_REQUIRE(B > 0 && R > 0 && S > 0 && Cin > 0 && Cout > 0, SH_ERR_INVALID_ARG,
                "sh_spiral_conv_fwd: non-positive size B=%d R=%d S=%d Cin=%d Cout=%d", B, R, S, Cin, Cout);
     SH_REQUIRE(act >= SH_ACT_IDENTITY && act <= SH_ACT_TANH, SH_ERR_INVALID_ARG, "sh_spiral_conv_fwd: unknown activation %d", act);
@@ -1889,15 +1891,18 @@ int sh_spiral_conv_fwd(const float* x, int64_t x_sv, int64_t x_sb, const int32_t
 
 int sh_spiral_conv_bwd_data(const float* dpre, int64_t dp_sv, int64_t dp_sb, const int32_t* table_t, const float* weight_t,
                             float* dx, int64_t dx_sv, int64_t dx_sb, const float* yprev, int64_t yp_sv, int64_t yp_sb,
-                            int act_prev, int zero_row, int B, int n_in, int S, int Cin, int Cout, sh_stream_t stream) {
+                            int act_prev, int zero_row, int B, int n_in, int S, int Cin, int Cout, int mma_mode, sh_stream_t stream) {
     return sh_spiral_conv_bwd_data_z(dpre, dp_sv, dp_sb, -1, table_t, weight_t, dx, dx_sv, dx_sb, yprev, yp_sv, yp_sb, act_prev, zero_row,
-                                     B, n_in, S, Cin, Cout, stream);
+                                     B, n_in, S, Cin, Cout, mma_mode, stream);
 }
 
 int sh_spiral_conv_bwd_data_z(const float* dpre, int64_t dp_sv, int64_t dp_sb, int dpre_zero_row, const int32_t* table_t,
                               const float* weight_t, float* dx, int64_t dx_sv, int64_t dx_sb, const float* yprev, int64_t yp_sv,
-                              int64_t yp_sb, int act_prev, int zero_row, int B, int n_in, int S, int Cin, int Cout, sh_stream_t stream) {
+                              int64_t yp_sb, int act_prev, int zero_row, int B, int n_in, int S, int Cin, int Cout, int mma_mode,
+                              sh_stream_t stream) {
     SH_REQUIRE(dpre && table_t && weight_t && dx, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_data: null pointer");
+    SH_REQUIRE(sh_mma_mode_valid(mma_mode), SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_data: unknown mma_mode %d", mma_mode);
+    ShMmaScope mma_scope(mma_mode);
     SH_REQUIRE(B > 0 && n_in > 0 && S > 0 && Cin > 0 && Cout > 0, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_data: non-positive size");
     SH_REQUIRE(act_prev >= SH_ACT_IDENTITY && act_prev <= SH_ACT_TANH, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_data: unknown activation %d", act_prev);
     GGParams p{};
@@ -1934,16 +1939,18 @@ size_t sh_spiral_conv_bwd_wgt_workspace(int B, int R, int S, int Cin, int Cout) 
 
 int sh_spiral_conv_bwd_wgt(const float* dpre, int64_t dp_sv, int64_t dp_sb, const float* x, int64_t x_sv, int64_t x_sb,
                            const int32_t* table, float* dW, float* dbias, void* workspace, size_t workspace_bytes, int B,
-                           int R, int S, int Cin, int Cout, sh_stream_t stream) {
+                           int R, int S, int Cin, int Cout, int mma_mode, sh_stream_t stream) {
     return sh_spiral_conv_bwd_wgt_presum(dpre, dp_sv, dp_sb, x, x_sv, x_sb, table, dW, dbias, workspace, workspace_bytes, nullptr, nullptr,
-                                         nullptr, nullptr, 0, B, R, S, Cin, Cout, stream);
+                                         nullptr, nullptr, 0, B, R, S, Cin, Cout, mma_mode, stream);
 }
 
 int sh_spiral_conv_bwd_wgt_presum(const float* dpre, int64_t dp_sv, int64_t dp_sb, const float* x, int64_t x_sv, int64_t x_sb,
                                   const int32_t* table, float* dW, float* dbias, void* workspace, size_t workspace_bytes,
                                   const int32_t* sum_rowptr, const int32_t* sum_col, const float* sum_val, float* sum_out, int sum_rows,
-                                  int B, int R, int S, int Cin, int Cout, sh_stream_t stream) {
+                                  int B, int R, int S, int Cin, int Cout, int mma_mode, sh_stream_t stream) {
     SH_REQUIRE(dpre && x && table && workspace, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_wgt: null pointer");
+    SH_REQUIRE(sh_mma_mode_valid(mma_mode), SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_wgt: unknown mma_mode %d", mma_mode);
+    ShMmaScope mma_scope(mma_mode);
     SH_REQUIRE(sum_rows == 0 || (sum_rows > 0 && sum_rowptr && sum_col && sum_val && sum_out), SH_ERR_INVALID_ARG,
                "sh_spiral_conv_bwd_wgt_presum: incomplete pre-sum job");
     SH_REQUIRE(B > 0 && R > 0 && S > 0 && Cin > 0 && Cout > 0, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_wgt: non-positive size");

@@ -33,14 +33,41 @@ int check_steps(int n, const sh_stack_step* st, int c0, const char* what) {
 
 }  // namespace
 
+namespace {
+
+// ---- three-plane form (SH_MMA_PLANES3): which steps run the ..._p3 kernels.  A conv step's forward takes the plane image of
+// its input when the caller supplied the buffers (planes of the producing step's output buffer, three-plane weight fragments)
+// and the kernels take the shape; its backward-data pass likewise with the image of its pre-activation gradient.
+struct P3Ctx {
+    int n, B, mode;
+    const sh_stack_step* st;
+    void* const* planes;              // forward: per step, image buffer of outs[i] (NULL: none)
+    const void* const* wfrag3;        // per conv step: forward operand (sh_stack_forward) / backward-data operand (sh_stack_backward)
+};
+inline bool p3_fwd(const P3Ctx& c, int i, bool in_vm) {
+    const sh_stack_step& s = c.st[i];
+    return c.mode == SH_MMA_PLANES3 && s.kind == 0 && i > 0 && in_vm && c.planes && c.planes[i - 1] && c.wfrag3 && c.wfrag3[i] &&
+           sh_spiral_conv_p3_ok(c.B, s.S, s.cin, s.cout);
+}
+// the conv step that gathers the buffer step i writes (through a folded up-sampling that appends to it), or -1
+inline int consumer_conv(const P3Ctx& c, int i) {
+    int j = i + 1;
+    if (j < c.n && c.st[j].kind == 1 && c.st[j].extend) ++j;
+    return (j < c.n && c.st[j].kind == 0) ? j : -1;
+}
+
+}  // namespace
+
 extern "C" {
 
 int sh_stack_forward(int n_steps, const sh_stack_step* steps, const float* x, int x_layout, int rows0, int c0, int B,
-                     const float* const* weights, const float* const* biases, float* const* outs, int out_layout,
-                     sh_stream_t stream) {
+                     const float* const* weights, const float* const* biases, float* const* outs, int out_layout, int mma_mode,
+                     void* const* planes, const void* const* wfrag3, sh_stream_t stream) {
     int rc = check_steps(n_steps, steps, c0, "sh_stack_forward");
     if (rc != SH_OK) return rc;
     SH_REQUIRE(x && weights && outs && B > 0, SH_ERR_INVALID_ARG, "sh_stack_forward: null pointer or empty batch");
+    SH_REQUIRE(sh_mma_mode_valid(mma_mode), SH_ERR_INVALID_ARG, "sh_stack_forward: unknown mma_mode %d", mma_mode);
+    const P3Ctx pc{n_steps, B, mma_mode, steps, planes, wfrag3};
     const float* cur = x;
     Lay cl = lay(x_layout, rows0, B, c0);
     int c = c0;
@@ -49,17 +76,32 @@ int sh_stack_forward(int n_steps, const sh_stack_step* steps, const float* x, in
         const int co = s.kind == 0 ? s.cout : c;
         const Lay ol = lay(i == n_steps - 1 ? out_layout : 0, out_rows(s), B, co);
         SH_REQUIRE(outs[i], SH_ERR_INVALID_ARG, "sh_stack_forward: no output buffer for step %d", i);
-        if (s.kind == 0)
-            rc = sh_spiral_conv_fwd(cur, cl.sv, cl.sb, s.table, weights[s.param], biases ? biases[s.param] : nullptr, outs[i],
-                                    ol.sv, ol.sb, B, s.R, s.S, s.cin, s.cout, s.act, s.zero_row, stream);
-        else if (s.extend) {
+        // does a three-plane conv gather the buffer this step writes?  then its image is written with it
+        const int cons = i < n_steps - 1 ? consumer_conv(pc, i) : -1;
+        void* img = (cons >= 0 && planes && planes[i] && mma_mode == SH_MMA_PLANES3 && wfrag3 && wfrag3[cons] &&
+                     sh_spiral_conv_p3_ok(B, steps[cons].S, steps[cons].cin, steps[cons].cout) && sh_p3_bytes(1, B, co)) ? planes[i] : nullptr;
+        if (s.kind == 0) {
+            if (p3_fwd(pc, i, cl.sb == c && cl.sv == (long)B * c)) {
+                rc = sh_spiral_conv_fwd_p3(planes[i - 1], s.table, wfrag3[i], biases ? biases[s.param] : nullptr, outs[i], ol.sv, ol.sb, img, B,
+                                           s.R, s.S, s.cin, s.cout, s.act, s.zero_row, stream);
+            } else {
+                rc = sh_spiral_conv_fwd(cur, cl.sv, cl.sb, s.table, weights[s.param], biases ? biases[s.param] : nullptr, outs[i],
+                                        ol.sv, ol.sb, B, s.R, s.S, s.cin, s.cout, s.act, s.zero_row, mma_mode, stream);
+                if (rc == SH_OK && img) rc = sh_to_p3(outs[i], ol.sv, ol.sb, img, B, s.R, s.cout, stream);
+            }
+        } else if (s.extend) {
             SH_REQUIRE(i > 0 && !is_last_step(i, n_steps) && outs[i] == outs[i - 1] && cl.sb == c, SH_ERR_INVALID_ARG,
                        "sh_stack_forward: step %d appends to its input, which must be the vertex-major output buffer of step %d", i, i - 1);
-            rc = sh_spmm(s.m.rowptr, s.m.col, s.m.val, cur, cl.sv, cl.sb, outs[i] + (long)s.m_cols * cl.sv, cl.sv, cl.sb, nullptr, 0, 0, 0, -1,
-                         B, s.m_rows, c, stream);
-        } else
+            SH_REQUIRE(!planes || planes[i] == planes[i - 1], SH_ERR_INVALID_ARG, "sh_stack_forward: step %d appends to its input: same image buffer", i);
+            float* dst = outs[i] + (long)s.m_cols * cl.sv;
+            rc = sh_spmm(s.m.rowptr, s.m.col, s.m.val, cur, cl.sv, cl.sb, dst, cl.sv, cl.sb, nullptr, 0, 0, 0, -1, B, s.m_rows, c, stream);
+            if (rc == SH_OK && img)
+                rc = sh_to_p3(dst, cl.sv, cl.sb, static_cast<char*>(img) + sh_p3_bytes(s.m_cols, B, c), B, s.m_rows, c, stream);
+        } else {
             rc = sh_spmm(s.m.rowptr, s.m.col, s.m.val, cur, cl.sv, cl.sb, outs[i], ol.sv, ol.sb, nullptr, 0, 0, 0, -1, B,
                          s.m_rows, c, stream);
+            if (rc == SH_OK && img) rc = sh_to_p3(outs[i], ol.sv, ol.sb, img, B, s.m_rows, c, stream);
+        }
         if (rc != SH_OK) return rc;
         cur = outs[i]; cl = ol; c = co;
     }
@@ -69,24 +111,38 @@ int sh_stack_forward(int n_steps, const sh_stack_step* steps, const float* x, in
 int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, int x_layout, int rows0, int c0, int B,
                       const float* const* acts, const float* g, int out_layout, const float* const* weights,
                       float* const* gin, float* dpre_last, float* const* weight_t, void* const* workspace,
-                      const size_t* workspace_bytes, float* const* dW, float* const* dbias, int need_x_grad,
-                      sh_stream_t stream) {
+                      const size_t* workspace_bytes, float* const* dW, float* const* dbias, int need_x_grad, int mma_mode,
+                      void* const* gin_planes, void* dpre_last_planes, const void* const* wfrag3_t, sh_stream_t stream) {
     int rc = check_steps(n_steps, steps, c0, "sh_stack_backward");
     if (rc != SH_OK) return rc;
     SH_REQUIRE(x && acts && g && weights && gin && dW && B > 0, SH_ERR_INVALID_ARG, "sh_stack_backward: null pointer or empty batch");
     SH_REQUIRE(n_steps <= 64, SH_ERR_UNSUPPORTED, "sh_stack_backward: more than 64 steps");
+    SH_REQUIRE(sh_mma_mode_valid(mma_mode), SH_ERR_INVALID_ARG, "sh_stack_backward: unknown mma_mode %d", mma_mode);
     const int last = n_steps - 1;
     int cin_of[64];                                            // channels entering step i
     {
         int c = c0;
         for (int i = 0; i < n_steps; ++i) { cin_of[i] = c; if (steps[i].kind == 0) c = steps[i].cout; }
     }
+    // three-plane form: conv step i's backward-data pass gathers the IMAGE of its pre-activation gradient when the caller gave
+    // a buffer for it (gin_planes[i + 1], or dpre_last_planes for the last step) and the fragments of the transposed weight
+    auto bwd_p3 = [&](int i) -> void* {
+        const sh_stack_step& s = steps[i];
+        if (mma_mode != SH_MMA_PLANES3 || s.kind != 0 || !(i > 0 || need_x_grad) || !s.table_t || !wfrag3_t || !wfrag3_t[i]) return nullptr;
+        if (!sh_spiral_conv_p3_ok(B, s.S, s.cout, s.cin)) return nullptr;
+        return i == last ? dpre_last_planes : (gin_planes ? gin_planes[i + 1] : nullptr);
+    };
     // all weight transposes of the stack: workgroups of the launch that opens the pass (the last step's activation backward),
     // or a launch of their own when the pass opens with a re-sampling step
     const float* tr_w[32]; float* tr_wt[32]; int tr_S[32], tr_Ci[32], tr_Co[32];
     int n_tr = 0;
     for (int i = 0; i < n_steps; ++i) {
         if (steps[i].kind != 0 || !(i > 0 || need_x_grad)) continue;
+        if (bwd_p3(i)) {                                       // reads fragments, not the transposed weight
+            const sh_stack_step& s = steps[i];
+            const bool thin = s.R == s.n_in && sh_spiral_conv_bwd_wgt_thin_ok(B, s.n_in, s.S, s.cin, s.cout, SH_DTYPE_F32);
+            if (!thin) continue;
+        }
         SH_REQUIRE(weight_t && weight_t[i], SH_ERR_INVALID_ARG, "sh_stack_backward: no weight_t buffer for step %d", i);
         SH_REQUIRE(n_tr < 32, SH_ERR_UNSUPPORTED, "sh_stack_backward: more than 32 conv steps");
         tr_w[n_tr] = weights[steps[i].param]; tr_wt[n_tr] = weight_t[i]; tr_S[n_tr] = steps[i].S; tr_Ci[n_tr] = steps[i].cin; tr_Co[n_tr] = steps[i].cout;
@@ -100,6 +156,8 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
     }
     // gradient entering the last step
     const float* cur; Lay cl;
+    void* cur_img = nullptr;                                   // image buffer of `cur` when its consumer gathers planes
+    bool cur_img_done = false;                                 // rows [0, R) of it already written by the producer
     {
         const sh_stack_step& s = steps[last];
         if (s.kind == 0) {
@@ -109,6 +167,7 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
                                     tr_w, tr_wt, tr_S, tr_Ci, tr_Co, stream);
             if (rc != SH_OK) return rc;
             cur = dpre_last; cl = dl;
+            cur_img = bwd_p3(last);
         } else {
             cur = g; cl = lay(out_layout, s.m_rows, B, cin_of[last]);
         }
@@ -128,12 +187,16 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
         if (i > 0 && steps[i - 1].kind == 0) {
             yprev = acts[i - 1]; yl = lay(0, 0, B, steps[i - 1].cout); act_prev = steps[i - 1].act; zero_prev = steps[i - 1].zero_row;
         }
+        // gin[i] is the pre-activation gradient of conv step i - 1: does that step's backward-data pass want its image?
+        void* gi_img = (want_in && i > 0 && steps[i - 1].kind == 0) ? bwd_p3(i - 1) : nullptr;
+        bool gi_img_done = false;
         if (s.kind == 0) {
             SH_REQUIRE(workspace && workspace[i], SH_ERR_INVALID_ARG, "sh_stack_backward: no workspace for step %d", i);
             // a 16 -> 3 channel layer takes its weight gradient in role-swapped form (wgrad_thin.hip): it reads the extended
             // gradient buffer through the transposed table, so it runs after the pre-sum launches below
             const bool thin = want_in && s.table_t && s.R == s.n_in && il.sb == s.cin && il.sv == (long)B * s.cin && cl.sb == s.cout &&
                               cl.sv == (long)B * s.cout && sh_spiral_conv_bwd_wgt_thin_ok(B, s.n_in, s.S, s.cin, s.cout, SH_DTYPE_F32);
+            const bool p3 = !thin && cur_img && cl.sb == s.cout && cl.sv == (long)B * s.cout;
             // the last pre-sum level of this layer rides in the weight-gradient launch (sh_spiral_conv_bwd_wgt_presum); an
             // earlier level (very long lists: two levels) runs first, on its own
             const bool ride = !thin && want_in && s.table_t && (s.n1 || s.n2);
@@ -149,7 +212,7 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
                 float* lout = mut0 + (long)(s.R + (s.n2 ? s.n1 : 0)) * cl.sv;
                 rc = sh_spiral_conv_bwd_wgt_presum(cur, cl.sv, cl.sb, inp, il.sv, il.sb, s.table, nullptr, nullptr, workspace[i],
                                                    workspace_bytes[i], ln ? lm.rowptr : nullptr, ln ? lm.col : nullptr,
-                                                   ln ? lm.val : nullptr, ln ? lout : nullptr, ln, B, s.R, s.S, s.cin, s.cout, stream);
+                                                   ln ? lm.val : nullptr, ln ? lout : nullptr, ln, B, s.R, s.S, s.cin, s.cout, mma_mode, stream);
                 if (rc != SH_OK) return rc;
             }
             job_ws[njobs] = workspace[i]; job_dW[njobs] = dW[s.param]; job_db[njobs] = dbias ? dbias[s.param] : nullptr;
@@ -180,10 +243,25 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
                     if (rc != SH_OK) return rc;
                 }
                 if (!thin_dx) {
-                    // the "no source" entries of table_t point at this step's own dummy row of dpre (stack.py ConvStep.finalize),
-                    // which its producer forced to zero
-                    rc = sh_spiral_conv_bwd_data_z(cur, cl.sv, cl.sb, s.zero_row, s.table_t, weight_t[i], gi, gl.sv, gl.sb, yprev, yl.sv,
-                                                   yl.sb, act_prev, zero_prev, B, s.n_in, s.S, s.cin, s.cout, stream);
+                    if (p3) {
+                        // image of the gradient rows this pass gathers: the R real rows unless their producer wrote them, and
+                        // the pre-summed rows behind them
+                        const int r0 = cur_img_done ? s.R : 0, r1 = s.R + s.n1 + s.n2;
+                        if (r1 > r0) {
+                            rc = sh_to_p3(cur + (long)r0 * cl.sv, cl.sv, cl.sb, static_cast<char*>(cur_img) + sh_p3_bytes(r0, B, s.cout), B, r1 - r0,
+                                          s.cout, stream);
+                            if (rc != SH_OK) return rc;
+                        }
+                        const bool img_out = gi_img && gl.sb == s.cin && gl.sv == (long)B * s.cin && sh_p3_bytes(1, B, s.cin);
+                        rc = sh_spiral_conv_bwd_data_p3(cur_img, s.table_t, wfrag3_t[i], gi, gl.sv, gl.sb, img_out ? gi_img : nullptr, yprev, yl.sv,
+                                                        yl.sb, act_prev, zero_prev, B, s.n_in, s.S, s.cin, s.cout, stream);
+                        gi_img_done = img_out;
+                    } else {
+                        // the "no source" entries of table_t point at this step's own dummy row of dpre (stack.py ConvStep.finalize),
+                        // which its producer forced to zero
+                        rc = sh_spiral_conv_bwd_data_z(cur, cl.sv, cl.sb, s.zero_row, s.table_t, weight_t[i], gi, gl.sv, gl.sb, yprev, yl.sv,
+                                                       yl.sb, act_prev, zero_prev, B, s.n_in, s.S, s.cin, s.cout, mma_mode, stream);
+                    }
                     if (rc != SH_OK) return rc;
                 }
             }
@@ -193,7 +271,7 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
                          zero_prev, B, s.m_cols, cin_of[i], stream);
             if (rc != SH_OK) return rc;
         }
-        if (want_in) { cur = gi; cl = gl; }
+        if (want_in) { cur = gi; cl = gl; cur_img = gi_img; cur_img_done = gi_img_done; }
     }
     for (int k = 0; k < njobs; k += 16) {
         const int n = njobs - k < 16 ? njobs - k : 16;

@@ -55,7 +55,7 @@ def spiral_conv_fwd(x, x_layout, table, weight, bias, y, y_layout, R, S, act, ze
     assert B == B2 and Ry >= R and weight.shape == (Cout, S * Cin) and table.dtype == torch.int32
     _check_index_range(x)
     check(_lib.load().sh_spiral_conv_fwd(ptr(x), xsv, xsb, ptr(table), ptr(weight), ptr(bias), ptr(y), ysv, ysb,
-                                         B, R, S, Cin, Cout, act, zero_row, stream_ptr()), "sh_spiral_conv_fwd")
+                                         B, R, S, Cin, Cout, act, zero_row, _lib.mma_id(), stream_ptr()), "sh_spiral_conv_fwd")
 
 
 def spiral_conv_bwd_data(dpre, dp_layout, table_t, weight_t, dx, dx_layout, yprev, yp_layout, act_prev, zero_row,
@@ -72,7 +72,7 @@ def spiral_conv_bwd_data(dpre, dp_layout, table_t, weight_t, dx, dx_layout, ypre
         ysv = ysb = 0
     check(_lib.load().sh_spiral_conv_bwd_data(ptr(dpre), dsv, dsb, ptr(table_t), ptr(weight_t), ptr(dx), xsv, xsb,
                                               ptr(yprev), ysv, ysb, act_prev, zero_row, B, n_in, S, Cin, Cout,
-                                              stream_ptr()), "sh_spiral_conv_bwd_data")
+                                              _lib.mma_id(), stream_ptr()), "sh_spiral_conv_bwd_data")
 
 
 def weight_transpose(weight, S, Cin, Cout):
@@ -91,7 +91,7 @@ def spiral_conv_bwd_wgt(dpre, dp_layout, x, x_layout, table, R, S, Cin, Cout, wa
     dW = torch.empty((Cout, S * Cin), dtype=torch.float32, device=x.device)
     db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
     check(lib.sh_spiral_conv_bwd_wgt(ptr(dpre), dsv, dsb, ptr(x), xsv, xsb, ptr(table), ptr(dW), ptr(db), ptr(ws),
-                                     nbytes, B, R, S, Cin, Cout, stream_ptr()), "sh_spiral_conv_bwd_wgt")
+                                     nbytes, B, R, S, Cin, Cout, _lib.mma_id(), stream_ptr()), "sh_spiral_conv_bwd_wgt")
     return dW, db
 
 
@@ -105,7 +105,7 @@ def spiral_conv_bwd_wgt_deferred(dpre, dp_layout, x, x_layout, table, R, S, Cin,
     nbytes = lib.sh_spiral_conv_bwd_wgt_workspace(B, R, S, Cin, Cout)
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
     check(lib.sh_spiral_conv_bwd_wgt(ptr(dpre), dsv, dsb, ptr(x), xsv, xsb, ptr(table), ptr(None), ptr(None), ptr(ws),
-                                     nbytes, B, R, S, Cin, Cout, stream_ptr()), "sh_spiral_conv_bwd_wgt")
+                                     nbytes, B, R, S, Cin, Cout, _lib.mma_id(), stream_ptr()), "sh_spiral_conv_bwd_wgt")
     dW = torch.empty((Cout, S * Cin), dtype=torch.float32, device=x.device)
     db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
     return dict(ws=ws, dW=dW, db=db, dims=(B, R, S, Cin, Cout))

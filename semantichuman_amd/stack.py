@@ -307,7 +307,55 @@ class Stack:
             db_off[st.param] = o
             o += _round(st.cout)
             shapes[st.param] = (st.cout, st.S * st.cin)
-        plan = dict(f_off=f_off * 4, f_total=f_total, dpre_last_off=dpre_last_off, g_off=g_off * 4, g_mask=g_mask,
+        # three-plane form (SH_MMA_PLANES3): byte offsets of the plane images of the forward buffers (one arena), of the gradient
+        # buffers (another; no aliasing - 288 GB) and of the weight fragments (forward and backward-data operand, one buffer
+        # filled by ONE conversion launch per forward pass); a zero mask = no image (shape outside the plane kernels)
+        al = lambda nbytes: (int(nbytes) + 255) // 256 * 256          # noqa: E731
+        pl_off, pl_mask, o3 = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64), 0
+        for i in range(n - 1):
+            if self._extends(i):
+                pl_off[i], pl_mask[i] = pl_off[i - 1], pl_mask[i - 1]
+                continue
+            nb = int(lib.sh_p3_bytes(self._buffer_rows(i), B, out_ch[i]))
+            if nb:
+                pl_off[i], pl_mask[i] = o3, 1
+                o3 += al(nb)
+        pl_total = o3
+        gpl_off, gpl_mask, o3 = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64), 0
+        for i in range(1, n):
+            prev = self.steps[i - 1]
+            if prev.kind != "conv":
+                continue
+            nb = int(lib.sh_p3_bytes(prev.R + prev.n_extra, B, prev.cout))
+            if nb and lib.sh_spiral_conv_p3_ok(B, prev.S, prev.cout, prev.cin):
+                gpl_off[i], gpl_mask[i] = o3, 1
+                o3 += al(nb)
+        dpl_off, dpl_mask = 0, 0
+        if last.kind == "conv" and lib.sh_spiral_conv_p3_ok(B, last.S, last.cout, last.cin):
+            nb = int(lib.sh_p3_bytes(last.R + last.n_extra, B, last.cout))
+            if nb:
+                dpl_off, dpl_mask = o3, 1
+                o3 += al(nb)
+        gpl_total = o3
+        wf3_off, wf3_mask, wf3t_off, wf3t_mask = (np.zeros(n, dtype=np.uint64) for _ in range(4))
+        o3 = 0
+        wf3_jobs = []                                                  # (step index, transpose, byte offset)
+        for i, st in enumerate(self.steps):
+            if st.kind != "conv":
+                continue
+            if i > 0 and lib.sh_spiral_conv_p3_ok(B, st.S, st.cin, st.cout):
+                wf3_off[i], wf3_mask[i] = o3, 1
+                wf3_jobs.append((i, 0, o3))
+                o3 += al(lib.sh_conv_wfrag3_bytes(st.S, st.cin, st.cout))
+            if lib.sh_spiral_conv_p3_ok(B, st.S, st.cout, st.cin):
+                wf3t_off[i], wf3t_mask[i] = o3, 1
+                wf3_jobs.append((i, 1, o3))
+                o3 += al(lib.sh_conv_wfrag3_bytes(st.S, st.cout, st.cin))
+        wf3_total = o3
+        plan = dict(pl_off=pl_off, pl_mask=pl_mask, pl_total=pl_total, gpl_off=gpl_off, gpl_mask=gpl_mask, dpl_off=dpl_off,
+                    dpl_mask=dpl_mask, gpl_total=gpl_total, wf3_off=wf3_off, wf3_mask=wf3_mask, wf3t_off=wf3t_off,
+                    wf3t_mask=wf3t_mask, wf3_jobs=wf3_jobs, wf3_total=wf3_total,
+                    f_off=f_off * 4, f_total=f_total, dpre_last_off=dpre_last_off, g_off=g_off * 4, g_mask=g_mask,
                     wt_off=wt_off * 4, wt_mask=wt_mask, ws_off=ws_off * 4, ws_mask=ws_mask, ws_bytes=ws_bytes, b_total=b_total,
                     dW_off=dW_off * 4, db_off=db_off * 4, dW_off_f=dW_off, db_off_f=db_off, shapes=shapes, p_total=o, npar=npar,
                     out_rows=out_rows, out_ch=out_ch)
@@ -318,8 +366,30 @@ class Stack:
     def _ptr_array(tensors):
         return (ctypes.c_void_p * len(tensors))(*[0 if t is None else t.data_ptr() for t in tensors])
 
-    def native_forward(self, x, in_layout, out_layout, weights, biases):
-        """-> (output, arena holding the outputs of the inner steps)."""
+    def _p3_prepare(self, plan, weights, with_backward: bool, device):
+        """Three-plane form: the image arena of the forward buffers and the weight fragments (one conversion launch: the
+        forward operand of every conv step the plane kernels take and, when a backward pass can follow, its backward-data
+        operand).  A fresh buffer per forward pass: the fragments belong to the weights as they were when it ran."""
+        lib = _lib.load()
+        jobs = [j for j in plan["wf3_jobs"] if with_backward or j[1] == 0]
+        planes = torch.empty(max(256, plan["pl_total"]), dtype=torch.uint8, device=device)
+        wf3 = torch.empty(max(256, plan["wf3_total"]), dtype=torch.uint8, device=device)
+        if jobs:
+            base = wf3.data_ptr()
+            arr = lambda vals, ct: (ct * len(jobs))(*vals)              # noqa: E731
+            sts = [self.steps[j[0]] for j in jobs]
+            for st in sts:
+                w = weights[st.param]
+                if not (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()):
+                    raise RuntimeError("semantichuman_amd: conv weights must be contiguous fp32 HIP tensors")
+            _lib.check(lib.sh_conv_wfrag3_prep_multi(
+                len(jobs), arr([weights[st.param].data_ptr() for st in sts], ctypes.c_void_p), arr([base + j[2] for j in jobs], ctypes.c_void_p),
+                arr([st.S for st in sts], ctypes.c_int), arr([st.cin for st in sts], ctypes.c_int), arr([st.cout for st in sts], ctypes.c_int),
+                arr([j[1] for j in jobs], ctypes.c_int), _lib.stream_ptr()), "sh_conv_wfrag3_prep_multi")
+        return planes, wf3
+
+    def native_forward(self, x, in_layout, out_layout, weights, biases, mma: str = "exact", with_backward: bool = False):
+        """-> (output, arena holding the outputs of the inner steps, three-plane state or None)."""
         B = x.shape[0] if in_layout == "bm" else x.shape[1]
         rows0 = x.shape[1] if in_layout == "bm" else x.shape[0]
         c0 = x.shape[2]
@@ -334,12 +404,21 @@ class Stack:
         out = ops.alloc(B, plan["out_rows"][-1], plan["out_ch"][-1], out_layout, x.device)
         outs = plan["f_off"] + np.uint64(arena.data_ptr())
         outs[n - 1] = out.data_ptr()
+        p3 = None
+        planes_p = wf3_p = None
+        if mma == "planes3" and B % 16 == 0 and plan["wf3_total"]:
+            planes, wf3 = self._p3_prepare(plan, weights, with_backward, x.device)
+            p3 = (planes, wf3)
+            pl = (plan["pl_off"] + np.uint64(planes.data_ptr())) * plan["pl_mask"]
+            wf = (plan["wf3_off"] + np.uint64(wf3.data_ptr())) * plan["wf3_mask"]
+            planes_p, wf3_p = pl.ctypes.data, wf.ctypes.data
         _lib.check(_lib.load().sh_stack_forward(n, self._native_steps(), _lib.ptr(x), _LAYOUT_ID[in_layout], rows0, c0, B,
                                                 self._ptr_array(weights), self._ptr_array(biases), outs.ctypes.data,
-                                                _LAYOUT_ID[out_layout], _lib.stream_ptr()), "sh_stack_forward")
-        return out, arena
+                                                _LAYOUT_ID[out_layout], _lib.mma_id(mma), planes_p, wf3_p, _lib.stream_ptr()),
+                   "sh_stack_forward")
+        return out, arena, p3
 
-    def native_backward(self, x, in_layout, out_layout, arena, out, g, weights, need_x_grad, need_bias):
+    def native_backward(self, x, in_layout, out_layout, arena, out, g, weights, need_x_grad, need_bias, mma: str = "exact", p3=None):
         """-> (grad_x or None, {param: (dW, db)})"""
         B = x.shape[0] if in_layout == "bm" else x.shape[1]
         rows0 = x.shape[1] if in_layout == "bm" else x.shape[0]
@@ -360,11 +439,20 @@ class Stack:
         dW = plan["dW_off"] + fbase
         assert len(need_bias) == plan["npar"] == len(weights)
         db = (plan["db_off"] + fbase) * np.array([1 if nb else 0 for nb in need_bias], dtype=np.uint64)
+        gpl_p = wf3t_p = None
+        dpl = ctypes.c_void_p(0)
+        if mma == "planes3" and p3 is not None:
+            gimg = torch.empty(max(256, plan["gpl_total"]), dtype=torch.uint8, device=dev)
+            gpl = (plan["gpl_off"] + np.uint64(gimg.data_ptr())) * plan["gpl_mask"]
+            wf = (plan["wf3t_off"] + np.uint64(p3[1].data_ptr())) * plan["wf3t_mask"]
+            gpl_p, wf3t_p = gpl.ctypes.data, wf.ctypes.data
+            if plan["dpl_mask"]:
+                dpl = ctypes.c_void_p(gimg.data_ptr() + int(plan["dpl_off"]))
         _lib.check(_lib.load().sh_stack_backward(
             n, self._native_steps(), _lib.ptr(x), _LAYOUT_ID[in_layout], rows0, c0, B, acts.ctypes.data, _lib.ptr(g),
             _LAYOUT_ID[out_layout], self._ptr_array(weights), gin.ctypes.data, ctypes.c_void_p(int(wbase) + 4 * plan["dpre_last_off"]),
             wt.ctypes.data, ws.ctypes.data, plan["ws_bytes"].ctypes.data, dW.ctypes.data, db.ctypes.data, 1 if need_x_grad else 0,
-            _lib.stream_ptr()), "sh_stack_backward")
+            _lib.mma_id(mma), gpl_p, dpl, wf3t_p, _lib.stream_ptr()), "sh_stack_backward")
         grads = {}
         for j, shp in enumerate(plan["shapes"]):
             if shp is None:
@@ -674,8 +762,11 @@ class StackFunction(torch.autograd.Function):
         ctx.stack, ctx.layouts = stack, (in_layout, out_layout)
         ctx.has_bias = [b is not None for b in biases]
         ctx.native = NATIVE and not (OVERLAP_WGRAD or OVERLAP_PRESUM)
+        # the arithmetic form of the node: what the caller's default says NOW; the backward pass (autograd's thread, later)
+        # runs in the same form whatever the default is by then
+        ctx.mma = _lib.get_f32_mma_mode()
         if ctx.native:
-            out, arena = stack.native_forward(x, in_layout, out_layout, weights, biases)
+            out, arena, ctx.p3 = stack.native_forward(x, in_layout, out_layout, weights, biases, ctx.mma, with_backward=need or ctx.needs_input_grad[3])
             ctx.save_for_backward(x, out, arena, *weights)
             return out
         out, acts = stack.run_forward(x, in_layout, out_layout, weights, biases, keep=need)
@@ -692,11 +783,18 @@ class StackFunction(torch.autograd.Function):
         need_bias = [hb and ctx.needs_input_grad[5 + 2 * j] for j, hb in enumerate(ctx.has_bias)]
         if ctx.native:
             x, out, arena, *weights = ctx.saved_tensors
-            gx, grads = stack.native_backward(x, in_layout, out_layout, arena, out, g, weights, ctx.needs_input_grad[3], need_bias)
+            gx, grads = stack.native_backward(x, in_layout, out_layout, arena, out, g, weights, ctx.needs_input_grad[3], need_bias,
+                                              ctx.mma, ctx.p3)
+            ctx.p3 = None
         else:
             x, out, *weights = ctx.saved_tensors
-            gx, grads = stack.run_backward(x, in_layout, out_layout, ctx.acts + [out], g, weights,
-                                           ctx.needs_input_grad[3], need_bias)
+            was = _lib.get_f32_mma_mode()
+            _lib.set_f32_mma_mode(ctx.mma)
+            try:
+                gx, grads = stack.run_backward(x, in_layout, out_layout, ctx.acts + [out], g, weights,
+                                               ctx.needs_input_grad[3], need_bias)
+            finally:
+                _lib.set_f32_mma_mode(was)
             ctx.acts = None
         res = [None, None, None, gx]
         for j in range(len(weights)):
@@ -812,6 +910,6 @@ def run_stack(stack: Stack, x, in_layout, out_layout, convs):
     if torch.is_grad_enabled() and (x.requires_grad or any(p is not None and p.requires_grad for p in params)):
         return StackFunction.apply(stack, in_layout, out_layout, x, *params)
     if NATIVE:
-        return stack.native_forward(x.contiguous(), in_layout, out_layout, params[0::2], params[1::2])[0]
+        return stack.native_forward(x.contiguous(), in_layout, out_layout, params[0::2], params[1::2], _lib.get_f32_mma_mode())[0]
     out, _ = stack.run_forward(x.contiguous(), in_layout, out_layout, params[0::2], params[1::2], keep=False)
     return out

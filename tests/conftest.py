@@ -28,9 +28,10 @@ def golden_dir():
     return GOLDEN
 
 
-# The fp32 path has two arithmetic forms of its matrix products (include/sh_kernels.h, sh_set_f32_mma_mode): the exact fp32
-# MFMA and the bf16x3 split (what bench.py's headline runs).  Every GPU parity test of the fp32 path runs in BOTH, with the
-# SAME tolerances - the condition under which the split form may be quoted as fp32 at all.
+# The fp32 path has three arithmetic forms of its matrix products (include/sh_kernels.h, enum sh_mma_mode): the exact fp32
+# MFMA (bench.py's default headline), the bf16x3 split done by every consumer, and the same arithmetic over three bf16 planes
+# written once by the producer.  Every GPU parity test of the fp32 path runs in ALL of them, with the SAME tolerances - the
+# condition under which a split form may be quoted as fp32 at all.
 F32_PARITY_MODULES = {"test_gpu_parity", "test_configs", "test_train_loop", "test_semantic", "test_editing", "test_wgrad_thin"}
 
 
@@ -38,7 +39,7 @@ def pytest_generate_tests(metafunc):
     mod = metafunc.module.__name__.split(".")[-1]
     if mod in F32_PARITY_MODULES and metafunc.definition.get_closest_marker("gpu") is not None and "f32_mma" not in metafunc.fixturenames:
         metafunc.fixturenames.append("f32_mma")
-        metafunc.parametrize("f32_mma", ["exact", "split3"], indirect=True)
+        metafunc.parametrize("f32_mma", ["exact", "split3", "planes3"], indirect=True)
 
 
 @pytest.fixture

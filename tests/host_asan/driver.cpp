@@ -2,7 +2,8 @@
 // -fsanitize=address,undefined, the kernel entry points replaced by stubs.cpp).  It builds a four-step stack with every feature
 // the sequencers handle - a conv with list pre-sums of both levels, a folded (extend) up-sampling, a conv behind it, a
 // 3-channel last conv with a batch-major output - allocates every buffer EXACTLY as include/sh_kernels.h sizes it (host
-// memory standing in for device memory) and runs forward + backward on the fp32 and the bf16 path.  A pointer the sequencer
+// memory standing in for device memory) and runs forward + backward on the fp32 path, the bf16 path and the fp32 path in its
+// three-plane form (batch 16: plane images behind the 16-channel tensors).  A pointer the sequencer
 // derives past a buffer, a mis-sized pointer table or an uninitialised step field is an ASan / UBSan report = non-zero exit.
 #include <stdint.h>
 #include <stdio.h>
@@ -31,7 +32,7 @@ static std::vector<int32_t> make_table(int rows, int S, int limit) {
 template <class T> static T* alloc(size_t n) { return static_cast<T*>(calloc(n ? n : 1, sizeof(T))); }      // exact size: ASan guards the end
 
 int main() {
-    const int B = 4, S = 3;
+    const int S = 3;
     // step 0: conv 8 -> 16, 6 rows out of 7 in; pre-sums 1 + 2.  step 1: extend, 4 blended rows behind the 6.  step 2: conv 16 -> 8 over
     // the 10 rows of Z, 9 rows out, one pre-sum.  step 3: conv 8 -> 3, 9 -> 9 rows, two pre-sums, batch-major output.
     struct L { int R, n_in, cin, cout, n1, n2; } L0{6, 7, 8, 16, 1, 2}, L2{9, 10, 16, 8, 0, 1}, L3{9, 9, 8, 3, 0, 2};
@@ -52,7 +53,8 @@ int main() {
     conv(st[3], L3, 2, t3.data(), tt3.data()); st[3].sum2 = s2_3.ref(); st[3].act = SH_ACT_IDENTITY;
     const L* Ls[3] = {&L0, &L2, &L3};
     int rc = 0;
-    for (int dtype = 0; dtype < 2 && rc == 0; ++dtype) {
+    for (int pass = 0; pass < 3 && rc == 0; ++pass) {
+        const int dtype = pass == 1 ? 1 : 0, B = pass == 2 ? 16 : 4, mma = pass == 2 ? SH_MMA_PLANES3 : SH_MMA_EXACT;
         const size_t e = dtype == SH_DTYPE_BF16 ? 2 : 4;
         // ---- parameters
         float* W[3]; float* bias[3]; float* dW[3]; float* db[3];
@@ -68,6 +70,7 @@ int main() {
         float* out = alloc<float>((size_t)B * L3.R * 3);
         void* outs[4] = {o0, o0, o2, out};
         void* wf[4] = {0, 0, 0, 0}, *wft[4] = {0, 0, 0, 0};
+        char* img0 = nullptr; char* imgg = nullptr; const void* wf3[4] = {0, 0, 0, 0}; const void* wf3t[4] = {0, 0, 0, 0};
         if (dtype == SH_DTYPE_BF16) {
             const int ci[4] = {0, -1, 2, 3};
             for (int i = 0; i < 4; ++i)
@@ -77,7 +80,13 @@ int main() {
                 }
             rc = sh_stack_forward_bf16(4, st, x, SH_DTYPE_BF16, 0, L0.n_in, L0.cin, B, W, bias, wf, 0, outs, SH_DTYPE_F32, 1, nullptr);
         } else {
-            rc = sh_stack_forward(4, st, reinterpret_cast<const float*>(x), 0, L0.n_in, L0.cin, B, W, bias, reinterpret_cast<float* const*>(outs), 1, nullptr);
+            if (pass == 2) {      // images of the 16-channel buffers: conv 0's output with the appended rows (gathered by conv 2), conv 0's dpre
+                img0 = alloc<char>(sh_p3_bytes(L0.R + n_b, B, L0.cout)); imgg = alloc<char>(sh_p3_bytes(L0.R + L0.n1 + L0.n2, B, L0.cout));
+                wf3[2] = alloc<char>(sh_conv_wfrag3_bytes(S, L2.cin, L2.cout)); wf3t[0] = alloc<char>(sh_conv_wfrag3_bytes(S, L0.cout, L0.cin));
+            }
+            void* planes[4] = {img0, img0, nullptr, nullptr};
+            rc = sh_stack_forward(4, st, reinterpret_cast<const float*>(x), 0, L0.n_in, L0.cin, B, W, bias, reinterpret_cast<float* const*>(outs), 1, mma,
+                                  planes, wf3, nullptr);
         }
         if (rc) { printf("forward rc=%d\n", rc); break; }
         // ---- backward buffers
@@ -96,16 +105,18 @@ int main() {
                 ws[i] = alloc<char>(wsb[i]);
                 wt[i] = alloc<float>((size_t)st[i].cin * S * st[i].cout);
             }
+        void* gpl[4] = {nullptr, imgg, nullptr, nullptr};
         if (dtype == SH_DTYPE_BF16)
             rc = sh_stack_backward_bf16(4, st, x, SH_DTYPE_BF16, 0, L0.n_in, L0.cin, B, outs, g, SH_DTYPE_F32, 1, W, gin, SH_DTYPE_BF16, dpre_last, wft, 0, ws,
                                         wsb, dW, db, 1, nullptr);
         else
             rc = sh_stack_backward(4, st, reinterpret_cast<const float*>(x), 0, L0.n_in, L0.cin, B, reinterpret_cast<const float* const*>(outs), g, 1, W,
-                                   reinterpret_cast<float* const*>(gin), dpre_last, wt, ws, wsb, dW, db, 1, nullptr);
+                                   reinterpret_cast<float* const*>(gin), dpre_last, wt, ws, wsb, dW, db, 1, mma, gpl, nullptr, wf3t, nullptr);
         if (rc) { printf("backward rc=%d\n", rc); break; }
         for (int p = 0; p < 3; ++p) { free(W[p]); free(bias[p]); free(dW[p]); free(db[p]); }
         free(x); free(o0); free(o2); free(out); free(g); free(gx); free(g1); free(g2); free(g3); free(dpre_last);
-        for (int i = 0; i < 4; ++i) { free(ws[i]); free(wt[i]); free(wf[i]); free(wft[i]); }
+        for (int i = 0; i < 4; ++i) { free(ws[i]); free(wt[i]); free(wf[i]); free(wft[i]); free(const_cast<void*>(wf3[i])); free(const_cast<void*>(wf3t[i])); }
+        free(img0); free(imgg);
     }
     for (const auto& c : g_calls) printf("%s\n", c.c_str());
     printf(rc == 0 ? "SEQUENCERS OK %zu calls\n" : "SEQUENCERS FAILED\n", g_calls.size());

@@ -33,7 +33,7 @@ static void log(const char* fmt, int a = 0, int b = 0, int c = 0) {
 
 extern "C" {
 int sh_spiral_conv_fwd(const float* x, int64_t x_sv, int64_t x_sb, const int32_t* table, const float* w, const float* bias, float* y, int64_t y_sv,
-                       int64_t y_sb, int B, int R, int S, int Cin, int Cout, int act, int zero_row, sh_stream_t) {
+                       int64_t y_sb, int B, int R, int S, int Cin, int Cout, int act, int zero_row, int, sh_stream_t) {
     int n_in = 0;
     for (long i = 0; i < (long)R * S; ++i) n_in = table[i] + 1 > n_in ? table[i] + 1 : n_in;
     touch_r(x, span(x_sv, x_sb, n_in, B, Cin, 4)); touch_r(w, (size_t)Cout * S * Cin * 4); touch_r(bias, bias ? Cout * 4 : 0);
@@ -92,7 +92,7 @@ int sh_act_backward_bf16(const void* dy, int64_t dy_sv, int64_t dy_sb, const voi
 size_t sh_spiral_conv_bwd_wgt_workspace(int B, int R, int S, int Cin, int Cout) { return (size_t)7 * ((size_t)Cout * S * Cin + Cout) * 4; }
 size_t sh_spiral_conv_bwd_wgt_workspace_bf16(int B, int R, int S, int Cin, int Cout) { return (size_t)5 * ((size_t)Cout * S * Cin + Cout) * 4; }
 int sh_spiral_conv_bwd_wgt(const float* dpre, int64_t dp_sv, int64_t dp_sb, const float* x, int64_t x_sv, int64_t x_sb, const int32_t* table, float* dW,
-                           float* db, void* ws, size_t ws_bytes, int B, int R, int S, int Cin, int Cout, sh_stream_t) {
+                           float* db, void* ws, size_t ws_bytes, int B, int R, int S, int Cin, int Cout, int, sh_stream_t) {
     int n_in = 0;
     for (long i = 0; i < (long)R * S; ++i) n_in = table[i] + 1 > n_in ? table[i] + 1 : n_in;
     touch_r(dpre, span(dp_sv, dp_sb, R, B, Cout, 4)); touch_r(x, span(x_sv, x_sb, n_in, B, Cin, 4));
@@ -103,9 +103,9 @@ int sh_spiral_conv_bwd_wgt(const float* dpre, int64_t dp_sv, int64_t dp_sb, cons
 }
 int sh_spiral_conv_bwd_wgt_presum(const float* dpre, int64_t dp_sv, int64_t dp_sb, const float* x, int64_t x_sv, int64_t x_sb, const int32_t* table,
                                   float* dW, float* db, void* ws, size_t ws_bytes, const int32_t* sum_rowptr, const int32_t* sum_col,
-                                  const float* sum_val, float* sum_out, int sum_rows, int B, int R, int S, int Cin, int Cout, sh_stream_t st) {
+                                  const float* sum_val, float* sum_out, int sum_rows, int B, int R, int S, int Cin, int Cout, int mma, sh_stream_t st) {
     // the rider reads and writes exactly what the sh_spmm launch it replaces does; logged in the order the work is visible in
-    const int rc = sh_spiral_conv_bwd_wgt(dpre, dp_sv, dp_sb, x, x_sv, x_sb, table, dW, db, ws, ws_bytes, B, R, S, Cin, Cout, st);
+    const int rc = sh_spiral_conv_bwd_wgt(dpre, dp_sv, dp_sb, x, x_sv, x_sb, table, dW, db, ws, ws_bytes, B, R, S, Cin, Cout, mma, st);
     if (rc != 0 || sum_rows == 0) return rc;
     return sh_spmm(sum_rowptr, sum_col, sum_val, dpre, dp_sv, dp_sb, sum_out, dp_sv, dp_sb, nullptr, 0, 0, 0, -1, B, sum_rows, Cout, st);
 }
@@ -134,17 +134,17 @@ static int bwd_data_common(const char* name, const void* dpre, size_t de, int64_
 }
 int sh_spiral_conv_bwd_data(const float* dpre, int64_t dp_sv, int64_t dp_sb, const int32_t* table_t, const float* weight_t, float* dx, int64_t dx_sv,
                             int64_t dx_sb, const float* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row, int B, int n_in, int S, int Cin,
-                            int Cout, sh_stream_t) {
+                            int Cout, int, sh_stream_t) {
     touch_r(weight_t, (size_t)Cin * S * Cout * 4);
     return bwd_data_common("bwd_data n_in=%d Cin=%d Cout=%d", dpre, 4, dp_sv, dp_sb, table_t, dx, 4, dx_sv, dx_sb, yprev, yp_sv, yp_sb, B, n_in, S, Cin, Cout);
 }
 int sh_spiral_conv_bwd_data_z(const float* dpre, int64_t dp_sv, int64_t dp_sb, int dpre_zero_row, const int32_t* table_t, const float* weight_t,
                               float* dx, int64_t dx_sv, int64_t dx_sb, const float* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row,
-                              int B, int n_in, int S, int Cin, int Cout, sh_stream_t st) {
+                              int B, int n_in, int S, int Cin, int Cout, int mma, sh_stream_t st) {
     // the zero row the no-source entries point at is one of dpre's own rows: reading it is covered by the same range
     if (dpre_zero_row >= 0) touch_r(dpre + (size_t)dpre_zero_row * dp_sv, (size_t)Cout * 4);
     return sh_spiral_conv_bwd_data(dpre, dp_sv, dp_sb, table_t, weight_t, dx, dx_sv, dx_sb, yprev, yp_sv, yp_sb, act_prev, zero_row, B, n_in, S, Cin,
-                                   Cout, st);
+                                   Cout, mma, st);
 }
 int sh_spiral_conv_bwd_data_bf16(const void* dpre, int dd, int64_t dp_sv, int64_t dp_sb, const int32_t* table_t, const void* wfrag_t, void* dx, int xd,
                                  int64_t dx_sv, int64_t dx_sb, const void* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row, int B, int n_in,
@@ -180,4 +180,39 @@ int sh_spiral_conv_bwd_wgt_reduce_multi(int n, const void* const* ws, float* con
                                         const int* Ci, const int* Co, sh_stream_t) { return reduce_common("reduce n=%d", n, ws, dW, db, S, Ci, Co); }
 int sh_spiral_conv_bwd_wgt_reduce_multi_bf16(int n, const void* const* ws, float* const* dW, float* const* db, const int* B, const int* R, const int* S,
                                              const int* Ci, const int* Co, sh_stream_t) { return reduce_common("reduce_bf16 n=%d", n, ws, dW, db, S, Ci, Co); }
+// ---- three-plane form: image sizes are the real formula (include/sh_kernels.h), the kernels touch the image ranges
+size_t sh_p3_bytes(int rows, int B, int C) {
+    if (rows <= 0 || B <= 0 || B % 16 || !(C == 16 || (C > 0 && C % 32 == 0))) return 0;
+    return (size_t)rows * (B / 16) * (C == 16 ? 1536 : (size_t)(C / 32) * 3072);
+}
+size_t sh_conv_wfrag3_bytes(int S, int Cg, int Nout) { return 3 * sh_conv_wfrag_bytes(S, Cg, Nout); }
+int sh_spiral_conv_p3_ok(int B, int S, int Cg, int Nout) { return B % 16 == 0 && (Cg == 16 || (Cg > 0 && Cg % 32 == 0)) && Nout % 4 == 0; }
+int sh_to_p3(const float* x, int64_t x_sv, int64_t x_sb, void* planes, int B, int rows, int C, sh_stream_t) {
+    touch_r(x, span(x_sv, x_sb, rows, B, C, 4)); touch_w(planes, sh_p3_bytes(rows, B, C));
+    log("to_p3 rows=%d C=%d", rows, C);
+    return sh_p3_bytes(rows, B, C) ? 0 : SH_ERR_UNSUPPORTED;
+}
+int sh_spiral_conv_fwd_p3(const void* xp, const int32_t* table, const void* wfrag3, const float* bias, float* y, int64_t y_sv, int64_t y_sb, void* yp,
+                          int B, int R, int S, int Cin, int Cout, int act, int zero_row, sh_stream_t) {
+    int n_in = 0;
+    for (long i = 0; i < (long)R * S; ++i) n_in = table[i] + 1 > n_in ? table[i] + 1 : n_in;
+    touch_r(xp, sh_p3_bytes(n_in, B, Cin)); touch_r(wfrag3, sh_conv_wfrag3_bytes(S, Cin, Cout)); touch_r(bias, bias ? Cout * 4 : 0);
+    if (y) touch_w(y, span(y_sv, y_sb, R, B, Cout, 4));
+    if (yp) touch_w(yp, sh_p3_bytes(R, B, Cout));
+    log("conv_fwd_p3 R=%d Cin=%d Cout=%d", R, Cin, Cout);
+    return 0;
+}
+int sh_spiral_conv_bwd_data_p3(const void* dprep, const int32_t* table_t, const void* wfrag3_t, float* dx, int64_t dx_sv, int64_t dx_sb, void* dxp,
+                               const float* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row, int B, int n_in, int S, int Cin, int Cout,
+                               sh_stream_t) {
+    int rows = 0;
+    for (long i = 0; i < (long)n_in * S; ++i) rows = table_t[i] + 1 > rows ? table_t[i] + 1 : rows;
+    touch_r(dprep, sh_p3_bytes(rows, B, Cout)); touch_r(wfrag3_t, sh_conv_wfrag3_bytes(S, Cout, Cin));
+    if (dx) touch_w(dx, span(dx_sv, dx_sb, n_in, B, Cin, 4));
+    if (dxp) touch_w(dxp, sh_p3_bytes(n_in, B, Cin));
+    if (yprev) touch_r(yprev, span(yp_sv, yp_sb, n_in, B, Cin, 4));
+    log("bwd_data_p3 n_in=%d Cin=%d Cout=%d", n_in, Cin, Cout);
+    return 0;
+}
 }  // extern "C"
+bool sh_mma_mode_valid(int mode) { return mode >= 0 && mode <= 2; }

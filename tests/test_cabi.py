@@ -37,7 +37,7 @@ def test_argument_validation_without_gpu():
     """Entry points validate their arguments before touching the device."""
     lib = _lib.load()
     null = ctypes.c_void_p(0)
-    rc = lib.sh_spiral_conv_fwd(null, 0, 0, null, null, null, null, 0, 0, 1, 1, 1, 1, 1, 2, -1, null)
+    rc = lib.sh_spiral_conv_fwd(null, 0, 0, null, null, null, null, 0, 0, 1, 1, 1, 1, 1, 2, -1, 0, null)
     assert rc == -1 and b"null pointer" in lib.sh_last_error()
     rc = lib.sh_l1_loss_fwd(null, null, 0, null, null, null)
     assert rc == -1

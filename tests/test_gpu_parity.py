@@ -481,12 +481,12 @@ def test_c_abi_error_contract():
     y = torch.zeros((2, 9, 4), device=d)
     st = _lib.stream_ptr()
     # null pointer -> SH_ERR_INVALID_ARG
-    assert lib.sh_spiral_conv_fwd(None, 4, 36, _lib.ptr(table), _lib.ptr(w), None, _lib.ptr(y), 4, 36, 2, 9, 3, 4, 4, 2, 8, st) == -1
+    assert lib.sh_spiral_conv_fwd(None, 4, 36, _lib.ptr(table), _lib.ptr(w), None, _lib.ptr(y), 4, 36, 2, 9, 3, 4, 4, 2, 8, 0, st) == -1
     assert b"null" in lib.sh_last_error()
     # unknown activation id
-    assert lib.sh_spiral_conv_fwd(_lib.ptr(x), 4, 36, _lib.ptr(table), _lib.ptr(w), None, _lib.ptr(y), 4, 36, 2, 9, 3, 4, 4, 17, 8, st) == -1
+    assert lib.sh_spiral_conv_fwd(_lib.ptr(x), 4, 36, _lib.ptr(table), _lib.ptr(w), None, _lib.ptr(y), 4, 36, 2, 9, 3, 4, 4, 17, 8, 0, st) == -1
     # a spiral longer than the kernels are built for -> SH_ERR_UNSUPPORTED, message names the limit
-    assert lib.sh_spiral_conv_fwd(_lib.ptr(x), 4, 36, _lib.ptr(table), _lib.ptr(w), None, _lib.ptr(y), 4, 36, 2, 9, 65, 4, 4, 2, 8, st) == -2
+    assert lib.sh_spiral_conv_fwd(_lib.ptr(x), 4, 36, _lib.ptr(table), _lib.ptr(w), None, _lib.ptr(y), 4, 36, 2, 9, 65, 4, 4, 2, 8, 0, st) == -2
     assert b"64" in lib.sh_last_error()
     # workspace too small -> SH_ERR_WORKSPACE
     need = lib.sh_spiral_conv_bwd_wgt_workspace(2, 9, 3, 4, 4)
@@ -494,18 +494,18 @@ def test_c_abi_error_contract():
     ws = torch.zeros(4, device=d)
     dW = torch.zeros((4, 12), device=d)
     rc = lib.sh_spiral_conv_bwd_wgt(_lib.ptr(y), 4, 36, _lib.ptr(x), 4, 36, _lib.ptr(table), _lib.ptr(dW), None, _lib.ptr(ws),
-                                    ctypes.c_size_t(16), 2, 9, 3, 4, 4, st)
+                                    ctypes.c_size_t(16), 2, 9, 3, 4, 4, 0, st)
     assert rc == -3 and b"workspace" in lib.sh_last_error()
     # whole-stack entry points: empty step table, channel mismatch between consecutive steps, missing output buffer
-    assert lib.sh_stack_forward(0, None, _lib.ptr(x), 1, 9, 4, 2, None, None, None, 1, st) == -1
+    assert lib.sh_stack_forward(0, None, _lib.ptr(x), 1, 9, 4, 2, None, None, None, 1, 0, None, None, st) == -1
     steps = (_lib.StackStep * 1)()
     steps[0].kind, steps[0].param, steps[0].table = 0, 0, table.data_ptr()
     steps[0].R, steps[0].S, steps[0].n_in, steps[0].cin, steps[0].cout, steps[0].act, steps[0].zero_row = 9, 3, 9, 8, 4, 2, 8
     wp, outs = (ctypes.c_void_p * 1)(w.data_ptr()), (ctypes.c_void_p * 1)(0)
-    assert lib.sh_stack_forward(1, steps, _lib.ptr(x), 1, 9, 4, 2, wp, None, outs, 1, st) == -1
+    assert lib.sh_stack_forward(1, steps, _lib.ptr(x), 1, 9, 4, 2, wp, None, outs, 1, 0, None, None, st) == -1
     assert b"channels" in lib.sh_last_error()
     steps[0].cin = 4
-    assert lib.sh_stack_forward(1, steps, _lib.ptr(x), 1, 9, 4, 2, wp, None, outs, 1, st) == -1
+    assert lib.sh_stack_forward(1, steps, _lib.ptr(x), 1, 9, 4, 2, wp, None, outs, 1, 0, None, None, st) == -1
     assert b"output buffer" in lib.sh_last_error()
     # the typed wrappers raise
     with pytest.raises(RuntimeError, match="status -2"):             # a spiral longer than the kernels' 64-entry table lines

@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""Per-layer probe of the three-plane form (csrc/p3_conv.hip) on the conv shapes of a template: error against a float64
+evaluation and kernel time, next to the exact fp32 MFMA form and the bf16x3 (split3) form.
+
+    python tools/p3_probe.py [batch] [template.npz] [--bwd] [--adversarial] [--reps N]
+
+Prints one line per conv step and direction:  shape | max|err| exact / split3 / p3 (relative to max|ref|) | us each.
+Test infrastructure (float64 on the GPU through torch); nothing here is on the product path."""
+from __future__ import annotations
+
+import ctypes
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import semantichuman_amd as sh                                    # noqa: E402
+from semantichuman_amd import _lib, ops                            # noqa: E402
+from semantichuman_amd.hierarchy import load_hierarchy            # noqa: E402
+
+FE = [[3, 16, 32, 64, 128], [[], [], [], [], []]]
+FD = [[128, 64, 32, 32, 16], [[], [], [], [], 3]]
+
+
+def arr(vals, ct):
+    return (ct * len(vals))(*vals)
+
+
+def wfrag3(w, S, cin, cout, tr):
+    lib = _lib.load()
+    nb = lib.sh_conv_wfrag3_bytes(S, cout if tr else cin, cin if tr else cout)
+    buf = torch.empty(nb, dtype=torch.uint8, device=w.device)
+    _lib.check(lib.sh_conv_wfrag3_prep_multi(1, arr([w.data_ptr()], ctypes.c_void_p), arr([buf.data_ptr()], ctypes.c_void_p),
+                                             arr([S], ctypes.c_int), arr([cin], ctypes.c_int), arr([cout], ctypes.c_int),
+                                             arr([1 if tr else 0], ctypes.c_int), _lib.stream_ptr()), "wfrag3")
+    return buf
+
+
+def to_p3(x):
+    """x: [rows][B][C] vertex-major fp32 -> plane image (uint8 tensor)."""
+    lib = _lib.load()
+    rows, B, C = x.shape
+    nb = lib.sh_p3_bytes(rows, B, C)
+    assert nb > 0, (rows, B, C)
+    buf = torch.empty(nb, dtype=torch.uint8, device=x.device)
+    _lib.check(lib.sh_to_p3(_lib.ptr(x), B * C, C, _lib.ptr(buf), B, rows, C, _lib.stream_ptr()), "sh_to_p3")
+    return buf
+
+
+def timed(fn, reps):
+    """Average kernel time per call in us, from the library's own per-launch HIP events (what rocprofv3 reports): host
+    call overhead does not enter."""
+    fn()
+    torch.cuda.synchronize()
+    _lib.profile_enable(True)
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    recs = _lib.profile_records()
+    _lib.profile_enable(False)
+    return 1e3 * sum(ms for _, ms in recs) / reps
+
+
+def rnd(shape, dev, adversarial, gen):
+    x = torch.randn(shape, device=dev, generator=gen)
+    if adversarial:
+        # six decades of dynamic range, and sums that cancel: magnitudes 10^U(-3,3), signs alternating along the last axis
+        mag = torch.pow(10.0, 6.0 * torch.rand(shape, device=dev, generator=gen) - 3.0)
+        sgn = torch.where(torch.arange(shape[-1], device=dev) % 2 == 0, 1.0, -1.0)
+        x = mag * sgn * (1.0 + 1e-3 * x)
+    return x.float().contiguous()
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    flags = [a for a in sys.argv[1:] if a.startswith("--")]
+    B = int(args[0]) if args else 64
+    tpl = args[1] if len(args) > 1 else os.path.join(ROOT, "tests", "golden", "template6890.npz")
+    reps = 20
+    for f in flags:
+        if f.startswith("--reps="):
+            reps = int(f.split("=")[1])
+    adversarial = "--adversarial" in flags
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    h = load_hierarchy(tpl)
+    torch.manual_seed(0)
+    model = sh.SpiralAutoencoder(FE, FD, 256, h.sizes, h.spiral_sizes, h.spirals, h.D, h.U, dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1)
+    print("%-34s %-30s %-30s" % ("layer", "max|err|/max|ref| exact split3 p3", "us exact split3 p3 (+to_p3)"))
+    for sname, stack in (("enc", model._enc_stack), ("dec", model._dec_stack)):
+        for i, st in enumerate(stack.steps):
+            if st.kind != "conv" or st.cin == 3 or st.cout == 3:
+                continue
+            R, S, cin, cout, n_in = st.R, st.S, st.cin, st.cout, st.n_in
+            table, table_t = st.dev["table"], st.dev["table_t"]
+            w = (torch.randn((cout, S * cin), device=dev, generator=gen) / (S * cin) ** 0.5).contiguous()
+            if adversarial:
+                w = rnd((cout, S * cin), dev, True, gen)
+            bias = torch.randn((cout,), device=dev, generator=gen).contiguous()
+            for bwd in ((False, True) if "--bwd" in flags or "--both" in flags else (False,)):
+                if "--bwd" in flags and not bwd:
+                    continue
+                if not bwd:
+                    Cg, Nout, rows_in, rows_out, tbl = cin, cout, n_in, R, table
+                    x = rnd((n_in, B, cin), dev, adversarial, gen)
+                else:
+                    Cg, Nout, rows_in, rows_out, tbl = cout, cin, R + st.n_extra, n_in, table_t
+                    x = rnd((R + st.n_extra, B, cout), dev, adversarial, gen)
+                ok = bool(lib.sh_spiral_conv_p3_ok(B, S, Cg, Nout))
+                # float64 reference on the device
+                x64, w64 = x.double(), w.double().view(cout, S, cin)
+                ref = torch.zeros((rows_out, B, Nout), dtype=torch.float64, device=dev)
+                for s in range(S):
+                    g = x64[tbl[:, s].long()]                                   # [rows_out][B][Cg]
+                    ws = w64[:, s, :]                                            # [cout][cin]
+                    ref += g @ (ws.t() if not bwd else ws)
+                if not bwd:
+                    ref += bias.double()
+                scale = float(ref.abs().max())
+                y = torch.empty((rows_out, B, Nout), dtype=torch.float32, device=dev)
+                wt = ops.weight_transpose(w, S, cin, cout) if bwd else None
+
+                def run_f32():
+                    if not bwd:
+                        ops.spiral_conv_fwd(x, "vm", table, w, bias, y, "vm", R, S, 0, -1)
+                    else:
+                        ops.spiral_conv_bwd_data(x, "vm", table_t, wt, y, "vm", None, "vm", 0, -1, n_in, S, cin, cout)
+                res = {}
+                for mode in ("exact", "split3"):
+                    _lib.set_f32_mma_mode(mode)
+                    t = timed(run_f32, reps)
+                    res[mode] = (float((y.double() - ref).abs().max()) / scale, t)
+                _lib.set_f32_mma_mode("exact")
+                if ok:
+                    wf = wfrag3(w, S, cin, cout, bwd)
+                    xp = to_p3(x)
+                    yp = torch.empty(max(16, lib.sh_p3_bytes(rows_out, B, Nout)), dtype=torch.uint8, device=dev) \
+                        if lib.sh_p3_bytes(rows_out, B, Nout) else None
+                    y.zero_()
+
+                    def run_p3():
+                        if not bwd:
+                            _lib.check(lib.sh_spiral_conv_fwd_p3(_lib.ptr(xp), _lib.ptr(table), _lib.ptr(wf), _lib.ptr(bias), _lib.ptr(y),
+                                                                 B * Nout, Nout, _lib.ptr(yp), B, R, S, cin, cout, 0, -1, _lib.stream_ptr()), "fwd_p3")
+                        else:
+                            _lib.check(lib.sh_spiral_conv_bwd_data_p3(_lib.ptr(xp), _lib.ptr(table_t), _lib.ptr(wf), _lib.ptr(y), B * Nout, Nout,
+                                                                      _lib.ptr(yp), None, 0, 0, 0, -1, B, n_in, S, cin, cout,
+                                                                      _lib.stream_ptr()), "bwd_p3")
+                    t = timed(run_p3, reps)
+                    e = float((y.double() - ref).abs().max()) / scale
+                    t2 = timed(lambda: to_p3(x), reps)
+                    # the plane image the kernel wrote of its own output must be the image of that output, bit for bit
+                    img_ok = ""
+                    if yp is not None:
+                        img_ok = " img=" + ("ok" if torch.equal(to_p3(y), yp) else "MISMATCH")
+                    p3s = "%.2e" % e
+                    t3 = "%6.1f (+%.1f)%s" % (t, t2, img_ok)
+                else:
+                    p3s, t3 = "   -   ", "  -"
+                print("%-34s %.2e %.2e %-9s   %6.1f %6.1f %s" % (
+                    "%s%d %s R=%d K=%d N=%d" % (sname, i, "bwd" if bwd else "fwd", rows_out, S * Cg, Nout),
+                    res["exact"][0], res["split3"][0], p3s, res["exact"][1], res["split3"][1], t3), flush=True)
+                del x64, w64, ref
+
+
+if __name__ == "__main__":
+    main()
