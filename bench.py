@@ -85,6 +85,10 @@ def parse_tag_f32(name, shape):
     try:
         if fam == "gather_gemm_kernel":
             return ("bwd" if targs[2] == "true" else "fwd", int(f["R"]), int(f["K"]), int(f["N"]))
+        if fam == "conv_p3_kernel":                        # three-plane form, LDS-resident weight: <NT, RT, C16, BWD, NP>
+            return ("bwd" if targs[3] == "true" else "fwd", int(f["R"]), int(f["K"]), int(f["N"]))
+        if fam == "conv_p3s_kernel":                       # three-plane form, streamed weight: <RT, BWD, NP>
+            return ("bwd" if targs[1] == "true" else "fwd", int(f["R"]), int(f["K"]), int(f["N"]))
         if fam == "conv_out3_linewise_kernel":             # forward of the <= 3-channel last layer on the VALU
             return ("fwd", int(f["R"]), int(f["K"]), int(f["N"]))
         if fam.startswith("gather_gemm_"):                 # direct / split3 / coalesced forms: <NT, BWD, ...>
@@ -355,19 +359,23 @@ def secondary_block(sh, h, B, dev, init_state, data, test, ft, cpu_l2_mm, args):
         r["f32_mma"] = _lib.get_f32_mma_mode()
         return r
 
-    def other_f32_leg():
-        other = "exact" if _lib.get_f32_mma_mode() == "split3" else "split3"
-        _lib.set_f32_mma_mode(other)
-        try:
-            res, model, _, _, _ = replayed_training(sh, h, B, "f32", dev, steps, warm)
-        finally:
-            _lib.set_f32_mma_mode("split3" if other == "exact" else "exact")
-        del model
-        res["f32_mma"] = other
-        res["config"] = "the headline's step with the other arithmetic form of the fp32 products (%s)" % other
-        return res
+    def other_f32_leg(other):
+        def run():
+            was = _lib.get_f32_mma_mode()
+            _lib.set_f32_mma_mode(other)
+            try:
+                res, model, _, _, _ = replayed_training(sh, h, B, "f32", dev, steps, warm)
+            finally:
+                _lib.set_f32_mma_mode(was)
+            del model
+            res["f32_mma"] = other
+            res["config"] = "the headline's step with another arithmetic form of the fp32 products (%s)" % other
+            return res
+        return run
 
-    leg("f32_other_mma_step", other_f32_leg)
+    for other in ("exact", "split3", "planes3"):
+        if other != _lib.get_f32_mma_mode():
+            leg("f32_%s_step" % other, other_f32_leg(other))
     leg("bf16_step", bf16_leg)
     leg("config4_27k", config4_leg)
     leg("decode_b1024", decode_leg)
@@ -468,7 +476,7 @@ def roofline_f32(recs, model, B, nprof, verts):
     if "tflops" in dom:
         a = agg[dom["kernel"]]
         # a bf16x3 kernel executes six bf16 MFMA FLOPs per algorithmic fp32 FLOP: its roof is the dense bf16 MFMA peak / 6
-        is_s3 = "split3" in dom["kernel"]
+        is_s3 = "split3" in dom["kernel"] or "conv_p3" in dom["kernel"]
         peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if is_s3 else PEAK_F32_MFMA_TFLOPS
         result["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": peak,
                               "unit": "TFLOP/s", "frac": dom["tflops"] / peak, "traffic": traffic,
@@ -763,11 +771,13 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="arithmetic of the kernels: f32 = BASELINE configs[1] (the headline), bf16 = configs[2] (bf16 activations and "
                          "working weights, fp32 accumulation, fp32 master weights / gradients / Adam)")
-    ap.add_argument("--f32-mma", choices=["exact", "split3"], default="exact",
+    ap.add_argument("--f32-mma", choices=["exact", "split3", "planes3"], default="exact",
                     help="arithmetic form of the fp32 path's matrix products (include/sh_kernels.h sh_set_f32_mma_mode): exact = fp32 "
                          "MFMA, the reference's arithmetic and the headline; split3 = every fp32 operand split exactly into three bf16 "
                          "terms, six partial products on the bf16 MFMA with fp32 accumulation (fp32-level error: the GPU parity tests run "
-                         "in both forms at the same tolerances).  The secondary block times the other form")
+                         "in every form at the same tolerances); planes3 = the same arithmetic with the split written ONCE by the producer "
+                         "of a tensor as three bf16 planes the conv kernels gather (csrc/p3_conv.hip; tests/test_p3.py gates its error "
+                         "against a float64 evaluation next to the exact form's).  The secondary block times the other forms")
     ap.add_argument("--cpu-iters", type=int, default=8, help="timed CPU-baseline steps (8 steps at batch 64 = ~13 s of host work)")
     ap.add_argument("--template", default=os.path.join("tests", "golden", "template6890.npz"),
                     help="mesh hierarchy fixture; tests/golden/template27554.npz + --batch 32 is BASELINE config 4")
@@ -966,8 +976,9 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": (("[fp32 products as exact bf16x3 operand splits, six partial products on the bf16 MFMA, fp32 accumulate] "
-                                 if args.f32_mma == "split3" else "[fp32 MFMA] ") if args.dtype == "f32"
+        "config": {"workload": (({"split3": "[fp32 products as exact bf16x3 operand splits, six partial products on the bf16 MFMA, fp32 accumulate] ",
+                                  "planes3": "[fp32 products as exact bf16x3 operand splits written once by the producer as three bf16 planes, "
+                                             "six partial products on the bf16 MFMA, fp32 accumulate] "}.get(args.f32_mma, "[fp32 MFMA] ")) if args.dtype == "f32"
                                 else "[bf16 kernels, fp32 master weights] ") +
                                "plain spiral AE training step (fwd + L1 + 1e-2*edge loss + bwd + Adam), %s, levels %s, "
                                "spiral sizes %s, nz 256, %.2fM params"

@@ -157,11 +157,13 @@ SH_API int sh_spiral_conv_bwd_wgt(const float* dpre, int64_t dp_sv, int64_t dp_s
  *     sum_out[r][b][:] = sum_e sum_val[e] * dpre[sum_col[e]][b][:]      r < sum_rows, strides of dpre, sh_spmm's arithmetic
  * - computed by extra workgroups of the weight-gradient launch (both only read the first R rows of dpre) instead of a launch of
  * its own, when a second wave of the kernel fits on a SIMD; otherwise the entry point issues sh_spmm itself, first.
+ * sum_out_planes != NULL: the three-plane image of those rows (sh_spmm_p3's y_planes) is written with them.
  * sum_rows == 0: exactly sh_spiral_conv_bwd_wgt. */
 SH_API int sh_spiral_conv_bwd_wgt_presum(const float* dpre, int64_t dp_sv, int64_t dp_sb, const float* x, int64_t x_sv, int64_t x_sb,
                                          const int32_t* table, float* dW, float* dbias, void* workspace, size_t workspace_bytes,
                                          const int32_t* sum_rowptr, const int32_t* sum_col, const float* sum_val, float* sum_out,
-                                         int sum_rows, int B, int R, int S, int Cin, int Cout, int mma_mode, sh_stream_t stream);
+                                         void* sum_out_planes, int sum_rows, int B, int R, int S, int Cin, int Cout, int mma_mode,
+                                         sh_stream_t stream);
 
 /* Batched forms for a whole stack of layers (one launch instead of one per layer; host arrays of
  * n_layers entries, passed by value into the kernel arguments -> graph-capturable):
@@ -515,12 +517,13 @@ SH_API int sh_spiral_conv_bwd_data_bf16(const void* dpre, int dp_dtype, int64_t 
  * same table and buffer): dx[u,b,:] = act_prev'(x[u,b,:]) * sum_s dpre_ext[table_t[u,s],b,:] . W[:, s, :], row zero_prev
  * forced to zero; dx [n_in (+ extra)][B][16] vertex-major of the path's dtype, weight = the fp32 master [3][S*16] (rounded to
  * bf16 in the kernel on the bf16 path, like the fragment copies); x is both the layer input and the activation output
- * whose derivative multiplies (act_prev = SH_ACT_IDENTITY: no factor). */
+ * whose derivative multiplies (act_prev = SH_ACT_IDENTITY: no factor).  dx_planes != NULL (fp32 path, with dx): the three-plane
+ * image of dx's n_in rows (see the ..._p3 entry points) is written with them. */
 SH_API int sh_spiral_conv_bwd_wgt_thin_ok(int B, int n_in, int S, int Cin, int Cout, int path_dtype);
 SH_API int sh_spiral_conv_bwd_wgt_thin(const float* dpre_ext, int64_t dp_sv, int64_t dp_sb, const void* x, int x_dtype, int64_t x_sv,
                                 int64_t x_sb, const int32_t* table_t, void* workspace, size_t workspace_bytes,
-                                const float* weight, void* dx, int64_t dx_sv, int64_t dx_sb, int act_prev, int zero_prev,
-                                int B, int R, int n_in, int S, int Cin, int Cout, int path_dtype, sh_stream_t stream);
+                                const float* weight, void* dx, int64_t dx_sv, int64_t dx_sb, void* dx_planes, int act_prev,
+                                int zero_prev, int B, int R, int n_in, int S, int Cin, int Cout, int path_dtype, sh_stream_t stream);
 
 /* sh_spiral_conv_bwd_wgt in bf16: x / dpre bf16 (channels % 8 == 0) or fp32 with exactly 3 channels; writes fp32 partial
  * slabs into `workspace` (>= sh_spiral_conv_bwd_wgt_workspace_bf16 bytes); sh_spiral_conv_bwd_wgt_reduce_multi_bf16 sums
@@ -599,14 +602,19 @@ SH_API size_t sh_conv_wfrag3_bytes(int S, int Cg, int Nout);
 SH_API int sh_conv_wfrag3_prep_multi(int n_layers, const float* const* weight, void* const* wfrag3, const int* S, const int* Cin,
                                      const int* Cout, const int* transpose, sh_stream_t stream);
 SH_API int sh_spiral_conv_p3_ok(int B, int S, int Cg, int Nout);
+/* sh_spmm that also writes the plane image of the rows it produces (y_planes: image of row 0 of y; NULL = plain sh_spmm) */
+SH_API int sh_spmm_p3(const int32_t* rowptr, const int32_t* col, const float* val, const float* x, int64_t x_sv, int64_t x_sb,
+                      float* y, int64_t y_sv, int64_t y_sb, void* y_planes, const float* yprev, int64_t yp_sv, int64_t yp_sb,
+                      int act_prev, int zero_row, int B, int rows, int C, sh_stream_t stream);
 /* sh_spiral_conv_fwd with x given as its plane image xp ([n_in] rows) */
 SH_API int sh_spiral_conv_fwd_p3(const void* xp, const int32_t* table, const void* wfrag3, const float* bias, float* y, int64_t y_sv,
                                  int64_t y_sb, void* yp, int B, int R, int S, int Cin, int Cout, int act, int zero_row,
                                  sh_stream_t stream);
-/* sh_spiral_conv_bwd_data with dpre given as its plane image dprep (all rows table_t refers to, pre-summed rows included) */
-SH_API int sh_spiral_conv_bwd_data_p3(const void* dprep, const int32_t* table_t, const void* wfrag3_t, float* dx, int64_t dx_sv,
-                                      int64_t dx_sb, void* dxp, const float* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev,
-                                      int zero_row, int B, int n_in, int S, int Cin, int Cout, sh_stream_t stream);
+/* sh_spiral_conv_bwd_data_z with dpre given as its plane image dprep (all rows table_t refers to, pre-summed rows included;
+ * dpre_zero_row >= 0: the all-zero row the "no source" entries point at - their products are skipped, bitwise the same result) */
+SH_API int sh_spiral_conv_bwd_data_p3(const void* dprep, int dpre_zero_row, const int32_t* table_t, const void* wfrag3_t, float* dx,
+                                      int64_t dx_sv, int64_t dx_sb, void* dxp, const float* yprev, int64_t yp_sv, int64_t yp_sb,
+                                      int act_prev, int zero_row, int B, int n_in, int S, int Cin, int Cout, sh_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -31,7 +31,7 @@ SIGNATURES = {
     "sh_weight_transpose": (c_int, [_P, _P, _I, _I, _I, _P]),
     "sh_spiral_conv_bwd_wgt_workspace": (c_size_t, [_I, _I, _I, _I, _I]),
     "sh_spiral_conv_bwd_wgt": (c_int, [_P, _L, _L, _P, _L, _L, _P, _P, _P, _P, c_size_t, _I, _I, _I, _I, _I, _I, _P]),
-    "sh_spiral_conv_bwd_wgt_presum": (c_int, [_P, _L, _L, _P, _L, _L, _P, _P, _P, _P, c_size_t, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "sh_spiral_conv_bwd_wgt_presum": (c_int, [_P, _L, _L, _P, _L, _L, _P, _P, _P, _P, c_size_t, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sh_spiral_conv_bwd_wgt_reduce_multi": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sh_weight_transpose_multi": (c_int, [_I, _P, _P, _P, _P, _P, _P]),
     "sh_act_backward": (c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _P]),
@@ -53,7 +53,7 @@ SIGNATURES = {
     "sh_edge_ratio_loss_fwd": (c_int, [_P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "sh_edge_ratio_loss_bwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "sh_spiral_conv_bwd_wgt_thin_ok": (c_int, [_I, _I, _I, _I, _I, _I]),
-    "sh_spiral_conv_bwd_wgt_thin": (c_int, [_P, _L, _L, _P, _I, _L, _L, _P, _P, c_size_t, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "sh_spiral_conv_bwd_wgt_thin": (c_int, [_P, _L, _L, _P, _I, _L, _L, _P, _P, c_size_t, _P, _P, _L, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sh_recon_loss_workspace": (c_size_t, []),
     "sh_recon_loss_fwd": (c_int, [_P, _P, _P, _I, _I, _I, c_float, _P, _P, _P, _P]),
     "sh_recon_loss_bwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, c_float, _P, _P, _P]),
@@ -100,8 +100,9 @@ SIGNATURES = {
     "sh_conv_wfrag3_bytes": (c_size_t, [_I, _I, _I]),
     "sh_conv_wfrag3_prep_multi": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P]),
     "sh_spiral_conv_p3_ok": (c_int, [_I, _I, _I, _I]),
+    "sh_spmm_p3": (c_int, [_P, _P, _P, _P, _L, _L, _P, _L, _L, _P, _P, _L, _L, _I, _I, _I, _I, _I, _P]),
     "sh_spiral_conv_fwd_p3": (c_int, [_P, _P, _P, _P, _P, _L, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "sh_spiral_conv_bwd_data_p3": (c_int, [_P, _P, _P, _P, _L, _L, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "sh_spiral_conv_bwd_data_p3": (c_int, [_P, _I, _P, _P, _P, _L, _L, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _P]),
 }
 DTYPE_IDS = {"float32": 0, "bfloat16": 1}
 

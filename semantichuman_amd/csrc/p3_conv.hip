@@ -42,11 +42,20 @@ struct P3Params {
     int B, R, S, Cg, Nout, nks, nt_tot, ncg;
     int act, zero_row;
     int n_vg, n_tiles, nsplit;
+    int skip_row;                              // backward-data: the all-zero row "no source" entries of the table point at, or -1
 };
 
+// k-steps of plane loads in flight per wave (ring slots): what the 128-VGPR budget leaves next to the accumulators and one
+// set of weight fragments.  These launches live on bytes in flight per CU (matrix pipe, LDS and vector L1 all sit near 30 %).
+#ifndef P3_BUDGET
+#define P3_BUDGET 88
+#endif
+#ifndef P3_DCAP
+#define P3_DCAP 4
+#endif
 constexpr int p3_depth(int NT, int RT) {
-    const int d = (88 - NT * RT * 4 - 12) / (RT * 12);
-    return d < 2 ? 2 : d > 4 ? 4 : d;
+    const int d = (P3_BUDGET - NT * RT * 4 - 12) / (RT * 12);
+    return d < 2 ? 2 : d > P3_DCAP ? P3_DCAP : d;
 }
 
 template <int J, int D, class F>
@@ -60,8 +69,11 @@ __device__ __forceinline__ bool p3_ring_steps(int ks, int nks, F&& f) {
     }
 }
 
+#ifndef P3_WAVES_PER_EU
+#define P3_WAVES_PER_EU 4
+#endif
 template <int NT, int RT, bool C16, bool BWD, int NP>
-__global__ __launch_bounds__(1024) void conv_p3_kernel(const P3Params p) {
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(P3_WAVES_PER_EU, 8))) void conv_p3_kernel(const P3Params p) {
     constexpr int D = p3_depth(NT, RT);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const u32x4* Wl = reinterpret_cast<const u32x4*>(smem);       // [nks][NT][3][64]
@@ -142,7 +154,34 @@ __global__ __launch_bounds__(1024) void conv_p3_kernel(const P3Params p) {
         for (int m = 0; m < RT; ++m)
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[m][n] = zero4;
+        int cs = 0, cc = 0;                                // position / channel group of the k-step being multiplied (uniform)
         auto compute = [&](int ks, const u32x4 (&a)[RT][3]) {
+            // "no source" entries (down-sampling levels: half of them) gather the zero row: exact zeros through the matrix pipe.
+            // The entry is wave-uniform (one vertex per 16 batch rows), so the products are skipped by a scalar branch - bitwise
+            // the same result.  (The loads are not skipped: a conditional load would make every wait a full drain, and the zero
+            // row is L1-resident.)
+            bool live[RT];
+            bool any = false;
+#pragma unroll
+            for (int m = 0; m < RT; ++m) {
+                live[m] = true;
+                if constexpr (BWD) {
+                    if (p.skip_row >= 0) {
+                        if constexpr (!C16) {
+                            live[m] = __builtin_amdgcn_readlane(tv[m], cs) != p.skip_row;
+                        } else {
+                            const int s1 = cs + 1 < S ? cs + 1 : cs;
+                            live[m] = __builtin_amdgcn_readlane(tv[m], cs) != p.skip_row || __builtin_amdgcn_readlane(tv[m], s1) != p.skip_row;
+                        }
+                    }
+                }
+                any = any || live[m];
+            }
+            if constexpr (BWD) {
+                if constexpr (C16) { cs += 2; if (cs >= S) cs = S - 1; }
+                else if (++cc >= p.ncg) { cc = 0; if (cs + 1 < S) ++cs; }
+            }
+            if (!any) return;
             const u32x4* wk = Wl + ((long)ks * NT) * 192 + lane;
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
@@ -151,6 +190,7 @@ __global__ __launch_bounds__(1024) void conv_p3_kernel(const P3Params p) {
                              wl = *reinterpret_cast<const bf16x8*>(&r2);
 #pragma unroll
                 for (int m = 0; m < RT; ++m) {
+                    if (RT > 1 && !live[m]) continue;
                     const bf16x8 xh = *reinterpret_cast<const bf16x8*>(&a[m][0]), xm = *reinterpret_cast<const bf16x8*>(&a[m][1]),
                                  xl2 = *reinterpret_cast<const bf16x8*>(&a[m][2]);
                     f32x4 c = acc[m][n];
@@ -219,6 +259,173 @@ __global__ __launch_bounds__(1024) void conv_p3_kernel(const P3Params p) {
         }
 #pragma unroll
         for (int m = 0; m < RT; ++m) tv[m] = tvn[m];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight-STREAMING form for layers whose three-plane weight does not fit LDS (the coarsest level: 512 x 128 and 1024 x 64
+// weights = 384 KiB of planes).  Same gather stream per wave (D = 4 k-steps of plane loads in flight, continuous over the whole
+// K loop), but the weight passes through LDS in chunks of KC = 4 k-steps x 4 channel tiles (48 KiB, double-buffered): the 16
+// waves of a workgroup each fetch 3 of a chunk's 48 fragments into registers while the previous chunk is multiplied, write them
+// to the idle buffer and meet at ONE barrier per chunk.  The weight loads are ordinary (compiler-visible) loads, so every wait is
+// a counted s_waitcnt for exactly those loads - the gather ring is never drained.  A wave owns ONE vertex x 16 batch entries x
+// 64 output channels per round; wider layers split their channels over workgroup slices (the gather repeats per slice: these
+// layers are matrix-bound).  Every wave of a workgroup runs the same number of rounds (idle waves multiply a clamped item and
+// store nothing): the barriers are uniform.
+constexpr int P3S_NT = 4, P3S_KC = 4;
+
+// RT vertices per wave share every weight fragment read: with one vertex a fragment (1 KiB of LDS) feeds 6 MFMAs = 96 cycles
+// of one SIMD, i.e. the four SIMDs ask for exactly the 128 bytes / clock LDS delivers - matrix pipe and LDS co-limited; with
+// two, half of that.  RT = 2 runs 8 waves per workgroup (two per SIMD, up to 256 VGPRs each), RT = 1 sixteen.
+template <int RT, bool BWD, int NP>
+__global__ __launch_bounds__(1024 / RT) void conv_p3s_kernel(const P3Params p) {
+    constexpr int NT = P3S_NT, D = P3S_KC, WAVES = 16 / RT, WF = 48 / WAVES;      // WF: fragments of a chunk this wave fetches
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u32x4* Wl = reinterpret_cast<u32x4*>(smem);                   // [2][KC][NT][3][64]
+    constexpr int CHUNK_PIECES = P3S_KC * NT * 192;               // 16-byte pieces per chunk buffer
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+    const int nwg_x = ((int)gridDim.x - xcd + 7) >> 3;
+    const int slice = li % p.nsplit, lj = li / p.nsplit;
+    const int ngrp = nwg_x / p.nsplit;
+    const int q8 = p.n_tiles >> 3, r8 = p.n_tiles & 7;
+    const int t_begin = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int t_end = t_begin + (xcd < r8 ? q8 + 1 : q8);
+    const int stride = ngrp * WAVES;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int S = p.S, sl = lane < S ? lane : S - 1;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const int nch = p.nks / P3S_KC;
+    int wsrc[WF], wdst[WF];                                        // 16-byte piece offsets of this wave's fragments of a chunk
+#pragma unroll
+    for (int j = 0; j < WF; ++j) {
+        const int f = WF * wave + j, pl = f % 3, n = (f / 3) % NT, kk = f / (3 * NT);
+        wsrc[j] = ((kk * p.nt_tot + slice * NT + n) * 3 + pl) * 64 + lane;      // + chunk * KC * nt_tot * 192
+        wdst[j] = f * 64 + lane;
+    }
+    const int wchunk = P3S_KC * p.nt_tot * 192;
+    const int rounds = (t_end - t_begin - lj * WAVES + stride - 1) / stride;      // of wave 0 of this workgroup: the most any wave has
+    int t = t_begin + lj * WAVES + wave;
+    for (int rd = 0; rd < rounds; ++rd, t += stride) {
+        const bool live = t < t_end;
+        const int tt = live ? t : t_end - 1;
+        const int bs = tt / p.n_vg, vg = tt - bs * p.n_vg;
+        const int v0 = vg * RT;
+        int tv[RT];
+#pragma unroll
+        for (int m = 0; m < RT; ++m) tv[m] = p.table[(long)(v0 + m < p.R ? v0 + m : p.R - 1) * S + sl];
+        const char* xl = p.xp + (long)bs * p.x_bgb + lane * 16;
+        int ls = 0, lc = 0;
+        u32x4 ring[D][RT][3];
+        auto issue = [&](u32x4 (&a)[RT][3]) {
+            const int s = ls < S ? ls : S - 1;
+#pragma unroll
+            for (int m = 0; m < RT; ++m) {
+                const int row = __builtin_amdgcn_readlane(tv[m], s);
+                const char* src = xl + (long)row * p.x_vb + (long)lc * 3072;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) a[m][pl] = *reinterpret_cast<const u32x4*>(src + pl * 1024);
+            }
+            if (++lc >= p.ncg) { lc = 0; ++ls; }
+        };
+        f32x4 acc[RT][NT];
+#pragma unroll
+        for (int m = 0; m < RT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = zero4;
+        int cs = 0, cc = 0;
+        auto compute = [&](const u32x4* wk, const u32x4 (&a)[RT][3]) {
+            bool live[RT];                                 // see conv_p3_kernel: products of "no source" entries are skipped
+            bool any = false;
+#pragma unroll
+            for (int m = 0; m < RT; ++m) {
+                live[m] = !BWD || p.skip_row < 0 || __builtin_amdgcn_readlane(tv[m], cs) != p.skip_row;
+                any = any || live[m];
+            }
+            if (BWD && ++cc >= p.ncg) { cc = 0; if (cs + 1 < S) ++cs; }
+            if (!any) return;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const u32x4 r0 = wk[n * 192], r1 = wk[n * 192 + 64], r2 = wk[n * 192 + 128];
+                const bf16x8 w[3] = {*reinterpret_cast<const bf16x8*>(&r0), *reinterpret_cast<const bf16x8*>(&r1),
+                                     *reinterpret_cast<const bf16x8*>(&r2)};
+                // products in ascending magnitude (weight plane, x plane); the RT accumulators alternate, so consecutive MFMAs
+                // are independent
+                constexpr int PW[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0}, PX[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int q = 9 - NP; q < 9; ++q)
+#pragma unroll
+                    for (int m = 0; m < RT; ++m)
+                        if (RT == 1 || live[m])
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[PW[q]], *reinterpret_cast<const bf16x8*>(&a[m][PX[q]]), acc[m][n], 0, 0, 0);
+            }
+        };
+        // chunk 0 of the weight -> buffer 0 (the previous round's last reads of it ended before that round's last barrier)
+        u32x4 wreg[WF];
+#pragma unroll
+        for (int j = 0; j < WF; ++j) wreg[j] = p.wfrag[wsrc[j]];
+#pragma unroll
+        for (int d = 0; d < D - 1; ++d) issue(ring[d]);
+#pragma unroll
+        for (int j = 0; j < WF; ++j) Wl[wdst[j]] = wreg[j];
+        __syncthreads();
+        for (int c = 0; c < nch; ++c) {
+            const bool more = c + 1 < nch;
+            if (more) {
+#pragma unroll
+                for (int j = 0; j < WF; ++j) wreg[j] = p.wfrag[wsrc[j] + (c + 1) * wchunk];
+            }
+            const u32x4* wb = Wl + (c & 1) * CHUNK_PIECES + lane;
+            auto step = [&](auto J, int) {
+                constexpr int j = decltype(J)::value;
+                issue(ring[(j + D - 1) % D]);             // (past the end of K: a clamped, unused load)
+                __builtin_amdgcn_sched_barrier(0);
+                compute(wb + j * NT * 192, ring[j]);
+            };
+            p3_ring_steps<0, D>(0, D, step);
+            if (more) {
+                u32x4* wn = Wl + ((c + 1) & 1) * CHUNK_PIECES;
+#pragma unroll
+                for (int j = 0; j < WF; ++j) wn[wdst[j]] = wreg[j];
+            }
+            __syncthreads();
+        }
+        // ---- epilogue (as conv_p3_kernel)
+        const int b = bs * 16 + r16;
+#pragma unroll
+        for (int m = 0; m < RT; ++m) {
+            const int v = v0 + m;
+            if (!live || v >= p.R || b >= p.B) continue;
+            const bool zero = v == p.zero_row;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int c0 = (slice * NT + n) * 16 + kq * 4;
+                if (c0 >= p.Nout) continue;
+                f32x4 a = acc[m][n];
+                if (!BWD) {
+                    if (p.bias) a += *reinterpret_cast<const f32x4*>(p.bias + c0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[j] = sh_act_fwd(a[j], p.act);
+                } else if (p.yprev) {
+                    const f32x4 yv = *reinterpret_cast<const f32x4*>(p.yprev + (long)v * p.yv_sv + (long)b * p.yv_sb + c0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[j] *= sh_act_grad_from_out(yv[j], p.act);
+                }
+                if (zero) a = zero4;
+                if (p.y) *reinterpret_cast<f32x4*>(p.y + (long)v * p.y_sv + (long)b * p.y_sb + c0) = a;
+                if (p.yp) {
+                    u32x2 h, mm, l;
+                    sh_split3_quad(a, h, mm, l);
+                    const bool o16 = p.Nout == 16;
+                    char* dst = p.yp + (long)v * p.yp_vb + (long)bs * p.yp_bgb +
+                                (o16 ? ((c0 >> 3) * 16 + r16) * 16 : (c0 >> 5) * 3072 + (((c0 & 31) >> 3) * 16 + r16) * 16) + (kq & 1) * 8;
+                    const int opb = o16 ? 512 : 1024;
+                    *reinterpret_cast<u32x2*>(dst) = h;
+                    *reinterpret_cast<u32x2*>(dst + opb) = mm;
+                    *reinterpret_cast<u32x2*>(dst + 2 * opb) = l;
+                }
+            }
+        }
     }
 }
 
@@ -304,12 +511,59 @@ inline P3Geom p3_geom(int S, int Cg, int Nout) {
     while (r.nt > 1 && (long)g.nks * r.nt * 3 > 150) { r.nt >>= 1; r.nsplit <<= 1; }
     return r;
 }
-inline bool p3_shape_ok(int B, int S, int Cg, int Nout) {
-    if (B <= 0 || B % 16 || S <= 0 || S > 64 || Nout % 4) return false;
-    if (!(Cg == 16 || (Cg > 0 && Cg % 32 == 0))) return false;
+// the streaming form: K in whole chunks, gathered channels in 32s, at least one full slice of 64 output channels
+inline bool p3s_shape_ok(int S, int Cg, int Nout) {
+    static const int on = sh_env_int("SH_P3_STREAM", 1, 0, 1);
+    if (!on || Cg % 32 || Nout % 64) return false;
+    const ShFragGeom g = sh_frag_geom(S, Cg, Nout);
+    return g.nks % P3S_KC == 0 && g.nt_tot % P3S_NT == 0;
+}
+inline bool p3_resident_ok(int S, int Cg, int Nout) {
     const P3Geom g = p3_geom(S, Cg, Nout);
     static const int max_split = sh_env_int("SH_P3_MAX_SPLIT", 1, 1, 8);      // output-channel slices re-gather the input
     return (long)g.nks * g.nt * 3 <= 150 && g.nsplit <= max_split;
+}
+inline bool p3_shape_ok(int B, int S, int Cg, int Nout) {
+    if (B <= 0 || B % 16 || S <= 0 || S > 64 || Nout % 4) return false;
+    if (!(Cg == 16 || (Cg > 0 && Cg % 32 == 0))) return false;
+    return p3_resident_ok(S, Cg, Nout) || p3s_shape_ok(S, Cg, Nout);
+}
+
+template <int RT, bool BWD, int NP>
+int launch_p3s(P3Params& p, hipStream_t st) {
+    auto kern = conv_p3s_kernel<RT, BWD, NP>;
+    constexpr int WAVES = 16 / RT;
+    const size_t smem = (size_t)2 * P3S_KC * P3S_NT * 3072;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            (void)hipGetLastError();
+            sh_set_error("conv_p3s: cannot raise the dynamic LDS limit to %zu bytes", smem);
+            return SH_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    p.nsplit = p.nt_tot / P3S_NT;
+    p.n_vg = sh_cdiv(p.R, RT);
+    const long tiles = (long)p.n_vg * (p.B / 16);
+    SH_REQUIRE(tiles < (1L << 30), SH_ERR_UNSUPPORTED, "conv_p3s: %ld work items", tiles);
+    p.n_tiles = (int)tiles;
+    long groups = (tiles + WAVES - 1) / WAVES;                         // workgroups per channel slice that still get an item
+    const long cap = (long)p3_num_cus() / p.nsplit;                    // one workgroup per CU (96 KiB of LDS)
+    if (groups > cap) groups = cap;
+    if (groups < 8) groups = 8;
+    groups = (groups + 7) / 8 * 8;
+    const int grid = (int)groups * p.nsplit;
+    ShProfScope ps(st, "conv_p3s_kernel<%d, %s, %d>|R=%d B=%d K=%d N=%d grid=%dx%d", RT, BWD ? "true" : "false", NP, p.R, p.B, p.S * p.Cg,
+                   p.Nout, grid, WAVES * 64);
+    SH_LAUNCH_PS(ps, kern, dim3(grid), dim3(WAVES * 64), smem, st, p);
+    SH_CHECK_LAUNCH("conv_p3s");
+    return SH_OK;
+}
+template <bool BWD, int NP>
+int dispatch_p3s(P3Params& p, hipStream_t st) {
+    static const int rt = sh_env_int("SH_P3S_RT", 2, 1, 2);
+    return rt == 2 ? launch_p3s<2, BWD, NP>(p, st) : launch_p3s<1, BWD, NP>(p, st);
 }
 
 template <int NT, int RT, bool C16, bool BWD, int NP>
@@ -330,8 +584,10 @@ int launch_p3(P3Params& p, hipStream_t st) {
     SH_REQUIRE(tiles < (1L << 30), SH_ERR_UNSUPPORTED, "conv_p3: %ld work items", tiles);
     p.n_tiles = (int)tiles;
     const int per_cu = smem <= 36 * 1024 ? 4 : smem <= 76 * 1024 ? 2 : 1;
-    int nw = 16 / per_cu;
-    while (nw > 4 && (long)p3_num_cus() * per_cu * (nw >> 1) >= tiles * p.nsplit) nw >>= 1;
+    static const int waves_cu = sh_env_int("SH_P3_WAVES_CU", 4 * P3_WAVES_PER_EU, 16, 32);      // resident waves per CU the registers allow
+    int nw = waves_cu / per_cu;
+    if (nw > 16) nw = 16;
+    while (nw > 4 && (nw & 1) == 0 && (long)p3_num_cus() * per_cu * (nw >> 1) >= tiles * p.nsplit) nw >>= 1;
     long groups = (tiles + nw - 1) / nw;
     const long cap = (long)p3_num_cus() * per_cu / p.nsplit;
     if (groups > cap) groups = cap;
@@ -381,6 +637,7 @@ int dispatch_p3(P3Params& p, hipStream_t st) {
                  reinterpret_cast<uintptr_t>(p.yprev) | reinterpret_cast<uintptr_t>(p.bias)) & 15) == 0 &&
                ((p.y_sv | p.y_sb | p.yv_sv | p.yv_sb) & 3) == 0, SH_ERR_INVALID_ARG, "conv_p3: tensors must be 16-byte aligned with strides %% 4 == 0");
     static const int np = sh_env_int("SH_P3_NP", 6, 6, 9);
+    if (!p3_resident_ok(p.S, p.Cg, p.Nout)) return np == 9 ? dispatch_p3s<BWD, 9>(p, st) : dispatch_p3s<BWD, 6>(p, st);
     if (p.Cg == 16) return np == 9 ? dispatch_p3_nt<true, BWD, 9>(p, g.nt, st) : dispatch_p3_nt<true, BWD, 6>(p, g.nt, st);
     return np == 9 ? dispatch_p3_nt<false, BWD, 9>(p, g.nt, st) : dispatch_p3_nt<false, BWD, 6>(p, g.nt, st);
 }
@@ -454,13 +711,13 @@ int sh_spiral_conv_fwd_p3(const void* xp, const int32_t* table, const void* wfra
     P3Params p{};
     p.xp = static_cast<const char*>(xp); p.table = table; p.wfrag = static_cast<const u32x4*>(wfrag3); p.bias = bias;
     p.y = y; p.y_sv = y_sv; p.y_sb = y_sb; p.yp = static_cast<char*>(yp);
-    p.B = B; p.R = R; p.S = S; p.Cg = Cin; p.Nout = Cout; p.act = act; p.zero_row = zero_row;
+    p.B = B; p.R = R; p.S = S; p.Cg = Cin; p.Nout = Cout; p.act = act; p.zero_row = zero_row; p.skip_row = -1;
     return dispatch_p3<false>(p, static_cast<hipStream_t>(stream));
 }
 
-int sh_spiral_conv_bwd_data_p3(const void* dprep, const int32_t* table_t, const void* wfrag3_t, float* dx, int64_t dx_sv, int64_t dx_sb,
-                               void* dxp, const float* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row, int B, int n_in,
-                               int S, int Cin, int Cout, sh_stream_t stream) {
+int sh_spiral_conv_bwd_data_p3(const void* dprep, int dpre_zero_row, const int32_t* table_t, const void* wfrag3_t, float* dx, int64_t dx_sv,
+                               int64_t dx_sb, void* dxp, const float* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row, int B,
+                               int n_in, int S, int Cin, int Cout, sh_stream_t stream) {
     SH_REQUIRE(dprep && table_t && wfrag3_t, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_data_p3: null pointer");
     SH_REQUIRE(B > 0 && n_in > 0 && S > 0 && Cin > 0 && Cout > 0, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_data_p3: non-positive size");
     SH_REQUIRE(act_prev >= SH_ACT_IDENTITY && act_prev <= SH_ACT_TANH, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_data_p3: unknown activation");
@@ -469,6 +726,8 @@ int sh_spiral_conv_bwd_data_p3(const void* dprep, const int32_t* table_t, const 
     p.y = dx; p.y_sv = dx_sv; p.y_sb = dx_sb; p.yp = static_cast<char*>(dxp);
     p.yprev = yprev; p.yv_sv = yp_sv; p.yv_sb = yp_sb;
     p.B = B; p.R = n_in; p.S = S; p.Cg = Cout; p.Nout = Cin; p.act = act_prev; p.zero_row = zero_row;
+    static const int skip_on = sh_env_int("SH_P3_SKIP", 1, 0, 1);
+    p.skip_row = skip_on ? dpre_zero_row : -1;
     return dispatch_p3<true>(p, static_cast<hipStream_t>(stream));
 }
 

@@ -1360,6 +1360,7 @@ struct WSParams {
     int grid_main, tail_blocks, tail_rows;
     const int* tail_rowptr; const int* tail_col; const float* tail_val;
     float* tail_y;                                    // same (row, batch) strides as dpre
+    char* tail_img; long tail_img_vb, tail_img_bgb;   // three-plane image of the tail rows (csrc/p3_conv.hip), or NULL
 };
 
 // the tail job: one 256-element part of an output row per step, as spmm_kernel<true> (bitwise the same sums)
@@ -1392,6 +1393,17 @@ __device__ __forceinline__ void ws_presum_tail(const WSParams& p) {
             for (int k = 0; k < 4; ++k) acc[k] = fmaf(w, xv[k], acc[k]);
         }
         *reinterpret_cast<f32x4*>(p.tail_y + (long)r * p.dp_sv + xo) = acc;
+        if (p.tail_img) {                                     // the image of the row just written, as spmm_kernel<true, true>
+            u32x2 h, m, l;
+            sh_split3_quad(acc, h, m, l);
+            const bool c16 = p.Cout == 16;
+            char* d = p.tail_img + (long)r * p.tail_img_vb + (long)(b >> 4) * p.tail_img_bgb +
+                      (c16 ? ((co >> 3) * 16 + (b & 15)) * 16 : (co >> 5) * 3072 + (((co & 31) >> 3) * 16 + (b & 15)) * 16) + ((co >> 2) & 1) * 8;
+            const int pb = c16 ? 512 : 1024;
+            *reinterpret_cast<u32x2*>(d) = h;
+            *reinterpret_cast<u32x2*>(d + pb) = m;
+            *reinterpret_cast<u32x2*>(d + 2 * pb) = l;
+        }
     }
 }
 
@@ -1941,13 +1953,14 @@ int sh_spiral_conv_bwd_wgt(const float* dpre, int64_t dp_sv, int64_t dp_sb, cons
                            const int32_t* table, float* dW, float* dbias, void* workspace, size_t workspace_bytes, int B,
                            int R, int S, int Cin, int Cout, int mma_mode, sh_stream_t stream) {
     return sh_spiral_conv_bwd_wgt_presum(dpre, dp_sv, dp_sb, x, x_sv, x_sb, table, dW, dbias, workspace, workspace_bytes, nullptr, nullptr,
-                                         nullptr, nullptr, 0, B, R, S, Cin, Cout, mma_mode, stream);
+                                         nullptr, nullptr, nullptr, 0, B, R, S, Cin, Cout, mma_mode, stream);
 }
 
 int sh_spiral_conv_bwd_wgt_presum(const float* dpre, int64_t dp_sv, int64_t dp_sb, const float* x, int64_t x_sv, int64_t x_sb,
                                   const int32_t* table, float* dW, float* dbias, void* workspace, size_t workspace_bytes,
-                                  const int32_t* sum_rowptr, const int32_t* sum_col, const float* sum_val, float* sum_out, int sum_rows,
-                                  int B, int R, int S, int Cin, int Cout, int mma_mode, sh_stream_t stream) {
+                                  const int32_t* sum_rowptr, const int32_t* sum_col, const float* sum_val, float* sum_out,
+                                  void* sum_out_planes, int sum_rows, int B, int R, int S, int Cin, int Cout, int mma_mode,
+                                  sh_stream_t stream) {
     SH_REQUIRE(dpre && x && table && workspace, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_wgt: null pointer");
     SH_REQUIRE(sh_mma_mode_valid(mma_mode), SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_wgt: unknown mma_mode %d", mma_mode);
     ShMmaScope mma_scope(mma_mode);
@@ -1988,13 +2001,21 @@ int sh_spiral_conv_bwd_wgt_presum(const float* dpre, int64_t dp_sv, int64_t dp_s
         bool fold = tail_on && sum_rows > 0 && sum_vec && Cout <= 128 && !(Cin == 3) &&
                     (ws_uses_split3(w.cot, s) ? w.cot == 2 : w.cot <= 4);
         if (sum_rows > 0 && !fold) {
-            rc = sh_spmm(sum_rowptr, sum_col, sum_val, dpre, dp_sv, dp_sb, sum_out, dp_sv, dp_sb, nullptr, 0, 0, 0, -1, B, sum_rows, Cout, stream);
+            rc = sh_spmm_p3(sum_rowptr, sum_col, sum_val, dpre, dp_sv, dp_sb, sum_out, dp_sv, dp_sb, sum_out_planes, nullptr, 0, 0, 0, -1, B,
+                            sum_rows, Cout, stream);
             if (rc != SH_OK) return rc;
         }
         if (fold) {
             const long items = (long)sum_rows * (((long)B * (Cout / 4) + 255) / 256);
             s.tail_blocks = (int)(items < tail_cap ? items : tail_cap);
             s.tail_rows = sum_rows; s.tail_rowptr = sum_rowptr; s.tail_col = sum_col; s.tail_val = sum_val; s.tail_y = sum_out;
+            if (sum_out_planes) {
+                SH_REQUIRE(dp_sb == Cout && dp_sv == (int64_t)B * Cout && sh_p3_bytes(1, B, Cout) && (reinterpret_cast<uintptr_t>(sum_out_planes) & 15) == 0,
+                           SH_ERR_UNSUPPORTED, "sh_spiral_conv_bwd_wgt_presum: B=%d Cout=%d has no plane image", B, Cout);
+                s.tail_img = static_cast<char*>(sum_out_planes);
+                s.tail_img_bgb = Cout == 16 ? 1536 : (long)(Cout / 32) * 3072;
+                s.tail_img_vb = s.tail_img_bgb * (B / 16);
+            }
         }
         rc = SH_OK;
         for (int co0 = 0; co0 < Cout && rc == SH_OK; co0 += 128) {          // one launch per group of <= 128 output channels
@@ -2005,7 +2026,8 @@ int sh_spiral_conv_bwd_wgt_presum(const float* dpre, int64_t dp_sv, int64_t dp_s
         }
     } else {
         if (sum_rows > 0) {
-            rc = sh_spmm(sum_rowptr, sum_col, sum_val, dpre, dp_sv, dp_sb, sum_out, dp_sv, dp_sb, nullptr, 0, 0, 0, -1, B, sum_rows, Cout, stream);
+            rc = sh_spmm_p3(sum_rowptr, sum_col, sum_val, dpre, dp_sv, dp_sb, sum_out, dp_sv, dp_sb, sum_out_planes, nullptr, 0, 0, 0, -1, B,
+                            sum_rows, Cout, stream);
             if (rc != SH_OK) return rc;
         }
         SH_REQUIRE(Cout <= 128, SH_ERR_UNSUPPORTED,

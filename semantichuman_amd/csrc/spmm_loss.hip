@@ -2,7 +2,7 @@
 // transposes) and the loss / metric reductions.  All are streaming kernels: 16-byte accesses
 // where the layout allows, grid capped at ~8 workgroups per CU with grid-stride loops, two-stage
 // fixed-order reductions (no atomics -> bitwise reproducible).
-#include "sh_common.h"
+#include "sh_bf16.h"
 
 namespace {
 
@@ -12,11 +12,14 @@ constexpr int RED_BLOCKS = 2048;   // partial sums of the first reduction stage
 // One workgroup per output row (grid-stride over rows): the row's CSR entries are wave-uniform
 // scalars, threads sweep the row's B*C elements (contiguous in the vertex-major layout) with
 // 32-bit index math only.
-template <bool VEC>
+// P3: the result's three-plane image (csrc/p3_conv.hip: fragment-major bf16 planes of the rows this launch writes) is
+// written beside the fp32 rows - the exact split of the value just stored, by the thread that holds it.
+template <bool VEC, bool P3 = false>
 __global__ __launch_bounds__(256) void spmm_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                    const float* __restrict__ val, const float* __restrict__ x, long x_sv, long x_sb,
                                                    float* __restrict__ y, long y_sv, long y_sb, const float* __restrict__ yprev,
-                                                   long yp_sv, long yp_sb, int act, int zero_row, int B, int rows, int C) {
+                                                   long yp_sv, long yp_sb, int act, int zero_row, int B, int rows, int C,
+                                                   char* __restrict__ img = nullptr, long img_vb = 0, long img_bgb = 0) {
     const int CW = VEC ? C >> 2 : C;
     const int per_row = B * CW;
     // work item = (row, 256-element part of the row): coarse levels have few, long rows (432 x 32 KB) and would not
@@ -57,6 +60,17 @@ __global__ __launch_bounds__(256) void spmm_kernel(const int* __restrict__ rowpt
                 }
                 if (zero) acc = (f32x4){0.f, 0.f, 0.f, 0.f};
                 *reinterpret_cast<f32x4*>(y + yo) = acc;
+                if constexpr (P3) {
+                    u32x2 h, m, l;
+                    sh_split3_quad(acc, h, m, l);
+                    const bool c16 = C == 16;
+                    char* d = img + (long)r * img_vb + (long)(b >> 4) * img_bgb +
+                              (c16 ? ((co >> 3) * 16 + (b & 15)) * 16 : (co >> 5) * 3072 + (((co & 31) >> 3) * 16 + (b & 15)) * 16) + ((co >> 2) & 1) * 8;
+                    const int pb = c16 ? 512 : 1024;
+                    *reinterpret_cast<u32x2*>(d) = h;
+                    *reinterpret_cast<u32x2*>(d + pb) = m;
+                    *reinterpret_cast<u32x2*>(d + 2 * pb) = l;
+                }
             } else {
                 float acc = 0.f;
                 for (int e = e0; e < e1; ++e) acc = fmaf(val[e], x[(long)col[e] * x_sv + xo], acc);
@@ -308,6 +322,12 @@ extern "C" {
 int sh_spmm(const int32_t* rowptr, const int32_t* col, const float* val, const float* x, int64_t x_sv, int64_t x_sb, float* y,
             int64_t y_sv, int64_t y_sb, const float* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row, int B,
             int rows, int C, sh_stream_t stream) {
+    return sh_spmm_p3(rowptr, col, val, x, x_sv, x_sb, y, y_sv, y_sb, nullptr, yprev, yp_sv, yp_sb, act_prev, zero_row, B, rows, C, stream);
+}
+
+int sh_spmm_p3(const int32_t* rowptr, const int32_t* col, const float* val, const float* x, int64_t x_sv, int64_t x_sb, float* y,
+               int64_t y_sv, int64_t y_sb, void* y_planes, const float* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row,
+               int B, int rows, int C, sh_stream_t stream) {
     SH_REQUIRE(rowptr && col && val && x && y, SH_ERR_INVALID_ARG, "sh_spmm: null pointer");
     SH_REQUIRE(B > 0 && rows > 0 && C > 0, SH_ERR_INVALID_ARG, "sh_spmm: non-positive size");
     SH_REQUIRE(act_prev >= SH_ACT_IDENTITY && act_prev <= SH_ACT_TANH, SH_ERR_INVALID_ARG, "sh_spmm: unknown activation %d", act_prev);
@@ -318,13 +338,23 @@ int sh_spmm(const int32_t* rowptr, const int32_t* col, const float* val, const f
     const long items = (long)rows * (((long)B * (vec ? C / 4 : C) + 255) / 256);
     const int grid = (int)(items < grid_cap ? items : grid_cap);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (y_planes) {
+        SH_REQUIRE(vec && y_sb == C && y_sv == (int64_t)B * C && sh_p3_bytes(1, B, C) && (reinterpret_cast<uintptr_t>(y_planes) & 15) == 0, SH_ERR_UNSUPPORTED,
+                   "sh_spmm_p3: B=%d C=%d has no plane image (vertex-major y; B %% 16 == 0; C == 16 or C %% 32 == 0; 16-byte aligned tensors)", B, C);
+        const long bgb = C == 16 ? 1536 : (long)(C / 32) * 3072;
+        ShProfScope ps(st, "spmm_kernel<true, p3>|rows=%d B=%d C=%d", rows, B, C);
+        SH_LAUNCH_PS(ps, (spmm_kernel<true, true>), dim3(grid), dim3(256), 0, st, rowptr, col, val, x, x_sv, x_sb, y, y_sv, y_sb,
+                     yprev, yp_sv, yp_sb, act_prev, zero_row, B, rows, C, static_cast<char*>(y_planes), bgb * (B / 16), bgb);
+        SH_CHECK_LAUNCH("spmm");
+        return SH_OK;
+    }
     ShProfScope ps(st, "spmm_kernel<%s>|rows=%d B=%d C=%d", vec ? "true" : "false", rows, B, C);
     if (vec)
-        SH_LAUNCH_PS(ps, spmm_kernel<true>, dim3(grid), dim3(256), 0, st, rowptr, col, val, x, x_sv, x_sb, y, y_sv, y_sb,
-                           yprev, yp_sv, yp_sb, act_prev, zero_row, B, rows, C);
+        SH_LAUNCH_PS(ps, (spmm_kernel<true, false>), dim3(grid), dim3(256), 0, st, rowptr, col, val, x, x_sv, x_sb, y, y_sv, y_sb,
+                           yprev, yp_sv, yp_sb, act_prev, zero_row, B, rows, C, nullptr, 0L, 0L);
     else
-        SH_LAUNCH_PS(ps, spmm_kernel<false>, dim3(grid), dim3(256), 0, st, rowptr, col, val, x, x_sv, x_sb, y, y_sv, y_sb,
-                           yprev, yp_sv, yp_sb, act_prev, zero_row, B, rows, C);
+        SH_LAUNCH_PS(ps, (spmm_kernel<false, false>), dim3(grid), dim3(256), 0, st, rowptr, col, val, x, x_sv, x_sb, y, y_sv, y_sb,
+                           yprev, yp_sv, yp_sb, act_prev, zero_row, B, rows, C, nullptr, 0L, 0L);
     SH_CHECK_LAUNCH("spmm");
     return SH_OK;
 }

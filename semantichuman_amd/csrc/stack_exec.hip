@@ -94,13 +94,11 @@ int sh_stack_forward(int n_steps, const sh_stack_step* steps, const float* x, in
                        "sh_stack_forward: step %d appends to its input, which must be the vertex-major output buffer of step %d", i, i - 1);
             SH_REQUIRE(!planes || planes[i] == planes[i - 1], SH_ERR_INVALID_ARG, "sh_stack_forward: step %d appends to its input: same image buffer", i);
             float* dst = outs[i] + (long)s.m_cols * cl.sv;
-            rc = sh_spmm(s.m.rowptr, s.m.col, s.m.val, cur, cl.sv, cl.sb, dst, cl.sv, cl.sb, nullptr, 0, 0, 0, -1, B, s.m_rows, c, stream);
-            if (rc == SH_OK && img)
-                rc = sh_to_p3(dst, cl.sv, cl.sb, static_cast<char*>(img) + sh_p3_bytes(s.m_cols, B, c), B, s.m_rows, c, stream);
+            rc = sh_spmm_p3(s.m.rowptr, s.m.col, s.m.val, cur, cl.sv, cl.sb, dst, cl.sv, cl.sb,
+                            img ? static_cast<char*>(img) + sh_p3_bytes(s.m_cols, B, c) : nullptr, nullptr, 0, 0, 0, -1, B, s.m_rows, c, stream);
         } else {
-            rc = sh_spmm(s.m.rowptr, s.m.col, s.m.val, cur, cl.sv, cl.sb, outs[i], ol.sv, ol.sb, nullptr, 0, 0, 0, -1, B,
-                         s.m_rows, c, stream);
-            if (rc == SH_OK && img) rc = sh_to_p3(outs[i], ol.sv, ol.sb, img, B, s.m_rows, c, stream);
+            rc = sh_spmm_p3(s.m.rowptr, s.m.col, s.m.val, cur, cl.sv, cl.sb, outs[i], ol.sv, ol.sb, img, nullptr, 0, 0, 0, -1, B,
+                            s.m_rows, c, stream);
         }
         if (rc != SH_OK) return rc;
         cur = outs[i]; cl = ol; c = co;
@@ -200,10 +198,11 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
             // the last pre-sum level of this layer rides in the weight-gradient launch (sh_spiral_conv_bwd_wgt_presum); an
             // earlier level (very long lists: two levels) runs first, on its own
             const bool ride = !thin && want_in && s.table_t && (s.n1 || s.n2);
+            char* pimg0 = p3 ? static_cast<char*>(cur_img) : nullptr;         // the riders / pre-sum launches write the image of their rows
             float* mut0 = const_cast<float*>(cur);
             if (ride && s.n1 && s.n2) {
-                rc = sh_spmm(s.sum1.rowptr, s.sum1.col, s.sum1.val, cur, cl.sv, cl.sb, mut0 + (long)s.R * cl.sv, cl.sv, cl.sb, nullptr, 0, 0,
-                             0, -1, B, s.n1, s.cout, stream);
+                rc = sh_spmm_p3(s.sum1.rowptr, s.sum1.col, s.sum1.val, cur, cl.sv, cl.sb, mut0 + (long)s.R * cl.sv, cl.sv, cl.sb,
+                                pimg0 ? pimg0 + sh_p3_bytes(s.R, B, s.cout) : nullptr, nullptr, 0, 0, 0, -1, B, s.n1, s.cout, stream);
                 if (rc != SH_OK) return rc;
             }
             if (!thin) {
@@ -212,7 +211,9 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
                 float* lout = mut0 + (long)(s.R + (s.n2 ? s.n1 : 0)) * cl.sv;
                 rc = sh_spiral_conv_bwd_wgt_presum(cur, cl.sv, cl.sb, inp, il.sv, il.sb, s.table, nullptr, nullptr, workspace[i],
                                                    workspace_bytes[i], ln ? lm.rowptr : nullptr, ln ? lm.col : nullptr,
-                                                   ln ? lm.val : nullptr, ln ? lout : nullptr, ln, B, s.R, s.S, s.cin, s.cout, mma_mode, stream);
+                                                   ln ? lm.val : nullptr, ln ? lout : nullptr,
+                                                   (ln && pimg0) ? pimg0 + sh_p3_bytes(s.R + (s.n2 ? s.n1 : 0), B, s.cout) : nullptr, ln, B, s.R,
+                                                   s.S, s.cin, s.cout, mma_mode, stream);
                 if (rc != SH_OK) return rc;
             }
             job_ws[njobs] = workspace[i]; job_dW[njobs] = dW[s.param]; job_db[njobs] = dbias ? dbias[s.param] : nullptr;
@@ -222,38 +223,42 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
             if (want_in) {
                 SH_REQUIRE(s.table_t, SH_ERR_INVALID_ARG, "sh_stack_backward: step %d has no transposed table", i);
                 float* mut = const_cast<float*>(cur);          // the extra rows behind the R real ones of this step's own buffer
+                char* pimg = p3 ? static_cast<char*>(cur_img) : nullptr;
                 if (s.n1 && !ride) {
-                    rc = sh_spmm(s.sum1.rowptr, s.sum1.col, s.sum1.val, cur, cl.sv, cl.sb, mut + (long)s.R * cl.sv, cl.sv, cl.sb,
-                                 nullptr, 0, 0, 0, -1, B, s.n1, s.cout, stream);
+                    rc = sh_spmm_p3(s.sum1.rowptr, s.sum1.col, s.sum1.val, cur, cl.sv, cl.sb, mut + (long)s.R * cl.sv, cl.sv, cl.sb,
+                                    pimg ? pimg + sh_p3_bytes(s.R, B, s.cout) : nullptr, nullptr, 0, 0, 0, -1, B, s.n1, s.cout, stream);
                     if (rc != SH_OK) return rc;
                 }
                 if (s.n2 && !ride) {
-                    rc = sh_spmm(s.sum2.rowptr, s.sum2.col, s.sum2.val, cur, cl.sv, cl.sb, mut + (long)(s.R + s.n1) * cl.sv,
-                                 cl.sv, cl.sb, nullptr, 0, 0, 0, -1, B, s.n2, s.cout, stream);
+                    rc = sh_spmm_p3(s.sum2.rowptr, s.sum2.col, s.sum2.val, cur, cl.sv, cl.sb, mut + (long)(s.R + s.n1) * cl.sv,
+                                    cl.sv, cl.sb, pimg ? pimg + sh_p3_bytes(s.R + s.n1, B, s.cout) : nullptr, nullptr, 0, 0, 0, -1, B, s.n2,
+                                    s.cout, stream);
                     if (rc != SH_OK) return rc;
                 }
                 // ... and computes the input gradient from the same staged gradient rows when that buffer is plain vertex-major
                 // and the activation to differentiate (if any) produced the layer input itself
                 const bool thin_dx = thin && gl.sb == s.cin && gl.sv == (long)B * s.cin && (!yprev || yprev == inp);
                 if (thin) {
+                    const bool img_out = thin_dx && gi_img && sh_p3_bytes(1, B, s.cin);
                     rc = sh_spiral_conv_bwd_wgt_thin(cur, cl.sv, cl.sb, inp, SH_DTYPE_F32, il.sv, il.sb, s.table_t, workspace[i],
                                                      workspace_bytes[i], weights[s.param], thin_dx ? gi : nullptr, gl.sv, gl.sb,
-                                                     yprev ? act_prev : SH_ACT_IDENTITY, zero_prev, B, s.R, s.n_in, s.S, s.cin, s.cout,
-                                                     SH_DTYPE_F32, stream);
+                                                     img_out ? gi_img : nullptr, yprev ? act_prev : SH_ACT_IDENTITY, zero_prev, B, s.R, s.n_in,
+                                                     s.S, s.cin, s.cout, SH_DTYPE_F32, stream);
                     if (rc != SH_OK) return rc;
+                    gi_img_done = img_out;
                 }
                 if (!thin_dx) {
                     if (p3) {
                         // image of the gradient rows this pass gathers: the R real rows unless their producer wrote them, and
                         // the pre-summed rows behind them
-                        const int r0 = cur_img_done ? s.R : 0, r1 = s.R + s.n1 + s.n2;
+                        const int r0 = 0, r1 = cur_img_done ? 0 : s.R;          // (the pre-sum launches wrote the image of their rows)
                         if (r1 > r0) {
                             rc = sh_to_p3(cur + (long)r0 * cl.sv, cl.sv, cl.sb, static_cast<char*>(cur_img) + sh_p3_bytes(r0, B, s.cout), B, r1 - r0,
                                           s.cout, stream);
                             if (rc != SH_OK) return rc;
                         }
                         const bool img_out = gi_img && gl.sb == s.cin && gl.sv == (long)B * s.cin && sh_p3_bytes(1, B, s.cin);
-                        rc = sh_spiral_conv_bwd_data_p3(cur_img, s.table_t, wfrag3_t[i], gi, gl.sv, gl.sb, img_out ? gi_img : nullptr, yprev, yl.sv,
+                        rc = sh_spiral_conv_bwd_data_p3(cur_img, s.zero_row, s.table_t, wfrag3_t[i], gi, gl.sv, gl.sb, img_out ? gi_img : nullptr, yprev, yl.sv,
                                                         yl.sb, act_prev, zero_prev, B, s.n_in, s.S, s.cin, s.cout, stream);
                         gi_img_done = img_out;
                     } else {
@@ -267,9 +272,11 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
             }
         } else if (want_in) {
             SH_REQUIRE(s.mt.rowptr && s.mt.col && s.mt.val, SH_ERR_INVALID_ARG, "sh_stack_backward: step %d has no transposed matrix", i);
-            rc = sh_spmm(s.mt.rowptr, s.mt.col, s.mt.val, cur, cl.sv, cl.sb, gi, gl.sv, gl.sb, yprev, yl.sv, yl.sb, act_prev,
-                         zero_prev, B, s.m_cols, cin_of[i], stream);
+            const bool img_out = gi_img && gl.sb == cin_of[i] && gl.sv == (long)B * cin_of[i] && sh_p3_bytes(1, B, cin_of[i]);
+            rc = sh_spmm_p3(s.mt.rowptr, s.mt.col, s.mt.val, cur, cl.sv, cl.sb, gi, gl.sv, gl.sb, img_out ? gi_img : nullptr, yprev, yl.sv, yl.sb,
+                            act_prev, zero_prev, B, s.m_cols, cin_of[i], stream);
             if (rc != SH_OK) return rc;
+            gi_img_done = img_out;
         }
         if (want_in) { cur = gi; cl = gl; cur_img = gi_img; cur_img_done = gi_img_done; }
     }
@@ -441,7 +448,7 @@ int sh_stack_backward_bf16(int n_steps, const sh_stack_step* steps, const void* 
                 if (thin) {
                     rc = sh_spiral_conv_bwd_wgt_thin(static_cast<const float*>(cur), cl.sv, cl.sb, inp, SH_DTYPE_BF16, il.sv, il.sb, s.table_t,
                                                      workspace[i], workspace_bytes[i], weights[s.param], thin_dx ? gi : nullptr, gl.sv, gl.sb,
-                                                     yprev ? act_prev : SH_ACT_IDENTITY, zero_prev, B, s.R, s.n_in, s.S, s.cin, s.cout,
+                                                     nullptr, yprev ? act_prev : SH_ACT_IDENTITY, zero_prev, B, s.R, s.n_in, s.S, s.cin, s.cout,
                                                      SH_DTYPE_BF16, stream);
                     if (rc != SH_OK) return rc;
                 }

@@ -36,6 +36,7 @@ struct WTParams {
     // dpre_ext[table_t[u,s],b,co] * W[co][s][ci]  (dx null: weight gradient only)
     const float* w;                      // fp32 master weight [3][S * 16]
     char* dx; long dx_rb;                // [n_in (+ extra rows)][B][16] of the path's dtype, rows contiguous
+    char* dx_img;                        // fp32 path: three-plane image of dx's rows (csrc/p3_conv.hip, 16-channel layout), or NULL
     int act_prev, zero_prev;             // activation whose output x is (identity: no factor), row of dx forced to zero (-1: none)
 };
 
@@ -197,6 +198,14 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(const WTParams p) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) o[r] = zrow ? 0.f : d[r] * sh_act_grad_from_out(yv[r], p.act_prev);
                         *reinterpret_cast<f32x4*>(p.dx + (long)cu * p.dx_rb + (long)(cb * 32 + b) * 64 + g4 * 16) = o;
+                        if (p.dx_img) {                       // the exact split of the values just stored
+                            u32x2 ph, pm, pl;
+                            sh_split3_quad(o, ph, pm, pl);
+                            char* di = p.dx_img + ((long)cu * (p.B >> 4) + cb * 2 + h) * 1536 + ((g4 >> 1) * 16 + (lane & 15)) * 16 + (g4 & 1) * 8;
+                            *reinterpret_cast<u32x2*>(di) = ph;
+                            *reinterpret_cast<u32x2*>(di + 512) = pm;
+                            *reinterpret_cast<u32x2*>(di + 1024) = pl;
+                        }
                     }
                 }
             }
@@ -257,8 +266,8 @@ int sh_spiral_conv_bwd_wgt_thin_ok(int B, int n_in, int S, int Cin, int Cout, in
 
 int sh_spiral_conv_bwd_wgt_thin(const float* dpre_ext, int64_t dp_sv, int64_t dp_sb, const void* x, int x_dtype, int64_t x_sv, int64_t x_sb,
                                 const int32_t* table_t, void* workspace, size_t workspace_bytes, const float* weight, void* dx, int64_t dx_sv,
-                                int64_t dx_sb, int act_prev, int zero_prev, int B, int R, int n_in, int S, int Cin, int Cout, int path_dtype,
-                                sh_stream_t stream) {
+                                int64_t dx_sb, void* dx_planes, int act_prev, int zero_prev, int B, int R, int n_in, int S, int Cin, int Cout,
+                                int path_dtype, sh_stream_t stream) {
     SH_REQUIRE(R == n_in, SH_ERR_UNSUPPORTED, "sh_spiral_conv_bwd_wgt_thin: the layer must keep the vertex count (R %d, n_in %d)", R, n_in);
     SH_REQUIRE(dpre_ext && x && table_t && workspace, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_wgt_thin: null pointer");
     SH_REQUIRE(path_dtype == SH_DTYPE_F32 || path_dtype == SH_DTYPE_BF16, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_wgt_thin: unknown path dtype");
@@ -277,7 +286,10 @@ int sh_spiral_conv_bwd_wgt_thin(const float* dpre_ext, int64_t dp_sv, int64_t dp
                        act_prev >= SH_ACT_IDENTITY && act_prev <= SH_ACT_TANH), SH_ERR_INVALID_ARG,
                "sh_spiral_conv_bwd_wgt_thin: the fused input gradient needs the weight and a contiguous vertex-major 16-channel buffer");
     WTParams p{};
+    SH_REQUIRE(!dx_planes || (dx && path_dtype == SH_DTYPE_F32 && B % 16 == 0 && (reinterpret_cast<uintptr_t>(dx_planes) & 15) == 0), SH_ERR_UNSUPPORTED,
+               "sh_spiral_conv_bwd_wgt_thin: the plane image of dx needs the fp32 path, the fused dx and B %% 16 == 0");
     p.w = weight; p.dx = static_cast<char*>(dx); p.dx_rb = dx_sv * xe; p.act_prev = act_prev; p.zero_prev = zero_prev;
+    p.dx_img = static_cast<char*>(dx_planes);
     p.g = reinterpret_cast<const char*>(dpre_ext); p.g_rb = dp_sv * 4;
     p.x = static_cast<const char*>(x); p.x_rb = x_sv * xe;
     p.tt = table_t; p.slab = static_cast<float*>(workspace);

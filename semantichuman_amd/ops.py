@@ -447,10 +447,10 @@ def wgrad_thin_ok(B, n_in, S, Cin, Cout, dtype) -> bool:
 
 def _thin_dx_args(dx, weight, B, Cin, act_prev, zero_prev):
     if dx is None:
-        return [None, None, 0, 0, 0, -1]
+        return [None, None, 0, 0, None, 0, -1]
     _, _, Cd, gsv, gsb = _dims(dx, "vm", _ANY)
     assert Cd == Cin and weight is not None
-    return [ptr(weight), ptr(dx), gsv, gsb, int(act_prev), int(zero_prev)]
+    return [ptr(weight), ptr(dx), gsv, gsb, None, int(act_prev), int(zero_prev)]
 
 
 def spiral_conv_bwd_wgt_thin_deferred(dpre_ext, x, table_t, R, S, Cin, Cout, want_bias=True, weight=None, dx=None, act_prev=0,

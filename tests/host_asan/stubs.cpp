@@ -65,6 +65,14 @@ int sh_spmm(const int32_t* rowptr, const int32_t* col, const float* val, const f
             int64_t y_sb, const float* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row, int B, int rows, int C, sh_stream_t) {
     return spmm_common("spmm rows=%d C=%d", rowptr, col, val, x, x_sv, x_sb, y, y_sv, y_sb, yprev, yp_sv, yp_sb, B, rows, C, 4);
 }
+size_t sh_p3_bytes(int rows, int B, int C);
+int sh_spmm_p3(const int32_t* rowptr, const int32_t* col, const float* val, const float* x, int64_t x_sv, int64_t x_sb, float* y, int64_t y_sv,
+               int64_t y_sb, void* y_planes, const float* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row, int B, int rows, int C,
+               sh_stream_t) {
+    if (y_planes) touch_w(y_planes, sh_p3_bytes(rows, B, C));
+    return spmm_common(y_planes ? "spmm+image rows=%d C=%d" : "spmm rows=%d C=%d", rowptr, col, val, x, x_sv, x_sb, y, y_sv, y_sb, yprev, yp_sv,
+                       yp_sb, B, rows, C, 4);
+}
 int sh_spmm_bf16(const int32_t* rowptr, const int32_t* col, const float* val, const void* x, int64_t x_sv, int64_t x_sb, void* y, int64_t y_sv,
                  int64_t y_sb, const void* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row, int B, int rows, int C, sh_stream_t) {
     return spmm_common("spmm_bf16 rows=%d C=%d", rowptr, col, val, x, x_sv, x_sb, y, y_sv, y_sb, yprev, yp_sv, yp_sb, B, rows, C, 2);
@@ -103,11 +111,12 @@ int sh_spiral_conv_bwd_wgt(const float* dpre, int64_t dp_sv, int64_t dp_sb, cons
 }
 int sh_spiral_conv_bwd_wgt_presum(const float* dpre, int64_t dp_sv, int64_t dp_sb, const float* x, int64_t x_sv, int64_t x_sb, const int32_t* table,
                                   float* dW, float* db, void* ws, size_t ws_bytes, const int32_t* sum_rowptr, const int32_t* sum_col,
-                                  const float* sum_val, float* sum_out, int sum_rows, int B, int R, int S, int Cin, int Cout, int mma, sh_stream_t st) {
+                                  const float* sum_val, float* sum_out, void* sum_out_planes, int sum_rows, int B, int R, int S, int Cin, int Cout, int mma,
+                                  sh_stream_t st) {
     // the rider reads and writes exactly what the sh_spmm launch it replaces does; logged in the order the work is visible in
     const int rc = sh_spiral_conv_bwd_wgt(dpre, dp_sv, dp_sb, x, x_sv, x_sb, table, dW, db, ws, ws_bytes, B, R, S, Cin, Cout, mma, st);
     if (rc != 0 || sum_rows == 0) return rc;
-    return sh_spmm(sum_rowptr, sum_col, sum_val, dpre, dp_sv, dp_sb, sum_out, dp_sv, dp_sb, nullptr, 0, 0, 0, -1, B, sum_rows, Cout, st);
+    return sh_spmm_p3(sum_rowptr, sum_col, sum_val, dpre, dp_sv, dp_sb, sum_out, dp_sv, dp_sb, sum_out_planes, nullptr, 0, 0, 0, -1, B, sum_rows, Cout, st);
 }
 int sh_spiral_conv_bwd_wgt_bf16(const void* dpre, int dd, int64_t dp_sv, int64_t dp_sb, const void* x, int xd, int64_t x_sv, int64_t x_sb,
                                 const int32_t* table, void* ws, size_t ws_bytes, int B, int R, int S, int Cin, int Cout, sh_stream_t) {
@@ -121,7 +130,7 @@ int sh_spiral_conv_bwd_wgt_bf16(const void* dpre, int dd, int64_t dp_sv, int64_t
 }
 int sh_spiral_conv_bwd_wgt_thin_ok(int, int, int, int, int, int) { return 0; }       // the general kernels' call sequence is the one checked
 int sh_spiral_conv_bwd_wgt_thin(const float*, int64_t, int64_t, const void*, int, int64_t, int64_t, const int32_t*, void*, size_t, const float*, void*,
-                                int64_t, int64_t, int, int, int, int, int, int, int, int, int, sh_stream_t) { return SH_ERR_UNSUPPORTED; }
+                                int64_t, int64_t, void*, int, int, int, int, int, int, int, int, int, sh_stream_t) { return SH_ERR_UNSUPPORTED; }
 static int bwd_data_common(const char* name, const void* dpre, size_t de, int64_t dp_sv, int64_t dp_sb, const int32_t* table_t, void* dx, size_t xe,
                            int64_t dx_sv, int64_t dx_sb, const void* yprev, int64_t yp_sv, int64_t yp_sb, int B, int n_in, int S, int Cin, int Cout) {
     int rows = 0;
@@ -202,7 +211,7 @@ int sh_spiral_conv_fwd_p3(const void* xp, const int32_t* table, const void* wfra
     log("conv_fwd_p3 R=%d Cin=%d Cout=%d", R, Cin, Cout);
     return 0;
 }
-int sh_spiral_conv_bwd_data_p3(const void* dprep, const int32_t* table_t, const void* wfrag3_t, float* dx, int64_t dx_sv, int64_t dx_sb, void* dxp,
+int sh_spiral_conv_bwd_data_p3(const void* dprep, int, const int32_t* table_t, const void* wfrag3_t, float* dx, int64_t dx_sv, int64_t dx_sb, void* dxp,
                                const float* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row, int B, int n_in, int S, int Cin, int Cout,
                                sh_stream_t) {
     int rows = 0;

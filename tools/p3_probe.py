@@ -97,6 +97,7 @@ def main():
             if st.kind != "conv" or st.cin == 3 or st.cout == 3:
                 continue
             R, S, cin, cout, n_in = st.R, st.S, st.cin, st.cout, st.n_in
+            ZROW = st.zero_row if '--noskip' not in flags else -1
             table, table_t = st.dev["table"], st.dev["table_t"]
             w = (torch.randn((cout, S * cin), device=dev, generator=gen) / (S * cin) ** 0.5).contiguous()
             if adversarial:
@@ -111,6 +112,7 @@ def main():
                 else:
                     Cg, Nout, rows_in, rows_out, tbl = cout, cin, R + st.n_extra, n_in, table_t
                     x = rnd((R + st.n_extra, B, cout), dev, adversarial, gen)
+                    x[st.zero_row] = 0                     # as in the stack: the dummy row of dpre is zero, 'no source' entries point at it
                 ok = bool(lib.sh_spiral_conv_p3_ok(B, S, Cg, Nout))
                 # float64 reference on the device
                 x64, w64 = x.double(), w.double().view(cout, S, cin)
@@ -148,7 +150,7 @@ def main():
                             _lib.check(lib.sh_spiral_conv_fwd_p3(_lib.ptr(xp), _lib.ptr(table), _lib.ptr(wf), _lib.ptr(bias), _lib.ptr(y),
                                                                  B * Nout, Nout, _lib.ptr(yp), B, R, S, cin, cout, 0, -1, _lib.stream_ptr()), "fwd_p3")
                         else:
-                            _lib.check(lib.sh_spiral_conv_bwd_data_p3(_lib.ptr(xp), _lib.ptr(table_t), _lib.ptr(wf), _lib.ptr(y), B * Nout, Nout,
+                            _lib.check(lib.sh_spiral_conv_bwd_data_p3(_lib.ptr(xp), ZROW, _lib.ptr(table_t), _lib.ptr(wf), _lib.ptr(y), B * Nout, Nout,
                                                                       _lib.ptr(yp), None, 0, 0, 0, -1, B, n_in, S, cin, cout,
                                                                       _lib.stream_ptr()), "bwd_p3")
                     t = timed(run_p3, reps)
