@@ -124,8 +124,11 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
     }
     // three-plane form: conv step i's backward-data pass gathers the IMAGE of its pre-activation gradient when the caller gave
     // a buffer for it (gin_planes[i + 1], or dpre_last_planes for the last step) and the fragments of the transposed weight
+    // SH_P3_BWD: 0 = the backward pass keeps the SPLIT3 kernels everywhere, 1 = three-plane backward-data wherever it can run
+    static const int p3_bwd_on = sh_env_int("SH_P3_BWD", 1, 0, 1);
     auto bwd_p3 = [&](int i) -> void* {
         const sh_stack_step& s = steps[i];
+        if (!p3_bwd_on) return nullptr;
         if (mma_mode != SH_MMA_PLANES3 || s.kind != 0 || !(i > 0 || need_x_grad) || !s.table_t || !wfrag3_t || !wfrag3_t[i]) return nullptr;
         if (!sh_spiral_conv_p3_ok(B, s.S, s.cout, s.cin)) return nullptr;
         return i == last ? dpre_last_planes : (gin_planes ? gin_planes[i + 1] : nullptr);

@@ -513,3 +513,28 @@ def test_bf16_step_runs_the_intended_kernels():
     assert sum(1 for n, _ in conv if n.split(",")[2].strip() in ("0", "3")) == 0      # no plain / full-line gathers left
     up = [t for _, t in fam.get("spmm_bf16_kernel", []) if "rows=3445 " in t or "rows=1722 " in t or "rows=861 " in t]
     assert len(up) == 3                                                     # folded up-sampling: only the blended rows
+
+
+def test_model_bf16_with_second_convs_per_level():
+    """reference models.py:72-75, 96-99: optional second conv per level (see tests/test_gpu_parity.py:
+    test_second_conv_per_level_vs_oracle) on the bf16 path - forward within 1e-2 of the fp32 oracle, gradients within 5e-2 (l2)."""
+    from semantichuman_amd import synthetic
+    FE2 = [[3, 16, 32, 64, 128], [[], 16, 32, [], []]]
+    FD2 = [[128, 64, 32, 32, 16], [[], 64, [], 32, 3]]
+    h = load_hierarchy(os.path.join(GOLDEN, "small_ae.npz"))
+    S, D, U = h.dense_constants()
+    torch.manual_seed(11)
+    om = ref_cpu.SpiralAEOracle(FE2, FD2, 32, h.sizes, h.spiral_sizes, S, D, U)
+    m = sh.SpiralAutoencoder(FE2, FD2, 32, h.sizes, h.spiral_sizes, h.spirals, h.D, h.U, dev())
+    m.load_state_dict(om.state_dict())
+    m.set_compute_dtype(torch.bfloat16)
+    x = torch.from_numpy(synthetic.synth_batch(h.verts, 16, seed=3))
+    xd = x.to(dev())
+    x_hat, z = m(xd)
+    xo, zo = om(x)
+    assert rel(x_hat, xo.detach()) <= 1e-2 and rel(z, zo.detach()) <= 1e-2
+    sh.l1_loss(xd, x_hat).backward()
+    torch.nn.functional.l1_loss(x, xo).backward()
+    for (n, a), b in zip(m.named_parameters(), om.parameters()):
+        ga, gb = a.grad.double().cpu(), b.grad.double()
+        assert float((ga - gb).norm() / gb.norm()) <= 5e-2, n

@@ -599,3 +599,39 @@ def test_folded_upsampling_is_bitwise_the_unfolded_one(golden_dir, dtype):
     assert torch.equal(res[True][0], res[False][0])
     for n, g in res[True][1].items():
         assert torch.equal(g, res[False][1][n]), n
+
+
+# the optional second conv of a level (reference models.py:72-75: `filters_enc[1][i]` truthy -> an extra SpiralConv in front of the
+# level's main one; :96-99: `filters_dec[1][i+1]` truthy -> one behind it) - the default configuration only uses the decoder's last
+FE2 = [[3, 16, 32, 64, 128], [[], 16, 32, [], []]]
+FD2 = [[128, 64, 32, 32, 16], [[], 64, [], 32, 3]]
+
+
+@pytest.mark.parametrize("cfg", [("small_ae.npz", 16), ("template6890.npz", 2)])
+def test_second_conv_per_level_vs_oracle(golden_dir, cfg):
+    """A model WITH second convs on several levels (encoder levels 1 and 2: 16 -> 16 -> 32 and 32 -> 32 -> 64, the level's
+    row-select D folding into the LAST conv of the level only; decoder levels 3 and 1: 128 -> 64 -> 64 and 32 -> 32 -> 32 behind
+    the up-sampling): forward, loss and every parameter gradient against the oracle's statement of models.py:69-113, at batch
+    16 (all three arithmetic forms can engage) and at full size."""
+    name, B = cfg
+    p = os.path.join(golden_dir, name)
+    h = load_hierarchy(p)
+    from semantichuman_amd import synthetic
+    S, D, U = h.dense_constants()
+    torch.manual_seed(11)
+    om = ref_cpu.SpiralAEOracle(FE2, FD2, 32, h.sizes, h.spiral_sizes, S, D, U)
+    m = sh.SpiralAutoencoder(FE2, FD2, 32, h.sizes, h.spiral_sizes, h.spirals, h.D, h.U, dev())
+    assert len(m.conv) == 6 and len(m.dconv) == 7 and [k for k in m.state_dict()] == [k for k in om.state_dict()]
+    m.load_state_dict(om.state_dict())
+    x = torch.from_numpy(synthetic.synth_batch(h.verts, B, seed=3))
+    xd = x.to(dev())
+    x_hat, z = m(xd)
+    xo, zo = om(x)
+    close(z, zo, FWD_TOL, "z")
+    close(x_hat, xo, FWD_TOL, "x_hat")
+    assert float(x_hat[:, -1].abs().max()) == 0.0
+    sh.l1_loss(xd, x_hat).backward()
+    torch.nn.functional.l1_loss(x, xo).backward()
+    gmax = max(float(po.grad.abs().max()) for po in om.parameters())
+    for (n, prm), po in zip(m.named_parameters(), om.parameters()):
+        close(prm.grad, po.grad, GRAD_TOL, "grad " + n, floor=1e-6 * gmax)

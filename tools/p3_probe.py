@@ -74,100 +74,109 @@ def rnd(shape, dev, adversarial, gen):
     return x.float().contiguous()
 
 
-def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    flags = [a for a in sys.argv[1:] if a.startswith("--")]
-    B = int(args[0]) if args else 64
-    tpl = args[1] if len(args) > 1 else os.path.join(ROOT, "tests", "golden", "template6890.npz")
-    reps = 20
-    for f in flags:
-        if f.startswith("--reps="):
-            reps = int(f.split("=")[1])
-    adversarial = "--adversarial" in flags
+def probe_layers(B=64, tpl=None, directions=("fwd", "bwd"), adversarial=False, reps=1, skip=True, seed=1):
+    """Yields one record per conv step (3-channel sides excluded) and direction of the template's plain autoencoder:
+    {"name", "bwd", "ok" (the three-plane kernels take the shape), "err": {form: max|err| / max|ref| against a float64
+    evaluation on the device}, "us": {form: kernel time}, "us_to_p3", "img_ok" (the image the kernel wrote of its output is
+    the image of that output, bit for bit)}."""
+    tpl = tpl or os.path.join(ROOT, "tests", "golden", "template6890.npz")
     dev = torch.device("cuda:0")
     lib = _lib.load()
     h = load_hierarchy(tpl)
     torch.manual_seed(0)
     model = sh.SpiralAutoencoder(FE, FD, 256, h.sizes, h.spiral_sizes, h.spirals, h.D, h.U, dev)
     gen = torch.Generator(device=dev)
-    gen.manual_seed(1)
-    print("%-34s %-30s %-30s" % ("layer", "max|err|/max|ref| exact split3 p3", "us exact split3 p3 (+to_p3)"))
-    for sname, stack in (("enc", model._enc_stack), ("dec", model._dec_stack)):
-        for i, st in enumerate(stack.steps):
-            if st.kind != "conv" or st.cin == 3 or st.cout == 3:
-                continue
-            R, S, cin, cout, n_in = st.R, st.S, st.cin, st.cout, st.n_in
-            ZROW = st.zero_row if '--noskip' not in flags else -1
-            table, table_t = st.dev["table"], st.dev["table_t"]
-            w = (torch.randn((cout, S * cin), device=dev, generator=gen) / (S * cin) ** 0.5).contiguous()
-            if adversarial:
-                w = rnd((cout, S * cin), dev, True, gen)
-            bias = torch.randn((cout,), device=dev, generator=gen).contiguous()
-            for bwd in ((False, True) if "--bwd" in flags or "--both" in flags else (False,)):
-                if "--bwd" in flags and not bwd:
+    gen.manual_seed(seed)
+    was = _lib.get_f32_mma_mode()
+    try:
+        for sname, stack in (("enc", model._enc_stack), ("dec", model._dec_stack)):
+            for i, st in enumerate(stack.steps):
+                if st.kind != "conv" or st.cin == 3 or st.cout == 3:
                     continue
-                if not bwd:
-                    Cg, Nout, rows_in, rows_out, tbl = cin, cout, n_in, R, table
-                    x = rnd((n_in, B, cin), dev, adversarial, gen)
-                else:
-                    Cg, Nout, rows_in, rows_out, tbl = cout, cin, R + st.n_extra, n_in, table_t
-                    x = rnd((R + st.n_extra, B, cout), dev, adversarial, gen)
-                    x[st.zero_row] = 0                     # as in the stack: the dummy row of dpre is zero, 'no source' entries point at it
-                ok = bool(lib.sh_spiral_conv_p3_ok(B, S, Cg, Nout))
-                # float64 reference on the device
-                x64, w64 = x.double(), w.double().view(cout, S, cin)
-                ref = torch.zeros((rows_out, B, Nout), dtype=torch.float64, device=dev)
-                for s in range(S):
-                    g = x64[tbl[:, s].long()]                                   # [rows_out][B][Cg]
-                    ws = w64[:, s, :]                                            # [cout][cin]
-                    ref += g @ (ws.t() if not bwd else ws)
-                if not bwd:
-                    ref += bias.double()
-                scale = float(ref.abs().max())
-                y = torch.empty((rows_out, B, Nout), dtype=torch.float32, device=dev)
-                wt = ops.weight_transpose(w, S, cin, cout) if bwd else None
-
-                def run_f32():
+                R, S, cin, cout, n_in = st.R, st.S, st.cin, st.cout, st.n_in
+                zrow = st.zero_row if skip else -1
+                table, table_t = st.dev["table"], st.dev["table_t"]
+                w = (torch.randn((cout, S * cin), device=dev, generator=gen) / (S * cin) ** 0.5).contiguous()
+                if adversarial:
+                    w = rnd((cout, S * cin), dev, True, gen)
+                bias = torch.randn((cout,), device=dev, generator=gen).contiguous()
+                for d in directions:
+                    bwd = d == "bwd"
                     if not bwd:
-                        ops.spiral_conv_fwd(x, "vm", table, w, bias, y, "vm", R, S, 0, -1)
+                        Cg, Nout, rows_out, tbl = cin, cout, R, table
+                        x = rnd((n_in, B, cin), dev, adversarial, gen)
                     else:
-                        ops.spiral_conv_bwd_data(x, "vm", table_t, wt, y, "vm", None, "vm", 0, -1, n_in, S, cin, cout)
-                res = {}
-                for mode in ("exact", "split3"):
-                    _lib.set_f32_mma_mode(mode)
-                    t = timed(run_f32, reps)
-                    res[mode] = (float((y.double() - ref).abs().max()) / scale, t)
-                _lib.set_f32_mma_mode("exact")
-                if ok:
-                    wf = wfrag3(w, S, cin, cout, bwd)
-                    xp = to_p3(x)
-                    yp = torch.empty(max(16, lib.sh_p3_bytes(rows_out, B, Nout)), dtype=torch.uint8, device=dev) \
-                        if lib.sh_p3_bytes(rows_out, B, Nout) else None
-                    y.zero_()
+                        Cg, Nout, rows_out, tbl = cout, cin, n_in, table_t
+                        x = rnd((R + st.n_extra, B, cout), dev, adversarial, gen)
+                        x[st.zero_row] = 0             # as in the stack: the dummy row of dpre is zero, "no source" entries point at it
+                    ok = bool(lib.sh_spiral_conv_p3_ok(B, S, Cg, Nout))
+                    x64, w64 = x.double(), w.double().view(cout, S, cin)
+                    ref = torch.zeros((rows_out, B, Nout), dtype=torch.float64, device=dev)
+                    for s in range(S):
+                        ref += x64[tbl[:, s].long()] @ (w64[:, s, :].t() if not bwd else w64[:, s, :])
+                    if not bwd:
+                        ref += bias.double()
+                    scale = float(ref.abs().max())
+                    y = torch.empty((rows_out, B, Nout), dtype=torch.float32, device=dev)
+                    wt = ops.weight_transpose(w, S, cin, cout) if bwd else None
 
-                    def run_p3():
+                    def run_f32():
                         if not bwd:
-                            _lib.check(lib.sh_spiral_conv_fwd_p3(_lib.ptr(xp), _lib.ptr(table), _lib.ptr(wf), _lib.ptr(bias), _lib.ptr(y),
-                                                                 B * Nout, Nout, _lib.ptr(yp), B, R, S, cin, cout, 0, -1, _lib.stream_ptr()), "fwd_p3")
+                            ops.spiral_conv_fwd(x, "vm", table, w, bias, y, "vm", R, S, 0, -1)
                         else:
-                            _lib.check(lib.sh_spiral_conv_bwd_data_p3(_lib.ptr(xp), ZROW, _lib.ptr(table_t), _lib.ptr(wf), _lib.ptr(y), B * Nout, Nout,
-                                                                      _lib.ptr(yp), None, 0, 0, 0, -1, B, n_in, S, cin, cout,
-                                                                      _lib.stream_ptr()), "bwd_p3")
-                    t = timed(run_p3, reps)
-                    e = float((y.double() - ref).abs().max()) / scale
-                    t2 = timed(lambda: to_p3(x), reps)
-                    # the plane image the kernel wrote of its own output must be the image of that output, bit for bit
-                    img_ok = ""
-                    if yp is not None:
-                        img_ok = " img=" + ("ok" if torch.equal(to_p3(y), yp) else "MISMATCH")
-                    p3s = "%.2e" % e
-                    t3 = "%6.1f (+%.1f)%s" % (t, t2, img_ok)
-                else:
-                    p3s, t3 = "   -   ", "  -"
-                print("%-34s %.2e %.2e %-9s   %6.1f %6.1f %s" % (
-                    "%s%d %s R=%d K=%d N=%d" % (sname, i, "bwd" if bwd else "fwd", rows_out, S * Cg, Nout),
-                    res["exact"][0], res["split3"][0], p3s, res["exact"][1], res["split3"][1], t3), flush=True)
-                del x64, w64, ref
+                            ops.spiral_conv_bwd_data(x, "vm", table_t, wt, y, "vm", None, "vm", 0, -1, n_in, S, cin, cout)
+                    rec = {"name": "%s%d %s R=%d K=%d N=%d" % (sname, i, d, rows_out, S * Cg, Nout), "bwd": bwd, "ok": ok,
+                           "err": {}, "us": {}, "scale": scale}
+                    for mode in ("exact", "split3"):
+                        _lib.set_f32_mma_mode(mode)
+                        rec["us"][mode] = timed(run_f32, reps)
+                        rec["err"][mode] = float((y.double() - ref).abs().max()) / scale
+                    _lib.set_f32_mma_mode("exact")
+                    if ok:
+                        wf = wfrag3(w, S, cin, cout, bwd)
+                        xp = to_p3(x)
+                        nimg = lib.sh_p3_bytes(rows_out, B, Nout)
+                        yp = torch.empty(nimg, dtype=torch.uint8, device=dev) if nimg else None
+                        y.zero_()
+
+                        def run_p3():
+                            if not bwd:
+                                _lib.check(lib.sh_spiral_conv_fwd_p3(_lib.ptr(xp), _lib.ptr(table), _lib.ptr(wf), _lib.ptr(bias), _lib.ptr(y),
+                                                                     B * Nout, Nout, _lib.ptr(yp), B, R, S, cin, cout, 0, -1, _lib.stream_ptr()),
+                                           "sh_spiral_conv_fwd_p3")
+                            else:
+                                _lib.check(lib.sh_spiral_conv_bwd_data_p3(_lib.ptr(xp), zrow, _lib.ptr(table_t), _lib.ptr(wf), _lib.ptr(y), B * Nout,
+                                                                          Nout, _lib.ptr(yp), None, 0, 0, 0, -1, B, n_in, S, cin, cout,
+                                                                          _lib.stream_ptr()), "sh_spiral_conv_bwd_data_p3")
+                        rec["us"]["planes3"] = timed(run_p3, reps)
+                        rec["err"]["planes3"] = float((y.double() - ref).abs().max()) / scale
+                        rec["us_to_p3"] = timed(lambda: to_p3(x), reps)
+                        rec["img_ok"] = None if yp is None else bool(torch.equal(to_p3(y), yp))
+                    yield rec
+                    del x64, w64, ref
+    finally:
+        _lib.set_f32_mma_mode(was)
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    flags = [a for a in sys.argv[1:] if a.startswith("--")]
+    B = int(args[0]) if args else 64
+    tpl = args[1] if len(args) > 1 else None
+    reps = 20
+    for f in flags:
+        if f.startswith("--reps="):
+            reps = int(f.split("=")[1])
+    dirs = ("bwd",) if "--bwd" in flags else (("fwd", "bwd") if "--both" in flags else ("fwd",))
+    print("%-34s %-30s %-30s" % ("layer", "max|err|/max|ref| exact split3 p3", "us exact split3 p3 (+to_p3)"))
+    for r in probe_layers(B, tpl, dirs, "--adversarial" in flags, reps, "--noskip" not in flags):
+        if r["ok"]:
+            p3s = "%.2e" % r["err"]["planes3"]
+            t3 = "%6.1f (+%.1f)%s" % (r["us"]["planes3"], r["us_to_p3"], "" if r["img_ok"] is None else " img=" + ("ok" if r["img_ok"] else "MISMATCH"))
+        else:
+            p3s, t3 = "   -   ", "  -"
+        print("%-34s %.2e %.2e %-9s   %6.1f %6.1f %s" % (r["name"], r["err"]["exact"], r["err"]["split3"], p3s, r["us"]["exact"],
+                                                         r["us"]["split3"], t3), flush=True)
 
 
 if __name__ == "__main__":
