@@ -261,6 +261,9 @@ def replayed_training(sh, h, B, dtype, dev, steps, warmup, n_data=None, seed=100
     with torch.cuda.graph(graph):
         one_step()
     model.load_state_dict(init_state)
+    if dtype == "bf16":                           # refresh the latent FCs' bf16 working copies eagerly (see main())
+        with torch.no_grad():
+            model(xin)
     for st in optim.state.values():
         for v in st.values():
             if torch.is_tensor(v):
@@ -933,6 +936,9 @@ def main():
                 graph, graph_note = None, "hipGraph capture failed on another rank; eager launches"
         # capture must not change what is measured: restore the initial weights / optimizer
         model.load_state_dict(init_state)
+        if args.dtype == "bf16":                  # the bf16 working copies of the latent FCs are refreshed by an EAGER read only:
+            with torch.no_grad():                 # without this the first replayed step would run on the warm-up state's copies
+                model(xin)
         for st in optim.state.values():
             for v in st.values():
                 if torch.is_tensor(v):

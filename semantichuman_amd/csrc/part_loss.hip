@@ -61,7 +61,7 @@ __device__ __forceinline__ int find_part(const int* tile_ptr, int P, int t) {
 // scale(graw) is that kernel's output bit for bit.
 // (One kernel whether graw is wanted or not: two instantiations summed the loss to different last bits.)
 __global__ __launch_bounds__(PNT) void pairdist_fwd_kernel(const PLParams q, float* __restrict__ partial, float* __restrict__ graw) {
-    constexpr bool GRAD = true;
+    const bool GRAD = graw != nullptr;                              // wave-uniform: validation / no-grad calls skip the gradient arithmetic
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.x / q.T, t = blockIdx.x - b * q.T;
     const int p = find_part(q.tile_ptr, q.P, t);

@@ -62,7 +62,11 @@ class SpiralConv(nn.Module):
         (weak reference), unmodified (`_version`) and unmoved (`data_ptr`, shape) since it last matched - e.g. a caller that
         keeps its index tensor.  Otherwise the first sample's index is compared with the cached one on the device and all
         samples are checked to share it (one fused comparison, one host read) - which cannot happen while a hipGraph is
-        being captured: that case raises with a message instead of an opaque capture error."""
+        being captured: that case raises with a message instead of an opaque capture error.
+        The fast path trusts `_version`: an index tensor must only be modified through version-bumping in-place ops (`copy_`,
+        indexing assignment, ...).  Writes that bypass the counter - `spiral_adj.data.copy_(...)`, a raw-pointer kernel, `set_`
+        onto storage at the same address - are NOT seen and leave the cached table in use (unsupported, as for any tensor
+        autograd has saved)."""
         adj = spiral_adj.detach()
         o = self._cache_obj
         if (o is not None and o[0]() is spiral_adj and o[1] == spiral_adj._version and o[2] == spiral_adj.data_ptr()

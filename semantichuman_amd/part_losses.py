@@ -47,7 +47,7 @@ class PartTables:
 
 class _PairDist(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x_rec, x_gt, bone, scale, tb: PartTables, w_mode, thr, relat):
+    def forward(ctx, x_rec, x_gt, bone, scale, tb: PartTables, w_mode, thr, relat, want_grad=True):
         x_rec, x_gt, bone = x_rec.contiguous(), x_gt.contiguous(), bone.contiguous()
         scale = None if scale is None else scale.contiguous()
         B, N1, _ = x_rec.shape
@@ -58,7 +58,8 @@ class _PairDist(torch.autograd.Function):
         ws = torch.empty(B * tb.T * 2, dtype=torch.float32, device=dev)
         # when the reconstruction carries a gradient the same sweep leaves the backward pass's row sums (everything but the
         # factor 2 g w_p / count_p): backward is then one scaling launch, not a second sweep over the pairs - the same bits
-        graw = torch.empty_like(x_rec) if ctx.needs_input_grad[0] else None
+        # (want_grad: the caller's grad mode - inside forward() it is always off, and needs_input_grad stays true under no_grad)
+        graw = torch.empty_like(x_rec) if (ctx.needs_input_grad[0] and want_grad) else None
         check(_lib.load().sh_part_pairdist_loss_fwd_grad(ptr(x_rec), ptr(x_gt), ptr(bone), ptr(scale), ptr(tb.part_ptr), ptr(tb.part_vert),
                                                          ptr(tb.tile_ptr), ptr(tb.flags), ptr(tb.w_part), B, N1, tb.P, tb.T, tb.max_part,
                                                          w_mode, thr, int(relat), ptr(loss), ptr(psum), ptr(pcnt), ptr(graw), ptr(ws),
@@ -81,7 +82,7 @@ class _PairDist(torch.autograd.Function):
             check(_lib.load().sh_part_pairdist_loss_bwd_scale(ptr(graw), ptr(tb.part_ptr), ptr(tb.part_vert), ptr(tb.w_part), ptr(pcnt),
                                                               ptr(g.contiguous()), B, N1, tb.P, int(tb.part_vert.numel()), ptr(grad),
                                                               stream_ptr()), "sh_part_pairdist_loss_bwd_scale")
-            return grad, None, None, None, None, None, None, None
+            return grad, None, None, None, None, None, None, None, None
         tb, w_mode, thr, relat, has_scale = ctx.args
         saved = ctx.saved_tensors
         x_rec, x_gt, bone, pcnt = saved[:4]
@@ -92,7 +93,7 @@ class _PairDist(torch.autograd.Function):
                                                     ptr(tb.tile_ptr), ptr(tb.flags), ptr(tb.w_part), B, N1, tb.P, tb.T, tb.max_part,
                                                     w_mode, thr, int(relat), ptr(pcnt), ptr(g.contiguous()), ptr(grad), stream_ptr()),
               "sh_part_pairdist_loss_bwd")
-        return grad, None, None, None, None, None, None, None
+        return grad, None, None, None, None, None, None, None, None
 
 
 _INDEX_CACHE = {}
@@ -173,7 +174,7 @@ def part_pairdist_loss(x_rec, x_gt, kps_gt, tables: PartTables, scale=None, w_mo
         raise NotImplementedError(w_mode)
     bone = bone_directions(kps_gt.detach(), skl_list)
     return _PairDist.apply(x_rec, x_gt.detach(), bone, None if scale is None else scale.detach(), tables, W_MODES[w_mode],
-                           float(w_threshold), bool(relat))
+                           float(w_threshold), bool(relat), torch.is_grad_enabled())
 
 
 # ----------------------------------------------------------------------------------------------

@@ -69,9 +69,12 @@ def load_checkpoint(path, model, optim=None, scheduler=None, finetune=False, map
         with _numpy_scalars_allowed():     # reference-written optimizer / scheduler state may hold numpy scalars (data, no code)
             ck = torch.load(path, map_location=map_location, weights_only=True)
     except (pickle.UnpicklingError, RuntimeError) as e:
-        # only the weights_only refusal is handled here (torch raises pickle.UnpicklingError, older versions a RuntimeError
-        # that names weights_only); a missing / unreadable / corrupt file or an out-of-memory error propagates unchanged
-        if isinstance(e, RuntimeError) and "weights_only" not in str(e) and "Unsupported" not in str(e):
+        # only the weights_only REFUSAL is handled here (torch names it in the message: "Weights only load failed" / "Unsupported
+        # global"); a missing / unreadable / corrupt file (also a pickle.UnpicklingError: "invalid load key") or an out-of-memory
+        # error propagates unchanged - a corrupt file must never steer the user towards trust_pickle=True
+        msg = str(e)
+        refusal = ("Weights only load failed" in msg or "Unsupported global" in msg or "weights_only" in msg or "Unsupported" in msg)
+        if not refusal or "invalid load key" in msg:           # e.g. a corrupt file: pickle.UnpicklingError('invalid load key ...')
             raise
         if not trust_pickle:
             raise RuntimeError("load_checkpoint: %s does not load with weights_only=True (%s); pass trust_pickle=True only "

@@ -321,3 +321,20 @@ def test_semantic_loop_bookkeeping_helpers_on_cpu():
     (p,) = ts._SplitRows.apply(y, 4)
     p.sum().backward()
     assert torch.equal(y.grad[:4], torch.ones(4, 4)) and torch.equal(y.grad[4:], torch.zeros(2, 4))
+
+
+def test_corrupt_checkpoint_is_not_reported_as_a_weights_only_refusal(tmp_path):
+    """torch.load on a corrupt file raises pickle.UnpicklingError('invalid load key ...'); load_checkpoint must
+    let it through unchanged instead of suggesting trust_pickle=True (which would unpickle - i.e. execute - the file)."""
+    import pickle
+
+    import torch
+
+    from semantichuman_amd import train_funcs
+    for k, blob in enumerate((b"this is not a checkpoint", b"\x00\x01garbage" * 7, b"")):
+        bad = tmp_path / ("corrupt%d.pth.tar" % k)
+        bad.write_bytes(blob)
+        with pytest.raises(Exception) as ei:                     # whatever the unpickler raises on these bytes, unchanged
+            train_funcs.load_checkpoint(str(bad), torch.nn.Linear(2, 2))
+        assert "trust_pickle" not in str(ei.value), ei.value
+    del pickle
