@@ -73,8 +73,11 @@ def load_checkpoint(path, model, optim=None, scheduler=None, finetune=False, map
         # global"); a missing / unreadable / corrupt file (also a pickle.UnpicklingError: "invalid load key") or an out-of-memory
         # error propagates unchanged - a corrupt file must never steer the user towards trust_pickle=True
         msg = str(e)
-        refusal = ("Weights only load failed" in msg or "Unsupported global" in msg or "weights_only" in msg or "Unsupported" in msg)
-        if not refusal or "invalid load key" in msg:           # e.g. a corrupt file: pickle.UnpicklingError('invalid load key ...')
+        # torch wraps EVERY failure of its restricted unpickler in "Weights only load failed ..." - also garbage bytes
+        # ("Unsupported operand 0", "invalid load key"); a refusal names the global / class it would not construct
+        refusal = ("Unsupported global" in msg or "not an allowed global" in msg or "Unsupported class" in msg
+                   or (isinstance(e, RuntimeError) and "weights_only" in msg and "Unsupported operand" not in msg))
+        if not refusal:
             raise
         if not trust_pickle:
             raise RuntimeError("load_checkpoint: %s does not load with weights_only=True (%s); pass trust_pickle=True only "
