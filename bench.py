@@ -339,9 +339,29 @@ def secondary_block(sh, h, B, dev, init_state, data, test, ft, cpu_l2_mm, args):
         res["config"] = "BASELINE configs[2] per-GPU shard: batch %d, bf16 kernels, fp32 master weights / gradients / Adam" % B
         return res
 
+    def f32_roofline_of(model, x, ftab, B4, verts, train=True):
+        """Per-launch HIP events of 3 eagerly launched steps (or decodes) -> the roofline block of that workload's dominant kernel."""
+        opt = sh.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-5) if train else None
+        _lib.profile_enable(True)
+        for _ in range(3):
+            if train:
+                opt.zero_grad(set_to_none=True)
+                loss, _ = sh.recon_loss(model(x)[0], x, ftab, 1e-2)
+                loss.backward()
+                opt.step()
+            else:
+                with torch.no_grad():
+                    model.decode(x)
+        torch.cuda.synchronize()
+        recs = _lib.profile_records_by_kernel()
+        _lib.profile_enable(False)
+        rf = roofline_f32(recs, model, B4, 3, verts)
+        return {"roofline": rf["roofline"], "hip_kernel_ms_per_step": rf["hip_kernel_ms_per_step"], "kernel_breakdown": rf["kernel_breakdown"][:5]}
+
     def config4_leg():
         h4 = load_hierarchy(os.path.join(ROOT, "tests", "golden", "template27554.npz"))
-        res, model, _, _, _ = replayed_training(sh, h4, 32, "f32", dev, steps, warm, n_data=64)
+        res, model, _, d4, ft4 = replayed_training(sh, h4, 32, "f32", dev, steps, warm, n_data=64)
+        res.update(f32_roofline_of(model, d4[:32], ft4, 32, h4.sizes[0]))
         del model
         res["config"] = "BASELINE configs[3]: 27 554 vertices, spiral length 18, batch 32, fp32"
         return res
@@ -350,6 +370,10 @@ def secondary_block(sh, h, B, dev, init_state, data, test, ft, cpu_l2_mm, args):
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_decode
         r = bench_decode.run(latents=20 * 1024, batch=1024, dev=dev)
+        torch.manual_seed(2)
+        md = sh.SpiralAutoencoder(FE, FD, 256, h.sizes, h.spiral_sizes, h.spirals, h.D, h.U, dev)
+        r.update(f32_roofline_of(md, torch.randn(1024, 256, device=dev), None, 1024, h.sizes[0], train=False))
+        del md
         r["config"] = "BASELINE configs[4] on a bounded sample: 20 batches of 1024 random latents (the full run is tools/bench_decode.py: 100k)"
         r["f32_mma"] = _lib.get_f32_mma_mode()
         return r
@@ -438,6 +462,22 @@ def roofline_bf16(recs, model, B, nprof, verts):
                           "algorithmic_bytes_per_launch": a["bytes"] / a["n"] if a["n"] else None,
                           "flops_per_launch": a["flops"] / a["n"] if a["n"] else None,
                           "mfma_tflops": dom.get("tflops"), "mfma_peak_tflops": 2500.0}
+    # `roofline` describes the kernel with the largest share of the step, whatever its family (in bf16 that is the optimizer:
+    # 7 fp32 streams + the bf16 working copy per parameter, priced below); the most expensive conv-family kernel keeps its own
+    # line, `roofline_conv_family`
+    top = kernels[0]
+    if top["kernel"] != dom["kernel"]:
+        result["roofline_conv_family"] = result["roofline"]
+        line = {"bound": "hbm", "kernel": top["kernel"], "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None,
+                "traffic": None, "avg_launch_ms": top["avg_ms"], "launches_per_step": top["launches_per_step"],
+                "ms_per_step": top["ms_per_step"]}
+        if top["kernel"].startswith("adam_kernel"):
+            n_par = sum(p.numel() for p in model.parameters())
+            byt = (7 * 4.0 + 2.0) * n_par                     # p, g, m, v read; p, m, v written; bf16 copy written
+            line.update(achieved=byt / (top["ms_per_step"] * 1e-3) / 1e9, algorithmic_bytes_per_step=byt,
+                        note="multi-tensor Adam over %.2fM parameters: 7 fp32 streams + the bf16 working copy" % (n_par / 1e6))
+            line["frac"] = line["achieved"] / PEAK_HBM_GBS
+        result["roofline"] = line
     result["kernel_families"] = {n: {"ms_per_step": v} for n, v in sorted(fam.items(), key=lambda kv: -kv[1])[:10]}
     result["kernel_breakdown"] = kernels[:10]
     result["hip_kernel_ms_per_step"] = sum(k["ms_per_step"] for k in kernels)
@@ -771,6 +811,10 @@ def main():
     ap.add_argument("--adam-overlap", action="store_true", help="update the big parameters on a side stream underneath backward (measured: no gain, the GPU is already saturated)")
     ap.add_argument("--grad-comm", choices=["fp32", "bf16"], default="fp32",
                     help="N > 1: type of the two large gradient messages (bf16 halves the xGMI bytes; fp32 is the measured default)")
+    ap.add_argument("--shard-optimizer", action="store_true",
+                    help="N > 1, fp32: reduce-scatter the two latent FC gradients, update 1/N of each FC per rank, all-gather the weights "
+                         "(same xGMI bytes as the all-reduce, 1/N of Adam's HBM traffic); weights bitwise those of the all-reduce path "
+                         "(tests/test_parallel_gloo.py).  Off by default: no N > 1 hardware run has measured it")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="arithmetic of the kernels: f32 = BASELINE configs[1] (the headline), bf16 = configs[2] (bf16 activations and "
                          "working weights, fp32 accumulation, fp32 master weights / gradients / Adam)")
@@ -843,17 +887,21 @@ def main():
     if args.dtype == "bf16":
         model.set_compute_dtype(torch.bfloat16)
     init_state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    ft = sh.FaceTables(h.faces, h.sizes[0] + 1, dev)
+    shard_opt = bool(args.shard_optimizer) and (world > 1 or force_reducer) and args.dtype == "f32" and not safe
+    reducer = GradientAllReducer(model, bucket_cap_mb=64.0, force_collectives=force_reducer, overlap=not safe,
+                                 average_in_collective=not safe, shard_large=shard_opt,
+                                 large_message_dtype=torch.bfloat16 if (args.grad_comm == "bf16" and not shard_opt) else None) \
+        if (world > 1 or force_reducer) else None
+    # the optimizer's parameters: the model's - or, with --shard-optimizer, this rank's 1 / world slice of the two latent FCs
+    # (reduce-scattered gradients, all-gathered weights; parallel.GradientAllReducer(shard_large=True))
+    opt_params = reducer.optimizer_params() if (reducer is not None and shard_opt) else list(model.parameters())
     if args.adam == "hip":                        # main.py:262
-        optim = sh.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-5)
+        optim = sh.optim.Adam(opt_params, lr=1e-3, weight_decay=5e-5)
         if world == 1 and args.adam_overlap:
             optim.overlap_backward()              # the two latent FCs (99 % of the parameters) update underneath the encoder backward
     else:
-        optim = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-5, capturable=True, fused=True)
-    ft = sh.FaceTables(h.faces, h.sizes[0] + 1, dev)
-    reducer = GradientAllReducer(model, bucket_cap_mb=64.0, force_collectives=force_reducer, overlap=not safe,
-                                 average_in_collective=not safe,
-                                 large_message_dtype=torch.bfloat16 if args.grad_comm == "bf16" else None) \
-        if (world > 1 or force_reducer) else None
+        optim = torch.optim.Adam(opt_params, lr=1e-3, weight_decay=5e-5, capturable=True, fused=True)
 
     n_data = 16 * B                               # resident synthetic set, disjoint per rank
     data = torch.from_numpy(synthetic.synth_batch(h.verts, n_data, seed=100 + rank)).to(dev)
@@ -877,6 +925,8 @@ def main():
         if reducer:
             reducer.finish()
         optim.step()
+        if reducer:
+            reducer.gather_weights()              # (--shard-optimizer: the updated slices of the large parameters; else nothing)
 
     # One hipGraph holds the whole step - forward, backward, the RCCL all-reduces (launched from the gradient hooks in the
     # middle of backward, on the process group's own stream: the capture forks to it and joins in finish()) and Adam - so
@@ -992,7 +1042,8 @@ def main():
                                   h.sizes, h.spiral_sizes[:-1], sum(p.numel() for p in model.parameters()) / 1e6),
                    "global_batch": world * B, "per_gpu_batch": B, "parallelism": "dp%d" % world,
                    "launch": (("hipGraph replay" + (" (RCCL all-reduces inside the graph)" if reducer else "")) if graph is not None
-                              else (graph_note or "eager")) + (" safe mode (SH_BENCH_DP_SAFE)" if safe and reducer else "") + attempt_note(),
+                              else (graph_note or "eager")) + (" safe mode (SH_BENCH_DP_SAFE)" if safe and reducer else "") +
+                             (" [sharded update of the large parameters: reduce-scatter / all-gather]" if shard_opt else "") + attempt_note(),
                    **({"gradient_messages": "%.1f MB %s all-reduce per step" % (
                        sum(b.numel * (2 if (b.inplace and args.grad_comm == "bf16") else 4) for b in reducer.buckets) / 1e6,
                        "bf16 (large) + fp32" if args.grad_comm == "bf16" else "fp32")} if reducer else {})},
@@ -1029,6 +1080,8 @@ def main():
             if reducer:
                 reducer.finish()
             optim.step()
+            if reducer:
+                reducer.gather_weights()
         torch.cuda.synchronize()
         _stack.OVERLAP_WGRAD = overlap_was
     if rank == 0 and not args.no_roofline:

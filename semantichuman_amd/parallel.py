@@ -50,12 +50,18 @@ class GradientAllReducer:
 
     def __init__(self, module: torch.nn.Module, process_group=None, bucket_cap_mb: float = 64.0, overlap: bool = True,
                  inplace_min_mb: float = 16.0, force_collectives: bool = False, large_message_dtype=None,
-                 average_in_collective: bool = True):
+                 average_in_collective: bool = True, shard_large: bool = False):
         """force_collectives: issue the collectives even in a world of one rank (exercises the RCCL path on a 1-GPU box).
         large_message_dtype: e.g. torch.bfloat16 - the large in-place gradients travel in that type (half the xGMI
         bytes: 57 MB instead of 114 MB for the plain autoencoder) and are converted back into the
         fp32 gradient after the collective.  Off by default: fp32 training exchanges fp32 gradients.
-        average_in_collective=False: never use ncclAvg (sum of pre-scaled gradients; bench.py's safe mode)."""
+        average_in_collective=False: never use ncclAvg (sum of pre-scaled gradients; bench.py's safe mode).
+        shard_large=True: the SHARDED update of the large parameters - their gradients are
+        reduce-SCATTERED (each rank receives the averaged 1 / world slice), the optimizer updates only that slice
+        (`optimizer_params()` hands it the slices as parameters of their own, so its moments are 1 / world the size), and
+        `gather_weights()` after `optimizer.step()` all-gathers the updated slices into every replica: the same bytes over
+        the links as the all-reduce, 1 / world of Adam's HBM traffic and state for 99 % of this model's parameters.  The
+        elementwise update of a slice is the update of those elements, so the weights are the all-reduce path's."""
         self.large_dtype = large_message_dtype
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -95,6 +101,25 @@ class GradientAllReducer:
         # ONE message in finish(): packed per parameter they were 20 copy launches (a ~5 us slot each on the compute
         # stream, profiles/r01_reducer_timeline.txt) and three messages for 1 % of the bytes.
         self._where = {b.params[0]: b for b in self.buckets if b.inplace}
+        # sharded update: slice [rank * n / world, (rank + 1) * n / world) of every large parameter, as a leaf of its own that
+        # shares the parameter's storage (the optimizer writes the replica's weight in place)
+        self.shard_large = bool(shard_large) and self.active
+        self.shards = {}
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        if self.shard_large:
+            if self.large_dtype is not None:
+                raise ValueError("shard_large and large_message_dtype are exclusive")
+            for b in self.buckets:
+                if not b.inplace:
+                    continue
+                p = b.params[0]
+                if p.numel() % self.world or not p.is_contiguous():
+                    raise ValueError("shard_large: a %s parameter does not split evenly over %d ranks" % (tuple(p.shape), self.world))
+                n = p.numel() // self.world
+                sh = torch.nn.Parameter(p.data.view(-1)[self.rank * n:(self.rank + 1) * n], requires_grad=True)
+                self.shards[p] = sh
+                b.shard_grad = torch.zeros(n, dtype=p.dtype, device=p.device)
+            self._rs_ok = None                                     # does this backend have reduce_scatter_tensor?
         self._hooks = []
         if self.active and overlap:
             for p in self._where:
@@ -111,7 +136,62 @@ class GradientAllReducer:
             b.work = None
         self._armed = True
 
+    def optimizer_params(self):
+        """What the optimizer is built over: the small parameters as they are and, with shard_large, this rank's slice of
+        every large one instead of the parameter itself."""
+        out = []
+        for b in self.buckets:
+            for p in b.params:
+                out.append(self.shards.get(p, p))
+        return out
+
+    def gather_weights(self):
+        """shard_large: after optimizer.step(), every replica's large parameters = the concatenation of all ranks' updated
+        slices (the slice leaves share the parameters' storage, so this rank's part is already in place)."""
+        if not self.shard_large:
+            return
+        for p, sh in self.shards.items():
+            flat = p.data.view(-1)
+            n = sh.numel()
+            if self._all_gather_into is not False:
+                try:
+                    dist.all_gather_into_tensor(flat, sh.data.clone() if flat.device.type == "cpu" else sh.data, group=self.group)
+                    self._all_gather_into = True
+                    continue
+                except (RuntimeError, NotImplementedError):
+                    if self._all_gather_into is True:
+                        raise
+                    self._all_gather_into = False
+            parts = [flat[r * n:(r + 1) * n] for r in range(self.world)]
+            dist.all_gather(parts, sh.data.clone(), group=self.group)
+
+    _all_gather_into = None
+
+    def _launch_sharded(self, b: GradBucket):
+        """Reduce-scatter of a large gradient: this rank keeps the averaged slice the optimizer will consume."""
+        p = b.params[0]
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        g = (p.grad if p.grad.is_contiguous() else p.grad.contiguous()).view(-1)
+        scale = 1.0 if self.avg else 1.0 / self.world
+        if scale != 1.0:
+            g.mul_(scale)
+        op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM
+        b.buf = g
+        if self._rs_ok is not False:
+            try:
+                b.work = dist.reduce_scatter_tensor(b.shard_grad, g, op=op, group=self.group, async_op=True)
+                self._rs_ok = True
+                return
+            except (RuntimeError, NotImplementedError):
+                if self._rs_ok is True:
+                    raise
+                self._rs_ok = False                              # e.g. gloo: all-reduce, then keep the slice (same values)
+        b.work = dist.all_reduce(g, op=op, group=self.group, async_op=True)
+
     def _launch(self, b: GradBucket):
+        if self.shard_large and b.inplace:
+            return self._launch_sharded(b)
         scale = 1.0 if self.avg else 1.0 / self.world
         if b.inplace:
             p = b.params[0]
@@ -150,6 +230,15 @@ class GradientAllReducer:
                 self._launch(b)
         for b in self.buckets:
             b.work.wait()
+            if self.shard_large and b.inplace:
+                p = b.params[0]
+                if not self._rs_ok:
+                    n = b.shard_grad.numel()
+                    b.shard_grad.copy_(b.buf[self.rank * n:(self.rank + 1) * n])
+                self.shards[p].grad = b.shard_grad
+                p.grad = None                                      # the optimizer owns the slice, not the parameter
+                b.buf = None
+                continue
             if b.inplace:
                 if b.full is not None:
                     b.full.copy_(b.buf)

@@ -338,3 +338,22 @@ def test_corrupt_checkpoint_is_not_reported_as_a_weights_only_refusal(tmp_path):
             train_funcs.load_checkpoint(str(bad), torch.nn.Linear(2, 2))
         assert "trust_pickle" not in str(ei.value), ei.value
     del pickle
+
+
+class _NotAllowed:                                   # a global the weights-only unpickler refuses
+    def __init__(self):
+        self.v = 3
+
+
+def test_checkpoint_with_pickled_objects_needs_trust_pickle(tmp_path):
+    """The other half: a well-formed checkpoint that holds a pickled object IS the weights_only refusal - reported with the
+    trust_pickle hint, loaded when the caller vouches for the file."""
+    import torch
+
+    from semantichuman_amd import train_funcs
+    m = torch.nn.Linear(2, 2)
+    p = tmp_path / "ck.pth.tar"
+    torch.save({"epoch": 4, "autoencoder_state_dict": m.state_dict(), "extra": _NotAllowed()}, p)
+    with pytest.raises(RuntimeError, match="trust_pickle"):
+        train_funcs.load_checkpoint(str(p), torch.nn.Linear(2, 2))
+    assert train_funcs.load_checkpoint(str(p), torch.nn.Linear(2, 2), trust_pickle=True) == 5
