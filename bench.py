@@ -90,6 +90,8 @@ def parse_tag_f32(name, shape):
         if fam == "conv_p3s_kernel":                       # three-plane form, streamed weight: <RT, BWD, NP>
             return ("bwd" if targs[1] == "true" else "fwd", int(f["R"]), int(f["K"]), int(f["N"]))
         if fam == "conv_out3_linewise_kernel":             # forward of the <= 3-channel last layer on the VALU
+            if f.get("pass") == "1":                       # first of two passes over a long spiral: the second carries the layer's key
+                return None
             return ("fwd", int(f["R"]), int(f["K"]), int(f["N"]))
         if fam.startswith("gather_gemm_"):                 # direct / split3 / coalesced forms: <NT, BWD, ...>
             return ("bwd" if targs[1] == "true" else "fwd", int(f["R"]), int(f["K"]), int(f["N"]))
@@ -818,9 +820,9 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="arithmetic of the kernels: f32 = BASELINE configs[1] (the headline), bf16 = configs[2] (bf16 activations and "
                          "working weights, fp32 accumulation, fp32 master weights / gradients / Adam)")
-    ap.add_argument("--f32-mma", choices=["exact", "split3", "planes3"], default="exact",
-                    help="arithmetic form of the fp32 path's matrix products (include/sh_kernels.h sh_set_f32_mma_mode): exact = fp32 "
-                         "MFMA, the reference's arithmetic and the headline; split3 = every fp32 operand split exactly into three bf16 "
+    ap.add_argument("--f32-mma", choices=["exact", "split3", "planes3"], default="planes3",
+                    help="arithmetic form of the fp32 path's matrix products (include/sh_kernels.h enum sh_mma_mode): exact = fp32 "
+                         "MFMA, the reference's own arithmetic (timed in secondary.f32_exact_step); split3 = every fp32 operand split exactly into three bf16 "
                          "terms, six partial products on the bf16 MFMA with fp32 accumulation (fp32-level error: the GPU parity tests run "
                          "in every form at the same tolerances); planes3 = the same arithmetic with the split written ONCE by the producer "
                          "of a tensor as three bf16 planes the conv kernels gather (csrc/p3_conv.hip; tests/test_p3.py gates its error "

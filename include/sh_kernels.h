@@ -606,6 +606,16 @@ SH_API int sh_spiral_conv_p3_ok(int B, int S, int Cg, int Nout);
 SH_API int sh_spmm_p3(const int32_t* rowptr, const int32_t* col, const float* val, const float* x, int64_t x_sv, int64_t x_sb,
                       float* y, int64_t y_sv, int64_t y_sb, void* y_planes, const float* yprev, int64_t yp_sv, int64_t yp_sb,
                       int act_prev, int zero_row, int B, int rows, int C, sh_stream_t stream);
+/* sh_spiral_conv_fwd / sh_act_backward_tr that also write the plane image of what they store (y_planes / dpre_planes != NULL;
+ * vertex-major result).  The conv writes it in its own epilogue where the kernel the dispatch picks has one, and issues
+ * sh_to_p3 itself otherwise: the image is complete when the call returns either way. */
+SH_API int sh_spiral_conv_fwd_img(const float* x, int64_t x_sv, int64_t x_sb, const int32_t* table, const float* weight,
+                                  const float* bias, float* y, int64_t y_sv, int64_t y_sb, void* y_planes, int B, int R, int S, int Cin,
+                                  int Cout, int act, int zero_row, int mma_mode, sh_stream_t stream);
+SH_API int sh_act_backward_tr_img(const float* dy, int64_t dy_sv, int64_t dy_sb, const float* y, int64_t y_sv, int64_t y_sb, float* dpre,
+                                  int64_t dp_sv, int64_t dp_sb, void* dpre_planes, int B, int R, int C, int act, int zero_row, int n_layers,
+                                  const float* const* weight, float* const* weight_t, const int* S, const int* Cin, const int* Cout,
+                                  sh_stream_t stream);
 /* sh_spiral_conv_fwd with x given as its plane image xp ([n_in] rows) */
 SH_API int sh_spiral_conv_fwd_p3(const void* xp, const int32_t* table, const void* wfrag3, const float* bias, float* y, int64_t y_sv,
                                  int64_t y_sb, void* yp, int B, int R, int S, int Cin, int Cout, int act, int zero_row,

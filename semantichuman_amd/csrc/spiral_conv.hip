@@ -55,6 +55,12 @@ struct GGParams {
     // MFMAs of that half-chunk are skipped - they would add exact zeros.
     unsigned skip_off;  // zero row * x_sv (element offset, like the entries of the LDS table tile)
     int skip_on;
+    // conv_out3_linewise_kernel over a RANGE of spiral positions (spirals longer than its register budget run as two passes):
+    // positions s0 .. s0 + <template S> - 1 of the p.S the table and the weight have; pass 0 = the only one, 1 = first of two
+    // (stores the raw partial sums), 2 = second (adds them, then bias / activation / mask)
+    int s0, pass;
+    // three-plane image of the output rows (csrc/p3_conv.hip), written by the STAGED kernel's epilogue beside y; or NULL
+    char* y_img; long img_vb, img_bgb;
 };
 
 // 3-channel rows (the xyz input of the first encoder layer, the xyz gradient entering the last decoder layer):
@@ -303,6 +309,17 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_kernel(const GGParams p)
                 }
                 if (zero) a = (f32x4){0.f, 0.f, 0.f, 0.f};
                 *reinterpret_cast<f32x4*>(yrow + n0) = a;
+                if (p.y_img) {                                     // the exact split of the values just stored
+                    u32x2 ph, pm, pl;
+                    sh_split3_quad(a, ph, pm, pl);
+                    const bool c16 = p.Nout == 16;
+                    char* d = p.y_img + (long)v * p.img_vb + (long)(b >> 4) * p.img_bgb +
+                              (c16 ? ((n0 >> 3) * 16 + (b & 15)) * 16 : (n0 >> 5) * 3072 + (((n0 & 31) >> 3) * 16 + (b & 15)) * 16) + ((n0 >> 2) & 1) * 8;
+                    const int pb = c16 ? 512 : 1024;
+                    *reinterpret_cast<u32x2*>(d) = ph;
+                    *reinterpret_cast<u32x2*>(d + pb) = pm;
+                    *reinterpret_cast<u32x2*>(d + 2 * pb) = pl;
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -826,7 +843,7 @@ __global__ __launch_bounds__(256) void conv_out3_linewise_kernel(const GGParams 
 #pragma unroll
     for (int s = 0; s < S; ++s)
 #pragma unroll
-        for (int n = 0; n < 3; ++n) w[s][n] = *reinterpret_cast<const f32x4*>(p.w + (long)(n < p.Nout ? n : 0) * p.Kw + s * 16 + 4 * cq);
+        for (int n = 0; n < 3; ++n) w[s][n] = *reinterpret_cast<const f32x4*>(p.w + (long)(n < p.Nout ? n : 0) * p.Kw + (p.s0 + s) * 16 + 4 * cq);
     const long lane_off = 4 * cq;
     const int nrows = lo + wl < hi ? (hi - lo - wl + nw - 1) / nw : 0;
     // unit = (batch slice of 64, row, 16-batch chunk of the slice), slice-major: a large batch is walked in slices so that the
@@ -843,7 +860,7 @@ __global__ __launch_bounds__(256) void conv_out3_linewise_kernel(const GGParams 
     auto load_table = [&](int u, long (&tt)[S]) {
         const int r = unit_row(min(u, units - 1));
 #pragma unroll
-        for (int s = 0; s < S; ++s) tt[s] = (long)p.table[(long)r * S + s] * p.x_sv;
+        for (int s = 0; s < S; ++s) tt[s] = (long)p.table[(long)r * p.S + p.s0 + s] * p.x_sv;
     };
     auto issue = [&](const long (&tt)[S], int u, f32x4 (&buf)[S]) {
         const int b = min(16 * unit_chunk(min(u, units - 1)) + bl, p.B - 1);
@@ -866,8 +883,12 @@ __global__ __launch_bounds__(256) void conv_out3_linewise_kernel(const GGParams 
         a0 += __shfl_xor(a0, 2, 64); a1 += __shfl_xor(a1, 2, 64); a2 += __shfl_xor(a2, 2, 64);
         const int b = 16 * j + bl;
         if (u < units && cq < p.Nout && b < p.B) {                     // lane cq stores channel cq
-            const float v = sh_act_fwd((cq == 0 ? a0 : cq == 1 ? a1 : a2) + bias, p.act);
-            p.y[(long)r * p.y_sv + (long)b * p.y_sb + cq] = r == p.zero_row ? 0.f : v;
+            float* dst = p.y + (long)r * p.y_sv + (long)b * p.y_sb + cq;
+            float acc = cq == 0 ? a0 : cq == 1 ? a1 : a2;
+            if (p.pass == 1) { *dst = acc; return; }                   // first of two passes: the raw partial sum
+            if (p.pass == 2) acc += *dst;
+            const float v = sh_act_fwd(acc + bias, p.act);
+            *dst = r == p.zero_row ? 0.f : v;
         }
     };
     f32x4 bufA[S], bufB[S];
@@ -888,14 +909,16 @@ __global__ __launch_bounds__(256) void conv_out3_linewise_kernel(const GGParams 
 template <int S>
 int launch_out3(const GGParams& p, hipStream_t st) {
     static const int grid = 8 * sh_env_int("SH_OUT3_WG_PER_XCD", 64, 1, 1024);       // 2 workgroups per CU
-    ShProfScope ps(st, "conv_out3_linewise_kernel<%d>|R=%d B=%d K=%d N=%d grid=%d", S, p.R, p.B, p.K, p.Nout, grid);
+    ShProfScope ps(st, "conv_out3_linewise_kernel<%d>|R=%d B=%d K=%d N=%d grid=%d pass=%d", S, p.R, p.B, p.pass == 1 ? S * 16 : p.K, p.Nout, grid, p.pass);
     SH_LAUNCH_PS(ps, conv_out3_linewise_kernel<S>, dim3(grid), dim3(256), 0, st, p);
     SH_CHECK_LAUNCH("conv_out3_linewise");
     return SH_OK;
 }
 
+thread_local bool tl_img_written = false;                  // did the kernel a dispatch picked write GGParams::y_img?
 template <int NT, bool VEC4, bool BWD_EPI, bool C3 = false>
 int launch_gg(const GGParams& p, int nblocks, hipStream_t st) {
+    if (p.y_img && p.vec_out) tl_img_written = true;
     const int TV = TM >> p.log2TB;
     const size_t smem = (size_t)(2 * TM * KC + 2 * NT * 16 * KC) * sizeof(float) + (size_t)(TV * p.S) * sizeof(int);
     {
@@ -946,17 +969,28 @@ int dispatch_gg(GGParams& p, hipStream_t st) {
                 (!p.yprev || ((p.yp_sv % 4 == 0) && (p.yp_sb % 4 == 0) && reinterpret_cast<uintptr_t>(p.yprev) % 16 == 0));
     // <= 3 output channels over 16-channel rows: the line-wise VALU kernel (both arithmetic forms: nothing for a split to win)
     static const int out3_on = sh_env_int("SH_GG_OUT3", 1, 0, 1);
-    if (!BWD_EPI && out3_on && p.Nout <= 3 && p.Cg == 16 && vec4 && p.S >= 6 && p.S <= 12) {
+    if (!BWD_EPI && out3_on && p.Nout <= 3 && p.Cg == 16 && vec4 && p.S >= 6 && p.S <= 24) {
         p.Kw = p.K;
-        switch (p.S) {
-            case 6: return launch_out3<6>(p, st);
-            case 7: return launch_out3<7>(p, st);
-            case 8: return launch_out3<8>(p, st);
-            case 9: return launch_out3<9>(p, st);
-            case 10: return launch_out3<10>(p, st);
-            case 11: return launch_out3<11>(p, st);
-            default: return launch_out3<12>(p, st);
-        }
+        auto run = [&](int n) -> int {
+            switch (n) {
+                case 6: return launch_out3<6>(p, st);
+                case 7: return launch_out3<7>(p, st);
+                case 8: return launch_out3<8>(p, st);
+                case 9: return launch_out3<9>(p, st);
+                case 10: return launch_out3<10>(p, st);
+                case 11: return launch_out3<11>(p, st);
+                default: return launch_out3<12>(p, st);
+            }
+        };
+        if (p.S <= 12) { p.s0 = 0; p.pass = 0; return run(p.S); }
+        // 13..24 positions (data-dependent spiral lengths, utils_spiral.py:72-82; BASELINE config 4 forces 18): two passes of
+        // 7..12 over the same rows - the second adds the first's partial sums (12 bytes per row) before bias / activation
+        const int s1 = (p.S + 1) / 2;
+        p.s0 = 0; p.pass = 1;
+        int rc = run(s1);
+        if (rc != SH_OK) return rc;
+        p.s0 = s1; p.pass = 2;
+        return run(p.S - s1);
     }
     // bf16x3 form (sh_set_f32_mma_mode): up to four channel tiles per workgroup, the rest split over workgroups
     static const int s3_min_nt = sh_env_int("SH_S3_MIN_NT", 4, 1, 8);      // layers with fewer channel tiles keep the exact form (no gain there)
@@ -1775,7 +1809,12 @@ int launch_ws3(const WSParams& p, hipStream_t st) {
 bool ws_uses_split3(int cot, const WSParams& p) {
     static const int s3_min_cot = sh_env_int("SH_S3_WG_MIN_COT", 2, 1, 16);
     const bool full = (p.B & ((1 << p.log2TB) - 1)) == 0;
-    return (cot == 2 || cot == 4) && sh_f32_mma_mode() != SH_MMA_EXACT && cot >= s3_min_cot && full && p.log2TB == 4 && p.Cin % 4 == 0;
+    // (the three-plane form keeps the exact weight-gradient kernels: they host the pre-sum riders up to four channel tiles, the
+    // split ones only with two - measured 30 us per step in their favour once the riders also write plane images)
+    static const int p3_wg_split = sh_env_int("SH_P3_WG_SPLIT3", 0, 0, 1);
+    const int mode = sh_f32_mma_mode();
+    const bool split = mode == SH_MMA_SPLIT3 || (mode == SH_MMA_PLANES3 && p3_wg_split);
+    return (cot == 2 || cot == 4) && split && cot >= s3_min_cot && full && p.log2TB == 4 && p.Cin % 4 == 0;
 }
 
 template <int COT>
@@ -1822,7 +1861,8 @@ template <bool VEC4>
 __global__ void act_backward_kernel(const float* __restrict__ dy, long dy_sv, long dy_sb,
                                     const float* __restrict__ y, long y_sv, long y_sb,
                                     float* __restrict__ dp, long dp_sv, long dp_sb,
-                                    int B, int R, int C, int act, int zero_row, int grid_main, const MultiTranspose tr) {
+                                    int B, int R, int C, int act, int zero_row, int grid_main, const MultiTranspose tr,
+                                    char* __restrict__ img, long img_vb, long img_bgb) {
     if ((int)blockIdx.x >= grid_main) { weight_transpose_block(tr, (int)blockIdx.x - grid_main); return; }
     const int cq = VEC4 ? C >> 2 : C;                 // elements (or quads) per (row, batch) entry
     const int per_row = B * cq;
@@ -1843,6 +1883,18 @@ __global__ void act_backward_kernel(const float* __restrict__ dy, long dy_sv, lo
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = zero ? 0.f : g[j] * sh_act_grad_from_out(yv[j], act);
                 *reinterpret_cast<f32x4*>(dpr + (long)b * dp_sb + 4 * c) = o;
+                if (img) {                                         // three-plane image of the row (vertex-major dpre)
+                    u32x2 ph, pm, pl;
+                    sh_split3_quad(o, ph, pm, pl);
+                    const int co = 4 * c;
+                    const bool c16 = C == 16;
+                    char* d = img + (long)r * img_vb + (long)(b >> 4) * img_bgb +
+                              (c16 ? ((co >> 3) * 16 + (b & 15)) * 16 : (co >> 5) * 3072 + (((co & 31) >> 3) * 16 + (b & 15)) * 16) + ((co >> 2) & 1) * 8;
+                    const int pb = c16 ? 512 : 1024;
+                    *reinterpret_cast<u32x2*>(d) = ph;
+                    *reinterpret_cast<u32x2*>(d + pb) = pm;
+                    *reinterpret_cast<u32x2*>(d + 2 * pb) = pl;
+                }
             } else {
                 const float g = dyr[(long)b * dy_sb + c] * sh_act_grad_from_out(yr[(long)b * y_sb + c], act);
                 dpr[(long)b * dp_sb + c] = zero ? 0.f : g;
@@ -1885,6 +1937,12 @@ extern "C" {
 int sh_spiral_conv_fwd(const float* x, int64_t x_sv, int64_t x_sb, const int32_t* table, const float* weight,
                        const float* bias, float* y, int64_t y_sv, int64_t y_sb, int B, int R, int S, int Cin,
                        int Cout, int act, int zero_row, int mma_mode, sh_stream_t stream) {
+    return sh_spiral_conv_fwd_img(x, x_sv, x_sb, table, weight, bias, y, y_sv, y_sb, nullptr, B, R, S, Cin, Cout, act, zero_row, mma_mode, stream);
+}
+
+int sh_spiral_conv_fwd_img(const float* x, int64_t x_sv, int64_t x_sb, const int32_t* table, const float* weight,
+                           const float* bias, float* y, int64_t y_sv, int64_t y_sb, void* y_planes, int B, int R, int S, int Cin,
+                           int Cout, int act, int zero_row, int mma_mode, sh_stream_t stream) {
     SH_REQUIRE(x && table && weight && y, SH_ERR_INVALID_ARG, "sh_spiral_conv_fwd: null pointer");
     SH_REQUIRE(sh_mma_mode_valid(mma_mode), SH_ERR_INVALID_ARG, "sh_spiral_conv_fwd: unknown mma_mode %d", mma_mode);
     ShMmaScope mma_scope(mma_mode);
@@ -1898,7 +1956,17 @@ int sh_spiral_conv_fwd(const float* x, int64_t x_sv, int64_t x_sb, const int32_t
     p.yprev = nullptr;
     p.B = B; p.R = R; p.S = S; p.Cg = Cin; p.Nout = Cout; p.K = S * Cin;
     p.act = act; p.zero_row = zero_row;
-    return dispatch_gg<false>(p, static_cast<hipStream_t>(stream));
+    if (y_planes) {
+        SH_REQUIRE(y_sb == Cout && y_sv == (int64_t)B * Cout && sh_p3_bytes(1, B, Cout) && (reinterpret_cast<uintptr_t>(y_planes) & 15) == 0,
+                   SH_ERR_UNSUPPORTED, "sh_spiral_conv_fwd_img: B=%d Cout=%d has no plane image (vertex-major y; B %% 16 == 0; Cout 16 or %% 32 == 0)", B, Cout);
+        p.y_img = static_cast<char*>(y_planes);
+        p.img_bgb = Cout == 16 ? 1536 : (long)(Cout / 32) * 3072;
+        p.img_vb = p.img_bgb * (B / 16);
+    }
+    tl_img_written = false;
+    const int rc = dispatch_gg<false>(p, static_cast<hipStream_t>(stream));
+    if (rc != SH_OK || !y_planes || tl_img_written) return rc;
+    return sh_to_p3(y, y_sv, y_sb, y_planes, B, R, Cout, stream);          // the dispatch picked a kernel without the image epilogue
 }
 
 int sh_spiral_conv_bwd_data(const float* dpre, int64_t dp_sv, int64_t dp_sb, const int32_t* table_t, const float* weight_t,
@@ -2118,6 +2186,14 @@ int sh_act_backward(const float* dy, int64_t dy_sv, int64_t dy_sb, const float* 
 int sh_act_backward_tr(const float* dy, int64_t dy_sv, int64_t dy_sb, const float* y, int64_t y_sv, int64_t y_sb, float* dpre,
                        int64_t dp_sv, int64_t dp_sb, int B, int R, int C, int act, int zero_row, int n_layers, const float* const* weight,
                        float* const* weight_t, const int* S, const int* Cin, const int* Cout, sh_stream_t stream) {
+    return sh_act_backward_tr_img(dy, dy_sv, dy_sb, y, y_sv, y_sb, dpre, dp_sv, dp_sb, nullptr, B, R, C, act, zero_row, n_layers, weight, weight_t,
+                                  S, Cin, Cout, stream);
+}
+
+int sh_act_backward_tr_img(const float* dy, int64_t dy_sv, int64_t dy_sb, const float* y, int64_t y_sv, int64_t y_sb, float* dpre,
+                           int64_t dp_sv, int64_t dp_sb, void* dpre_planes, int B, int R, int C, int act, int zero_row, int n_layers,
+                           const float* const* weight, float* const* weight_t, const int* S, const int* Cin, const int* Cout,
+                           sh_stream_t stream) {
     SH_REQUIRE(dy && y && dpre && B > 0 && R > 0 && C > 0, SH_ERR_INVALID_ARG, "sh_act_backward: bad argument");
     SH_REQUIRE(n_layers >= 0 && n_layers <= MR_MAX && (n_layers == 0 || (weight && weight_t && S && Cin && Cout)), SH_ERR_INVALID_ARG,
                "sh_act_backward_tr: bad transpose list (at most %d layers)", MR_MAX);
@@ -2138,6 +2214,13 @@ int sh_act_backward_tr(const float* dy, int64_t dy_sv, int64_t dy_sb, const floa
     // batch-major in, vertex-major out, few channels: turn tiles through LDS
     const bool turn = C <= 8 && dy_sv == C && y_sv == C && dy_sb == y_sb && dy_sb >= (int64_t)R * C && dp_sb == C && dp_sv == (int64_t)B * C &&
                       (size_t)AB_TV * ((size_t)B * C + 1) * sizeof(float) <= 64 * 1024;
+    char* img = static_cast<char*>(dpre_planes);
+    long img_bgb = 0;
+    if (img) {
+        SH_REQUIRE(vec && !turn && dp_sb == C && dp_sv == (int64_t)B * C && sh_p3_bytes(1, B, C) && (reinterpret_cast<uintptr_t>(img) & 15) == 0,
+                   SH_ERR_UNSUPPORTED, "sh_act_backward_tr_img: B=%d C=%d has no plane image (vertex-major dpre; B %% 16 == 0; C 16 or %% 32 == 0)", B, C);
+        img_bgb = C == 16 ? 1536 : (long)(C / 32) * 3072;
+    }
     if (turn) {
         const int gm = (R + AB_TV - 1) / AB_TV;
         hipLaunchKernelGGL(act_backward_turn_kernel, dim3(gm + tr_blocks), dim3(256), (size_t)AB_TV * ((size_t)B * C + 1) * sizeof(float), st,
@@ -2147,10 +2230,10 @@ int sh_act_backward_tr(const float* dy, int64_t dy_sv, int64_t dy_sb, const floa
     }
     if (vec)
         hipLaunchKernelGGL(act_backward_kernel<true>, dim3(blocks + tr_blocks), dim3(256), 0, st, dy, dy_sv, dy_sb, y, y_sv, y_sb, dpre, dp_sv, dp_sb,
-                           B, R, C, act, zero_row, blocks, tr);
+                           B, R, C, act, zero_row, blocks, tr, img, img_bgb * (B / 16), img_bgb);
     else
         hipLaunchKernelGGL(act_backward_kernel<false>, dim3(blocks + tr_blocks), dim3(256), 0, st, dy, dy_sv, dy_sb, y, y_sv, y_sb, dpre, dp_sv, dp_sb,
-                           B, R, C, act, zero_row, blocks, tr);
+                           B, R, C, act, zero_row, blocks, tr, (char*)nullptr, 0L, 0L);
     SH_CHECK_LAUNCH("act_backward");
     return SH_OK;
 }

@@ -85,9 +85,8 @@ int sh_stack_forward(int n_steps, const sh_stack_step* steps, const float* x, in
                 rc = sh_spiral_conv_fwd_p3(planes[i - 1], s.table, wfrag3[i], biases ? biases[s.param] : nullptr, outs[i], ol.sv, ol.sb, img, B,
                                            s.R, s.S, s.cin, s.cout, s.act, s.zero_row, stream);
             } else {
-                rc = sh_spiral_conv_fwd(cur, cl.sv, cl.sb, s.table, weights[s.param], biases ? biases[s.param] : nullptr, outs[i],
-                                        ol.sv, ol.sb, B, s.R, s.S, s.cin, s.cout, s.act, s.zero_row, mma_mode, stream);
-                if (rc == SH_OK && img) rc = sh_to_p3(outs[i], ol.sv, ol.sb, img, B, s.R, s.cout, stream);
+                rc = sh_spiral_conv_fwd_img(cur, cl.sv, cl.sb, s.table, weights[s.param], biases ? biases[s.param] : nullptr, outs[i],
+                                            ol.sv, ol.sb, img, B, s.R, s.S, s.cin, s.cout, s.act, s.zero_row, mma_mode, stream);
             }
         } else if (s.extend) {
             SH_REQUIRE(i > 0 && !is_last_step(i, n_steps) && outs[i] == outs[i - 1] && cl.sb == c, SH_ERR_INVALID_ARG,
@@ -164,11 +163,14 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
         if (s.kind == 0) {
             SH_REQUIRE(dpre_last, SH_ERR_INVALID_ARG, "sh_stack_backward: no dpre_last buffer");
             const Lay ol = lay(out_layout, s.R, B, s.cout), dl = lay(0, 0, B, s.cout);
-            rc = sh_act_backward_tr(g, ol.sv, ol.sb, acts[last], ol.sv, ol.sb, dpre_last, dl.sv, dl.sb, B, s.R, s.cout, s.act, s.zero_row, n_tr,
-                                    tr_w, tr_wt, tr_S, tr_Ci, tr_Co, stream);
+            cur_img = bwd_p3(last);
+            // the image of dpre rides in the launch when that is the plain element-wise form (16-byte quads, no tile turning)
+            const bool img_in = cur_img && s.cout % 4 == 0 && s.cout > 8 && ((ol.sv | ol.sb) % 4 == 0);
+            rc = sh_act_backward_tr_img(g, ol.sv, ol.sb, acts[last], ol.sv, ol.sb, dpre_last, dl.sv, dl.sb, img_in ? cur_img : nullptr, B, s.R,
+                                        s.cout, s.act, s.zero_row, n_tr, tr_w, tr_wt, tr_S, tr_Ci, tr_Co, stream);
             if (rc != SH_OK) return rc;
             cur = dpre_last; cl = dl;
-            cur_img = bwd_p3(last);
+            cur_img_done = img_in;
         } else {
             cur = g; cl = lay(out_layout, s.m_rows, B, cin_of[last]);
         }

@@ -22,10 +22,10 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import mesh_ops, ops
+from . import _lib, mesh_ops, ops
 from .mesh_ops import CSR
 from .linear import grouped_linear, latent_linear, latent_linear_bf16
-from .stack import ConvStep, SpmmStep, Stack, prepare_wfrags, run_stack, run_stack_bf16
+from .stack import ConvStep, SpmmStep, Stack, prepare_p3_frags, prepare_wfrags, run_stack, run_stack_bf16
 
 
 def _as_csr(m) -> CSR:
@@ -237,11 +237,20 @@ class SpiralAutoencoder(nn.Module):
 
     def forward(self, x):
         wf = None
+        if getattr(self, "compute_dtype", torch.float32) == torch.float32 and x.is_cuda and _lib.get_f32_mma_mode() == "planes3":
+            # three-plane form: the weight fragments of both stacks (forward and backward-data operand) in one conversion launch
+            grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+            prepare_p3_frags([(self._enc_stack, self.conv, x.shape[2]), (self._dec_stack, self.dconv, self.filters_dec[0][0])],
+                             x.shape[0], grad)
         if getattr(self, "compute_dtype", torch.float32) == torch.bfloat16 and x.is_cuda:
             # the bf16 working copies of all conv weights (encoder and decoder, forward and backward-data operand): one launch
             wf = prepare_wfrags([(self._enc_stack, self.conv), (self._dec_stack, self.dconv)])
-        z = self.encode(x, self.VAE_flag, wf)
-        return self.decode(z, wf), z
+        try:
+            z = self.encode(x, self.VAE_flag, wf)
+            return self.decode(z, wf), z
+        finally:                                   # fragments converted for THIS pass never outlive it (the weights may change)
+            self._enc_stack.__dict__.pop("_p3_next", None)
+            self._dec_stack.__dict__.pop("_p3_next", None)
 
 
 class SpiralAutoencoder_multiz_partkps(nn.Module):

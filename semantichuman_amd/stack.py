@@ -367,26 +367,15 @@ class Stack:
         return (ctypes.c_void_p * len(tensors))(*[0 if t is None else t.data_ptr() for t in tensors])
 
     def _p3_prepare(self, plan, weights, with_backward: bool, device):
-        """Three-plane form: the image arena of the forward buffers and the weight fragments (one conversion launch: the
-        forward operand of every conv step the plane kernels take and, when a backward pass can follow, its backward-data
-        operand).  A fresh buffer per forward pass: the fragments belong to the weights as they were when it ran."""
-        lib = _lib.load()
-        jobs = [j for j in plan["wf3_jobs"] if with_backward or j[1] == 0]
+        """Three-plane form: the image arena of the forward buffers and the weight fragments - this stack's own conversion
+        launch, unless `prepare_p3_frags` already converted them together with other stacks' (one launch per training step)."""
         planes = torch.empty(max(256, plan["pl_total"]), dtype=torch.uint8, device=device)
+        pre = self.__dict__.pop("_p3_next", None)
+        if pre is not None and pre[2] == id(plan) and (pre[3] or not with_backward):
+            return planes, pre[0], pre[1]
         wf3 = torch.empty(max(256, plan["wf3_total"]), dtype=torch.uint8, device=device)
-        if jobs:
-            base = wf3.data_ptr()
-            arr = lambda vals, ct: (ct * len(jobs))(*vals)              # noqa: E731
-            sts = [self.steps[j[0]] for j in jobs]
-            for st in sts:
-                w = weights[st.param]
-                if not (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()):
-                    raise RuntimeError("semantichuman_amd: conv weights must be contiguous fp32 HIP tensors")
-            _lib.check(lib.sh_conv_wfrag3_prep_multi(
-                len(jobs), arr([weights[st.param].data_ptr() for st in sts], ctypes.c_void_p), arr([base + j[2] for j in jobs], ctypes.c_void_p),
-                arr([st.S for st in sts], ctypes.c_int), arr([st.cin for st in sts], ctypes.c_int), arr([st.cout for st in sts], ctypes.c_int),
-                arr([j[1] for j in jobs], ctypes.c_int), _lib.stream_ptr()), "sh_conv_wfrag3_prep_multi")
-        return planes, wf3
+        convert_p3_frags([(self, plan, weights, wf3, 0)], with_backward)
+        return planes, wf3, 0
 
     def native_forward(self, x, in_layout, out_layout, weights, biases, mma: str = "exact", with_backward: bool = False):
         """-> (output, arena holding the outputs of the inner steps, three-plane state or None)."""
@@ -407,10 +396,10 @@ class Stack:
         p3 = None
         planes_p = wf3_p = None
         if mma == "planes3" and B % 16 == 0 and plan["wf3_total"]:
-            planes, wf3 = self._p3_prepare(plan, weights, with_backward, x.device)
-            p3 = (planes, wf3)
+            planes, wf3, wbase = self._p3_prepare(plan, weights, with_backward, x.device)
+            p3 = (planes, wf3, wbase)
             pl = (plan["pl_off"] + np.uint64(planes.data_ptr())) * plan["pl_mask"]
-            wf = (plan["wf3_off"] + np.uint64(wf3.data_ptr())) * plan["wf3_mask"]
+            wf = (plan["wf3_off"] + np.uint64(wf3.data_ptr() + wbase)) * plan["wf3_mask"]
             planes_p, wf3_p = pl.ctypes.data, wf.ctypes.data
         _lib.check(_lib.load().sh_stack_forward(n, self._native_steps(), _lib.ptr(x), _LAYOUT_ID[in_layout], rows0, c0, B,
                                                 self._ptr_array(weights), self._ptr_array(biases), outs.ctypes.data,
@@ -444,7 +433,7 @@ class Stack:
         if mma == "planes3" and p3 is not None:
             gimg = torch.empty(max(256, plan["gpl_total"]), dtype=torch.uint8, device=dev)
             gpl = (plan["gpl_off"] + np.uint64(gimg.data_ptr())) * plan["gpl_mask"]
-            wf = (plan["wf3t_off"] + np.uint64(p3[1].data_ptr())) * plan["wf3t_mask"]
+            wf = (plan["wf3t_off"] + np.uint64(p3[1].data_ptr() + p3[2])) * plan["wf3t_mask"]
             gpl_p, wf3t_p = gpl.ctypes.data, wf.ctypes.data
             if plan["dpl_mask"]:
                 dpl = ctypes.c_void_p(gimg.data_ptr() + int(plan["dpl_off"]))
@@ -748,6 +737,52 @@ class Stack:
                     db.record_stream(main)
             del keep_alive
         return (cur if need_x_grad else None), grads
+
+
+def convert_p3_frags(items, with_backward: bool):
+    """ONE sh_conv_wfrag3_prep_multi launch for the three-plane weight fragments of several stacks.
+    items: [(stack, plan, weights, buffer, byte offset of the stack's fragments in the buffer)]."""
+    lib = _lib.load()
+    w_p, o_p, S, Ci, Co, tr = [], [], [], [], [], []
+    for stack, plan, weights, buf, base in items:
+        for i, t, off in plan["wf3_jobs"]:
+            if t and not with_backward:
+                continue
+            st = stack.steps[i]
+            w = weights[st.param]
+            if not (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()):
+                raise RuntimeError("semantichuman_amd: conv weights must be contiguous fp32 HIP tensors")
+            w_p.append(w.data_ptr()); o_p.append(buf.data_ptr() + base + off)
+            S.append(st.S); Ci.append(st.cin); Co.append(st.cout); tr.append(t)
+    n = len(w_p)
+    if not n:
+        return
+    arr = lambda vals, ct: (ct * n)(*vals)                              # noqa: E731
+    _lib.check(lib.sh_conv_wfrag3_prep_multi(n, arr(w_p, ctypes.c_void_p), arr(o_p, ctypes.c_void_p), arr(S, ctypes.c_int),
+                                             arr(Ci, ctypes.c_int), arr(Co, ctypes.c_int), arr(tr, ctypes.c_int), _lib.stream_ptr()),
+               "sh_conv_wfrag3_prep_multi")
+
+
+def prepare_p3_frags(stacks_convs_c0, B: int, with_backward: bool):
+    """Three-plane form (SH_MMA_PLANES3): the weight fragments of several stacks - forward and, when a backward pass can
+    follow, backward-data operands - converted by ONE launch; each stack's next forward pass picks its share up
+    (Stack._p3_prepare) instead of launching its own conversion.  stacks_convs_c0: [(stack, ModuleList of SpiralConv, c0)]."""
+    if B % 16:
+        return
+    items, total = [], 0
+    for stack, convs, c0 in stacks_convs_c0:
+        plan = stack._plan(B, c0)
+        if not plan["wf3_total"]:
+            continue
+        items.append((stack, plan, [m.conv.weight for m in convs], None, total))
+        total += (int(plan["wf3_total"]) + 255) // 256 * 256
+    if not items:
+        return
+    buf = torch.empty(total, dtype=torch.uint8, device=items[0][2][0].device)
+    items = [(st, pl, ws, buf, off) for st, pl, ws, _, off in items]
+    convert_p3_frags(items, with_backward)
+    for st, pl, ws, _, off in items:
+        st._p3_next = (buf, off, id(pl), with_backward)
 
 
 class StackFunction(torch.autograd.Function):

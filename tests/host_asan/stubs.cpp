@@ -41,6 +41,12 @@ int sh_spiral_conv_fwd(const float* x, int64_t x_sv, int64_t x_sb, const int32_t
     log("conv_fwd R=%d Cin=%d Cout=%d", R, Cin, Cout);
     return 0;
 }
+int sh_to_p3(const float* x, int64_t x_sv, int64_t x_sb, void* planes, int B, int rows, int C, sh_stream_t);
+int sh_spiral_conv_fwd_img(const float* x, int64_t x_sv, int64_t x_sb, const int32_t* table, const float* w, const float* bias, float* y, int64_t y_sv,
+                           int64_t y_sb, void* y_planes, int B, int R, int S, int Cin, int Cout, int act, int zero_row, int mma, sh_stream_t st) {
+    const int rc = sh_spiral_conv_fwd(x, x_sv, x_sb, table, w, bias, y, y_sv, y_sb, B, R, S, Cin, Cout, act, zero_row, mma, st);
+    return (rc == 0 && y_planes) ? sh_to_p3(y, y_sv, y_sb, y_planes, B, R, Cout, st) : rc;
+}
 int sh_spiral_conv_fwd_bf16(const void* x, int xd, int64_t x_sv, int64_t x_sb, const int32_t* table, const void* wfrag, const float* bias, void* y,
                             int yd, int64_t y_sv, int64_t y_sb, int B, int R, int S, int Cin, int Cout, int act, int zero_row, sh_stream_t) {
     int n_in = 0;
@@ -90,6 +96,13 @@ int sh_act_backward_tr(const float* dy, int64_t dy_sv, int64_t dy_sb, const floa
     touch_r(dy, span(dy_sv, dy_sb, R, B, C, 4)); touch_r(y, span(y_sv, y_sb, R, B, C, 4)); touch_w(dp, span(dp_sv, dp_sb, R, B, C, 4));
     log("act_backward R=%d C=%d transposes=%d", R, C, n);
     return 0;
+}
+size_t sh_p3_bytes(int rows, int B, int C);
+int sh_act_backward_tr_img(const float* dy, int64_t dy_sv, int64_t dy_sb, const float* y, int64_t y_sv, int64_t y_sb, float* dp, int64_t dp_sv,
+                           int64_t dp_sb, void* dpre_planes, int B, int R, int C, int act, int zero_row, int n, const float* const* w,
+                           float* const* wt, const int* S, const int* Ci, const int* Co, sh_stream_t st) {
+    if (dpre_planes) touch_w(dpre_planes, sh_p3_bytes(R, B, C));
+    return sh_act_backward_tr(dy, dy_sv, dy_sb, y, y_sv, y_sb, dp, dp_sv, dp_sb, B, R, C, act, zero_row, n, w, wt, S, Ci, Co, st);
 }
 int sh_act_backward_bf16(const void* dy, int64_t dy_sv, int64_t dy_sb, const void* y, int64_t y_sv, int64_t y_sb, void* dp, int64_t dp_sv, int64_t dp_sb,
                          int B, int R, int C, int act, int zero_row, sh_stream_t) {

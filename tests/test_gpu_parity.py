@@ -81,6 +81,8 @@ SHAPES = [  # (B, n_rows, S, Cin, Cout)  - ragged / odd cases on purpose
     (16, 200, 6, 16, 160), (5, 90, 4, 192, 272), (16, 300, 5, 160, 8), (3, 70, 3, 8, 132),
     # <= 3 output channels over 16-channel rows: the line-wise VALU forward (spiral lengths 6..12), full / ragged batch slices
     (64, 500, 10, 16, 3), (20, 130, 12, 16, 2), (7, 90, 6, 16, 1), (33, 64, 13, 16, 3),
+    # ... and spirals of 13..24 (two passes over halves of the positions; config 4 forces 18), past 24 the general kernels
+    (32, 300, 18, 16, 3), (16, 120, 24, 16, 3), (5, 60, 22, 16, 2), (8, 40, 25, 16, 3),
     (64, 400, 10, 3, 16), (9, 77, 7, 3, 16),
 ]
 
@@ -533,7 +535,7 @@ def test_bench_launch_table_matches_the_library(golden_dir, cfg):
         sh.l1_loss(x, m(x)[0]).backward()
     was = _lib.get_f32_mma_mode()
     try:
-        for mode in ("exact", "split3"):
+        for mode in ("exact", "split3", "planes3"):
             _lib.set_f32_mma_mode(mode)
             step()
             torch.cuda.synchronize()
@@ -545,7 +547,9 @@ def test_bench_launch_table_matches_the_library(golden_dir, cfg):
             table = bench.f32_work_table(m, B)
             hit = {}
             for kname, shape, _ms in recs:
-                if kname.startswith(("gather_gemm", "wgrad", "conv_out3")):
+                if kname.startswith(("gather_gemm", "wgrad", "conv_out3", "conv_p3")):
+                    if "pass=1" in shape:                     # first half of a two-pass launch pair: priced with the second
+                        continue
                     key = bench.parse_tag_f32(kname, shape)
                     assert key in table, (mode, kname, shape)
                     hit[id(table[key])] = hit.get(id(table[key]), 0) + 1
