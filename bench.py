@@ -98,6 +98,8 @@ def parse_tag_f32(name, shape):
         if fam in ("wgrad_stream_kernel", "wgrad_kernel", "wgrad_split3_kernel"):
             return ("wgt", int(f["R"]), int(f["K"]), int(f["N"]))
         if fam == "wgrad_thin_kernel":
+            if "pass" in f and f["pass"].split("/")[0] != f["pass"].split("/")[1]:     # an earlier launch of a multi-pass layer: priced with the last
+                return None
             return ("wgt+bwd" if f.get("dx") == "1" else "wgt", int(f["R"]), int(f["S"]) * int(f["Cin"]), int(f["N"]))
     except (KeyError, ValueError, IndexError):
         return None
@@ -175,7 +177,7 @@ def measured_traffic(kernel, workload):
     batch, dtype, arithmetic form), on THIS build of the kernel library (sh_build_id() of the loaded .so) and with the same
     SH_* switches; anything else yields (None, reason) instead of a silently wrong number."""
     from semantichuman_amd import _lib
-    name = "r03_pmc_traffic_%s.json" % workload
+    name = "r04_pmc_traffic_%s.json" % workload
     path = os.path.join(ROOT, "profiles", name)
     try:
         pmc = json.load(open(path))

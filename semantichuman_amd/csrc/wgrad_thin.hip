@@ -37,6 +37,10 @@ struct WTParams {
     const float* w;                      // fp32 master weight [3][S * 16]
     char* dx; long dx_rb;                // [n_in (+ extra rows)][B][16] of the path's dtype, rows contiguous
     char* dx_img;                        // fp32 path: three-plane image of dx's rows (csrc/p3_conv.hip, 16-channel layout), or NULL
+    // a launch covers spiral positions s0 .. s0 + S - 1 of the S_tot the table / weight / slab have (spirals longer than 10 run as
+    // several launches, fp32 path): `first` writes the bias sums and STORES the partial input gradient, later ones add to it,
+    // `last` applies the activation derivative / zero row / image
+    int S_tot, s0, first, last;
     int act_prev, zero_prev;             // activation whose output x is (identity: no factor), row of dx forced to zero (-1: none)
 };
 
@@ -65,7 +69,10 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(const WTParams p) {
     if (nst > 0) {   // this wave's table lines -> LDS (ordinary loads, finished before the DMA loop starts)
         const int u_last = (it1 - 1) / nblk;
         const int n = (u_last - u_first + 1) * S;
-        for (int i = lane; i < n; i += 64) Tl[i] = p.tt[(long)u_first * S + i];
+        for (int i = lane; i < n; i += 64) {
+            const int v = i / S, j = i - v * S;
+            Tl[i] = p.tt[(long)(u_first + v) * p.S_tot + p.s0 + j];
+        }
     }
     typedef __attribute__((address_space(3))) char* lptr_t;
     auto dma16 = [](const char* gsrc, unsigned lds_dst) {
@@ -132,7 +139,7 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(const WTParams p) {
         const bool ok = n < 3 * S;
         const int s = ok ? n / 3 : 0, co = ok ? n - 3 * s : 0;
         doff[j] = XB + s * 384 + co * 4;                                // n past 3 S: reads column 0 against a zero weight
-        const float wv = (want_dx && ok) ? p.w[(long)co * S * 16 + s * 16 + (lane & 15)] : 0.f;
+        const float wv = (want_dx && ok) ? p.w[(long)co * p.S_tot * 16 + (p.s0 + s) * 16 + (lane & 15)] : 0.f;
         if (XB16) wf16[j] = (__bf16)wv; else wf32[j] = wv;
     }
     int cu = u_first, cb = it0 - u_first * nblk;                       // (vertex, batch block) of the item being consumed
@@ -194,11 +201,15 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(const WTParams p) {
                             d = __builtin_amdgcn_mfma_f32_16x16x4f32(wf32[t], gv, d, 0, 0, 0);
                         }
                         const f32x4 yv = *reinterpret_cast<const f32x4*>(slot + b * 64 + g4 * 16);
-                        f32x4 o;
+                        f32x4* dxp = reinterpret_cast<f32x4*>(p.dx + (long)cu * p.dx_rb + (long)(cb * 32 + b) * 64 + g4 * 16);
+                        if (!p.first) d += *dxp;               // the partial sum of the positions earlier launches covered
+                        f32x4 o = d;
+                        if (p.last) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = zrow ? 0.f : d[r] * sh_act_grad_from_out(yv[r], p.act_prev);
-                        *reinterpret_cast<f32x4*>(p.dx + (long)cu * p.dx_rb + (long)(cb * 32 + b) * 64 + g4 * 16) = o;
-                        if (p.dx_img) {                       // the exact split of the values just stored
+                            for (int r = 0; r < 4; ++r) o[r] = zrow ? 0.f : d[r] * sh_act_grad_from_out(yv[r], p.act_prev);
+                        }
+                        *dxp = o;
+                        if (p.dx_img && p.last) {             // the exact split of the values just stored
                             u32x2 ph, pm, pl;
                             sh_split3_quad(o, ph, pm, pl);
                             char* di = p.dx_img + ((long)cu * (p.B >> 4) + cb * 2 + h) * 1536 + ((g4 >> 1) * 16 + (lane & 15)) * 16 + (g4 & 1) * 8;
@@ -230,9 +241,9 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(const WTParams p) {
         float v = 0.f;
         for (int w = 0; w < nw; ++w) v += red[w * 608 + t];
         const int s = n / 3, co = n - 3 * s;
-        slab[(long)co * S * 16 + s * 16 + ci] = v;
+        slab[(long)co * p.S_tot * 16 + (p.s0 + s) * 16 + ci] = v;
     }
-    if (threadIdx.x < 3) {
+    if (threadIdx.x < 3 && p.first) {
         float v = 0.f;
         for (int w = 0; w < nw; ++w)
             for (int e = threadIdx.x; e < 96; e += 3) v += red[w * 608 + 512 + e];
@@ -253,14 +264,17 @@ static int wt_waves(int nslab, bool b16) {
 extern "C" {
 
 int sh_spiral_conv_bwd_wgt_thin_ok(int B, int n_in, int S, int Cin, int Cout, int path_dtype) {
-    if (!(Cout == 3 && Cin == 16 && S >= 1 && S <= 10 && B > 0 && B % 32 == 0 && n_in > 0)) return 0;
+    // spirals of 11..20 positions (data-dependent lengths, utils_spiral.py:72-82; BASELINE config 4 forces 18): fp32 path, as two
+    // launches over halves of the positions
+    const int smax = path_dtype == SH_DTYPE_F32 ? 20 : 10;
+    if (!(Cout == 3 && Cin == 16 && S >= 1 && S <= smax && B > 0 && B % 32 == 0 && n_in > 0)) return 0;
     static const int on = sh_env_int("SH_WGRAD_THIN", 1, 0, 1);
     if (!on) return 0;
     const int nslab = path_dtype == SH_DTYPE_BF16 ? sh_wgrad_bf16_nsplit(B, n_in, S, Cin, Cout) : sh_wgrad_f32_nsplit(B, n_in, S, Cin, Cout);
     const int nw = wt_waves(nslab, path_dtype == SH_DTYPE_BF16);
     const long items = (long)n_in * (B / 32);
     const long ipw = (items + (long)nslab * nw - 1) / ((long)nslab * nw);
-    const long max_v = WT_TBL_INTS / S - 2;                               // table lines a wave can hold
+    const long max_v = WT_TBL_INTS / (S > 10 ? (S + 1) / 2 : S) - 2;      // table lines a wave can hold (per launch)
     return ipw / (B / 32) + 2 <= max_v;
 }
 
@@ -273,7 +287,7 @@ int sh_spiral_conv_bwd_wgt_thin(const float* dpre_ext, int64_t dp_sv, int64_t dp
     SH_REQUIRE(path_dtype == SH_DTYPE_F32 || path_dtype == SH_DTYPE_BF16, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_wgt_thin: unknown path dtype");
     SH_REQUIRE(x_dtype == path_dtype, SH_ERR_UNSUPPORTED, "sh_spiral_conv_bwd_wgt_thin: x must have the path's dtype");
     SH_REQUIRE(sh_spiral_conv_bwd_wgt_thin_ok(B, n_in, S, Cin, Cout, path_dtype), SH_ERR_UNSUPPORTED,
-               "sh_spiral_conv_bwd_wgt_thin: shape not covered (needs Cout 3, Cin 16, S <= 10, B %% 32 == 0)");
+               "sh_spiral_conv_bwd_wgt_thin: shape not covered (needs Cout 3, Cin 16, S <= 10 - fp32: 20 -, B %% 32 == 0)");
     const long xe = x_dtype == SH_DTYPE_BF16 ? 2 : 4;
     SH_REQUIRE(dp_sb == 3 && dp_sv == (int64_t)B * 3 && x_sb == 16 && x_sv == (int64_t)B * 16, SH_ERR_UNSUPPORTED,
                "sh_spiral_conv_bwd_wgt_thin: vertex-major contiguous operands required");
@@ -310,10 +324,19 @@ int sh_spiral_conv_bwd_wgt_thin(const float* dpre_ext, int64_t dp_sv, int64_t dp
         }
         attr_set[b16] = true;
     }
-    ShProfScope ps(st, "wgrad_thin_kernel<%s>|R=%d B=%d S=%d Cin=%d N=%d grid=%d waves=%d dx=%d", b16 ? "true" : "false", n_in, B, S, Cin, Cout, nslab, nw, dx ? 1 : 0);
-    if (b16) SH_LAUNCH_PS(ps, wgrad_thin_kernel<true>, dim3(nslab), dim3(64 * nw), smem, st, p);
-    else SH_LAUNCH_PS(ps, wgrad_thin_kernel<false>, dim3(nslab), dim3(64 * nw), smem, st, p);
-    SH_CHECK_LAUNCH("wgrad_thin");
+    // positions in launches of at most 10 (the kernel's two 16-column output tiles hold 3 x 10 columns)
+    const int npass = S > 10 ? 2 : 1, s_first = npass == 2 ? (S + 1) / 2 : S;
+    p.S_tot = S;
+    for (int k = 0; k < npass; ++k) {
+        p.s0 = k == 0 ? 0 : s_first;
+        p.S = k == 0 ? s_first : S - s_first;
+        p.first = k == 0; p.last = k == npass - 1;
+        ShProfScope ps(st, "wgrad_thin_kernel<%s>|R=%d B=%d S=%d Cin=%d N=%d grid=%d waves=%d dx=%d pass=%d/%d", b16 ? "true" : "false", n_in, B, S,
+                       Cin, Cout, nslab, nw, dx ? 1 : 0, k + 1, npass);
+        if (b16) SH_LAUNCH_PS(ps, wgrad_thin_kernel<true>, dim3(nslab), dim3(64 * nw), smem, st, p);
+        else SH_LAUNCH_PS(ps, wgrad_thin_kernel<false>, dim3(nslab), dim3(64 * nw), smem, st, p);
+        SH_CHECK_LAUNCH("wgrad_thin");
+    }
     return SH_OK;
 }
 

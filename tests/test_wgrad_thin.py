@@ -33,9 +33,15 @@ def rand_table(R, S, seed):
 
 # (B, R, S): batch blocks 1 / 2 / 3, odd and even spiral lengths (the self chunk lands in either half of a chunk pair),
 # vertex counts that leave waves without work and ragged last ranges
-@pytest.mark.parametrize("B,R,S", [(64, 301, 10), (32, 97, 9), (96, 55, 7), (64, 1200, 10), (32, 20, 1), (64, 700, 4)])
+# spirals of 11..20 (fp32 path only: two launches over halves of the positions; BASELINE config 4 forces 18)
+LONG = [(64, 400, 18), (32, 130, 12), (64, 260, 20), (32, 77, 11)]
+
+
+@pytest.mark.parametrize("B,R,S", [(64, 301, 10), (32, 97, 9), (96, 55, 7), (64, 1200, 10), (32, 20, 1), (64, 700, 4)] + LONG)
 @pytest.mark.parametrize("path", ["f32", "bf16"])
 def test_thin_wgrad_matches_the_ordinary_form(B, R, S, path):
+    if path == "bf16" and S > 10:
+        pytest.skip("the bf16 path's thin kernel takes spirals of at most 10")
     torch.manual_seed(5)
     table = rand_table(R, S, 6)
     tt = mesh_ops.transpose_table_dense(table, R, none_row=R - 1, skip_row=-1)
@@ -73,12 +79,14 @@ def test_thin_wgrad_matches_the_ordinary_form(B, R, S, path):
     assert float((db - dbg).abs().max()) <= (2.0 ** -7 * np.sqrt(R * B) if path == "bf16" else tol * float(dbg.abs().max())) + 1e-4
 
 
-@pytest.mark.parametrize("B,R,S", [(64, 301, 10), (32, 97, 9), (96, 55, 7)])
+@pytest.mark.parametrize("B,R,S", [(64, 301, 10), (32, 97, 9), (96, 55, 7)] + LONG)
 @pytest.mark.parametrize("path", ["f32", "bf16"])
 @pytest.mark.parametrize("act", ["elu", "identity"])
 def test_thin_launch_also_gives_the_input_gradient(B, R, S, path, act):
     """dx of the same launch = backward-data over the transposed table times act'(x), dummy row forced to zero; the
     weight gradient of that launch is the one of the launch without dx, bit for bit."""
+    if path == "bf16" and S > 10:
+        pytest.skip("the bf16 path's thin kernel takes spirals of at most 10")
     torch.manual_seed(7)
     table = rand_table(R, S, 8)
     tt = mesh_ops.transpose_table_dense(table, R, none_row=R - 1, skip_row=-1)
