@@ -602,6 +602,8 @@ SH_API size_t sh_conv_wfrag3_bytes(int S, int Cg, int Nout);
 SH_API int sh_conv_wfrag3_prep_multi(int n_layers, const float* const* weight, void* const* wfrag3, const int* S, const int* Cin,
                                      const int* Cout, const int* transpose, sh_stream_t stream);
 SH_API int sh_spiral_conv_p3_ok(int B, int S, int Cg, int Nout);
+/* 0: not taken; 1: LDS-resident weight (backward-data also takes rows without an image: dpre_f32 below); 2: streamed weight */
+SH_API int sh_spiral_conv_p3_kind(int B, int S, int Cg, int Nout);
 /* sh_spmm that also writes the plane image of the rows it produces (y_planes: image of row 0 of y; NULL = plain sh_spmm) */
 SH_API int sh_spmm_p3(const int32_t* rowptr, const int32_t* col, const float* val, const float* x, int64_t x_sv, int64_t x_sb,
                       float* y, int64_t y_sv, int64_t y_sb, void* y_planes, const float* yprev, int64_t yp_sv, int64_t yp_sb,
@@ -620,11 +622,14 @@ SH_API int sh_act_backward_tr_img(const float* dy, int64_t dy_sv, int64_t dy_sb,
 SH_API int sh_spiral_conv_fwd_p3(const void* xp, const int32_t* table, const void* wfrag3, const float* bias, float* y, int64_t y_sv,
                                  int64_t y_sb, void* yp, int B, int R, int S, int Cin, int Cout, int act, int zero_row,
                                  sh_stream_t stream);
-/* sh_spiral_conv_bwd_data_z with dpre given as its plane image dprep (all rows table_t refers to, pre-summed rows included;
- * dpre_zero_row >= 0: the all-zero row the "no source" entries point at - their products are skipped, bitwise the same result) */
-SH_API int sh_spiral_conv_bwd_data_p3(const void* dprep, int dpre_zero_row, const int32_t* table_t, const void* wfrag3_t, float* dx,
-                                      int64_t dx_sv, int64_t dx_sb, void* dxp, const float* yprev, int64_t yp_sv, int64_t yp_sb,
-                                      int act_prev, int zero_row, int B, int n_in, int S, int Cin, int Cout, sh_stream_t stream);
+/* sh_spiral_conv_bwd_data_z with dpre given as its plane image dprep (dpre_zero_row >= 0: the all-zero row the "no source"
+ * entries point at - their products are skipped, bitwise the same result).  dpre_f32 != NULL: only rows < n_image_rows of dprep
+ * are valid; the rows behind them (the pre-summed rows the transposed table refers to) are read from the fp32 tensor
+ * (element strides dp_sv, dp_sb) and split by the kernel - their producers then need not write images. */
+SH_API int sh_spiral_conv_bwd_data_p3(const void* dprep, int dpre_zero_row, const float* dpre_f32, int64_t dp_sv, int64_t dp_sb,
+                                      int n_image_rows, const int32_t* table_t, const void* wfrag3_t, float* dx, int64_t dx_sv,
+                                      int64_t dx_sb, void* dxp, const float* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev,
+                                      int zero_row, int B, int n_in, int S, int Cin, int Cout, sh_stream_t stream);
 
 #ifdef __cplusplus
 }

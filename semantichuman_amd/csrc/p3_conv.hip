@@ -43,6 +43,10 @@ struct P3Params {
     int act, zero_row;
     int n_vg, n_tiles, nsplit;
     int skip_row;                              // backward-data: the all-zero row "no source" entries of the table point at, or -1
+    // backward-data: rows >= n_img of the gathered tensor (the pre-summed rows behind the real ones) have NO image - the kernel
+    // reads their fp32 values (element strides xf_sv, xf_sb) and splits them itself (~6 % of the gathered tiles: cheaper than
+    // having their producers - riders inside the weight-gradient launches - stream 6 more bytes per element)
+    const float* xf; long xf_sv, xf_sb; int n_img;
 };
 
 // k-steps of plane loads in flight per wave (ring slots): what the 128-VGPR budget leaves next to the accumulators and one
@@ -72,7 +76,7 @@ __device__ __forceinline__ bool p3_ring_steps(int ks, int nks, F&& f) {
 #ifndef P3_WAVES_PER_EU
 #define P3_WAVES_PER_EU 4
 #endif
-template <int NT, int RT, bool C16, bool BWD, int NP>
+template <int NT, int RT, bool C16, bool BWD, int NP, bool F32R = false>      // F32R: rows >= n_img are read as fp32 and split here
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(P3_WAVES_PER_EU, 8))) void conv_p3_kernel(const P3Params p) {
     constexpr int D = p3_depth(NT, RT);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -126,14 +130,21 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(P3_WAVES_P
         int ls = 0, lc = 0;                                // running load position (uniform)
         u32x4 ring[D][RT][3];
         auto issue = [&](u32x4 (&a)[RT][3]) {
+            // Three loads per (vertex, k-step) whatever the row is - an image row: its three planes; an fp32-only row (BWD, row >=
+            // n_img): the lane's 8 channels as two quads (+ a repeat), split into planes when the k-step is multiplied.  Only the
+            // ADDRESSES depend on the kind of row, never whether a load is issued: the waits stay counted.
             if constexpr (!C16) {
                 const int s = ls < S ? ls : S - 1;
 #pragma unroll
                 for (int m = 0; m < RT; ++m) {
                     const int row = __builtin_amdgcn_readlane(tv[m], s);
-                    const char* src = xl + (long)row * p.x_vb + (long)lc * 3072;
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) a[m][pl] = *reinterpret_cast<const u32x4*>(src + pl * PB);
+                    const bool f32row = F32R && row >= p.n_img;                   // wave-uniform
+                    const char* src = f32row ? reinterpret_cast<const char*>(p.xf + (long)row * p.xf_sv + (long)(bs * 16 + r16) * p.xf_sb + lc * 32 + kq * 8)
+                                             : xl + (long)row * p.x_vb + (long)lc * 3072;
+                    const int o1 = f32row ? 16 : PB, o2 = f32row ? 0 : 2 * PB;
+                    a[m][0] = *reinterpret_cast<const u32x4*>(src);
+                    a[m][1] = *reinterpret_cast<const u32x4*>(src + o1);
+                    a[m][2] = *reinterpret_cast<const u32x4*>(src + o2);
                 }
                 if (++lc >= p.ncg) { lc = 0; ++ls; }
             } else {
@@ -142,9 +153,13 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(P3_WAVES_P
                 for (int m = 0; m < RT; ++m) {
                     const int r0 = __builtin_amdgcn_readlane(tv[m], s0), r1 = __builtin_amdgcn_readlane(tv[m], s1);
                     const int row = (kq & 2) ? r1 : r0;
-                    const char* src = xl + (long)row * p.x_vb;
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) a[m][pl] = *reinterpret_cast<const u32x4*>(src + pl * PB);
+                    const bool f32row = F32R && row >= p.n_img;                   // per half-wave
+                    const char* src = f32row ? reinterpret_cast<const char*>(p.xf + (long)row * p.xf_sv + (long)(bs * 16 + r16) * p.xf_sb + (kq & 1) * 8)
+                                             : xl + (long)row * p.x_vb;
+                    const int o1 = f32row ? 16 : PB, o2 = f32row ? 0 : 2 * PB;
+                    a[m][0] = *reinterpret_cast<const u32x4*>(src);
+                    a[m][1] = *reinterpret_cast<const u32x4*>(src + o1);
+                    a[m][2] = *reinterpret_cast<const u32x4*>(src + o2);
                 }
                 ls += 2;
             }
@@ -155,13 +170,14 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(P3_WAVES_P
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[m][n] = zero4;
         int cs = 0, cc = 0;                                // position / channel group of the k-step being multiplied (uniform)
-        auto compute = [&](int ks, const u32x4 (&a)[RT][3]) {
+        auto compute = [&](int ks, u32x4 (&a)[RT][3]) {
             // "no source" entries (down-sampling levels: half of them) gather the zero row: exact zeros through the matrix pipe.
             // The entry is wave-uniform (one vertex per 16 batch rows), so the products are skipped by a scalar branch - bitwise
             // the same result.  (The loads are not skipped: a conditional load would make every wait a full drain, and the zero
             // row is L1-resident.)
             bool live[RT];
             bool any = false;
+            const int cs_was = cs;
 #pragma unroll
             for (int m = 0; m < RT; ++m) {
                 live[m] = true;
@@ -182,6 +198,25 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(P3_WAVES_P
                 else if (++cc >= p.ncg) { cc = 0; if (cs + 1 < S) ++cs; }
             }
             if (!any) return;
+            // planes of this k-step's gathered operand: the loaded image pieces, or the split of an fp32-only row
+#pragma unroll
+            for (int m = 0; m < RT; ++m) {
+                if constexpr (F32R) {
+                    bool f32row;
+                    if constexpr (!C16) {
+                        f32row = __builtin_amdgcn_readlane(tv[m], cs_was) >= p.n_img;
+                    } else {
+                        const int s1 = cs_was + 1 < S ? cs_was + 1 : cs_was;
+                        const int r0 = __builtin_amdgcn_readlane(tv[m], cs_was), r1 = __builtin_amdgcn_readlane(tv[m], s1);
+                        f32row = ((kq & 2) ? r1 : r0) >= p.n_img;
+                    }
+                    if (__builtin_amdgcn_ballot_w64(f32row)) {                    // uniform: any lane of the wave
+                        u32x4 h, mm, l;
+                        sh_split3(*reinterpret_cast<const f32x4*>(&a[m][0]), *reinterpret_cast<const f32x4*>(&a[m][1]), h, mm, l);
+                        if (f32row) { a[m][0] = h; a[m][1] = mm; a[m][2] = l; }
+                    }
+                }
+            }
             const u32x4* wk = Wl + ((long)ks * NT) * 192 + lane;
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
@@ -322,9 +357,13 @@ __global__ __launch_bounds__(1024 / RT) void conv_p3s_kernel(const P3Params p) {
 #pragma unroll
             for (int m = 0; m < RT; ++m) {
                 const int row = __builtin_amdgcn_readlane(tv[m], s);
-                const char* src = xl + (long)row * p.x_vb + (long)lc * 3072;
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) a[m][pl] = *reinterpret_cast<const u32x4*>(src + pl * 1024);
+                const bool f32row = false;                                        // (this form's layers image their pre-summed rows)
+                const char* src = f32row ? reinterpret_cast<const char*>(p.xf + (long)row * p.xf_sv + (long)(bs * 16 + r16) * p.xf_sb + lc * 32 + kq * 8)
+                                         : xl + (long)row * p.x_vb + (long)lc * 3072;
+                const int o1 = f32row ? 16 : 1024, o2 = f32row ? 0 : 2048;
+                a[m][0] = *reinterpret_cast<const u32x4*>(src);
+                a[m][1] = *reinterpret_cast<const u32x4*>(src + o1);
+                a[m][2] = *reinterpret_cast<const u32x4*>(src + o2);
             }
             if (++lc >= p.ncg) { lc = 0; ++ls; }
         };
@@ -334,12 +373,13 @@ __global__ __launch_bounds__(1024 / RT) void conv_p3s_kernel(const P3Params p) {
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[m][n] = zero4;
         int cs = 0, cc = 0;
-        auto compute = [&](const u32x4* wk, const u32x4 (&a)[RT][3]) {
+        auto compute = [&](const u32x4* wk, u32x4 (&a)[RT][3]) {
             bool live[RT];                                 // see conv_p3_kernel: products of "no source" entries are skipped
             bool any = false;
 #pragma unroll
             for (int m = 0; m < RT; ++m) {
-                live[m] = !BWD || p.skip_row < 0 || __builtin_amdgcn_readlane(tv[m], cs) != p.skip_row;
+                const int row = BWD ? __builtin_amdgcn_readlane(tv[m], cs) : 0;
+                live[m] = !BWD || p.skip_row < 0 || row != p.skip_row;
                 any = any || live[m];
             }
             if (BWD && ++cc >= p.ncg) { cc = 0; if (cs + 1 < S) ++cs; }
@@ -566,9 +606,9 @@ int dispatch_p3s(P3Params& p, hipStream_t st) {
     return rt == 2 ? launch_p3s<2, BWD, NP>(p, st) : launch_p3s<1, BWD, NP>(p, st);
 }
 
-template <int NT, int RT, bool C16, bool BWD, int NP>
+template <int NT, int RT, bool C16, bool BWD, int NP, bool F32R = false>
 int launch_p3(P3Params& p, hipStream_t st) {
-    auto kern = conv_p3_kernel<NT, RT, C16, BWD, NP>;
+    auto kern = conv_p3_kernel<NT, RT, C16, BWD, NP, F32R>;
     const size_t smem = (size_t)p.nks * NT * 3072;
     static size_t attr_set = 0;
     if (smem > 65536 && smem > attr_set) {
@@ -594,24 +634,24 @@ int launch_p3(P3Params& p, hipStream_t st) {
     if (groups < 8) groups = 8;
     groups = (groups + 7) / 8 * 8;
     const int grid = (int)groups * p.nsplit;
-    ShProfScope ps(st, "conv_p3_kernel<%d, %d, %s, %s, %d>|R=%d B=%d K=%d N=%d grid=%dx%d", NT, RT, C16 ? "true" : "false",
-                   BWD ? "true" : "false", NP, p.R, p.B, p.S * p.Cg, p.Nout, grid, nw * 64);
+    ShProfScope ps(st, "conv_p3_kernel<%d, %d, %s, %s, %d>|R=%d B=%d K=%d N=%d grid=%dx%d%s", NT, RT, C16 ? "true" : "false",
+                   BWD ? "true" : "false", NP, p.R, p.B, p.S * p.Cg, p.Nout, grid, nw * 64, F32R ? " f32rows" : "");
     SH_LAUNCH_PS(ps, kern, dim3(grid), dim3(nw * 64), smem, st, p);
     SH_CHECK_LAUNCH("conv_p3");
     return SH_OK;
 }
 
-template <bool C16, bool BWD, int NP>
+template <bool C16, bool BWD, int NP, bool F32R = false>
 int dispatch_p3_nt(P3Params& p, int nt, hipStream_t st) {
     const long tiles16 = (long)p.R * (p.B / 16);
     const long fill = 2L * p3_num_cus() * 16;
     static const int rt_force = sh_env_int("SH_P3_RT", 0, 0, 2);
     const bool two = rt_force ? rt_force == 2 : tiles16 / 2 >= fill;
-    if (nt == 1) return two ? launch_p3<1, 2, C16, BWD, NP>(p, st) : launch_p3<1, 1, C16, BWD, NP>(p, st);
-    if (nt == 2) return two ? launch_p3<2, 2, C16, BWD, NP>(p, st) : launch_p3<2, 1, C16, BWD, NP>(p, st);
+    if (nt == 1) return two ? launch_p3<1, 2, C16, BWD, NP, F32R>(p, st) : launch_p3<1, 1, C16, BWD, NP, F32R>(p, st);
+    if (nt == 2) return two ? launch_p3<2, 2, C16, BWD, NP, F32R>(p, st) : launch_p3<2, 1, C16, BWD, NP, F32R>(p, st);
     if constexpr (!C16) {
-        if (nt == 4) return two ? launch_p3<4, 2, C16, BWD, NP>(p, st) : launch_p3<4, 1, C16, BWD, NP>(p, st);
-        if (nt == 8) return launch_p3<8, 1, C16, BWD, NP>(p, st);
+        if (nt == 4) return two ? launch_p3<4, 2, C16, BWD, NP, F32R>(p, st) : launch_p3<4, 1, C16, BWD, NP, F32R>(p, st);
+        if (nt == 8) return launch_p3<8, 1, C16, BWD, NP, F32R>(p, st);
     }
     sh_set_error("conv_p3: %d channel tiles per workgroup with %d gathered channels is not built", nt, p.Cg);
     return SH_ERR_UNSUPPORTED;
@@ -637,7 +677,16 @@ int dispatch_p3(P3Params& p, hipStream_t st) {
                  reinterpret_cast<uintptr_t>(p.yprev) | reinterpret_cast<uintptr_t>(p.bias)) & 15) == 0 &&
                ((p.y_sv | p.y_sb | p.yv_sv | p.yv_sb) & 3) == 0, SH_ERR_INVALID_ARG, "conv_p3: tensors must be 16-byte aligned with strides %% 4 == 0");
     static const int np = sh_env_int("SH_P3_NP", 6, 6, 9);
-    if (!p3_resident_ok(p.S, p.Cg, p.Nout)) return np == 9 ? dispatch_p3s<BWD, 9>(p, st) : dispatch_p3s<BWD, 6>(p, st);
+    if (!p3_resident_ok(p.S, p.Cg, p.Nout)) {
+        SH_REQUIRE(!p.xf, SH_ERR_UNSUPPORTED, "conv_p3: the weight-streaming form takes imaged rows only (sh_spiral_conv_p3_kind() == 2)");
+        return np == 9 ? dispatch_p3s<BWD, 9>(p, st) : dispatch_p3s<BWD, 6>(p, st);
+    }
+    if constexpr (BWD) {
+        if (p.xf) {                                            // rows without an image: the six-product kernels that split them
+            SH_REQUIRE(np == 6, SH_ERR_UNSUPPORTED, "conv_p3: fp32 rows are built for the six-product form (SH_P3_NP=6)");
+            return p.Cg == 16 ? dispatch_p3_nt<true, true, 6, true>(p, g.nt, st) : dispatch_p3_nt<false, true, 6, true>(p, g.nt, st);
+        }
+    }
     if (p.Cg == 16) return np == 9 ? dispatch_p3_nt<true, BWD, 9>(p, g.nt, st) : dispatch_p3_nt<true, BWD, 6>(p, g.nt, st);
     return np == 9 ? dispatch_p3_nt<false, BWD, 9>(p, g.nt, st) : dispatch_p3_nt<false, BWD, 6>(p, g.nt, st);
 }
@@ -702,6 +751,10 @@ int sh_conv_wfrag3_prep_multi(int n_layers, const float* const* weight, void* co
 }
 
 int sh_spiral_conv_p3_ok(int B, int S, int Cg, int Nout) { return p3_shape_ok(B, S, Cg, Nout) ? 1 : 0; }
+int sh_spiral_conv_p3_kind(int B, int S, int Cg, int Nout) {
+    if (!p3_shape_ok(B, S, Cg, Nout)) return 0;
+    return p3_resident_ok(S, Cg, Nout) ? 1 : 2;
+}
 
 int sh_spiral_conv_fwd_p3(const void* xp, const int32_t* table, const void* wfrag3, const float* bias, float* y, int64_t y_sv,
                           int64_t y_sb, void* yp, int B, int R, int S, int Cin, int Cout, int act, int zero_row, sh_stream_t stream) {
@@ -711,13 +764,14 @@ int sh_spiral_conv_fwd_p3(const void* xp, const int32_t* table, const void* wfra
     P3Params p{};
     p.xp = static_cast<const char*>(xp); p.table = table; p.wfrag = static_cast<const u32x4*>(wfrag3); p.bias = bias;
     p.y = y; p.y_sv = y_sv; p.y_sb = y_sb; p.yp = static_cast<char*>(yp);
-    p.B = B; p.R = R; p.S = S; p.Cg = Cin; p.Nout = Cout; p.act = act; p.zero_row = zero_row; p.skip_row = -1;
+    p.B = B; p.R = R; p.S = S; p.Cg = Cin; p.Nout = Cout; p.act = act; p.zero_row = zero_row; p.skip_row = -1; p.n_img = 0x7fffffff;
     return dispatch_p3<false>(p, static_cast<hipStream_t>(stream));
 }
 
-int sh_spiral_conv_bwd_data_p3(const void* dprep, int dpre_zero_row, const int32_t* table_t, const void* wfrag3_t, float* dx, int64_t dx_sv,
-                               int64_t dx_sb, void* dxp, const float* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row, int B,
-                               int n_in, int S, int Cin, int Cout, sh_stream_t stream) {
+int sh_spiral_conv_bwd_data_p3(const void* dprep, int dpre_zero_row, const float* dpre_f32, int64_t dp_sv, int64_t dp_sb, int n_image_rows,
+                               const int32_t* table_t, const void* wfrag3_t, float* dx, int64_t dx_sv, int64_t dx_sb, void* dxp,
+                               const float* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row, int B, int n_in, int S, int Cin,
+                               int Cout, sh_stream_t stream) {
     SH_REQUIRE(dprep && table_t && wfrag3_t, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_data_p3: null pointer");
     SH_REQUIRE(B > 0 && n_in > 0 && S > 0 && Cin > 0 && Cout > 0, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_data_p3: non-positive size");
     SH_REQUIRE(act_prev >= SH_ACT_IDENTITY && act_prev <= SH_ACT_TANH, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_data_p3: unknown activation");
@@ -728,6 +782,12 @@ int sh_spiral_conv_bwd_data_p3(const void* dprep, int dpre_zero_row, const int32
     p.B = B; p.R = n_in; p.S = S; p.Cg = Cout; p.Nout = Cin; p.act = act_prev; p.zero_row = zero_row;
     static const int skip_on = sh_env_int("SH_P3_SKIP", 1, 0, 1);
     p.skip_row = skip_on ? dpre_zero_row : -1;
+    p.n_img = 0x7fffffff;
+    if (dpre_f32) {
+        SH_REQUIRE(n_image_rows >= 0 && (reinterpret_cast<uintptr_t>(dpre_f32) & 15) == 0 && ((dp_sv | dp_sb) & 3) == 0, SH_ERR_INVALID_ARG,
+                   "sh_spiral_conv_bwd_data_p3: the fp32 gradient must be 16-byte aligned with strides %% 4 == 0");
+        p.xf = dpre_f32; p.xf_sv = dp_sv; p.xf_sb = dp_sb; p.n_img = n_image_rows;
+    }
     return dispatch_p3<true>(p, static_cast<hipStream_t>(stream));
 }
 

@@ -203,7 +203,15 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
             // the last pre-sum level of this layer rides in the weight-gradient launch (sh_spiral_conv_bwd_wgt_presum); an
             // earlier level (very long lists: two levels) runs first, on its own
             const bool ride = !thin && want_in && s.table_t && (s.n1 || s.n2);
-            char* pimg0 = p3 ? static_cast<char*>(cur_img) : nullptr;         // the riders / pre-sum launches write the image of their rows
+            // SH_P3_PRESUM_IMG=1: the riders / pre-sum launches write the image of their rows; default 0: they stay plain and the
+            // backward-data kernel splits those rows itself from the fp32 buffer (they are ~6 % of what it gathers)
+            // pre-summed rows: imaged by their producers (the riders / pre-sum launches), or - LDS-resident plane kernel and at
+            // least half as many of them as real rows - left fp32 and split by the backward-data kernel itself (they are ~6 % of
+            // what it gathers; the riders' image stores cost their hosts more).  SH_P3_PRESUM_IMG: 0 / 1 force, 2 = that rule
+            static const int presum_mode = sh_env_int("SH_P3_PRESUM_IMG", 2, 0, 2);
+            const bool presum_img = !p3 ? false : presum_mode == 1 ? true
+                                    : !(sh_spiral_conv_p3_kind(B, s.S, s.cout, s.cin) == 1 && (presum_mode == 0 || 2 * (s.n1 + s.n2) >= s.R));
+            char* pimg0 = (p3 && presum_img) ? static_cast<char*>(cur_img) : nullptr;
             float* mut0 = const_cast<float*>(cur);
             if (ride && s.n1 && s.n2) {
                 rc = sh_spmm_p3(s.sum1.rowptr, s.sum1.col, s.sum1.val, cur, cl.sv, cl.sb, mut0 + (long)s.R * cl.sv, cl.sv, cl.sb,
@@ -228,7 +236,7 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
             if (want_in) {
                 SH_REQUIRE(s.table_t, SH_ERR_INVALID_ARG, "sh_stack_backward: step %d has no transposed table", i);
                 float* mut = const_cast<float*>(cur);          // the extra rows behind the R real ones of this step's own buffer
-                char* pimg = p3 ? static_cast<char*>(cur_img) : nullptr;
+                char* pimg = pimg0;
                 if (s.n1 && !ride) {
                     rc = sh_spmm_p3(s.sum1.rowptr, s.sum1.col, s.sum1.val, cur, cl.sv, cl.sb, mut + (long)s.R * cl.sv, cl.sv, cl.sb,
                                     pimg ? pimg + sh_p3_bytes(s.R, B, s.cout) : nullptr, nullptr, 0, 0, 0, -1, B, s.n1, s.cout, stream);
@@ -263,7 +271,7 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
                             if (rc != SH_OK) return rc;
                         }
                         const bool img_out = gi_img && gl.sb == s.cin && gl.sv == (long)B * s.cin && sh_p3_bytes(1, B, s.cin);
-                        rc = sh_spiral_conv_bwd_data_p3(cur_img, s.zero_row, s.table_t, wfrag3_t[i], gi, gl.sv, gl.sb, img_out ? gi_img : nullptr, yprev, yl.sv,
+                        rc = sh_spiral_conv_bwd_data_p3(cur_img, s.zero_row, presum_img ? nullptr : cur, cl.sv, cl.sb, s.R, s.table_t, wfrag3_t[i], gi, gl.sv, gl.sb, img_out ? gi_img : nullptr, yprev, yl.sv,
                                                         yl.sb, act_prev, zero_prev, B, s.n_in, s.S, s.cin, s.cout, stream);
                         gi_img_done = img_out;
                     } else {

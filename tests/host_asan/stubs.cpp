@@ -208,6 +208,7 @@ size_t sh_p3_bytes(int rows, int B, int C) {
     return (size_t)rows * (B / 16) * (C == 16 ? 1536 : (size_t)(C / 32) * 3072);
 }
 size_t sh_conv_wfrag3_bytes(int S, int Cg, int Nout) { return 3 * sh_conv_wfrag_bytes(S, Cg, Nout); }
+int sh_spiral_conv_p3_kind(int B, int S, int Cg, int Nout) { return (B % 16 == 0 && (Cg == 16 || (Cg > 0 && Cg % 32 == 0)) && Nout % 4 == 0) ? 1 : 0; }
 int sh_spiral_conv_p3_ok(int B, int S, int Cg, int Nout) { return B % 16 == 0 && (Cg == 16 || (Cg > 0 && Cg % 32 == 0)) && Nout % 4 == 0; }
 int sh_to_p3(const float* x, int64_t x_sv, int64_t x_sb, void* planes, int B, int rows, int C, sh_stream_t) {
     touch_r(x, span(x_sv, x_sb, rows, B, C, 4)); touch_w(planes, sh_p3_bytes(rows, B, C));
@@ -224,12 +225,13 @@ int sh_spiral_conv_fwd_p3(const void* xp, const int32_t* table, const void* wfra
     log("conv_fwd_p3 R=%d Cin=%d Cout=%d", R, Cin, Cout);
     return 0;
 }
-int sh_spiral_conv_bwd_data_p3(const void* dprep, int, const int32_t* table_t, const void* wfrag3_t, float* dx, int64_t dx_sv, int64_t dx_sb, void* dxp,
+int sh_spiral_conv_bwd_data_p3(const void* dprep, int, const float* dpre_f32, int64_t dp_sv, int64_t dp_sb, int n_img, const int32_t* table_t, const void* wfrag3_t, float* dx, int64_t dx_sv, int64_t dx_sb, void* dxp,
                                const float* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row, int B, int n_in, int S, int Cin, int Cout,
                                sh_stream_t) {
     int rows = 0;
     for (long i = 0; i < (long)n_in * S; ++i) rows = table_t[i] + 1 > rows ? table_t[i] + 1 : rows;
-    touch_r(dprep, sh_p3_bytes(rows, B, Cout)); touch_r(wfrag3_t, sh_conv_wfrag3_bytes(S, Cout, Cin));
+    touch_r(dprep, sh_p3_bytes(dpre_f32 ? (n_img < rows ? n_img : rows) : rows, B, Cout)); touch_r(wfrag3_t, sh_conv_wfrag3_bytes(S, Cout, Cin));
+    if (dpre_f32) touch_r(dpre_f32, span(dp_sv, dp_sb, rows, B, Cout, 4));
     if (dx) touch_w(dx, span(dx_sv, dx_sb, n_in, B, Cin, 4));
     if (dxp) touch_w(dxp, sh_p3_bytes(n_in, B, Cin));
     if (yprev) touch_r(yprev, span(yp_sv, yp_sb, n_in, B, Cin, 4));

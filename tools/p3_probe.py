@@ -74,7 +74,7 @@ def rnd(shape, dev, adversarial, gen):
     return x.float().contiguous()
 
 
-def probe_layers(B=64, tpl=None, directions=("fwd", "bwd"), adversarial=False, reps=1, skip=True, seed=1):
+def probe_layers(B=64, tpl=None, directions=("fwd", "bwd"), adversarial=False, reps=1, skip=True, seed=1, f32_presum_rows=True):
     """Yields one record per conv step (3-channel sides excluded) and direction of the template's plain autoencoder:
     {"name", "bwd", "ok" (the three-plane kernels take the shape), "err": {form: max|err| / max|ref| against a float64
     evaluation on the device}, "us": {form: kernel time}, "us_to_p3", "img_ok" (the image the kernel wrote of its output is
@@ -88,6 +88,7 @@ def probe_layers(B=64, tpl=None, directions=("fwd", "bwd"), adversarial=False, r
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
     was = _lib.get_f32_mma_mode()
+    F32ROWS = f32_presum_rows      # backward-data: the pre-summed rows (>= R) are read from the fp32 tensor, as the stack sequencer runs it
     try:
         for sname, stack in (("enc", model._enc_stack), ("dec", model._dec_stack)):
             for i, st in enumerate(stack.steps):
@@ -145,7 +146,7 @@ def probe_layers(B=64, tpl=None, directions=("fwd", "bwd"), adversarial=False, r
                                                                      B * Nout, Nout, _lib.ptr(yp), B, R, S, cin, cout, 0, -1, _lib.stream_ptr()),
                                            "sh_spiral_conv_fwd_p3")
                             else:
-                                _lib.check(lib.sh_spiral_conv_bwd_data_p3(_lib.ptr(xp), zrow, _lib.ptr(table_t), _lib.ptr(wf), _lib.ptr(y), B * Nout,
+                                _lib.check(lib.sh_spiral_conv_bwd_data_p3(_lib.ptr(xp), zrow, _lib.ptr(x) if (F32ROWS and lib.sh_spiral_conv_p3_kind(B, S, Cg, Nout) == 1) else None, B * cout, cout, R, _lib.ptr(table_t), _lib.ptr(wf), _lib.ptr(y), B * Nout,
                                                                           Nout, _lib.ptr(yp), None, 0, 0, 0, -1, B, n_in, S, cin, cout,
                                                                           _lib.stream_ptr()), "sh_spiral_conv_bwd_data_p3")
                         rec["us"]["planes3"] = timed(run_p3, reps)
