@@ -634,8 +634,8 @@ int launch_p3(P3Params& p, hipStream_t st) {
     if (groups < 8) groups = 8;
     groups = (groups + 7) / 8 * 8;
     const int grid = (int)groups * p.nsplit;
-    ShProfScope ps(st, "conv_p3_kernel<%d, %d, %s, %s, %d>|R=%d B=%d K=%d N=%d grid=%dx%d%s", NT, RT, C16 ? "true" : "false",
-                   BWD ? "true" : "false", NP, p.R, p.B, p.S * p.Cg, p.Nout, grid, nw * 64, F32R ? " f32rows" : "");
+    ShProfScope ps(st, "conv_p3_kernel<%d, %d, %s, %s, %d, %s>|R=%d B=%d K=%d N=%d grid=%dx%d", NT, RT, C16 ? "true" : "false",
+                   BWD ? "true" : "false", NP, F32R ? "true" : "false", p.R, p.B, p.S * p.Cg, p.Nout, grid, nw * 64);
     SH_LAUNCH_PS(ps, kern, dim3(grid), dim3(nw * 64), smem, st, p);
     SH_CHECK_LAUNCH("conv_p3");
     return SH_OK;
