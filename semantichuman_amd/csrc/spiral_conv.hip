@@ -1388,6 +1388,10 @@ struct WSParams {
     int B, R, S, Cin, Cout, K;
     int log2TB, n_btiles, nvc, vpc, ncg, n_items;     // vpc = vertices per chunk
     int co0;                                          // first output channel of this launch (groups of <= 128 channels)
+    // vertex assignment of a row chunk: 0 = vc * vpc .. + vpc - 1 (a contiguous block per wave), 1 = vc, vc + nvc, vc + 2 nvc, ...
+    // (the waves of an XCD walk the mesh TOGETHER: at any time they gather from ~nvc neighbouring vertices, which stay in the
+    // XCD's L2, instead of from one block of vpc vertices each - measured: the level-0 launch fetched 270 MB for 85 MB of input)
+    int vstride;
     // tail job (sh_spiral_conv_bwd_wgt_presum): workgroups grid_main .. grid_main + tail_blocks - 1 of the launch fill the
     // pre-summed rows the layer's backward-data pass reads through its transposed table - y[r] = sum_e val[e] dpre[col[e]],
     // sh_spmm's arithmetic entry for entry - beside the weight-gradient workgroups instead of in a launch of their own
@@ -1454,10 +1458,13 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_stream_kernel(const WSParams p
     const int rc = item / p.ncg, cg = item - rc * p.ncg;
     const int bt = rc / p.nvc, vc = rc - bt * p.nvc;
     const int b0 = bt << p.log2TB;
-    const int v_begin = vc * p.vpc;
-    const int nv = active ? min(p.vpc, p.R - v_begin) : 0;
+    const int v_begin = p.vstride ? vc : vc * p.vpc, v_step = p.vstride ? p.nvc : 1;      // vertex of local index vl: v_begin + vl * v_step
+    const int nv = !active ? 0 : p.vstride ? (vc < p.R ? (p.R - vc + p.nvc - 1) / p.nvc : 0) : min(p.vpc, p.R - v_begin);
     const int S = p.S;
-    for (int i = lane; i < nv * S; i += 64) Tl[i] = p.table[(long)v_begin * S + i];
+    for (int i = lane; i < nv * S; i += 64) {
+        const int vl = i / S, j = i - vl * S;
+        Tl[i] = p.table[(long)(v_begin + vl * v_step) * S + j];
+    }
     __syncthreads();
     if (nv <= 0) return;
 
@@ -1485,7 +1492,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_stream_kernel(const WSParams p
     auto load_v = [&](int vl, f32x4 (&g4)[NG], float (&pp)[NG][COT]) {
         vl = vl < nv ? vl : nv - 1;
         const float* gsrc = xb + (long)Tl[vl * S + s_l] * p.x_sv;
-        const float* psrc = pb + (long)vl * p.dp_sv;
+        const float* psrc = pb + (long)vl * v_step * p.dp_sv;
 #pragma unroll
         for (int g = 0; g < NG; ++g)
             g4[g] = C3 ? sh_ld3(gsrc + (long)bcl[g] * p.x_sb) : *reinterpret_cast<const f32x4*>(gsrc + (long)bcl[g] * p.x_sb);
@@ -1680,10 +1687,13 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_split3_kernel(const WSParams p
     const int rc = item / p.ncg, cg = item - rc * p.ncg;
     const int bt = rc / p.nvc, vc = rc - bt * p.nvc;
     const int b0 = bt << p.log2TB;                               // log2TB == 4: a slice of 16 batch entries
-    const int v_begin = vc * p.vpc;
-    const int nv = active ? min(p.vpc, p.R - v_begin) : 0;
+    const int v_begin = p.vstride ? vc : vc * p.vpc, v_step = p.vstride ? p.nvc : 1;      // as wgrad_stream_kernel
+    const int nv = !active ? 0 : p.vstride ? (vc < p.R ? (p.R - vc + p.nvc - 1) / p.nvc : 0) : min(p.vpc, p.R - v_begin);
     const int S = p.S;
-    for (int i = lane; i < nv * S; i += 64) Tl[i] = p.table[(long)v_begin * S + i];
+    for (int i = lane; i < nv * S; i += 64) {
+        const int vl = i / S, j = i - vl * S;
+        Tl[i] = p.table[(long)(v_begin + vl * v_step) * S + j];
+    }
     __syncthreads();
     if (nv <= 0) return;
 
@@ -1705,7 +1715,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_split3_kernel(const WSParams p
         int vv = vl + dv;
         vv = vv < nv ? vv : nv - 1;                              // past the chunk: a valid row; its dpre values are zeroed below
         const float* gsrc = p.x + (long)Tl[vv * S + s_l] * p.x_sv + xo;
-        const float* psrc = pb + (long)vv * p.dp_sv;
+        const float* psrc = pb + (long)vv * v_step * p.dp_sv;
 #pragma unroll
         for (int j = 0; j < 8; ++j) g[j] = *reinterpret_cast<const f32x4*>(gsrc + (long)j * p.x_sb);
 #pragma unroll
@@ -2060,6 +2070,8 @@ int sh_spiral_conv_bwd_wgt_presum(const float* dpre, int64_t dp_sv, int64_t dp_s
         s.log2TB = w.log2TB; s.n_btiles = w.n_btiles; s.nvc = w.nvc; s.vpc = w.vpc; s.ncg = w.ncg;
         s.n_items = w.nrc * w.ncg;
         s.grid_main = sh_cdiv(s.n_items, 4);
+        static const int vstride = sh_env_int("SH_WS_VSTRIDE", 1, 0, 1);
+        s.vstride = vstride;
         // The pre-sum job rides as tail workgroups of this launch when a second wave of the kernel fits beside the first on
         // a SIMD (exact form: up to four channel tiles; bf16x3 form: two) and the rows take 16-byte accesses; otherwise it is
         // the launch of its own it used to be.  Measured: the seven foldable launches of a step were 58 us + their gaps.
