@@ -510,7 +510,8 @@ SH_API int sh_spiral_conv_bwd_data_bf16(const void* dpre, int dp_dtype, int64_t 
  * x is read once and the three-channel gradient is gathered through the TRANSPOSED table - the table and the extended
  * gradient buffer (rows of irregular vertices pre-summed behind the R real rows) that sh_spiral_conv_bwd_data[_bf16] takes,
  * so the caller runs the pre-sum launches first.  dpre_ext fp32 [rows][B][3], x [n_in][B][16] of the path's dtype, both
- * vertex-major and contiguous; needs R == n_in, S <= 10, B % 32 == 0 (sh_spiral_conv_bwd_wgt_thin_ok() tells).  Writes
+ * vertex-major and contiguous; needs R == n_in, B % 16 == 0 and S <= 10 (fp32 path: S <= 30, run as two or three launches over
+ * shares of the positions) - sh_spiral_conv_bwd_wgt_thin_ok() tells.  Writes
  * partial slabs into `workspace` in the layout and count of sh_spiral_conv_bwd_wgt (path_dtype SH_DTYPE_F32) or
  * sh_spiral_conv_bwd_wgt_bf16 (SH_DTYPE_BF16): the matching ..._reduce_multi launch finishes dW and dbias.
  * dx != NULL: the same launch also writes the layer's backward-data (what sh_spiral_conv_bwd_data[_bf16] computes from the

@@ -31,7 +31,8 @@ struct WTParams {
     const char* x; long x_rb;            // x [n_in][B][16], a row contiguous
     const int* tt;                       // table_t [n_in][S]
     float* slab; long slab_stride, bias_off;
-    int B, n_in, S, nblk, n_items, ipw;  // nblk = B / 32 items per vertex; ipw = items per wave
+    int B, n_in, S, nblk, n_items, ipw;  // nblk = ceil(B / 32) items per vertex; ipw = items per wave
+    int half;                            // B % 32 == 16: a vertex's last item holds 16 batch entries (its upper half is masked)
     // optional backward-data of the same layer, from the same staged gradient chunks: dx[u,b,ci] = act'(x[u,b,ci]) * sum_{s,co}
     // dpre_ext[table_t[u,s],b,co] * W[co][s][ci]  (dx null: weight gradient only)
     const float* w;                      // fp32 master weight [3][S * 16]
@@ -95,15 +96,18 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(const WTParams p) {
     int issued = 0;
     auto issue = [&]() {
         const unsigned slot = ring_lds + (unsigned)((issued % R) * STAGE);
-        const char* xs = p.x + (long)iu * p.x_rb + (long)ib * XB + lane * 16;
+        // a half item's upper 16 entries lie behind the row: those lanes re-read the lower half (never read past the buffer; the
+        // consumer masks them)
+        const bool hb = p.half && ib == nblk - 1;
+        const char* xs = p.x + (long)iu * p.x_rb + (long)ib * XB + lane * 16 - ((XB16 && hb && lane >= 32) ? 512 : 0);
         dma16(xs, slot);
-        if (!XB16) dma16(xs + 1024, slot + 1024u);
+        if (!XB16) dma16(hb ? xs : xs + 1024, slot + 1024u);
         const int* tl = Tl + (iu - u_first) * S;
         const long goff = (long)ib * 384;
 #pragma unroll
         for (int q = 0; q < WT_NG; ++q) {
             const int row = cq[q] < S ? tl[cq[q]] : iu;
-            const char* src = p.g + (unsigned long)(unsigned)row * (unsigned long)p.g_rb + goff + oq[q];
+            const char* src = p.g + (unsigned long)(unsigned)row * (unsigned long)p.g_rb + goff + oq[q] - ((hb && oq[q] >= 192) ? 192 : 0);
             // lanes whose 16 bytes lie past the S + 1 chunks stay idle; lane 0 of every instruction is kept so that the
             // instruction (and the vmcnt it is counted with) exists for every S
             if (q * 1024 + lane * 16 < (S + 1) * 384 || lane == 0) dma16(src, slot + (unsigned)(XB + q * 1024));
@@ -151,8 +155,10 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(const WTParams p) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * NL) : "memory");
             issue();
             const char* slot = ring + (st % R) * STAGE;
+            const bool hc = p.half && cb == nblk - 1;                     // half item: entries 16..31 contribute nothing
             if constexpr (XB16) {
-                const bf16x8 fa = tg_tr_frag(slot, 0, 0, lane);           // k order: rows {4g..4g+3} u {16+4g..16+4g+3}
+                bf16x8 fa = tg_tr_frag(slot, 0, 0, lane);                 // k order: rows {4g..4g+3} u {16+4g..16+4g+3}
+                if (hc) { fa[4] = (__bf16)0.f; fa[5] = (__bf16)0.f; fa[6] = (__bf16)0.f; fa[7] = (__bf16)0.f; }
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
                     const char* gp = slot + goffs[nt];
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(const WTParams p) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int b = 4 * j + g4;
-                    const float a = xs[b * 16];
+                    const float a = (hc && j >= 4) ? 0.f : xs[b * 16];
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) {
                         const float gv = *reinterpret_cast<const float*>(slot + goffs[nt] + b * 12);
@@ -177,11 +183,11 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(const WTParams p) {
                     }
                 }
             }
-            if (lane < 24) bsum += *reinterpret_cast<const f32x4*>(slot + self_off);
+            if (lane < (hc ? 12 : 24)) bsum += *reinterpret_cast<const f32x4*>(slot + self_off);
             if (want_dx) {
                 const bool zrow = cu == p.zero_prev;
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
+                for (int h = 0; h < (hc ? 1 : 2); ++h) {
                     const int b = 16 * h + (lane & 15);
                     f32x4 d = {0.f, 0.f, 0.f, 0.f};
                     if constexpr (XB16) {
@@ -264,18 +270,19 @@ static int wt_waves(int nslab, bool b16) {
 extern "C" {
 
 int sh_spiral_conv_bwd_wgt_thin_ok(int B, int n_in, int S, int Cin, int Cout, int path_dtype) {
-    // spirals of 11..20 positions (data-dependent lengths, utils_spiral.py:72-82; BASELINE config 4 forces 18): fp32 path, as two
-    // launches over halves of the positions
-    const int smax = path_dtype == SH_DTYPE_F32 ? 20 : 10;
-    if (!(Cout == 3 && Cin == 16 && S >= 1 && S <= smax && B > 0 && B % 32 == 0 && n_in > 0)) return 0;
+    // spirals of 11..30 positions (data-dependent lengths, utils_spiral.py:72-82; BASELINE config 4 forces 18): fp32 path, as two or
+    // three launches over equal shares of the positions
+    const int smax = path_dtype == SH_DTYPE_F32 ? 30 : 10;
+    if (!(Cout == 3 && Cin == 16 && S >= 1 && S <= smax && B > 0 && B % 16 == 0 && n_in > 0)) return 0;
     static const int on = sh_env_int("SH_WGRAD_THIN", 1, 0, 1);
     if (!on) return 0;
     const int nslab = path_dtype == SH_DTYPE_BF16 ? sh_wgrad_bf16_nsplit(B, n_in, S, Cin, Cout) : sh_wgrad_f32_nsplit(B, n_in, S, Cin, Cout);
     const int nw = wt_waves(nslab, path_dtype == SH_DTYPE_BF16);
-    const long items = (long)n_in * (B / 32);
+    const int nblk = (B + 31) / 32, npass = (S + 9) / 10;
+    const long items = (long)n_in * nblk;
     const long ipw = (items + (long)nslab * nw - 1) / ((long)nslab * nw);
-    const long max_v = WT_TBL_INTS / (S > 10 ? (S + 1) / 2 : S) - 2;      // table lines a wave can hold (per launch)
-    return ipw / (B / 32) + 2 <= max_v;
+    const long max_v = WT_TBL_INTS / ((S + npass - 1) / npass) - 2;        // table lines a wave can hold (per launch)
+    return ipw / nblk + 2 <= max_v;
 }
 
 int sh_spiral_conv_bwd_wgt_thin(const float* dpre_ext, int64_t dp_sv, int64_t dp_sb, const void* x, int x_dtype, int64_t x_sv, int64_t x_sb,
@@ -287,7 +294,7 @@ int sh_spiral_conv_bwd_wgt_thin(const float* dpre_ext, int64_t dp_sv, int64_t dp
     SH_REQUIRE(path_dtype == SH_DTYPE_F32 || path_dtype == SH_DTYPE_BF16, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_wgt_thin: unknown path dtype");
     SH_REQUIRE(x_dtype == path_dtype, SH_ERR_UNSUPPORTED, "sh_spiral_conv_bwd_wgt_thin: x must have the path's dtype");
     SH_REQUIRE(sh_spiral_conv_bwd_wgt_thin_ok(B, n_in, S, Cin, Cout, path_dtype), SH_ERR_UNSUPPORTED,
-               "sh_spiral_conv_bwd_wgt_thin: shape not covered (needs Cout 3, Cin 16, S <= 10 - fp32: 20 -, B %% 32 == 0)");
+               "sh_spiral_conv_bwd_wgt_thin: shape not covered (needs Cout 3, Cin 16, S <= 10 - fp32: 30 -, B %% 16 == 0)");
     const long xe = x_dtype == SH_DTYPE_BF16 ? 2 : 4;
     SH_REQUIRE(dp_sb == 3 && dp_sv == (int64_t)B * 3 && x_sb == 16 && x_sv == (int64_t)B * 16, SH_ERR_UNSUPPORTED,
                "sh_spiral_conv_bwd_wgt_thin: vertex-major contiguous operands required");
@@ -308,7 +315,7 @@ int sh_spiral_conv_bwd_wgt_thin(const float* dpre_ext, int64_t dp_sv, int64_t dp
     p.x = static_cast<const char*>(x); p.x_rb = x_sv * xe;
     p.tt = table_t; p.slab = static_cast<float*>(workspace);
     p.slab_stride = (long)Cout * S * Cin; p.bias_off = (long)nslab * p.slab_stride;
-    p.B = B; p.n_in = n_in; p.S = S; p.nblk = B / 32; p.n_items = n_in * p.nblk;
+    p.B = B; p.n_in = n_in; p.S = S; p.nblk = (B + 31) / 32; p.half = B % 32 == 16; p.n_items = n_in * p.nblk;
     const int nw = wt_waves(nslab, path_dtype == SH_DTYPE_BF16);
     p.ipw = (int)(((long)p.n_items + (long)nslab * nw - 1) / ((long)nslab * nw));
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -325,11 +332,11 @@ int sh_spiral_conv_bwd_wgt_thin(const float* dpre_ext, int64_t dp_sv, int64_t dp
         attr_set[b16] = true;
     }
     // positions in launches of at most 10 (the kernel's two 16-column output tiles hold 3 x 10 columns)
-    const int npass = S > 10 ? 2 : 1, s_first = npass == 2 ? (S + 1) / 2 : S;
+    const int npass = (S + 9) / 10, s_per = (S + npass - 1) / npass;
     p.S_tot = S;
     for (int k = 0; k < npass; ++k) {
-        p.s0 = k == 0 ? 0 : s_first;
-        p.S = k == 0 ? s_first : S - s_first;
+        p.s0 = k * s_per;
+        p.S = k == npass - 1 ? S - p.s0 : s_per;
         p.first = k == 0; p.last = k == npass - 1;
         ShProfScope ps(st, "wgrad_thin_kernel<%s>|R=%d B=%d S=%d Cin=%d N=%d grid=%d waves=%d dx=%d pass=%d/%d", b16 ? "true" : "false", n_in, B, S,
                        Cin, Cout, nslab, nw, dx ? 1 : 0, k + 1, npass);

@@ -33,11 +33,13 @@ def rand_table(R, S, seed):
 
 # (B, R, S): batch blocks 1 / 2 / 3, odd and even spiral lengths (the self chunk lands in either half of a chunk pair),
 # vertex counts that leave waves without work and ragged last ranges
-# spirals of 11..20 (fp32 path only: two launches over halves of the positions; BASELINE config 4 forces 18)
-LONG = [(64, 400, 18), (32, 130, 12), (64, 260, 20), (32, 77, 11)]
+# spirals of 11..30 (fp32 path only: two or three launches over shares of the positions; BASELINE config 4 forces 18)
+LONG = [(64, 400, 18), (32, 130, 12), (64, 260, 20), (32, 77, 11), (48, 150, 22), (32, 90, 30), (16, 60, 21)]
+# batches of 16 (mod 32): a vertex's last item is a half item (the semantic loop's three passes of 16 meshes run as one batch of 48)
+HALF = [(48, 301, 10), (16, 97, 9), (80, 55, 7), (48, 1200, 10), (16, 20, 1)]
 
 
-@pytest.mark.parametrize("B,R,S", [(64, 301, 10), (32, 97, 9), (96, 55, 7), (64, 1200, 10), (32, 20, 1), (64, 700, 4)] + LONG)
+@pytest.mark.parametrize("B,R,S", [(64, 301, 10), (32, 97, 9), (96, 55, 7), (64, 1200, 10), (32, 20, 1), (64, 700, 4)] + LONG + HALF)
 @pytest.mark.parametrize("path", ["f32", "bf16"])
 def test_thin_wgrad_matches_the_ordinary_form(B, R, S, path):
     if path == "bf16" and S > 10:
@@ -79,7 +81,7 @@ def test_thin_wgrad_matches_the_ordinary_form(B, R, S, path):
     assert float((db - dbg).abs().max()) <= (2.0 ** -7 * np.sqrt(R * B) if path == "bf16" else tol * float(dbg.abs().max())) + 1e-4
 
 
-@pytest.mark.parametrize("B,R,S", [(64, 301, 10), (32, 97, 9), (96, 55, 7)] + LONG)
+@pytest.mark.parametrize("B,R,S", [(64, 301, 10), (32, 97, 9), (96, 55, 7)] + LONG + HALF)
 @pytest.mark.parametrize("path", ["f32", "bf16"])
 @pytest.mark.parametrize("act", ["elu", "identity"])
 def test_thin_launch_also_gives_the_input_gradient(B, R, S, path, act):
@@ -118,8 +120,8 @@ def test_thin_launch_also_gives_the_input_gradient(B, R, S, path, act):
 
 
 def test_thin_wgrad_rejects_what_it_does_not_cover():
-    x = torch.zeros((10, 16, 16), device=dev())
-    g = torch.zeros((10, 16, 3), device=dev())
+    x = torch.zeros((10, 24, 16), device=dev())
+    g = torch.zeros((10, 24, 3), device=dev())
     t = torch.zeros((10, 4), dtype=torch.int32, device=dev())
     with pytest.raises(RuntimeError):
-        ops.spiral_conv_bwd_wgt_thin(g, x, t, 10, 4, 16, 3)              # batch not a multiple of 32
+        ops.spiral_conv_bwd_wgt_thin(g, x, t, 10, 4, 16, 3)              # batch not a multiple of 16

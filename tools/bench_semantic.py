@@ -33,7 +33,7 @@ def voronoi_parts(v, k):
     return [np.sort(np.nonzero(owner == j)[0]) for j in range(k)]
 
 
-def run(batch=16, steps=50, graph=False, dev=None, warmup=10):
+def run(batch=16, steps=50, graph=False, dev=None, warmup=10, torch_ops=False):
     """The measurement as a function (bench.py's `secondary` block calls it with graph=True)."""
     a = SimpleNamespace(batch=batch, steps=steps, graph=graph)
     dev = dev or torch.device("cuda:0")
@@ -66,6 +66,24 @@ def run(batch=16, steps=50, graph=False, dev=None, warmup=10):
     for _ in range(warmup):                          # also lets the caching allocator grow to its steady-state pool
         step()
     torch.cuda.synchronize()
+    if torch_ops:                                    # which tensor-library launches are left in the iteration, and where from
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+        rows = {}
+        for e in prof.events():
+            if not e.name.startswith("aten::") or not e.kernels:
+                continue
+            frame = next((f for f in e.stack if "semantichuman_amd" in f or "bench_semantic" in f), e.stack[0] if e.stack else "?")
+            key = (e.name, frame.split("/root/repo/")[-1][:110])
+            r = rows.setdefault(key, [0, 0.0])
+            r[0] += 1
+            r[1] += sum(k.duration for k in e.kernels)
+        for (name, frame), (n, us) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
+            print("%5.1f launches/it %7.1f us/it  %-28s %s" % (n / 3, us / 3, name, frame))
+        return {}
     if a.graph:                                      # fixed edit factor / exchange kind: nothing host-side varies per replay
         sidestream = torch.cuda.Stream()
         sidestream.wait_stream(torch.cuda.current_stream())
@@ -96,8 +114,9 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--graph", action="store_true", help="capture the iteration into a hipGraph and replay it")
+    ap.add_argument("--torch-ops", action="store_true", help="list the tensor-library launches left in the iteration, by call site")
     a = ap.parse_args()
-    print(json.dumps(run(a.batch, a.steps, a.graph)))
+    print(json.dumps(run(a.batch, a.steps, a.graph, torch_ops=a.torch_ops)))
 
 
 if __name__ == "__main__":
