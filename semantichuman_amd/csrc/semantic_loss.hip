@@ -193,30 +193,36 @@ __global__ __launch_bounds__(256) void kps2skl_kernel(const float* __restrict__ 
 }
 
 // bones -> joints, from the root outwards in list order: joint tail[k] = joint head[k] - bone k, joints not assigned yet are the
-// origin (utils_SH.py:77-83); then the kept joints are gathered.  One thread per batch entry (the chain is sequential).
+// origin (utils_SH.py:77-83); then the kept joints are gathered.  The chain is sequential per batch entry; one WAVE per batch
+// entry: the entry's bone rows and the head / tail lists are staged in LDS with coalesced loads first (one thread per entry
+// walking them in global memory, with the joints in scratch, was a chain of ~70 dependent round trips: 49 us for 16 entries),
+// then lanes 0..2 walk the chain, one coordinate each, with the joints in LDS.  The arithmetic is unchanged (same bits).
 // mode 0: bone = skl[:3] * skl[3]   1: skl[:3] of 4   2: skl[:3] of 3
 constexpr int SKL_MAX_J = 64;
 __global__ __launch_bounds__(64) void skl2kps_kernel(const float* __restrict__ skl, const int* __restrict__ head, const int* __restrict__ tail,
                                                      int B, int nb, int n_j, int mode, const int* __restrict__ keep, int n_keep,
                                                      float* __restrict__ out) {
 #pragma clang fp contract(off)
-    const int b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= B) return;
-    float kp[SKL_MAX_J][3];
-    for (int j = 0; j < n_j; ++j) kp[j][0] = kp[j][1] = kp[j][2] = 0.f;
+    __shared__ float row[SKL_MAX_J * 4];
+    __shared__ float kp[SKL_MAX_J * 3];
+    __shared__ int hd[SKL_MAX_J], tl[SKL_MAX_J];
+    const int b = blockIdx.x, lane = threadIdx.x;
     const int w = mode == 2 ? 3 : 4;
     const float* sb = skl + (long)b * nb * w;
-    for (int k = 0; k < nb; ++k) {
-        const float m = mode == 0 ? sb[k * w + 3] : 1.f;
-        const int h = head[k], tl = tail[k];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float bone = mode == 0 ? sb[k * w + c] * m : sb[k * w + c];
-            kp[tl][c] = kp[h][c] - bone;
+    for (int i = lane; i < nb * w; i += 64) row[i] = sb[i];
+    for (int i = lane; i < nb; i += 64) { hd[i] = head[i]; tl[i] = tail[i]; }
+    for (int i = lane; i < n_j * 3; i += 64) kp[i] = 0.f;
+    __syncthreads();
+    if (lane < 3) {
+        const int c = lane;
+        for (int k = 0; k < nb; ++k) {
+            const float bone = mode == 0 ? row[k * w + c] * row[k * w + 3] : row[k * w + c];
+            kp[tl[k] * 3 + c] = kp[hd[k] * 3 + c] - bone;
         }
     }
+    __syncthreads();
     float* o = out + (long)b * n_keep * 3;
-    for (int m = 0; m < n_keep; ++m) { o[3 * m] = kp[keep[m]][0]; o[3 * m + 1] = kp[keep[m]][1]; o[3 * m + 2] = kp[keep[m]][2]; }
+    for (int i = lane; i < n_keep * 3; i += 64) o[i] = kp[keep[i / 3] * 3 + i % 3];
 }
 
 // total = t0 * w0 (w0 == 1: t0 itself) + w1 * t1 + ... in sequence - the loop's `loss = loss + w * term` chain as one launch;
@@ -253,7 +259,8 @@ int sh_skl2kps(const float* skl, int B, int n_bones, int mode, const int32_t* he
     SH_REQUIRE(skl && head && tail && keep && out && B > 0 && n_bones > 0 && n_keep > 0, SH_ERR_INVALID_ARG, "sh_skl2kps: bad argument");
     SH_REQUIRE(mode >= 0 && mode <= 2, SH_ERR_INVALID_ARG, "sh_skl2kps: unknown mode %d", mode);
     SH_REQUIRE(n_joints > 0 && n_joints <= SKL_MAX_J, SH_ERR_UNSUPPORTED, "sh_skl2kps: %d joints (at most %d)", n_joints, SKL_MAX_J);
-    hipLaunchKernelGGL(skl2kps_kernel, dim3((unsigned)sh_cdiv(B, 64)), dim3(64), 0, static_cast<hipStream_t>(stream), skl, head, tail, B, n_bones,
+    SH_REQUIRE(n_bones <= SKL_MAX_J, SH_ERR_UNSUPPORTED, "sh_skl2kps: %d bones (at most %d)", n_bones, SKL_MAX_J);
+    hipLaunchKernelGGL(skl2kps_kernel, dim3((unsigned)B), dim3(64), 0, static_cast<hipStream_t>(stream), skl, head, tail, B, n_bones,
                        n_joints, mode, keep, n_keep, out);
     SH_CHECK_LAUNCH("skl2kps");
     return SH_OK;

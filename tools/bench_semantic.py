@@ -76,8 +76,11 @@ def run(batch=16, steps=50, graph=False, dev=None, warmup=10, torch_ops=False):
         for e in prof.events():
             if not e.name.startswith("aten::") or not e.kernels:
                 continue
-            frame = next((f for f in e.stack if "semantichuman_amd" in f or "bench_semantic" in f), e.stack[0] if e.stack else "?")
-            key = (e.name, frame.split("/root/repo/")[-1][:110])
+            chain, q = [], e.cpu_parent                        # the enclosing operators / autograd nodes say where it comes from
+            while q is not None and len(chain) < 4:
+                chain.append(q.name.replace("autograd::engine::evaluate_function: ", "bwd "))
+                q = q.cpu_parent
+            key = (e.name, " < ".join(chain)[:150])
             r = rows.setdefault(key, [0, 0.0])
             r[0] += 1
             r[1] += sum(k.duration for k in e.kernels)
