@@ -1615,7 +1615,11 @@ WGPlan plan_wgrad(int B, int R, int S, int Cin, int Cout) {
     w.stream = (stream_on && (Cin % 4 == 0 || Cin == 3)) ? 1 : 0;
     w.vpc = 0;
     if (w.stream) {
-        static const int items_target = sh_env_int("SH_WS_ITEMS", 1024, 64, 1 << 20);
+        static const int items_env = sh_env_int("SH_WS_ITEMS", 1024, 64, 1 << 20);
+        // the 16 -> 3 layer's slabs are written by the role-swapped kernel (wgrad_thin.hip: one workgroup of four waves per slab, each
+        // wave paced by the latency of its own load ring): 512 slabs = two waves per SIMD instead of 340 = 1.33 (45 -> 36 us at 6890
+        // vertices, batch 64; the slabs are 1.9 KB each)
+        const int items_target = (Cin == 16 && Cout <= 3 && items_env < 1536) ? 1536 : items_env;
         static const int slab_mb = sh_env_int("SH_WS_SLAB_MB", 32, 1, 4096);
         const int tbs = B <= 4 ? 4 : 16;                       // batch slice: 1 or 4 groups of 4 rows
         w.log2TB = sh_ilog2_floor(tbs);
