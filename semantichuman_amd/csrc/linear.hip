@@ -327,6 +327,109 @@ __global__ __launch_bounds__(LTHREADS) void linear_fwd_stream_kernel(const LSPar
     }
 }
 
+// forward, LDS-DMA form (round 4).  Measured on the kernel above (profiles/r04_fc_experiments.txt): it is paced neither by HBM
+// nor by the matrix pipe - every load instruction fetches 64-byte pieces of 16 rows, i.e. half of 16 different 128-byte lines,
+// the batch operand is fetched once per wave, and one step of loads is all a wave has in flight.  Here a workgroup's four waves
+// are the four 64-column groups of ONE k range (or four neighbouring groups when nothing is split): the batch operand's tile is
+// fetched once per workgroup, every operand streams memory -> LDS with global_load_lds_dwordx4 in WHOLE lines (eight lanes take
+// the eight 16-byte pieces of a row's 128 bytes = 32 k), three stages of 40 KiB (8 KiB shared x + 4 x 8 KiB weight) rotate with
+// one barrier per stage and two stages in flight, and the MFMA fragments are read back with ds_read_b128 (pieces XOR-swizzled
+// by the row so that the sixteen rows of a fragment hit different banks).  Same products in the same order as the kernel
+// above: bit-identical results.
+constexpr int LFD_STAGE = 40 * 1024, LFD_LDS = 3 * LFD_STAGE;
+template <int MT>
+__global__ __launch_bounds__(LTHREADS) void linear_fwd_dma_kernel(const LSParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int item = sh_xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;       // groups % 4 == 0: the four items share sp
+    const int ng = item % p.groups, sp = item / p.groups;
+    const int n0 = ng * 64, k_begin = sp * p.range;
+    const int nst = (min(p.K, k_begin + p.range) - k_begin) >> 5;          // stages of 32 k
+    const int lr = lane & 15, kq = lane >> 4;
+    typedef __attribute__((address_space(3))) char* lptr_t;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_t)smem);
+    auto dma16 = [](const void* gsrc, unsigned lds_dst) {
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory", "m0");
+    };
+    // DMA instruction q of a 64-row tile covers rows 8 q .. 8 q + 7: lane -> row 8 q + (lane >> 3), slot lane & 7 holds piece
+    // slot ^ ((row >> 1) & 7) of the row's eight.  A wave fetches its own weight tile (8 instructions) and a quarter of the
+    // shared x tile (instructions 2 wave, 2 wave + 1).
+    const int drow = lane >> 3;
+    const float* wsrc[8];
+    const float* xsrc[2];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int r = 8 * q + drow, piece = (lane & 7) ^ ((r >> 1) & 7);
+        wsrc[q] = p.w + (long)(n0 + r) * p.K + k_begin + 4 * piece;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = 8 * (2 * wave + j) + drow, piece = (lane & 7) ^ ((r >> 1) & 7);
+        xsrc[j] = p.a + (long)min(r, p.M - 1) * p.K + k_begin + 4 * piece;
+    }
+    auto issue = [&](int st) {
+        const unsigned slot = lds0 + (unsigned)((st % 3) * LFD_STAGE);
+        const int off = 32 * (st < nst ? st : nst - 1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) dma16(xsrc[j] + off, slot + (unsigned)((2 * wave + j) * 1024));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dma16(wsrc[q] + off, slot + (unsigned)(8192 + wave * 8192 + q * 1024));
+    };
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // fragment (tile t, step h of the stage): row 16 t + lr, piece 4 h + kq -> byte (16 t + lr) * 128 + ((4 h + kq) ^ ((lr >> 1) & 7)) * 16
+    const int sw = (lr >> 1) & 7;
+    const int foff0 = lr * 128 + ((kq ^ sw) << 4), foff1 = lr * 128 + (((4 + kq) ^ sw) << 4);
+    if (nst > 0) {                                                          // uniform over the workgroup (same sp)
+        issue(0);
+        issue(1);
+        for (int st = 0; st < nst; ++st) {
+            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");               // this wave's part of stage st has landed (st + 1 may be in flight)
+            __syncthreads();                                                // ... everybody's has; and everybody is done with stage st - 1
+            issue(st + 2);                                                  // into the slot of stage st - 1
+            const char* sl = smem + (st % 3) * LFD_STAGE;
+            const char* wl = sl + 8192 + wave * 8192;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int fo = h == 0 ? foff0 : foff1;
+                f32x4 w4[4], x4[MT];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) w4[nt] = *reinterpret_cast<const f32x4*>(wl + nt * 2048 + fo);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) x4[mt] = *reinterpret_cast<const f32x4*>(sl + mt * 2048 + fo);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[nt][t], x4[mt][t], acc[mt][nt], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // lane holds y[m = 16 mt + lr][n0 + 16 nt + 4 kq .. +3]
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = 16 * mt + lr;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n = n0 + 16 * nt + 4 * kq;
+            f32x4 v = acc[mt][nt];
+            if (p.nsplit > 1) {
+                *reinterpret_cast<f32x4*>(p.slab + ((long)sp * p.M + m) * p.N + n) = v;
+            } else {
+                if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                *reinterpret_cast<f32x4*>(p.out + (long)m * p.N + n) = v;
+            }
+        }
+    }
+}
+
 // backward-data: dx[m][k] = sum_n dy[m][n] W[n][k].  Item = (64 output columns k, n range).  The weight quad runs along
 // the OUTPUT index: lane (a, rr) loads W[nb + 4 rr + e][k0 + 4 a ..+3] for e = 0..3; MFMA (e, t) reduces over the four rows
 // {nb + 4 rr' + e} and produces the columns {k0 + 4 a' + t}.  dy quads run along n: element e pairs with weight row e.
@@ -620,7 +723,27 @@ int run_stream(LSParams& p, const LSPlan& pl, int cols, void* ws, size_t ws_byte
 #define SH_LS_CASE(MTV)                                                                                                   \
     if (FWD) SH_LAUNCH_PS(ps, linear_fwd_stream_kernel<MTV>, dim3(grid), dim3(LTHREADS), 0, st, p);                     \
     else SH_LAUNCH_PS(ps, linear_bwd_data_stream_kernel<MTV>, dim3(grid), dim3(LTHREADS), 0, st, p)
-        if (mt == 1) { SH_LS_CASE(1); } else if (mt == 2) { SH_LS_CASE(2); } else if (mt == 3) { SH_LS_CASE(3); } else { SH_LS_CASE(4); }
+        static const int dma_on = sh_env_int("SH_LIN_DMA", 1, 0, 1);
+        const bool dma = FWD && dma_on && p.K % 32 == 0 && p.range % 32 == 0 && p.groups % 4 == 0;
+        if (dma) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                const void* ks[4] = {reinterpret_cast<const void*>(linear_fwd_dma_kernel<1>), reinterpret_cast<const void*>(linear_fwd_dma_kernel<2>),
+                                     reinterpret_cast<const void*>(linear_fwd_dma_kernel<3>), reinterpret_cast<const void*>(linear_fwd_dma_kernel<4>)};
+                for (const void* k : ks)
+                    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                        (void)hipGetLastError();
+                        sh_set_error("%s: cannot raise the dynamic LDS limit to %d bytes", what, LFD_LDS);
+                        return SH_ERR_LAUNCH;
+                    }
+                attr_set = true;
+            }
+            snprintf(ps.name, sizeof ps.name, "linear_fwd_dma_kernel<%d>|M=%d N=%d K=%d split=%d", mt, p.M, p.N, p.K, p.nsplit);
+            if (mt == 1) SH_LAUNCH_PS(ps, linear_fwd_dma_kernel<1>, dim3(grid), dim3(LTHREADS), LFD_LDS, st, p);
+            else if (mt == 2) SH_LAUNCH_PS(ps, linear_fwd_dma_kernel<2>, dim3(grid), dim3(LTHREADS), LFD_LDS, st, p);
+            else if (mt == 3) SH_LAUNCH_PS(ps, linear_fwd_dma_kernel<3>, dim3(grid), dim3(LTHREADS), LFD_LDS, st, p);
+            else SH_LAUNCH_PS(ps, linear_fwd_dma_kernel<4>, dim3(grid), dim3(LTHREADS), LFD_LDS, st, p);
+        } else if (mt == 1) { SH_LS_CASE(1); } else if (mt == 2) { SH_LS_CASE(2); } else if (mt == 3) { SH_LS_CASE(3); } else { SH_LS_CASE(4); }
 #undef SH_LS_CASE
     }
     if (p.nsplit > 1) {
