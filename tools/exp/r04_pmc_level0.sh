@@ -13,6 +13,6 @@ for set in "$A" "$B" "$C"; do
   timeout 600 rocprofv3 --pmc $set --kernel-trace -d $O/p$i -o p --output-format csv -- python3 tools/layer_report.py 64 > $O/p$i.log 2>&1
 done
 python3 tools/pmc_table.py $O/table.txt $O/p1 $O/p2 $O/p3 > /dev/null 2>&1
-grep -A1 -E "^wgrad_thin|^gather_gemm_kernel<1, true|^conv_out3|^wgrad_stream_kernel<1" $O/table.txt > $O/level0_kernels.txt
+grep -A1 -E "^wgrad_thin|^wgrad_swap|^conv_out3|^wgrad_stream_kernel<1" $O/table.txt > $O/level0_kernels.txt
 rm -rf $O/p1 $O/p2 $O/p3
 wc -l $O/table.txt
