@@ -64,14 +64,15 @@ __device__ __forceinline__ float sh_act_fwd(float v, int act) {
 // ... and its derivative expressed through the activation OUTPUT y, so the backward pass needs
 // nothing but the tensor the next layer consumed anyway (no saved pre-activation).
 __device__ __forceinline__ float sh_act_grad_from_out(float y, int act) {
-    switch (act) {
-        case SH_ACT_RELU: return y > 0.f ? 1.f : 0.f;
-        case SH_ACT_ELU: return y > 0.f ? 1.f : y + 1.f;          // exp(x) = elu(x) + 1 for x <= 0
-        case SH_ACT_LEAKY_RELU: return y > 0.f ? 1.f : 0.02f;
-        case SH_ACT_SIGMOID: return y * (1.f - y);
-        case SH_ACT_TANH: return 1.f - y * y;
-        default: return 1.f;
-    }
+    // SELECT form, no switch: `act` is wave-uniform, and a switch becomes a chain of scalar branches that the epilogues and the
+    // role-swapped weight-gradient kernels would run once per element (measured in wgrad_thin: ~40 taken branches per item).  Every
+    // candidate is a couple of VALU operations; the expressions are the ones the switch had (same bits).
+    const float neg = act == SH_ACT_ELU ? y + 1.f : act == SH_ACT_LEAKY_RELU ? 0.02f : 0.f;          // exp(x) = elu(x) + 1 for x <= 0
+    const float piece = y > 0.f ? 1.f : neg;
+    const float smooth = act == SH_ACT_SIGMOID ? y * (1.f - y) : 1.f - y * y;
+    const bool is_piece = act == SH_ACT_RELU || act == SH_ACT_ELU || act == SH_ACT_LEAKY_RELU;
+    const bool is_smooth = act == SH_ACT_SIGMOID || act == SH_ACT_TANH;
+    return is_piece ? piece : is_smooth ? smooth : 1.f;
 }
 
 // XCD-aware work-item order.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8
