@@ -1461,9 +1461,13 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_stream_kernel(const WSParams p
     const int v_begin = p.vstride ? vc : vc * p.vpc, v_step = p.vstride ? p.nvc : 1;      // vertex of local index vl: v_begin + vl * v_step
     const int nv = !active ? 0 : p.vstride ? (vc < p.R ? (p.R - vc + p.nvc - 1) / p.nvc : 0) : min(p.vpc, p.R - v_begin);
     const int S = p.S;
+    // table lines, PRE-MULTIPLIED by the row stride of x (in 16-byte units - the stride is a multiple of 4 floats - so that 32 bits
+    // reach 64 GB; the 3-channel form in elements, its launcher checks the range): the gather
+    // addresses of a vertex are then one add away from the LDS read instead of behind two 64-bit multiplies - these kernels live
+    // on how early their gathers are issued
     for (int i = lane; i < nv * S; i += 64) {
         const int vl = i / S, j = i - vl * S;
-        Tl[i] = p.table[(long)(v_begin + vl * v_step) * S + j];
+        Tl[i] = (int)((unsigned)p.table[(long)(v_begin + vl * v_step) * S + j] * (unsigned)(C3 ? p.x_sv : p.x_sv >> 2));
     }
     __syncthreads();
     if (nv <= 0) return;
@@ -1481,25 +1485,29 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_stream_kernel(const WSParams p
         bok |= (b < p.B ? 1u : 0u) << g;
         bcl[g] = b < p.B ? b : p.B - 1;
     }
-    const float* xb = p.x + c_l;
     const float* pb = p.dpre + (long)v_begin * p.dp_sv;
     int pco[COT];
 #pragma unroll
     for (int b = 0; b < COT; ++b) pco[b] = min(p.co0 + 16 * b + la, p.Cout - 1);      // channels past Cout: duplicate, never stored
+    // loop-invariant parts of the addresses, formed once: x column + batch entry, dpre batch entry
+    const float* xg[NG];
+    long pbo[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) { xg[g] = p.x + c_l + (long)bcl[g] * p.x_sb; pbo[g] = (long)bcl[g] * p.dp_sb; }
+    const long pv_step = (long)v_step * p.dp_sv;
 
     f32x4 gr[DEPTH][NG];
     float pr[DEPTH][NG][COT];
     auto load_v = [&](int vl, f32x4 (&g4)[NG], float (&pp)[NG][COT]) {
         vl = vl < nv ? vl : nv - 1;
-        const float* gsrc = xb + (long)Tl[vl * S + s_l] * p.x_sv;
-        const float* psrc = pb + (long)vl * v_step * p.dp_sv;
+        const long goff = C3 ? (long)Tl[vl * S + s_l] : (long)(unsigned)Tl[vl * S + s_l] << 2;
+        const float* psrc = pb + (long)vl * pv_step;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) g4[g] = C3 ? sh_ld3(xg[g] + goff) : *reinterpret_cast<const f32x4*>(xg[g] + goff);
 #pragma unroll
         for (int g = 0; g < NG; ++g)
-            g4[g] = C3 ? sh_ld3(gsrc + (long)bcl[g] * p.x_sb) : *reinterpret_cast<const f32x4*>(gsrc + (long)bcl[g] * p.x_sb);
 #pragma unroll
-        for (int g = 0; g < NG; ++g)
-#pragma unroll
-            for (int b = 0; b < COT; ++b) pp[g][b] = psrc[(long)bcl[g] * p.dp_sb + pco[b]];
+            for (int b = 0; b < COT; ++b) pp[g][b] = psrc[pbo[g] + pco[b]];
     };
 
     f32x4 acc[4][COT];
@@ -2067,6 +2075,8 @@ int sh_spiral_conv_bwd_wgt_presum(const float* dpre, int64_t dp_sv, int64_t dp_s
     if (w.stream) {
         SH_REQUIRE(Cin == 3 || ((x_sv % 4 == 0) && (x_sb % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0)), SH_ERR_UNSUPPORTED,
                    "sh_spiral_conv_bwd_wgt: x must be 16-byte aligned with strides that are multiples of 4 floats");
+        SH_REQUIRE(Cin != 3 || (long)2 * (R + 1) * x_sv < 0x7fffffffL, SH_ERR_UNSUPPORTED,
+                   "sh_spiral_conv_bwd_wgt: 3-channel input too large for 32-bit row offsets (R %d, row stride %ld)", R, (long)x_sv);
         WSParams s{};
         s.dpre = dpre; s.dp_sv = dp_sv; s.dp_sb = dp_sb; s.x = x; s.x_sv = x_sv; s.x_sb = x_sb; s.table = table;
         s.slab = p.slab; s.slab_stride = p.slab_stride; s.bias_off = p.bias_off;
