@@ -214,7 +214,9 @@ __global__ __launch_bounds__(256) void wgrad_bf16_dma_kernel(const BDParams p) {
     if (nst > 0) {   // this wave's table lines -> LDS (ordinary loads, finished before the DMA loop starts)
         const int v_last = (int)(((st0 + nst) * 32 - 1) / B);
         const int n = (v_last - v_first + 1) * S;
-        for (int i = lane; i < n; i += 64) Tl[i] = p.table[(long)v_first * S + i];
+        // pre-multiplied by the row stride of x in 16-byte units (the stride is a multiple of 16 bytes; 32 bits reach 64 GB): the
+        // gather addresses are one shift and add away from the LDS read instead of behind a 64-bit multiply each
+        for (int i = lane; i < n; i += 64) Tl[i] = (int)((unsigned)p.table[(long)v_first * S + i] * (unsigned)(p.x_rb >> 4));
     }
     // per 16-column block: (spiral position, first channel); blocks past K / Cout duplicate block 0 (their products are never stored)
     int s_blk[QT], c_blk[QT], co_blk[PT];
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_dma_kernel(const BDParams p) {
         const char* xb = p.x + (long)ib * p.x_bb + 2 * half8;
         const char* db = p.dpre + (long)iv * p.dp_rb + (long)ib * p.dp_bb + 2 * half8;
 #pragma unroll
-        for (int k = 0; k < QT; ++k) dma16(xb + (unsigned long)(unsigned)tl[s_blk[k]] * (unsigned long)p.x_rb + 2 * c_blk[k], slot + (unsigned)(k * TG_TR_BLK));
+        for (int k = 0; k < QT; ++k) dma16(xb + ((unsigned long)(unsigned)tl[s_blk[k]] << 4) + 2 * c_blk[k], slot + (unsigned)(k * TG_TR_BLK));
 #pragma unroll
         for (int k = 0; k < PT; ++k) dma16(db + 2 * co_blk[k], slot + (unsigned)((QT + k) * TG_TR_BLK));
         ++issued;
