@@ -384,20 +384,25 @@ __global__ __launch_bounds__(1024 / RT) void conv_p3s_kernel(const P3Params p) {
             }
             if (BWD && ++cc >= p.ncg) { cc = 0; if (cs + 1 < S) ++cs; }
             if (!any) return;
+            // one scalar branch per (channel tile, row tile) instead of one around every MFMA (two branches per MFMA in the
+            // instruction stream: 366 around 192 MFMAs), the products of an accumulator in ascending magnitude (weight plane,
+            // x plane) as ONE chain: v_mfma_f32_16x16x32_bf16 issues every 16 cycles on one accumulator, every 22 on rotating ones
+            // (tools/exp/mfma_rate.hip)
+            constexpr int PW[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0}, PX[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0};
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 const u32x4 r0 = wk[n * 192], r1 = wk[n * 192 + 64], r2 = wk[n * 192 + 128];
                 const bf16x8 w[3] = {*reinterpret_cast<const bf16x8*>(&r0), *reinterpret_cast<const bf16x8*>(&r1),
                                      *reinterpret_cast<const bf16x8*>(&r2)};
-                // products in ascending magnitude (weight plane, x plane); the RT accumulators alternate, so consecutive MFMAs
-                // are independent
-                constexpr int PW[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0}, PX[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0};
 #pragma unroll
-                for (int q = 9 - NP; q < 9; ++q)
+                for (int m = 0; m < RT; ++m) {
+                    if (RT > 1 && !live[m]) continue;
+                    f32x4 c = acc[m][n];
 #pragma unroll
-                    for (int m = 0; m < RT; ++m)
-                        if (RT == 1 || live[m])
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[PW[q]], *reinterpret_cast<const bf16x8*>(&a[m][PX[q]]), acc[m][n], 0, 0, 0);
+                    for (int q = 9 - NP; q < 9; ++q)
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[PW[q]], *reinterpret_cast<const bf16x8*>(&a[m][PX[q]]), c, 0, 0, 0);
+                    acc[m][n] = c;
+                }
             }
         };
         // chunk 0 of the weight -> buffer 0 (the previous round's last reads of it ended before that round's last barrier)
