@@ -271,8 +271,7 @@ __global__ __launch_bounds__(1024) void conv_bf16_kernel(const BCParams p) {
                             a += *reinterpret_cast<const f32x4*>(p.bias + c0);
                         }
                     }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) a[j] = sh_act_fwd(a[j], p.act);
+                    a = sh_act_fwd4(a, p.act);
                 } else if (yp) {
                     const f32x4 yv = sh_from_bf16x4(*reinterpret_cast<const bf16x4*>(yp + 2 * c0));
 #pragma unroll

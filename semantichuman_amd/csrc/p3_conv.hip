@@ -270,8 +270,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(P3_WAVES_P
                 f32x4 a = acc[m][n];
                 if (!BWD) {
                     if (p.bias) a += *reinterpret_cast<const f32x4*>(p.bias + c0);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) a[j] = sh_act_fwd(a[j], p.act);
+                    a = sh_act_fwd4(a, p.act);
                 } else if (p.yprev) {
                     const f32x4 yv = *reinterpret_cast<const f32x4*>(p.yprev + (long)v * p.yv_sv + (long)b * p.yv_sb + c0);
 #pragma unroll
@@ -449,8 +448,7 @@ __global__ __launch_bounds__(1024 / RT) void conv_p3s_kernel(const P3Params p) {
                 f32x4 a = acc[m][n];
                 if (!BWD) {
                     if (p.bias) a += *reinterpret_cast<const f32x4*>(p.bias + c0);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) a[j] = sh_act_fwd(a[j], p.act);
+                    a = sh_act_fwd4(a, p.act);
                 } else if (p.yprev) {
                     const f32x4 yv = *reinterpret_cast<const f32x4*>(p.yprev + (long)v * p.yv_sv + (long)b * p.yv_sb + c0);
 #pragma unroll

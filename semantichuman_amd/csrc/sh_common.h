@@ -61,6 +61,18 @@ __device__ __forceinline__ float sh_act_fwd(float v, int act) {
         default: return v;
     }
 }
+// A quad at once: ONE wave-uniform branch per four elements instead of the switch per element (the conv epilogues ran a chain
+// of scalar branches for each of up to 32 elements per lane and item), the model's own activation (ELU) tested first.
+__device__ __forceinline__ f32x4 sh_act_fwd4(f32x4 a, int act) {
+    if (act == SH_ACT_ELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = a[j] > 0.f ? a[j] : expm1f(a[j]);
+    } else if (act != SH_ACT_IDENTITY) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = sh_act_fwd(a[j], act);
+    }
+    return a;
+}
 // ... and its derivative expressed through the activation OUTPUT y, so the backward pass needs
 // nothing but the tensor the next layer consumed anyway (no saved pre-activation).
 __device__ __forceinline__ float sh_act_grad_from_out(float y, int act) {

@@ -300,8 +300,7 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_kernel(const GGParams p)
             if (p.vec_out) {
                 if (!BWD_EPI) {
                     if (p.bias) a += *reinterpret_cast<const f32x4*>(p.bias + n0);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) a[j] = sh_act_fwd(a[j], p.act);
+                    a = sh_act_fwd4(a, p.act);
                 } else if (yp) {
                     const f32x4 yv = *reinterpret_cast<const f32x4*>(yp + n0);
 #pragma unroll
@@ -541,8 +540,7 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_direct_kernel(const GGPa
             if (p.vec_out) {
                 if (!BWD_EPI) {
                     if (p.bias) a += *reinterpret_cast<const f32x4*>(p.bias + n0);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) a[j] = sh_act_fwd(a[j], p.act);
+                    a = sh_act_fwd4(a, p.act);
                 } else if (yp) {
                     const f32x4 yv = *reinterpret_cast<const f32x4*>(yp + n0);
 #pragma unroll
@@ -755,8 +753,7 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_split3_kernel(const GGPa
             f32x4 a = acc[m][n];
             if (!BWD_EPI) {
                 if (p.bias) a += *reinterpret_cast<const f32x4*>(p.bias + n0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) a[j] = sh_act_fwd(a[j], p.act);
+                a = sh_act_fwd4(a, p.act);
             } else if (yp) {
                 const f32x4 yv = *reinterpret_cast<const f32x4*>(yp + n0);
 #pragma unroll
