@@ -94,13 +94,17 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(P3_WAVES_P
     const int S = p.S, sl = lane < S ? lane : S - 1;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
+    const unsigned rowmul = (unsigned)(p.x_vb >> 4);
+    const int skip_key = F32R ? p.skip_row : (int)((unsigned)p.skip_row * rowmul);      // what a "no source" entry looks like in tv[]
     auto load_table = [&](int t, int (&tv)[RT]) {
         const int tt = t < t_end ? t : (t_end > 0 ? t_end - 1 : 0);
         const int vg = tt % p.n_vg;
 #pragma unroll
         for (int m = 0; m < RT; ++m) {
             const int v = vg * RT + m < p.R ? vg * RT + m : p.R - 1;
-            tv[m] = p.table[(long)v * S + sl];
+            // (without fp32-only rows the entry is kept PRE-MULTIPLIED by the image's row stride in 16-byte units: a gather address
+            // is a shift and an add away from the v_readlane instead of behind a 64-bit multiply)
+            tv[m] = F32R ? p.table[(long)v * S + sl] : (int)((unsigned)p.table[(long)v * S + sl] * rowmul);
         }
     };
 
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(P3_WAVES_P
                     const int row = __builtin_amdgcn_readlane(tv[m], s);
                     const bool f32row = F32R && row >= p.n_img;                   // wave-uniform
                     const char* src = f32row ? reinterpret_cast<const char*>(p.xf + (long)row * p.xf_sv + (long)(bs * 16 + r16) * p.xf_sb + lc * 32 + kq * 8)
-                                             : xl + (long)row * p.x_vb + (long)lc * 3072;
+                                             : xl + (F32R ? (long)row * p.x_vb : (long)((unsigned long)(unsigned)row << 4)) + (long)lc * 3072;
                     const int o1 = f32row ? 16 : PB, o2 = f32row ? 0 : 2 * PB;
                     a[m][0] = *reinterpret_cast<const u32x4*>(src);
                     a[m][1] = *reinterpret_cast<const u32x4*>(src + o1);
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(P3_WAVES_P
                     const int row = (kq & 2) ? r1 : r0;
                     const bool f32row = F32R && row >= p.n_img;                   // per half-wave
                     const char* src = f32row ? reinterpret_cast<const char*>(p.xf + (long)row * p.xf_sv + (long)(bs * 16 + r16) * p.xf_sb + (kq & 1) * 8)
-                                             : xl + (long)row * p.x_vb;
+                                             : xl + (F32R ? (long)row * p.x_vb : (long)((unsigned long)(unsigned)row << 4));
                     const int o1 = f32row ? 16 : PB, o2 = f32row ? 0 : 2 * PB;
                     a[m][0] = *reinterpret_cast<const u32x4*>(src);
                     a[m][1] = *reinterpret_cast<const u32x4*>(src + o1);
@@ -184,10 +188,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(P3_WAVES_P
                 if constexpr (BWD) {
                     if (p.skip_row >= 0) {
                         if constexpr (!C16) {
-                            live[m] = __builtin_amdgcn_readlane(tv[m], cs) != p.skip_row;
+                            live[m] = __builtin_amdgcn_readlane(tv[m], cs) != skip_key;
                         } else {
                             const int s1 = cs + 1 < S ? cs + 1 : cs;
-                            live[m] = __builtin_amdgcn_readlane(tv[m], cs) != p.skip_row || __builtin_amdgcn_readlane(tv[m], s1) != p.skip_row;
+                            live[m] = __builtin_amdgcn_readlane(tv[m], cs) != skip_key || __builtin_amdgcn_readlane(tv[m], s1) != skip_key;
                         }
                     }
                 }
@@ -338,6 +342,8 @@ __global__ __launch_bounds__(1024 / RT) void conv_p3s_kernel(const P3Params p) {
         wdst[j] = f * 64 + lane;
     }
     const int wchunk = P3S_KC * p.nt_tot * 192;
+    const unsigned rowmul = (unsigned)(p.x_vb >> 4);
+    const int skip_key = (int)((unsigned)p.skip_row * rowmul);
     const int rounds = (t_end - t_begin - lj * WAVES + stride - 1) / stride;      // of wave 0 of this workgroup: the most any wave has
     int t = t_begin + lj * WAVES + wave;
     for (int rd = 0; rd < rounds; ++rd, t += stride) {
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(1024 / RT) void conv_p3s_kernel(const P3Params p) {
         const int v0 = vg * RT;
         int tv[RT];
 #pragma unroll
-        for (int m = 0; m < RT; ++m) tv[m] = p.table[(long)(v0 + m < p.R ? v0 + m : p.R - 1) * S + sl];
+        for (int m = 0; m < RT; ++m) tv[m] = (int)((unsigned)p.table[(long)(v0 + m < p.R ? v0 + m : p.R - 1) * S + sl] * rowmul);      // pre-multiplied, as in conv_p3_kernel
         const char* xl = p.xp + (long)bs * p.x_bgb + lane * 16;
         int ls = 0, lc = 0;
         u32x4 ring[D][RT][3];
@@ -358,7 +364,7 @@ __global__ __launch_bounds__(1024 / RT) void conv_p3s_kernel(const P3Params p) {
                 const int row = __builtin_amdgcn_readlane(tv[m], s);
                 const bool f32row = false;                                        // (this form's layers image their pre-summed rows)
                 const char* src = f32row ? reinterpret_cast<const char*>(p.xf + (long)row * p.xf_sv + (long)(bs * 16 + r16) * p.xf_sb + lc * 32 + kq * 8)
-                                         : xl + (long)row * p.x_vb + (long)lc * 3072;
+                                         : xl + (long)((unsigned long)(unsigned)row << 4) + (long)lc * 3072;
                 const int o1 = f32row ? 16 : 1024, o2 = f32row ? 0 : 2048;
                 a[m][0] = *reinterpret_cast<const u32x4*>(src);
                 a[m][1] = *reinterpret_cast<const u32x4*>(src + o1);
@@ -378,7 +384,7 @@ __global__ __launch_bounds__(1024 / RT) void conv_p3s_kernel(const P3Params p) {
 #pragma unroll
             for (int m = 0; m < RT; ++m) {
                 const int row = BWD ? __builtin_amdgcn_readlane(tv[m], cs) : 0;
-                live[m] = !BWD || p.skip_row < 0 || row != p.skip_row;
+                live[m] = !BWD || p.skip_row < 0 || row != skip_key;
                 any = any || live[m];
             }
             if (BWD && ++cc >= p.ncg) { cc = 0; if (cs + 1 < S) ++cs; }
