@@ -1626,7 +1626,11 @@ WGPlan plan_wgrad(int B, int R, int S, int Cin, int Cout) {
         // vertices, batch 64; the slabs are 1.9 KB each)
         const int items_target = (Cin == 16 && Cout <= 3 && items_env < 1536) ? 1536 : items_env;
         static const int slab_mb = sh_env_int("SH_WS_SLAB_MB", 32, 1, 4096);
-        const int tbs = B <= 4 ? 4 : 16;                       // batch slice: 1 or 4 groups of 4 rows
+        // batch slice: 1 or 4 groups of 4 rows; 8 groups for ONE channel tile (a vertex is then 32 MFMAs instead of 16 behind the
+        // same table read and address arithmetic: 69.5 -> 62 us on the level-0 32 -> 16 layer; with two tiles the registers of the
+        // deeper prefetch cost more than that: 72 -> 78 us.  SH_WS_TBS=16 keeps the narrow slice everywhere)
+        static const int tbs_env = sh_env_int("SH_WS_TBS", 32, 16, 32);
+        const int tbs = B <= 4 ? 4 : (tbs_env == 32 && B % 32 == 0 && Cout <= 16 && Cin != 3) ? 32 : 16;
         w.log2TB = sh_ilog2_floor(tbs);
         w.n_btiles = sh_cdiv(B, tbs);
         w.ncg = sh_cdiv(Cin == 3 ? 4 * S : K, 64);            // 3-channel inputs: columns counted in padded quads
@@ -1841,6 +1845,9 @@ int dispatch_ws(const WSParams& p, hipStream_t st) {
     const bool full = (p.B & ((1 << p.log2TB) - 1)) == 0;
     if ((COT == 2 || COT == 4) && ws_uses_split3(COT, p)) return launch_ws3<(COT == 4 ? 4 : 2)>(p, st);
     if (p.log2TB == 2) return full ? launch_ws<COT, 1, true>(p, st) : launch_ws<COT, 1, false>(p, st);
+    if constexpr (COT == 1) {
+        if (p.log2TB == 5) return launch_ws<COT, 8, true>(p, st);
+    }
     return full ? launch_ws<COT, 4, true>(p, st) : launch_ws<COT, 4, false>(p, st);
 }
 
