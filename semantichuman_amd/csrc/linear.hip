@@ -327,7 +327,7 @@ __global__ __launch_bounds__(LTHREADS) void linear_fwd_stream_kernel(const LSPar
     }
 }
 
-// forward, LDS-DMA form (round 4).  Measured on the kernel above (profiles/r04_fc_experiments.txt): it is paced neither by HBM
+// forward, LDS-DMA form (round 4).  Measured on the kernel above (profiles/r04_kernel_experiments.txt): it is paced neither by HBM
 // nor by the matrix pipe - every load instruction fetches 64-byte pieces of 16 rows, i.e. half of 16 different 128-byte lines,
 // the batch operand is fetched once per wave, and one step of loads is all a wave has in flight.  Here a workgroup's four waves
 // are the four 64-column groups of ONE k range (or four neighbouring groups when nothing is split): the batch operand's tile is
