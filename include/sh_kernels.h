@@ -605,6 +605,11 @@ SH_API int sh_conv_wfrag3_prep_multi(int n_layers, const float* const* weight, v
 SH_API int sh_spiral_conv_p3_ok(int B, int S, int Cg, int Nout);
 /* 0: not taken; 1: LDS-resident weight (backward-data also takes rows without an image: dpre_f32 below); 2: streamed weight */
 SH_API int sh_spiral_conv_p3_kind(int B, int S, int Cg, int Nout);
+/* Diagnostics (like sh_profile_*; selects nothing): the number of plane-conv kernel launches (conv_p3 / conv_p3s, forward and
+ * backward-data) this process has issued so far.  A caller that asked for SH_MMA_PLANES3 can tell whether the plane kernels
+ * really ran or the SPLIT3 kernels served the call (batch not a multiple of 16, shapes sh_spiral_conv_p3_ok() refuses):
+ * tests/conftest.py reports the [planes3] instance of a test that never moved this counter as skipped, not passed. */
+SH_API int64_t sh_p3_launch_count(void);
 /* sh_spmm that also writes the plane image of the rows it produces (y_planes: image of row 0 of y; NULL = plain sh_spmm) */
 SH_API int sh_spmm_p3(const int32_t* rowptr, const int32_t* col, const float* val, const float* x, int64_t x_sv, int64_t x_sb,
                       float* y, int64_t y_sv, int64_t y_sb, void* y_planes, const float* yprev, int64_t yp_sv, int64_t yp_sb,

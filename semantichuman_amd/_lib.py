@@ -101,6 +101,7 @@ SIGNATURES = {
     "sh_conv_wfrag3_prep_multi": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P]),
     "sh_spiral_conv_p3_ok": (c_int, [_I, _I, _I, _I]),
     "sh_spiral_conv_p3_kind": (c_int, [_I, _I, _I, _I]),
+    "sh_p3_launch_count": (c_int64, []),
     "sh_spiral_conv_fwd_img": (c_int, [_P, _L, _L, _P, _P, _P, _P, _L, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sh_act_backward_tr_img": (c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "sh_spmm_p3": (c_int, [_P, _P, _P, _P, _L, _L, _P, _L, _L, _P, _P, _L, _L, _I, _I, _I, _I, _I, _P]),

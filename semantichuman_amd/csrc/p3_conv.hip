@@ -27,9 +27,12 @@
 // in flight, no barrier in the loop, table line of a vertex in one VGPR across the wave (v_readlane -> scalar row base).
 #include "sh_bf16.h"
 
+#include <atomic>
 #include <type_traits>
 
 namespace {
+
+std::atomic<long> g_p3_launches{0};                // sh_p3_launch_count(): diagnostics only
 
 struct P3Params {
     const char* xp; long x_vb, x_bgb;          // plane image of the gathered tensor: bytes per row / per 16-batch group
@@ -607,6 +610,7 @@ int launch_p3s(P3Params& p, hipStream_t st) {
                    p.Nout, grid, WAVES * 64);
     SH_LAUNCH_PS(ps, kern, dim3(grid), dim3(WAVES * 64), smem, st, p);
     SH_CHECK_LAUNCH("conv_p3s");
+    g_p3_launches.fetch_add(1, std::memory_order_relaxed);
     return SH_OK;
 }
 template <bool BWD, int NP>
@@ -647,6 +651,7 @@ int launch_p3(P3Params& p, hipStream_t st) {
                    BWD ? "true" : "false", NP, F32R ? "true" : "false", p.R, p.B, p.S * p.Cg, p.Nout, grid, nw * 64);
     SH_LAUNCH_PS(ps, kern, dim3(grid), dim3(nw * 64), smem, st, p);
     SH_CHECK_LAUNCH("conv_p3");
+    g_p3_launches.fetch_add(1, std::memory_order_relaxed);
     return SH_OK;
 }
 
@@ -758,6 +763,8 @@ int sh_conv_wfrag3_prep_multi(int n_layers, const float* const* weight, void* co
     }
     return SH_OK;
 }
+
+int64_t sh_p3_launch_count(void) { return (int64_t)g_p3_launches.load(std::memory_order_relaxed); }
 
 int sh_spiral_conv_p3_ok(int B, int S, int Cg, int Nout) { return p3_shape_ok(B, S, Cg, Nout) ? 1 : 0; }
 int sh_spiral_conv_p3_kind(int B, int S, int Cg, int Nout) {

@@ -1389,6 +1389,13 @@ struct WSParams {
     // (the waves of an XCD walk the mesh TOGETHER: at any time they gather from ~nvc neighbouring vertices, which stay in the
     // XCD's L2, instead of from one block of vpc vertices each - measured: the level-0 launch fetched 270 MB for 85 MB of input)
     int vstride;
+    // vstride == 2 (round 5): the strided walk INSIDE one vertex range per XCD.  With 1 / 2 / 4 / 8 batch slices, G = 8 / slices
+    // XCDs share a slice; the plain strided walk had each of them stream EVERY vertex of the slice through its own L2 (PMC: the
+    // level-0 launch fetched 318 MB for 85 MB of input = the G = 4 XCDs of a slice each reading all of it).  Here XCD x (= blockIdx & 7:
+    // workgroups are dealt round-robin) owns batch slice x / G and the vertex range [(x % G) Vg, (x % G + 1) Vg) of it; its cpg row
+    // chunks walk that range together (chunk j: lo + j, lo + j + cpg, ...), its items are (chunk, column group) pairs, slab index
+    // x cpg + j.  Every gathered row is then fetched by ONE XCD (plus the range borders' neighbours).
+    int xg_G, xg_cpg, xg_Vg;
     // tail job (sh_spiral_conv_bwd_wgt_presum): workgroups grid_main .. grid_main + tail_blocks - 1 of the launch fill the
     // pre-summed rows the layer's backward-data pass reads through its transposed table - y[r] = sum_e val[e] dpre[col[e]],
     // sh_spmm's arithmetic entry for entry - beside the weight-gradient workgroups instead of in a launch of their own
@@ -1442,6 +1449,36 @@ __device__ __forceinline__ void ws_presum_tail(const WSParams& p) {
     }
 }
 
+// work item of a wave: (slab index rc, column group cg, first batch entry, vertices v_begin + vl * v_step for vl < nv)
+struct WSItem { bool active; int rc, cg, b0, v_begin, v_step, nv; };
+__device__ __forceinline__ WSItem ws_item(const WSParams& p, int wave) {
+    WSItem it;
+    if (p.vstride == 2) {
+        const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+        const int local = li * 4 + wave;
+        it.active = local < p.xg_cpg * p.ncg;
+        const int l2 = it.active ? local : 0;
+        const int j = l2 / p.ncg;
+        it.cg = l2 - j * p.ncg;
+        const int bt = xcd / p.xg_G, g = xcd - bt * p.xg_G;
+        const int lo = g * p.xg_Vg, hi = min(p.R, lo + p.xg_Vg);
+        it.rc = xcd * p.xg_cpg + j;
+        it.b0 = bt << p.log2TB;
+        it.v_begin = lo + j; it.v_step = p.xg_cpg;
+        it.nv = (it.active && it.v_begin < hi) ? (hi - it.v_begin + p.xg_cpg - 1) / p.xg_cpg : 0;
+        return it;
+    }
+    const int item_raw = sh_xcd_remap(blockIdx.x, p.grid_main) * 4 + wave;
+    it.active = item_raw < p.n_items;
+    const int item = it.active ? item_raw : 0;
+    it.rc = item / p.ncg; it.cg = item - it.rc * p.ncg;
+    const int bt = it.rc / p.nvc, vc = it.rc - bt * p.nvc;
+    it.b0 = bt << p.log2TB;
+    it.v_begin = p.vstride ? vc : vc * p.vpc; it.v_step = p.vstride ? p.nvc : 1;      // vertex of local index vl: v_begin + vl * v_step
+    it.nv = !it.active ? 0 : p.vstride ? (vc < p.R ? (p.R - vc + p.nvc - 1) / p.nvc : 0) : min(p.vpc, p.R - it.v_begin);
+    return it;
+}
+
 // C3: Cin == 3, columns counted in zero-padded quads (k' = 4 s + c), dwordx3 gathers, scalar slab stores.
 template <int COT, int NG, int DEPTH, bool FULL, bool C3 = false>
 __global__ __launch_bounds__(NTHREADS) void wgrad_stream_kernel(const WSParams p) {
@@ -1449,14 +1486,8 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_stream_kernel(const WSParams p
     if ((int)blockIdx.x >= p.grid_main) { ws_presum_tail(p); return; }    // tail job (whole workgroups; before any barrier)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int* Tl = reinterpret_cast<int*>(smem) + wave * p.vpc * p.S;          // this wave's table lines
-    const int item_raw = sh_xcd_remap(blockIdx.x, p.grid_main) * 4 + wave;
-    const bool active = item_raw < p.n_items;
-    const int item = active ? item_raw : 0;
-    const int rc = item / p.ncg, cg = item - rc * p.ncg;
-    const int bt = rc / p.nvc, vc = rc - bt * p.nvc;
-    const int b0 = bt << p.log2TB;
-    const int v_begin = p.vstride ? vc : vc * p.vpc, v_step = p.vstride ? p.nvc : 1;      // vertex of local index vl: v_begin + vl * v_step
-    const int nv = !active ? 0 : p.vstride ? (vc < p.R ? (p.R - vc + p.nvc - 1) / p.nvc : 0) : min(p.vpc, p.R - v_begin);
+    const WSItem wi = ws_item(p, wave);
+    const int rc = wi.rc, cg = wi.cg, b0 = wi.b0, v_begin = wi.v_begin, v_step = wi.v_step, nv = wi.nv;
     const int S = p.S;
     // table lines, PRE-MULTIPLIED by the row stride of x (in 16-byte units - the stride is a multiple of 4 floats - so that 32 bits
     // reach 64 GB; the 3-channel form in elements, its launcher checks the range): the gather
@@ -1467,7 +1498,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_stream_kernel(const WSParams p
         Tl[i] = (int)((unsigned)p.table[(long)(v_begin + vl * v_step) * S + j] * (unsigned)(C3 ? p.x_sv : p.x_sv >> 2));
     }
     __syncthreads();
-    if (nv <= 0) return;
+    if (!wi.active) return;           // (an active item whose vertex range is empty still owns a slab: it writes zeros)
 
     const int la = lane & 15, kq = lane >> 4;
     const int k0 = cg * 64 + 4 * la;
@@ -1533,8 +1564,10 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_stream_kernel(const WSParams p
         }
     };
 
+    if (nv > 0) {
 #pragma unroll
-    for (int d = 0; d < DEPTH - 1; ++d) load_v(d, gr[d], pr[d]);
+        for (int d = 0; d < DEPTH - 1; ++d) load_v(d, gr[d], pr[d]);
+    }
     for (int vl = 0; vl < nv; vl += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
@@ -1580,10 +1613,12 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_stream_kernel(const WSParams p
 struct WGPlan {
     int log2TB, n_btiles, n_vtiles, nvc, steps_per_block, nrc, ncg, ctw, cot;
     int stream, vpc;    // streaming form: batch slice 1 << log2TB, nvc chunks of vpc vertices, ncg = ceil(K / 64)
+    int xg_G, xg_cpg, xg_Vg;      // > 0: one vertex range per XCD (WSParams::vstride == 2)
 };
 
 WGPlan plan_wgrad(int B, int R, int S, int Cin, int Cout) {
     WGPlan w;
+    w.xg_G = w.xg_cpg = w.xg_Vg = 0;
     const int K = S * Cin;
     static const int tb_pref = sh_env_int("SH_WG_TB", 8, 1, TMW);
     static const int blocks_target = sh_env_int("SH_WG_BLOCKS", 1024, 64, 65536);
@@ -1661,6 +1696,25 @@ WGPlan plan_wgrad(int B, int R, int S, int Cin, int Cout) {
         w.vpc = vpc;
         w.nvc = sh_cdiv(R, vpc);
         w.nrc = w.nvc * w.n_btiles;
+        // one vertex range per XCD (WSParams::xg_*): 1 / 2 / 4 / 8 batch slices, not the layer the role-swapped kernel serves
+        static const int xg_on = sh_env_int("SH_WS_XCD_RANGES", 1, 0, 1);
+        w.xg_G = w.xg_cpg = w.xg_Vg = 0;
+        if (xg_on && (w.n_btiles == 1 || w.n_btiles == 2 || w.n_btiles == 4 || w.n_btiles == 8) && Cout > 3) {
+            const int G = 8 / w.n_btiles;
+            const int Vg = sh_cdiv(R, G);
+            // chunks per XCD: the item target (one wave per SIMD = 128 items per XCD of 32 CUs) and the slab budget decide
+            long cpg_t = items_target / 8 / w.ncg;
+            if (cpg_t * 8 > cap) cpg_t = cap / 8;
+            int cpg = (int)cpg_t;
+            if (cpg < 1) cpg = 1;
+            if (cpg > Vg) cpg = Vg;
+            const int vcap2 = 2048 / S > 0 ? 2048 / S : 1;
+            if (sh_cdiv(Vg, cpg) > vcap2) cpg = sh_cdiv(Vg, vcap2);      // table lines of a wave: <= 8 KiB of LDS
+            w.xg_G = G; w.xg_cpg = cpg; w.xg_Vg = Vg;
+            w.vpc = sh_cdiv(Vg, cpg);
+            w.nvc = cpg * G;
+            w.nrc = 8 * cpg;
+        }
     }
     return w;
 }
@@ -1694,21 +1748,15 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_split3_kernel(const WSParams p
     if ((int)blockIdx.x >= p.grid_main) { ws_presum_tail(p); return; }    // tail job (whole workgroups; before any barrier)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int* Tl = reinterpret_cast<int*>(smem) + wave * p.vpc * p.S;
-    const int item_raw = sh_xcd_remap(blockIdx.x, p.grid_main) * 4 + wave;
-    const bool active = item_raw < p.n_items;
-    const int item = active ? item_raw : 0;
-    const int rc = item / p.ncg, cg = item - rc * p.ncg;
-    const int bt = rc / p.nvc, vc = rc - bt * p.nvc;
-    const int b0 = bt << p.log2TB;                               // log2TB == 4: a slice of 16 batch entries
-    const int v_begin = p.vstride ? vc : vc * p.vpc, v_step = p.vstride ? p.nvc : 1;      // as wgrad_stream_kernel
-    const int nv = !active ? 0 : p.vstride ? (vc < p.R ? (p.R - vc + p.nvc - 1) / p.nvc : 0) : min(p.vpc, p.R - v_begin);
+    const WSItem wi = ws_item(p, wave);                          // (log2TB == 4: a slice of 16 batch entries)
+    const int rc = wi.rc, cg = wi.cg, b0 = wi.b0, v_begin = wi.v_begin, v_step = wi.v_step, nv = wi.nv;
     const int S = p.S;
     for (int i = lane; i < nv * S; i += 64) {
         const int vl = i / S, j = i - vl * S;
         Tl[i] = p.table[(long)(v_begin + vl * v_step) * S + j];
     }
     __syncthreads();
-    if (nv <= 0) return;
+    if (!wi.active) return;           // (an active item whose vertex range is empty still owns a slab: it writes zeros)
 
     const int la = lane & 15, kb = lane >> 4;
     const int k0 = cg * 64 + 4 * la;
@@ -1780,7 +1828,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_split3_kernel(const WSParams p
         }
     };
 
-    load_step(0, g4[0], pr[0]);
+    if (nv > 0) load_step(0, g4[0], pr[0]);
     for (int vl = 0; vl < nv; vl += 4) {
         load_step(vl + 2, g4[1], pr[1]);
         __builtin_amdgcn_sched_barrier(0);                       // prefetch loads stay ahead of the MFMAs
@@ -2090,6 +2138,10 @@ int sh_spiral_conv_bwd_wgt_presum(const float* dpre, int64_t dp_sv, int64_t dp_s
         s.grid_main = sh_cdiv(s.n_items, 4);
         static const int vstride = sh_env_int("SH_WS_VSTRIDE", 1, 0, 1);
         s.vstride = vstride;
+        if (w.xg_G > 0) {
+            s.vstride = 2; s.xg_G = w.xg_G; s.xg_cpg = w.xg_cpg; s.xg_Vg = w.xg_Vg;
+            s.grid_main = 8 * sh_cdiv(w.xg_cpg * w.ncg, 4);
+        }
         // The pre-sum job rides as tail workgroups of this launch when a second wave of the kernel fits beside the first on
         // a SIMD (exact form: up to four channel tiles; bf16x3 form: two) and the rows take 16-byte accesses; otherwise it is
         // the launch of its own it used to be.  Measured: the seven foldable launches of a step were 58 us + their gaps.

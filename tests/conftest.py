@@ -29,23 +29,62 @@ def golden_dir():
 
 
 # The fp32 path has three arithmetic forms of its matrix products (include/sh_kernels.h, enum sh_mma_mode): the exact fp32
-# MFMA (bench.py's default headline), the bf16x3 split done by every consumer, and the same arithmetic over three bf16 planes
-# written once by the producer.  Every GPU parity test of the fp32 path runs in ALL of them, with the SAME tolerances - the
-# condition under which a split form may be quoted as fp32 at all.
+# MFMA (the library's default), the bf16x3 split done by every consumer, and the same arithmetic over three bf16 planes written
+# once by the producer (bench.py's default headline).  Every GPU parity test of the fp32 path runs in ALL of them, with the SAME
+# tolerances - the condition under which a split form may be quoted as fp32 at all.
+#
+# The plane kernels need a batch that is a multiple of 16 (sh_spiral_conv_p3_ok); otherwise a "planes3" call is served by the
+# split3 kernels.  A [planes3] instance that never launched a plane kernel therefore re-tests split3: it is REPORTED AS SKIPPED
+# ("= split3 here"), not as a pass (`sh_p3_launch_count` before / after the test body), so the pass count only holds instances
+# in which the plane kernels ran.  tests/test_headline.py pins the form at the benchmark's own sizes.
 F32_PARITY_MODULES = {"test_gpu_parity", "test_configs", "test_train_loop", "test_semantic", "test_editing", "test_wgrad_thin"}
 
 
 def pytest_generate_tests(metafunc):
     mod = metafunc.module.__name__.split(".")[-1]
-    if mod in F32_PARITY_MODULES and metafunc.definition.get_closest_marker("gpu") is not None and "f32_mma" not in metafunc.fixturenames:
-        metafunc.fixturenames.append("f32_mma")
+    if mod in F32_PARITY_MODULES and metafunc.definition.get_closest_marker("gpu") is not None:
+        if "f32_mma" not in metafunc.fixturenames:
+            metafunc.fixturenames.append("f32_mma")           # parametrizes the item; `_f32_mma_switch` (autouse) applies the form
         metafunc.parametrize("f32_mma", ["exact", "split3", "planes3"], indirect=True)
+
+
+def _p3_launches():
+    from semantichuman_amd import _lib
+    return int(_lib.load().sh_p3_launch_count())
 
 
 @pytest.fixture
 def f32_mma(request):
+    """The form of this instance (tests that want to know it may name this fixture; the switching itself is `_f32_mma_switch`)."""
+    return request.param
+
+
+@pytest.fixture(autouse=True)
+def _f32_mma_switch(request):
+    """Applies the instance's form.  Autouse and keyed on the item's own parameters: a fixture that is only APPENDED to
+    `metafunc.fixturenames` in pytest_generate_tests is parametrized (the ids show it) but never set up by pytest >= 8 - found in
+    round 5: the round-4 instances all ran in the process default.  `test_the_forms_are_really_switched` guards this."""
+    cs = getattr(request.node, "callspec", None)
+    form = cs.params.get("f32_mma") if cs is not None else None
+    if form is None:
+        yield
+        return
     from semantichuman_amd import _lib
     was = _lib.get_f32_mma_mode()
-    _lib.set_f32_mma_mode(request.param)
-    yield request.param
+    _lib.set_f32_mma_mode(form)
+    request.node._sh_p3_count0 = _p3_launches() if form == "planes3" else None
+    yield
     _lib.set_f32_mma_mode(was)
+
+
+@pytest.hookimpl(hookwrapper=True)
+def pytest_runtest_makereport(item, call):
+    outcome = yield
+    rep = outcome.get_result()
+    c0 = getattr(item, "_sh_p3_count0", None)
+    if rep.when == "call" and rep.passed and c0 is not None and _p3_launches() == c0:
+        # the test body asked for planes3 and no plane kernel ran: this instance is the split3 instance once more
+        rep.outcome = "skipped"
+        rep.longrepr = (str(item.fspath), item.location[1] or 0,
+                        "Skipped: [planes3] = [split3] here - no plane-conv kernel was launched (batch % 16 != 0 or shapes outside "
+                        "sh_spiral_conv_p3_ok); the body passed, it is not counted as planes3 coverage")

@@ -40,6 +40,21 @@ def close(got, ref, tol, what="", floor=0.0):
     assert err <= tol * scale + floor + 1e-30, "%s: err %.3e > %.1e * %.3e + %.1e" % (what, err, tol, scale, floor)
 
 
+def test_the_forms_are_really_switched(request):
+    """tests/conftest.py parametrizes every GPU test of this module over the three arithmetic forms of the fp32 products; the
+    instance's id must be the form the library calls run in (pytest >= 8 no longer sets up a fixture that was only appended to
+    metafunc.fixturenames: in round 4 all three instances ran in the process default)."""
+    from semantichuman_amd import _lib
+    form = request.node.callspec.params["f32_mma"]
+    assert request.node.name.endswith("[%s]" % form)
+    assert _lib.get_f32_mma_mode() == form and _lib.mma_id() == _lib.MMA_MODES[form]
+
+
+def test_the_form_is_visible_as_a_fixture(f32_mma):
+    from semantichuman_amd import _lib
+    assert _lib.get_f32_mma_mode() == f32_mma
+
+
 def test_native_library_is_loaded():
     from semantichuman_amd import _lib
     lib = _lib.load()

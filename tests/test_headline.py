@@ -1,0 +1,130 @@
+"""The benchmark's own arithmetic form at the benchmark's own sizes, against the CPU oracle.
+
+bench.py's headline runs the fp32 step in the three-plane form (SH_MMA_PLANES3, csrc/p3_conv.hip); the plane kernels need a batch
+that is a multiple of 16, so the suite's B = 2 oracle comparisons exercise the split3 kernels in their [planes3] instances.  Here
+a FULL training step - forward, L1 + 1e-2 x edge-ratio loss (train_funcs.py:501-508), EVERY parameter gradient, one Adam step
+(main.py:262: lr 1e-3, coupled weight decay 5e-5) - of the plain autoencoder (models.py:34-53, 115-162) runs at
+
+    6890 vertices,  batch 16 and batch 64 (BASELINE config 2: the headline)
+    27 554 vertices, spiral length 18, batch 16 (BASELINE config 4's template)
+
+in the exact fp32 form, in split3 and in planes3, against oracle/ref_cpu.py on the same inputs and weights, at the suite's
+tolerances (FWD 1e-5, GRAD 1e-4); and the library's own profiler is asked which kernels ran: in planes3 every conv launch the
+plane kernels are built for must BE a plane kernel, and the producers must have written images.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu
+from semantichuman_amd.hierarchy import load_hierarchy
+
+pytestmark = pytest.mark.gpu
+FE = [[3, 16, 32, 64, 128], [[], [], [], [], []]]
+FD = [[128, 64, 32, 32, 16], [[], [], [], [], 3]]
+FWD_TOL, GRAD_TOL = 1e-5, 1e-4
+EDGE_W, LR, WD = 1e-2, 1e-3, 5e-5
+
+CASES = [("template6890.npz", 16), ("template6890.npz", 64), ("template27554.npz", 16)]
+# conv launches of a planes3 step that must be plane kernels: every forward / backward-data launch except the 3-channel sides
+# (enc0 forward; dec4 forward, whose backward-data is fused into the thin weight-gradient launch; enc0 has no backward-data)
+P3_LAUNCHES = {"template6890.npz": 14, "template27554.npz": 14}
+
+
+@pytest.fixture(scope="module", params=CASES, ids=lambda c: "%s-B%d" % (c[0].split(".")[0], c[1]))
+def case(request, golden_dir):
+    """Template, batch, initial weights and the ORACLE's step on them (computed once per case, shared by the three forms)."""
+    tpl, B = request.param
+    from semantichuman_amd import synthetic
+    h = load_hierarchy(os.path.join(golden_dir, tpl))
+    S = [torch.from_numpy(s.astype(np.int64))[None] for s in h.spirals]
+    if h.sizes[0] > 10000:          # dense D / U of this template: 4 GB and 0.4 TFLOP per product - the pinned sparse form
+        D, U = [ref_cpu.sparse_operator(d) for d in h.D], [ref_cpu.sparse_operator(u) for u in h.U]
+    else:
+        _, D, U = h.dense_constants()
+    torch.manual_seed(20 + B)
+    om = ref_cpu.SpiralAEOracle(FE, FD, 256, h.sizes, h.spiral_sizes, S, D, U)       # nn.Linear's default initialisation
+    sd0 = {k: v.clone() for k, v in om.state_dict().items()}
+    x = torch.from_numpy(synthetic.synth_batch(h.verts, B, seed=7))
+    opt = torch.optim.Adam(om.parameters(), lr=LR, weight_decay=WD)
+    opt.zero_grad()
+    xo, zo = om(x)
+    rec, edge = torch.nn.functional.l1_loss(x, xo), ref_cpu.edge_ratio_loss(xo, x, h.faces)
+    (rec + EDGE_W * edge).backward()
+    grads = {n: p.grad.clone() for n, p in om.named_parameters()}
+    opt.step()
+    w1 = {n: p.detach().clone() for n, p in om.named_parameters()}
+    del om, opt
+    return dict(tpl=tpl, B=B, h=h, x=x, sd0=sd0, x_hat=xo.detach(), z=zo.detach(), rec=float(rec), edge=float(edge), grads=grads, w1=w1)
+
+
+def close(got, ref, tol, what, floor=0.0):
+    got, ref = got.detach().cpu().numpy(), ref.detach().cpu().numpy()
+    assert got.shape == ref.shape and np.isfinite(got).all(), what
+    err, scale = np.abs(got - ref).max(), np.abs(ref).max()
+    assert err <= tol * scale + floor + 1e-30, "%s: err %.3e > %.1e * %.3e + %.1e" % (what, err, tol, scale, floor)
+    return err / (scale + 1e-30)
+
+
+@pytest.mark.parametrize("form", ["exact", "split3", "planes3"])
+def test_full_training_step_vs_oracle(case, form, record_property):
+    import semantichuman_amd as sh
+    from semantichuman_amd import _lib
+    dev = torch.device("cuda:0")
+    h, B = case["h"], case["B"]
+    was = _lib.get_f32_mma_mode()
+    _lib.set_f32_mma_mode(form)
+    try:
+        m = sh.SpiralAutoencoder(FE, FD, 256, h.sizes, h.spiral_sizes, h.spirals, h.D, h.U, dev)
+        m.load_state_dict(case["sd0"])
+        opt = sh.optim.Adam(m.parameters(), lr=LR, weight_decay=WD)
+        ft = sh.FaceTables(h.faces, h.sizes[0] + 1, dev)
+        x = case["x"].to(dev)
+        _lib.profile_enable(True)
+        opt.zero_grad()
+        x_hat, z = m(x)
+        rec, edge = sh.l1_loss(x, x_hat), sh.edge_ratio_loss(x_hat, x, ft)
+        (rec + EDGE_W * edge).backward()
+        torch.cuda.synchronize()
+        names = [n for n, _, _ in _lib.profile_records_by_kernel()]
+        _lib.profile_enable(False)
+        # ---- which kernels ran
+        n_p3 = sum(1 for n in names if n.startswith("conv_p3"))
+        off_plane = [n for n in names if n.startswith(("gather_gemm_direct", "gather_gemm_split3", "to_p3"))]
+        if form == "planes3":
+            assert n_p3 == P3_LAUNCHES[case["tpl"]], (n_p3, sorted(set(names)))
+            assert not off_plane, off_plane                           # no conv left on the exact / split3 kernels, no stand-alone image pass
+            assert sum(1 for n in names if n.startswith("spmm_kernel<true, p3>")) >= 6      # re-sampling + U^T launches wrote images
+            assert any(n.startswith("wfrag3_prep") for n in names)
+        else:
+            assert n_p3 == 0 and not any("p3" in n for n in names), sorted(set(names))
+        # ---- forward, loss
+        e_x = close(x_hat, case["x_hat"], FWD_TOL, "x_hat")
+        e_z = close(z, case["z"], FWD_TOL, "z")
+        assert float(x_hat[:, -1].abs().max()) == 0.0
+        assert rec.item() == pytest.approx(case["rec"], rel=1e-5) and edge.item() == pytest.approx(case["edge"], rel=1e-5)
+        # ---- every parameter gradient
+        gmax = max(float(g.abs().max()) for g in case["grads"].values())
+        worst = 0.0
+        for name, prm in m.named_parameters():
+            worst = max(worst, close(prm.grad, case["grads"][name], GRAD_TOL, "grad " + name, floor=1e-6 * gmax))
+        # ---- one Adam step.  The first update is -lr g / (|g| + 1e-8) ~ -lr sign(g): where |g| is far above the gradient
+        # tolerance the weights must agree to fp32 rounding; where g ~ 0 the sign is ill-conditioned and an element may move
+        # by up to 2 lr.
+        opt.step()
+        torch.cuda.synchronize()
+        for name, prm in m.named_parameters():
+            g, w1 = case["grads"][name], case["w1"][name]
+            d = (prm.detach().cpu() - w1).abs()
+            big = g.abs() >= 100 * GRAD_TOL * float(g.abs().max())
+            assert float(d.max()) <= 2 * LR * 1.05, name
+            if bool(big.any()):       # d(update) = lr eps dg / (|g| + eps)^2: <= 0.5 % of lr for |dg| <= 1e-2 |g|
+                assert float(d[big].max()) <= 5e-6 + 1e-6 * float(w1.abs().max()), (name, float(d[big].max()))
+            assert float(d.mean()) <= 2e-6, (name, float(d.mean()))
+        record_property("rel_err", {"x_hat": e_x, "z": e_z, "worst_grad": worst})
+        print("%s B=%d %s: x_hat %.2e z %.2e worst grad %.2e plane launches %d" % (case["tpl"], B, form, e_x, e_z, worst, n_p3))
+    finally:
+        _lib.profile_enable(False)
+        _lib.set_f32_mma_mode(was)

@@ -40,8 +40,10 @@ def read(path, counter):
 def main():
     fetch, write, out = read(sys.argv[1], "FETCH_SIZE"), read(sys.argv[2], "WRITE_SIZE"), sys.argv[3]
     workload = sys.argv[4] if len(sys.argv) > 4 else None       # bench.workload_tag(...) of the profiled run, e.g. 6890v_b64_f32
-    ours = lambda n: any(k in n for k in ("gather_gemm", "wgrad", "spmm", "skinny", "linear_", "adam", "slab_reduce", "split_reduce",  # noqa: E731
-                                          "conv_bf16", "conv_out3", "tgemm", "tg_reduce", "wfrag"))
+    # every kernel of libsh_kernels.so, whatever its family (round 4's allow-list of name fragments had no entry for the plane
+    # convs, the activation backward, the loss and the image conversion: the planes3 profiles silently lacked them) - i.e.
+    # everything that is not torch's (at::), a BLAS library's (Cijk_) or RCCL's
+    ours = lambda n: not any(k in n for k in ("at::", "Cijk_", "ccl", "rocprim", "hipcub", "__amd_rocclr"))  # noqa: E731
     agg = defaultdict(lambda: [0, 0.0, 0.0])
     for (_, n, _, v) in fetch:
         if ours(n):
