@@ -177,7 +177,7 @@ def measured_traffic(kernel, workload):
     batch, dtype, arithmetic form), on THIS build of the kernel library (sh_build_id() of the loaded .so) and with the same
     SH_* switches; anything else yields (None, reason) instead of a silently wrong number."""
     from semantichuman_amd import _lib
-    name = "r04_pmc_traffic_%s.json" % workload
+    name = "r05_pmc_traffic_%s.json" % workload
     path = os.path.join(ROOT, "profiles", name)
     try:
         pmc = json.load(open(path))
@@ -228,6 +228,124 @@ def step_work(model, B, dtype):
     w_bytes = n_par * (2 if dtype == "bf16" else 4)
     byt += 2 * w_bytes + 4.0 * n_par + 7 * 4.0 * n_par + (2.0 * n_par if dtype == "bf16" else 0)   # weights fwd + dgrad, dW, Adam (+ bf16 copies)
     return flops, byt
+
+
+def matrix_pipe_split(model, B, dtype, mma):
+    """Algorithmic matrix FLOPs of one training step by the pipe that executes them, and the time they need at the dense peaks
+    (one `frac_mfma` against the fp32 peak mis-states a step whose conv products run on the bf16 pipe at six
+    instruction FLOPs per algorithmic FLOP).  planes3: forward / backward-data of every conv step the plane kernels take run on
+    v_mfma_f32_16x16x32_bf16 (x6), weight gradients and latent FCs on v_mfma_f32_16x16x4_f32; exact: everything on the fp32
+    pipe; bf16: everything on the bf16 pipe (x1).  (split3 partitions by tile count inside the library: not split here.)"""
+    from semantichuman_amd import _lib
+    lib = _lib.load()
+    f32 = b16 = 0.0
+    first = True
+    for stack in (model._enc_stack, model._dec_stack):
+        for i, st in enumerate(stack.steps):
+            if st.kind != "conv":
+                continue
+            f = 2.0 * B * st.R * st.S * st.cin * st.cout
+            has_bwd = not (first and stack is model._enc_stack)
+            first = False
+            if dtype == "bf16":
+                b16 += f * (3 if has_bwd else 2)
+                continue
+            p3 = mma == "planes3" and B % 16 == 0
+            fwd_p3 = p3 and i > 0 and bool(lib.sh_spiral_conv_p3_ok(B, st.S, st.cin, st.cout))
+            bwd_p3 = p3 and has_bwd and bool(lib.sh_spiral_conv_p3_ok(B, st.S, st.cout, st.cin))
+            b16 += (f if fwd_p3 else 0.0) + (f if bwd_p3 else 0.0)
+            f32 += (0.0 if fwd_p3 else f) + ((0.0 if bwd_p3 else f) if has_bwd else 0.0) + f
+    fc = sum(3 * 2.0 * B * m.in_features * m.out_features for m in (model.fc_latent_enc, model.fc_latent_dec))
+    if dtype == "bf16":
+        b16 += fc
+    else:
+        f32 += fc
+    mult = 1.0 if dtype == "bf16" else 6.0
+    t_f32, t_b16 = f32 / (PEAK_F32_MFMA_TFLOPS * 1e12), mult * b16 / (PEAK_BF16_MFMA_TFLOPS * 1e12)
+    return {"f32_pipe": {"algorithmic_flops": f32, "peak_tflops": PEAK_F32_MFMA_TFLOPS, "min_ms": 1e3 * t_f32},
+            "bf16_pipe": {"algorithmic_flops": b16, "instruction_flops": mult * b16, "peak_tflops": PEAK_BF16_MFMA_TFLOPS, "min_ms": 1e3 * t_b16},
+            "min_ms_both": 1e3 * (t_f32 + t_b16)}
+
+
+def whole_step_block(model, B, dtype, dt, mma=None):
+    """`whole_step`: algorithmic FLOPs / fused-ideal bytes of one step over the measured step time `dt` (seconds), the matrix work
+    split by pipe; `frac_mfma` = the time the step's matrix work needs at the dense peak of the pipe it runs on / dt."""
+    fl, by = step_work(model, B, dtype)
+    pipes = matrix_pipe_split(model, B, dtype, mma) if mma != "split3" else None
+    blk = {"flops": fl, "hbm_bytes_ideal": by, "tflops": fl / dt / 1e12, "gbps": by / dt / 1e9,
+           "frac_hbm": by / dt / 1e9 / PEAK_HBM_GBS,
+           "note": "algorithmic FLOPs and fused-ideal bytes of one step (SURVEY 8d) / measured ms_per_step, per GPU"}
+    if pipes is not None:
+        blk["matrix_pipes"] = pipes
+        blk["frac_mfma"] = pipes["min_ms_both"] * 1e-3 / dt
+        blk["frac_mfma_note"] = "time the matrix work needs at the dense peak of the pipe each part runs on (matrix_pipes) / step time"
+    else:
+        blk["frac_mfma"] = None
+        blk["frac_mfma_note"] = "split3 chooses the pipe per launch inside the library: see kernel_breakdown"
+    blk["tflops_vs_f32_mfma_peak"] = fl / dt / 1e12 / PEAK_F32_MFMA_TFLOPS
+    return blk
+
+
+def hbm_work_table(model, B):
+    """Algorithmic HBM bytes of the launches that are bound by them, keyed by (family, shape tag fields):
+      ("spmm", rows, C) -> [bytes per launch, ...] in the order a step issues launches with that key: every output element
+          written once + every DISTINCT input row read once, 4 bytes per element (the plane images a producer also writes in
+          the planes3 form are overhead of that form, not algorithm);
+      ("adam",) -> 7 fp32 streams per parameter."""
+    import numpy as np
+    out = {}
+
+    def add(csr, C):
+        if csr is None or csr.rows == 0:
+            return
+        distinct = int(np.unique(csr.col).size)
+        out.setdefault(("spmm", int(csr.rows), int(C)), []).append(4.0 * B * C * (csr.rows + distinct))
+    for stack in (model._enc_stack, model._dec_stack):                  # forward launches
+        c = 3 if stack is model._enc_stack else model.filters_dec[0][0]
+        for st in stack.steps:
+            if st.kind == "conv":
+                c = st.cout
+            else:
+                add(st.csr_fwd, c)
+    for stack in (model._dec_stack, model._enc_stack):                  # backward launches, reverse order
+        chans, c = [], (3 if stack is model._enc_stack else model.filters_dec[0][0])
+        for st in stack.steps:
+            chans.append(c)
+            if st.kind == "conv":
+                c = st.cout
+        for st, cin in reversed(list(zip(stack.steps, chans))):
+            if st.kind == "conv":
+                add(st.tt.csr1, st.cout)
+                add(st.tt.csr2, st.cout)
+            else:
+                add(st.csr_t, cin)
+    out[("adam",)] = [7 * 4.0 * sum(p.numel() for p in model.parameters())]
+    return out
+
+
+def parse_tag_hbm(name, shape):
+    fam = name.split("<")[0]
+    f = dict(kv.split("=") for kv in shape.split() if "=" in kv)
+    try:
+        if fam == "spmm_kernel":
+            return ("spmm", int(f["rows"]), int(f["C"]))
+        if fam == "adam_kernel":
+            return ("adam",)
+    except (KeyError, ValueError):
+        return None
+    return None
+
+
+def parse_tag_linear(name, shape):
+    """(flops, bytes) of a latent-FC launch from its tag (M = batch, N x K weight), or None."""
+    if not name.startswith("linear_"):
+        return None
+    f = dict(kv.split("=") for kv in shape.split() if "=" in kv)
+    try:
+        M, N, K = int(f["M"]), int(f["N"]), int(f["K"])
+    except (KeyError, ValueError):
+        return None
+    return 2.0 * M * N * K, 4.0 * (N * K + M * K + M * N)
 
 
 def replayed_training(sh, h, B, dtype, dev, steps, warmup, n_data=None, seed=100):
@@ -285,14 +403,11 @@ def replayed_training(sh, h, B, dtype, dev, steps, warmup, n_data=None, seed=100
         step(warmup + i)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    fl, by = step_work(model, B, dtype)
+    from semantichuman_amd import _lib
     res = {"ms_per_step": 1e3 * dt, "meshes_per_s": B / dt, "steps": steps, "warmup": warmup, "batch": B, "dtype": dtype,
            "vertices": int(h.sizes[0]), "spiral_sizes": [int(v) for v in h.spiral_sizes[:-1]], "launch": "hipGraph replay",
-           "whole_step": {"flops": fl, "hbm_bytes_ideal": by, "tflops": fl / dt / 1e12, "gbps": by / dt / 1e9,
-                          "frac_mfma": fl / dt / 1e12 / (2500.0 if dtype == "bf16" else PEAK_F32_MFMA_TFLOPS),
-                          "frac_hbm": by / dt / 1e9 / PEAK_HBM_GBS}}
+           "whole_step": whole_step_block(model, B, dtype, dt, _lib.get_f32_mma_mode() if dtype == "f32" else None)}
     if dtype == "f32":
-        from semantichuman_amd import _lib
         res["f32_mma"] = _lib.get_f32_mma_mode()
     del graph
     return res, model, init_state, data, ft
@@ -360,7 +475,10 @@ def secondary_block(sh, h, B, dev, init_state, data, test, ft, cpu_l2_mm, args):
         recs = _lib.profile_records_by_kernel()
         _lib.profile_enable(False)
         rf = roofline_f32(recs, model, B4, 3, verts)
-        return {"roofline": rf["roofline"], "hip_kernel_ms_per_step": rf["hip_kernel_ms_per_step"], "kernel_breakdown": rf["kernel_breakdown"][:5]}
+        out = {"roofline": rf["roofline"], "hip_kernel_ms_per_step": rf["hip_kernel_ms_per_step"], "kernel_breakdown": rf["kernel_breakdown"][:5]}
+        if "roofline_matrix_family" in rf:
+            out["roofline_matrix_family"] = rf["roofline_matrix_family"]
+        return out
 
     def config4_leg():
         h4 = load_hierarchy(os.path.join(ROOT, "tests", "golden", "template27554.npz"))
@@ -489,54 +607,89 @@ def roofline_bf16(recs, model, B, nprof, verts):
 
 
 def roofline_f32(recs, model, B, nprof, verts):
-    """The same for the fp32 path (MFMA roof)."""
+    """`roofline` / `roofline_matrix_family` / `kernel_families` / `kernel_breakdown` of an fp32 run from the library's per-launch
+    HIP-event records of `nprof` eagerly launched steps.
+
+    `roofline` describes the kernel NAME with the largest share of the step, whatever its family: a matrix
+    kernel against the dense peak of the pipe it runs on (fp32 MFMA 157.3 TF; a bf16x3 kernel - conv_p3*, *split3* - executes
+    six bf16 MFMA FLOPs per algorithmic fp32 FLOP: dense bf16 peak / 6 = 416.7 TF), a streaming kernel (re-sampling, Adam)
+    against HBM from its algorithmic bytes (hbm_work_table).  `roofline_matrix_family` keeps the most expensive kernel that
+    does matrix work when that is another one."""
     from semantichuman_amd import _lib
     result = {}
     work = f32_work_table(model, B)
+    hbm = hbm_work_table(model, B)
+    seen = {}
     agg = {}
     for name, shape, ms in recs:
-        a = agg.setdefault(name, {"n": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "matched": 0})
+        a = agg.setdefault(name, {"n": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "matched": 0, "hbm": 0})
         a["n"] += 1; a["ms"] += ms
         key = parse_tag_f32(name, shape)
+        lin = parse_tag_linear(name, shape)
+        hk = parse_tag_hbm(name, shape)
         if key in work:
             a["flops"] += work[key]["flops"]; a["bytes"] += work[key]["bytes"]; a["matched"] += 1
+        elif lin is not None:
+            a["flops"] += lin[0]; a["bytes"] += lin[1]; a["matched"] += 1
+        elif hk in hbm:
+            lst = hbm[hk]
+            k = seen.get(hk, 0)
+            seen[hk] = k + 1
+            a["bytes"] += lst[k % len(lst)]; a["matched"] += 1; a["hbm"] += 1
+    PEAK_X3 = PEAK_BF16_MFMA_TFLOPS / 6.0
+
+    def is_x3(name):
+        return "split3" in name or name.startswith("conv_p3")
     kernels = []
     for name, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
         e = {"kernel": name, "launches_per_step": a["n"] / nprof, "avg_ms": a["ms"] / a["n"], "ms_per_step": a["ms"] / nprof}
         if a["matched"] == a["n"] and a["n"]:
-            e["tflops"] = a["flops"] / (a["ms"] * 1e-3) / 1e12
+            if a["flops"] > 0:
+                peak = PEAK_X3 if is_x3(name) else PEAK_F32_MFMA_TFLOPS
+                e["tflops"] = a["flops"] / (a["ms"] * 1e-3) / 1e12
+                e["peak_tflops"] = peak
+                e["frac"] = e["tflops"] / peak
+            e["gbps_algorithmic"] = a["bytes"] / (a["ms"] * 1e-3) / 1e9
         kernels.append(e)
-    # The roofline is quoted for the single most expensive kernel instantiation of the step that does matrix work (the
-    # fused gather + MFMA conv kernels, forward / backward-data / weight gradient), under the exact name rocprofv3
-    # prints (profiles/); achieved = algorithmic FLOPs of its launches / their measured duration.
-    conv = [k for k in kernels if "tflops" in k]
-    dom = conv[0] if conv else kernels[0]
     fam = {}
     for k in kernels:
         f = fam.setdefault(k["kernel"].split("<")[0].split("|")[0], [0.0, 0.0])
         f[0] += k["ms_per_step"]
         f[1] += agg[k["kernel"]]["flops"] / nprof
-    # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
-    # collected separately; tools/pmc_traffic.py) - measured on the same workload, not in this run
     mma = _lib.get_f32_mma_mode()
-    traffic, traffic_note = measured_traffic(dom["kernel"], workload_tag(verts, B, "f32", mma))
-    if "tflops" in dom:
-        a = agg[dom["kernel"]]
-        # a bf16x3 kernel executes six bf16 MFMA FLOPs per algorithmic fp32 FLOP: its roof is the dense bf16 MFMA peak / 6
-        is_s3 = "split3" in dom["kernel"] or "conv_p3" in dom["kernel"]
-        peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if is_s3 else PEAK_F32_MFMA_TFLOPS
-        result["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": peak,
-                              "unit": "TFLOP/s", "frac": dom["tflops"] / peak, "traffic": traffic,
-                              "peak_note": ("dense bf16 MFMA peak %.0f TF / 6 partial products per fp32 product" % PEAK_BF16_MFMA_TFLOPS) if is_s3
-                                           else "fp32-input MFMA dense peak",
-                              "frac_of_f32_mfma_peak": dom["tflops"] / PEAK_F32_MFMA_TFLOPS,
-                              "traffic_unit": traffic_note,
-                              "avg_launch_ms": dom["avg_ms"], "launches_per_step": dom["launches_per_step"],
-                              "flops_per_launch": a["flops"] / a["n"], "algorithmic_bytes_per_launch": a["bytes"] / a["n"],
-                              "f32_mma": mma}
-    else:
-        result["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                              "frac": None, "traffic": None, "avg_launch_ms": dom["avg_ms"]}
+
+    def line(k):
+        a = agg[k["kernel"]]
+        traffic, traffic_note = measured_traffic(k["kernel"], workload_tag(verts, B, "f32", mma))
+        base = {"kernel": k["kernel"], "traffic": traffic, "traffic_unit": traffic_note, "avg_launch_ms": k["avg_ms"],
+                "launches_per_step": k["launches_per_step"], "ms_per_step": k["ms_per_step"], "f32_mma": mma,
+                "algorithmic_bytes_per_launch": (a["bytes"] / a["n"]) if a["matched"] == a["n"] else None}
+        # FLOPs / byte of the launch decides the roof: below the ridge of the pipe it runs on it is an HBM line
+        if "tflops" in k and not k["kernel"].startswith("linear_"):
+            x3 = is_x3(k["kernel"])
+            base.update({"bound": "mfma", "achieved": k["tflops"], "peak": k["peak_tflops"], "unit": "TFLOP/s", "frac": k["frac"],
+                         "peak_note": ("dense bf16 MFMA peak %.0f TF / 6 partial products per fp32 product" % PEAK_BF16_MFMA_TFLOPS) if x3
+                                      else "fp32-input MFMA dense peak",
+                         "frac_of_f32_mfma_peak": k["tflops"] / PEAK_F32_MFMA_TFLOPS, "flops_per_launch": a["flops"] / a["n"]})
+        elif "gbps_algorithmic" in k:
+            base.update({"bound": "hbm", "achieved": k["gbps_algorithmic"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": k["gbps_algorithmic"] / PEAK_HBM_GBS,
+                         "note": "algorithmic bytes (outputs written once + distinct inputs read once, fp32) of its launches / their HIP-event time"})
+            if "tflops" in k:
+                base.update({"mfma_tflops": k["tflops"], "mfma_frac_of_f32_peak": k["tflops"] / PEAK_F32_MFMA_TFLOPS})
+        else:
+            base.update({"bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None})
+        return base
+    result["roofline"] = line(kernels[0])
+    mat = [k for k in kernels if "tflops" in k and not k["kernel"].startswith("linear_")]
+    if mat and mat[0]["kernel"] != kernels[0]["kernel"]:
+        result["roofline_matrix_family"] = line(mat[0])
+    # matrix FLOPs of the step by the pipe that executed them, from the records themselves
+    f32p = sum(a["flops"] for n, a in agg.items() if not is_x3(n)) / nprof
+    x3p = sum(a["flops"] for n, a in agg.items() if is_x3(n)) / nprof
+    result["matrix_pipes_measured"] = {
+        "f32_pipe": {"algorithmic_flops_per_step": f32p, "kernel_ms_per_step": sum(a["ms"] for n, a in agg.items() if a["flops"] > 0 and not is_x3(n)) / nprof},
+        "bf16_pipe_x6": {"algorithmic_flops_per_step": x3p, "kernel_ms_per_step": sum(a["ms"] for n, a in agg.items() if a["flops"] > 0 and is_x3(n)) / nprof}}
     result["kernel_families"] = {n: {"ms_per_step": v[0], "tflops": (v[1] / (v[0] * 1e-3) / 1e12) if v[1] else None}
                                  for n, v in sorted(fam.items(), key=lambda kv: -kv[1][0])[:8]}
     result["kernel_breakdown"] = kernels[:8]
@@ -620,12 +773,23 @@ def self_launch(n, argv):
     env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on this pool (RCCL needs it)
     env.setdefault("OMP_NUM_THREADS", "4")
+    job_dir = None
+    if n > 1:                                                  # the supervisors' marker files: a fresh directory per job
+        import tempfile
+        job_dir = tempfile.mkdtemp(prefix="sh_bench_")
+        env["SH_BENCH_JOB_DIR"] = job_dir
+    import signal
+
+    def on_signal(signum, _frame):                             # `timeout N python bench.py --gpus N`: leave through the finally below
+        raise SystemExit(128 + signum)
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sig, on_signal)
     procs = []
-    for r in range(n):
-        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e))
     rc = 0
     try:
+        for r in range(n):
+            e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e))
         while procs:
             for p in list(procs):
                 st = p.poll()
@@ -635,12 +799,29 @@ def self_launch(n, argv):
                 if st != 0 and rc == 0:
                     rc = st
                     for q in procs:                            # a dead rank leaves the others blocked in a collective
-                        q.terminate()
+                        q.terminate()                          # SIGTERM: a supervisor ends its GPU child before it exits
             time.sleep(0.05)
     finally:
-        for p in procs:
-            p.kill()
+        _stop_processes(procs)
+        if job_dir:
+            import shutil
+            shutil.rmtree(job_dir, ignore_errors=True)
     return rc
+
+
+def _stop_processes(procs, grace=15.0):
+    """SIGTERM, a grace period, only then SIGKILL: the processes are SUPERVISORS whose SIGTERM handler ends their own GPU
+    child (a bare kill() would orphan a rank that is blocked in a collective and holds the GPU)."""
+    for p in procs:
+        if p.poll() is None:
+            p.terminate()
+    t0 = time.time()
+    for p in procs:
+        try:
+            p.wait(max(0.1, grace - (time.time() - t0)))
+        except Exception:      # noqa: BLE001 - subprocess.TimeoutExpired
+            p.kill()
+            p.wait()
 
 
 # ---- N > 1: every rank runs under a GPU-free supervisor that can start the rank's work again in a more conservative mode
@@ -676,8 +857,56 @@ def supervise_rank(argv):
     import threading
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ["WORLD_SIZE"])
     port0 = os.environ.get("MASTER_PORT", "29500")
-    job = os.path.join(tempfile.gettempdir(), "sh_bench_%s_%d_%s" % (port0, os.getppid(), os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")))
+    job = os.environ.get("SH_BENCH_JOB_DIR")                    # `python bench.py --gpus N`: made (mkdtemp) and removed by the launcher
+    own_job = job is None
+    if own_job:
+        # torch.distributed.run: every supervisor of the job has the same parent (the agent).  Port 29500 is the default and PIDs
+        # are recycled, so the name also carries the parent's START TIME (/proc/<pid>/stat field 22): a later job can never
+        # inherit this job's attempt<k>.ok / .failed markers.  Rank 0 removes the directory when everybody has read the verdict.
+        try:
+            start = open("/proc/%d/stat" % os.getppid()).read().rsplit(")", 1)[1].split()[19]
+        except (OSError, IndexError):
+            start = "0"
+        job = os.path.join(tempfile.gettempdir(), "sh_bench_%s_%d_%s_%s" % (port0, os.getppid(), start, os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")))
     os.makedirs(job, exist_ok=True)
+    child = {"p": None}
+
+    def stop_child():
+        p = child["p"]
+        if p is not None and p.poll() is None:
+            p.terminate()
+            try:
+                p.wait(10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+
+    def on_signal(signum, _frame):                             # SIGTERM / SIGINT from the launcher: leave through the finally below
+        raise SystemExit(128 + signum)
+    import signal
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sig, on_signal)
+    try:
+        return _supervise_attempts(argv, rank, world, job, child)
+    finally:
+        stop_child()                                           # never leave a rank behind (blocked in a collective, holding the GPU)
+        if own_job:
+            if rank == 0:
+                t0 = time.time()                                # the other supervisors read the verdict, then say so
+                while time.time() - t0 < 10 and sum(1 for f in os.listdir(job) if f.startswith("done.")) < world - 1:
+                    time.sleep(0.05)
+                import shutil
+                shutil.rmtree(job, ignore_errors=True)
+            else:
+                try:
+                    _touch(os.path.join(job, "done.%d" % rank))
+                except OSError:
+                    pass
+
+
+def _supervise_attempts(argv, rank, world, job, child):
+    import subprocess
+    import threading
     timeout = float(os.environ.get("SH_BENCH_ATTEMPT_TIMEOUT", "900"))
     grace = float(os.environ.get("SH_BENCH_FAIL_GRACE", "20"))
     attempts = [a for a in ATTEMPTS if not (a[0] == "graph" and os.environ.get("SH_BENCH_DP_GRAPH", "1") == "0")]
@@ -706,6 +935,7 @@ def supervise_rank(argv):
             env.pop("TORCHELASTIC_USE_AGENT_STORE", None)   # rank 0's child hosts the store itself
         p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                              stdout=subprocess.PIPE if rank == 0 else None, text=True if rank == 0 else None)
+        child["p"] = p                                          # the caller's finally / signal handler ends it
         lines = []
         reader = None
         if rank == 0:
@@ -770,6 +1000,9 @@ def injected_rank_failure(rank):
         print("bench.py[rank %d]: injected failure (SH_BENCH_TEST_RANK_FAIL=%s)" % (rank, spec), file=sys.stderr)
         sys.stdout.flush()
         os._exit(7)
+    hang = os.environ.get("SH_BENCH_TEST_RANK_HANG")     # '<attempt>:<rank>' or '*:*': that rank never gets past the rendezvous
+    if hang and hang in ("%s:%d" % (os.environ.get("SH_BENCH_ATTEMPT", "0"), rank), "*:%d" % rank, "*:*"):
+        time.sleep(3600)
 
 
 def dry_run(args, world, rank):
@@ -845,6 +1078,17 @@ def main():
         sys.exit(2)
     if world > 1 and "SH_BENCH_ATTEMPT" not in os.environ and os.environ.get("SH_BENCH_SUPERVISE", "1") != "0":
         sys.exit(supervise_rank(sys.argv[1:]))     # this process stays GPU-free; the rank's work runs in children
+    if "SH_BENCH_ATTEMPT" in os.environ:
+        # a supervisor's child: die with the supervisor even when that one is SIGKILLed (its finally block cannot run then) - set
+        # before this process touches the GPU; a supervisor that is already gone means there is nobody to report to
+        try:
+            import ctypes
+            import signal
+            ctypes.CDLL(None, use_errno=True).prctl(1, int(signal.SIGKILL), 0, 0, 0)      # PR_SET_PDEATHSIG
+            if os.getppid() == 1:
+                sys.exit(1)
+        except (OSError, AttributeError):
+            pass
     if os.environ.get("SH_BENCH_DRYRUN", "0") != "0":
         if args.gpus != world:
             sys.exit(2)
@@ -1055,12 +1299,7 @@ def main():
         "recon_l2_mm_after_run": l2mm,
     }
 
-    fl_step, by_step = step_work(model, B, args.dtype)
-    result["whole_step"] = {"flops": fl_step, "hbm_bytes_ideal": by_step, "tflops": fl_step / (elapsed / args.steps) / 1e12,
-                            "gbps": by_step / (elapsed / args.steps) / 1e9,
-                            "frac_mfma": fl_step / (elapsed / args.steps) / 1e12 / (2500.0 if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS),
-                            "frac_hbm": by_step / (elapsed / args.steps) / 1e9 / PEAK_HBM_GBS,
-                            "note": "algorithmic FLOPs and fused-ideal bytes of one step (SURVEY 8d) / measured ms_per_step, per GPU"}
+    result["whole_step"] = whole_step_block(model, B, args.dtype, elapsed / args.steps, args.f32_mma if args.dtype == "f32" else None)
 
     # ---- the data-parallel job as RCCL saw it: ranks, devices, and the gradient messages timed alone (HIP events on this
     # rank's stream around blocking all-reduces of the step's own message sizes, MAX over ranks)

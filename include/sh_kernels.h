@@ -273,14 +273,17 @@ SH_API int sh_stack_backward(int n_steps, const sh_stack_step* steps, const floa
  *   fwd       y[M,N]  = x[M,K] . weight^T + bias        (bias may be NULL)
  *   bwd_data  dx[M,K] = dy[M,N] . weight
  *   bwd_wgt   dW[N,K] = dy^T . x ;  dbias[N] = column sums of dy (dbias may be NULL)
+ * mma_mode (enum sh_mma_mode, round 5): SH_MMA_EXACT = fp32 MFMA; SH_MMA_SPLIT3 / SH_MMA_PLANES3 = both fp32 operands split
+ * exactly into three bf16 terms inside the kernel, six partial products on the bf16 MFMA, fp32 accumulation (batch <= 64 and the
+ * streaming kernels' shapes; other shapes run the fp32 MFMA kernels whatever the mode).  Nothing is written in bf16.
  */
 SH_API size_t sh_linear_workspace(int M, int N, int K);
 SH_API int sh_linear_fwd(const float* x, const float* weight, const float* bias, float* y, int M, int N, int K,
-                  void* workspace, size_t workspace_bytes, sh_stream_t stream);
+                  void* workspace, size_t workspace_bytes, int mma_mode, sh_stream_t stream);
 SH_API int sh_linear_bwd_data(const float* dy, const float* weight, float* dx, int M, int N, int K,
-                       void* workspace, size_t workspace_bytes, sh_stream_t stream);
+                       void* workspace, size_t workspace_bytes, int mma_mode, sh_stream_t stream);
 SH_API int sh_linear_bwd_wgt(const float* dy, const float* x, float* dW, float* dbias, int M, int N, int K,
-                      void* workspace, size_t workspace_bytes, sh_stream_t stream);
+                      void* workspace, size_t workspace_bytes, int mma_mode, sh_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Grouped (ragged) dense layers: the 3 x 17 per-part nn.Linear layers of SpiralAutoencoder_multiz_partkps
@@ -624,7 +627,12 @@ SH_API int sh_act_backward_tr_img(const float* dy, int64_t dy_sv, int64_t dy_sb,
                                   int64_t dp_sv, int64_t dp_sb, void* dpre_planes, int B, int R, int C, int act, int zero_row, int n_layers,
                                   const float* const* weight, float* const* weight_t, const int* S, const int* Cin, const int* Cout,
                                   sh_stream_t stream);
-/* sh_spiral_conv_fwd with x given as its plane image xp ([n_in] rows) */
+/* sh_spiral_conv_fwd with x given as its plane image xp ([n_in] rows).
+ * Size limit of the gathered image (here and in sh_spiral_conv_bwd_data_p3): the kernels keep table entries pre-multiplied by
+ * the image's row stride in 16-byte units in 32 bits, so the image must be smaller than 64 GiB (rows x B x C x 6 bytes); the
+ * same holds for the fp32 tensor x of the streaming weight gradients (sh_spiral_conv_bwd_wgt*: rows x B x C x 4 bytes).  The
+ * entry points do not know the gathered tensor's row count and cannot check it; sh_stack_forward / sh_stack_backward refuse
+ * any tensor of 2^32 elements or more (SH_ERR_UNSUPPORTED), which is inside both limits. */
 SH_API int sh_spiral_conv_fwd_p3(const void* xp, const int32_t* table, const void* wfrag3, const float* bias, float* y, int64_t y_sv,
                                  int64_t y_sb, void* yp, int B, int R, int S, int Cin, int Cout, int act, int zero_row,
                                  sh_stream_t stream);

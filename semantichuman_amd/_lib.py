@@ -40,9 +40,9 @@ SIGNATURES = {
     "sh_stack_forward": (c_int, [_I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
     "sh_stack_backward": (c_int, [_I, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "sh_linear_workspace": (c_size_t, [_I, _I, _I]),
-    "sh_linear_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, c_size_t, _P]),
-    "sh_linear_bwd_data": (c_int, [_P, _P, _P, _I, _I, _I, _P, c_size_t, _P]),
-    "sh_linear_bwd_wgt": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, c_size_t, _P]),
+    "sh_linear_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, c_size_t, _I, _P]),
+    "sh_linear_bwd_data": (c_int, [_P, _P, _P, _I, _I, _I, _P, c_size_t, _I, _P]),
+    "sh_linear_bwd_wgt": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, c_size_t, _I, _P]),
     "sh_grouped_linear_fwd": (c_int, [_I, _P, _L, _P, _P, _P, _P, _L, _P, _I, _P, _P, _P]),
     "sh_grouped_linear_bwd_data": (c_int, [_I, _P, _L, _P, _P, _P, _L, _P, _I, _P, _P, _P]),
     "sh_grouped_linear_bwd_wgt": (c_int, [_I, _P, _L, _P, _P, _L, _P, _P, _P, _I, _P, _P, _P]),

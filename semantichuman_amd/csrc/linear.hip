@@ -13,7 +13,7 @@
 // whichever of the two dimensions is contiguous, transposing on the way into LDS if needed),
 // v_mfma_f32_16x16x4_f32, optional split of the reduction over workgroups with partial slabs
 // summed in a fixed order by a second kernel (deterministic, no atomics).
-#include "sh_common.h"
+#include "sh_bf16.h"
 
 #include <type_traits>
 
@@ -336,8 +336,30 @@ __global__ __launch_bounds__(LTHREADS) void linear_fwd_stream_kernel(const LSPar
 // one barrier per stage and two stages in flight, and the MFMA fragments are read back with ds_read_b128 (pieces XOR-swizzled
 // by the row so that the sixteen rows of a fragment hit different banks).  Same products in the same order as the kernel
 // above: bit-identical results.
+// X3 (round 5; mma_mode SH_MMA_SPLIT3 / SH_MMA_PLANES3): the products in the bf16x3 form of the conv kernels.  A stage is ONE
+// k-step of v_mfma_f32_16x16x32_bf16: a lane's eight k are the two pieces it reads anyway (k-slots {4 kq ..+3} and {16 + 4 kq ..+3},
+// the same for both operands - which k a slot holds is free as long as the operands agree), split exactly into three bf16 terms
+// (sh_split3) in registers, six partial products per (row tile, column tile): 96 MFMAs of 16 cycles per stage and wave against
+// 128 of 32 (round 4 measured these passes paced by the fp32 MFMA issue, not by the 56.6 MB stream).
 constexpr int LFD_STAGE = 40 * 1024, LFD_LDS = 3 * LFD_STAGE;
-template <int MT>
+// the six leading partial products of (ah + am + al)(bh + bm + bl), smallest first, on one accumulator
+__device__ __forceinline__ f32x4 lin_x3_mma(const bf16x8 ah, const bf16x8 am, const bf16x8 al, const bf16x8 bh, const bf16x8 bm, const bf16x8 bl,
+                                            f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+}
+struct LinX3 { bf16x8 h, m, l; };
+__device__ __forceinline__ LinX3 lin_split(const f32x4 a, const f32x4 b) {
+    u32x4 h, m, l;
+    sh_split3(a, b, h, m, l);
+    return LinX3{__builtin_bit_cast(bf16x8, h), __builtin_bit_cast(bf16x8, m), __builtin_bit_cast(bf16x8, l)};
+}
+
+template <int MT, bool X3 = false>
 __global__ __launch_bounds__(LTHREADS) void linear_fwd_dma_kernel(const LSParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -393,6 +415,19 @@ __global__ __launch_bounds__(LTHREADS) void linear_fwd_dma_kernel(const LSParams
             issue(st + 2);                                                  // into the slot of stage st - 1
             const char* sl = smem + (st % 3) * LFD_STAGE;
             const char* wl = sl + 8192 + wave * 8192;
+            if constexpr (X3) {
+                LinX3 xs[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    xs[mt] = lin_split(*reinterpret_cast<const f32x4*>(sl + mt * 2048 + foff0), *reinterpret_cast<const f32x4*>(sl + mt * 2048 + foff1));
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const LinX3 ws = lin_split(*reinterpret_cast<const f32x4*>(wl + nt * 2048 + foff0), *reinterpret_cast<const f32x4*>(wl + nt * 2048 + foff1));
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = lin_x3_mma(ws.h, ws.m, ws.l, xs[mt].h, xs[mt].m, xs[mt].l, acc[mt][nt]);
+                }
+                continue;
+            }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int fo = h == 0 ? foff0 : foff1;
@@ -490,6 +525,75 @@ __global__ __launch_bounds__(LTHREADS) void linear_bwd_data_stream_kernel(const 
     }
 }
 
+// backward-data in the bf16x3 form (round 5).  Steps of 32 rows of W: lane (a, rr) loads the quads W[n(j)][k0 + 4 a ..+3] of ITS
+// eight reduction rows n(j) = nb + 4 rr + j (j < 4), nb + 16 + 4 rr + (j - 4) - every load instruction covers four whole 256-byte
+// row segments - and dy[m][n(0..3)], dy[m][n(4..7)] (two quads); element t of the eight weight quads, split exactly into three
+// bf16 terms, is the A operand for the output columns {k0 + 4 a' + t}, the dy quads the B operand: 4 MT x 6 MFMAs of 16 cycles
+// per 32 rows against 16 MT x 2 of 32 in the fp32 form, behind 4 + MT splits.  Same items, slabs and output mapping.
+template <int MT>
+__global__ __launch_bounds__(LTHREADS) void linear_bwd_data_x3_kernel(const LSParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int item = sh_xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
+    if (item >= p.groups * p.nsplit) return;
+    const int kg = item % p.groups, sp = item / p.groups;
+    const int k0 = kg * 64, n_begin = sp * p.range;
+    const int nsteps = (min(p.N, n_begin + p.range) - n_begin) >> 5;          // range % 32 == 0
+    const int la = lane & 15, rr = lane >> 4;
+    const float* drow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) drow[mt] = p.a + (long)min(16 * mt + la, p.M - 1) * p.N + n_begin + 4 * rr;
+    const float* wbase = p.w + (long)(n_begin + 4 * rr) * p.K + k0 + 4 * la;
+    f32x4 dq[2][MT][2], wq[2][8], acc[4][MT];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[t][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto load = [&](int s, f32x4 (&d4)[MT][2], f32x4 (&w4)[8]) {
+        const int nb = 32 * (s < nsteps ? s : nsteps - 1);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            d4[mt][0] = *reinterpret_cast<const f32x4*>(drow[mt] + nb);
+            d4[mt][1] = *reinterpret_cast<const f32x4*>(drow[mt] + nb + 16);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            w4[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wbase + (long)(nb + (j & 3) + 16 * (j >> 2)) * p.K));
+    };
+    auto mma = [&](const f32x4 (&d4)[MT][2], const f32x4 (&w4)[8]) {
+        LinX3 ds[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) ds[mt] = lin_split(d4[mt][0], d4[mt][1]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const LinX3 ws = lin_split((f32x4){w4[0][t], w4[1][t], w4[2][t], w4[3][t]}, (f32x4){w4[4][t], w4[5][t], w4[6][t], w4[7][t]});
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[t][mt] = lin_x3_mma(ws.h, ws.m, ws.l, ds[mt].h, ds[mt].m, ds[mt].l, acc[t][mt]);
+        }
+    };
+    if (nsteps > 0) {
+        load(0, dq[0], wq[0]);
+        for (int s = 0; s < nsteps; s += 2) {
+            load(s + 1, dq[1], wq[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(dq[0], wq[0]);
+            if (s + 1 >= nsteps) break;
+            load(s + 2, dq[0], wq[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(dq[1], wq[1]);
+        }
+    }
+    // acc[t][mt][jj] = dx[m = 16 mt + la][k0 + 16 rr + 4 jj + t]
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = 16 * mt + la;
+        if (m >= p.M) continue;
+        float* dst = (p.nsplit > 1 ? p.slab + ((long)sp * p.M + m) * p.K : p.out + (long)m * p.K) + k0 + 16 * rr;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+            *reinterpret_cast<f32x4*>(dst + 4 * jj) = (f32x4){acc[0][mt][jj], acc[1][mt][jj], acc[2][mt][jj], acc[3][mt][jj]};
+    }
+}
+
 // weight gradient: dW[n][k] = sum_m dy[m][n] x[m][k].  Item = 64 x 64 output tile; the reduction index m (<= 64) is the
 // MFMA K dimension, both operands are loaded as quads along their OUTPUT index: lane (a, rr) holds dy[m0+rr][n0+4a..] and
 // x[m0+rr][k0+4a..]; MFMA (t', t) produces dW[n0 + 4 i + t'][k0 + 4 j + t] - one pair of loads feeds 16 MFMAs.
@@ -565,7 +669,11 @@ __global__ __launch_bounds__(LTHREADS) void linear_bwd_wgt_stream_kernel(const L
 // so that the four row groups of a fragment read hit different banks), one wait, one barrier, then the same 16 x 16 MFMAs
 // per 4 reduction rows as above with both quads read from LDS.  80 KiB per workgroup: two per CU, one loading while the
 // other multiplies.  Same products in the same order as the streaming kernel: bit-identical results.
+// X3 (round 5): steps of 32 reduction rows on v_mfma_f32_16x16x32_bf16; a lane's eight rows are m = 32 s + 4 j + rr (j = 0..7; rows
+// 4 apart, so that the four row groups of a read keep their different swizzles: no bank conflicts), element tn / tk of its eight
+// dy / x quads split exactly into three bf16 terms: 16 x 6 MFMAs of 16 cycles per 32 rows against 8 x 16 of 32.
 constexpr int LWD_TILE = 16 * 1024, LWD_LDS = 5 * LWD_TILE;
+template <bool X3 = false>
 __global__ __launch_bounds__(LTHREADS) void linear_bwd_wgt_dma_kernel(const LSParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -608,6 +716,29 @@ __global__ __launch_bounds__(LTHREADS) void linear_bwd_wgt_dma_kernel(const LSPa
     const bool own_bias = kt == 0 && p.dbias != nullptr;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     const int roff = rr * 256 + ((la ^ (rr << 2)) << 4);               // row (4 s + rr): (row & 3) == rr
+    if constexpr (X3) {
+        const int nst32 = (p.M + 31) >> 5;
+        for (int s = 0; s < nst32; ++s) {
+            f32x4 d[8], x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {                               // row 32 s + 4 j + rr = step (8 s + j) of the layout above
+                d[j] = *reinterpret_cast<const f32x4*>(ds + (8 * s + j) * 1024 + roff);
+                x[j] = *reinterpret_cast<const f32x4*>(xs + (8 * s + j) * 1024 + roff);
+                if (32 * s + 4 * j + rr >= p.M) d[j] = (f32x4){0.f, 0.f, 0.f, 0.f};      // rows are the reduction index
+                if (own_bias) bsum += d[j];
+            }
+            LinX3 xk[4];
+#pragma unroll
+            for (int tk = 0; tk < 4; ++tk)
+                xk[tk] = lin_split((f32x4){x[0][tk], x[1][tk], x[2][tk], x[3][tk]}, (f32x4){x[4][tk], x[5][tk], x[6][tk], x[7][tk]});
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) {
+                const LinX3 dn = lin_split((f32x4){d[0][tn], d[1][tn], d[2][tn], d[3][tn]}, (f32x4){d[4][tn], d[5][tn], d[6][tn], d[7][tn]});
+#pragma unroll
+                for (int tk = 0; tk < 4; ++tk) acc[tn][tk] = lin_x3_mma(dn.h, dn.m, dn.l, xk[tk].h, xk[tk].m, xk[tk].l, acc[tn][tk]);
+            }
+        }
+    } else
     for (int s = 0; s < nsteps; ++s) {
         f32x4 d4 = *reinterpret_cast<const f32x4*>(ds + s * 1024 + roff);
         const f32x4 x4 = *reinterpret_cast<const f32x4*>(xs + s * 1024 + roff);
@@ -639,15 +770,15 @@ __global__ __launch_bounds__(LTHREADS) void linear_bwd_wgt_dma_kernel(const LSPa
 
 // plan of the streaming forms: enough items for one wave per SIMD (1024), reduction ranges multiples of 16
 struct LSPlan { bool ok; int range, nsplit, groups; };
-LSPlan plan_stream(int M, int out_cols, int red_len) {
+LSPlan plan_stream(int M, int out_cols, int red_len, int gran = 16) {        // gran: the reduction steps of the kernel (bf16x3 forms: 32)
     LSPlan pl{false, red_len, 1, out_cols / 64};
     static const int on = sh_env_int("SH_LIN_STREAM", 1, 0, 1);
-    if (!on || M > 64 || out_cols % 64 != 0 || red_len % 16 != 0) return pl;
+    if (!on || M > 64 || out_cols % 64 != 0 || red_len % gran != 0) return pl;
     pl.ok = true;
     static const int items = sh_env_int("SH_LIN_ITEMS", 1024, 64, 1 << 20);
     if (pl.groups < items / 2 && red_len >= 1024) {
         int ns = items / pl.groups;
-        int rg = sh_cdiv(sh_cdiv(red_len, ns), 16) * 16;
+        int rg = sh_cdiv(sh_cdiv(red_len, ns), gran) * gran;
         if (rg < 64) rg = 64;
         pl.range = rg;
         pl.nsplit = sh_cdiv(red_len, rg);
@@ -708,8 +839,14 @@ int run_gemm(SGParams& p, void* ws, size_t ws_bytes, hipStream_t st, const char*
 }
 
 // launches the forward / backward-data streaming kernel (+ the split reduction); `cols` = output columns
+// does this call run the bf16x3 kernels?  (mma_mode SH_MMA_SPLIT3 / SH_MMA_PLANES3; SH_LIN_X3=0 keeps the fp32 MFMA kernels)
+inline bool lin_x3(int mma_mode) {
+    static const int on = sh_env_int("SH_LIN_X3", 1, 0, 1);
+    return on && (mma_mode == SH_MMA_SPLIT3 || mma_mode == SH_MMA_PLANES3);
+}
+
 template <bool FWD>
-int run_stream(LSParams& p, const LSPlan& pl, int cols, void* ws, size_t ws_bytes, hipStream_t st, const char* what) {
+int run_stream(LSParams& p, const LSPlan& pl, int cols, void* ws, size_t ws_bytes, hipStream_t st, const char* what, bool x3 = false) {
     p.range = pl.range; p.nsplit = pl.nsplit; p.groups = pl.groups;
     const float* bias = p.bias;
     if (p.nsplit > 1) {
@@ -725,7 +862,31 @@ int run_stream(LSParams& p, const LSPlan& pl, int cols, void* ws, size_t ws_byte
     else SH_LAUNCH_PS(ps, linear_bwd_data_stream_kernel<MTV>, dim3(grid), dim3(LTHREADS), 0, st, p)
         static const int dma_on = sh_env_int("SH_LIN_DMA", 1, 0, 1);
         const bool dma = FWD && dma_on && p.K % 32 == 0 && p.range % 32 == 0 && p.groups % 4 == 0;
-        if (dma) {
+        if (x3 && !FWD) {
+            snprintf(ps.name, sizeof ps.name, "linear_bwd_data_x3_kernel<%d>|M=%d N=%d K=%d split=%d", mt, p.M, p.N, p.K, p.nsplit);
+            if (mt == 1) SH_LAUNCH_PS(ps, linear_bwd_data_x3_kernel<1>, dim3(grid), dim3(LTHREADS), 0, st, p);
+            else if (mt == 2) SH_LAUNCH_PS(ps, linear_bwd_data_x3_kernel<2>, dim3(grid), dim3(LTHREADS), 0, st, p);
+            else if (mt == 3) SH_LAUNCH_PS(ps, linear_bwd_data_x3_kernel<3>, dim3(grid), dim3(LTHREADS), 0, st, p);
+            else SH_LAUNCH_PS(ps, linear_bwd_data_x3_kernel<4>, dim3(grid), dim3(LTHREADS), 0, st, p);
+        } else if (x3 && dma) {
+            static bool attr3_set = false;
+            if (!attr3_set) {
+                const void* ks[4] = {reinterpret_cast<const void*>(linear_fwd_dma_kernel<1, true>), reinterpret_cast<const void*>(linear_fwd_dma_kernel<2, true>),
+                                     reinterpret_cast<const void*>(linear_fwd_dma_kernel<3, true>), reinterpret_cast<const void*>(linear_fwd_dma_kernel<4, true>)};
+                for (const void* k : ks)
+                    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                        (void)hipGetLastError();
+                        sh_set_error("%s: cannot raise the dynamic LDS limit to %d bytes", what, LFD_LDS);
+                        return SH_ERR_LAUNCH;
+                    }
+                attr3_set = true;
+            }
+            snprintf(ps.name, sizeof ps.name, "linear_fwd_x3_kernel<%d>|M=%d N=%d K=%d split=%d", mt, p.M, p.N, p.K, p.nsplit);
+            if (mt == 1) SH_LAUNCH_PS(ps, (linear_fwd_dma_kernel<1, true>), dim3(grid), dim3(LTHREADS), LFD_LDS, st, p);
+            else if (mt == 2) SH_LAUNCH_PS(ps, (linear_fwd_dma_kernel<2, true>), dim3(grid), dim3(LTHREADS), LFD_LDS, st, p);
+            else if (mt == 3) SH_LAUNCH_PS(ps, (linear_fwd_dma_kernel<3, true>), dim3(grid), dim3(LTHREADS), LFD_LDS, st, p);
+            else SH_LAUNCH_PS(ps, (linear_fwd_dma_kernel<4, true>), dim3(grid), dim3(LTHREADS), LFD_LDS, st, p);
+        } else if (dma) {
             static bool attr_set = false;
             if (!attr_set) {
                 const void* ks[4] = {reinterpret_cast<const void*>(linear_fwd_dma_kernel<1>), reinterpret_cast<const void*>(linear_fwd_dma_kernel<2>),
@@ -768,9 +929,11 @@ size_t sh_linear_workspace(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     size_t need = 0;
     {   // streaming forms: forward splits K (output [M][N]), backward-data splits N (output [M][K])
-        const LSPlan f = plan_stream(M, N, K), d = plan_stream(M, K, N);
-        if (f.ok && f.nsplit > 1) need = (size_t)f.nsplit * M * N * sizeof(float);
-        if (d.ok && d.nsplit > 1 && (size_t)d.nsplit * M * K * sizeof(float) > need) need = (size_t)d.nsplit * M * K * sizeof(float);
+        for (int gran : {16, 32}) {                                  // fp32 MFMA forms / bf16x3 forms
+            const LSPlan f = plan_stream(M, N, K, gran), d = plan_stream(M, K, N, gran);
+            if (f.ok && f.nsplit > 1 && (size_t)f.nsplit * M * N * sizeof(float) > need) need = (size_t)f.nsplit * M * N * sizeof(float);
+            if (d.ok && d.nsplit > 1 && (size_t)d.nsplit * M * K * sizeof(float) > need) need = (size_t)d.nsplit * M * K * sizeof(float);
+        }
     }
     const int dims[3][3] = {{M, N, K}, {M, K, N}, {N, K, M}};      // fwd, bwd_data, bwd_wgt as (rows, cols, reduction)
     for (auto& d : dims) {
@@ -784,14 +947,17 @@ size_t sh_linear_workspace(int M, int N, int K) {
 }
 
 int sh_linear_fwd(const float* x, const float* weight, const float* bias, float* y, int M, int N, int K, void* workspace,
-                  size_t workspace_bytes, sh_stream_t stream) {
+                  size_t workspace_bytes, int mma_mode, sh_stream_t stream) {
     SH_REQUIRE(x && weight && y && M > 0 && N > 0 && K > 0, SH_ERR_INVALID_ARG, "sh_linear_fwd: bad argument");
+    SH_REQUIRE(sh_mma_mode_valid(mma_mode), SH_ERR_INVALID_ARG, "sh_linear_fwd: unknown mma_mode %d", mma_mode);
     {
-        const LSPlan pl = plan_stream(M, N, K);
+        // bf16x3 form: the LDS-DMA kernel's shapes (32-wide stages, four column groups per workgroup); anything else keeps fp32 MFMA
+        const bool x3 = lin_x3(mma_mode) && K % 32 == 0 && (N / 64) % 4 == 0;
+        const LSPlan pl = plan_stream(M, N, K, x3 ? 32 : 16);
         if (pl.ok && aligned16(x, weight, y) && (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0)) {
             LSParams s{};
             s.a = x; s.w = weight; s.bias = bias; s.out = y; s.M = M; s.N = N; s.K = K;
-            return run_stream<true>(s, pl, N, workspace, workspace_bytes, static_cast<hipStream_t>(stream), "linear_fwd");
+            return run_stream<true>(s, pl, N, workspace, workspace_bytes, static_cast<hipStream_t>(stream), "linear_fwd", x3);
         }
     }
     SGParams p{};
@@ -803,14 +969,16 @@ int sh_linear_fwd(const float* x, const float* weight, const float* bias, float*
 }
 
 int sh_linear_bwd_data(const float* dy, const float* weight, float* dx, int M, int N, int K, void* workspace,
-                       size_t workspace_bytes, sh_stream_t stream) {
+                       size_t workspace_bytes, int mma_mode, sh_stream_t stream) {
     SH_REQUIRE(dy && weight && dx && M > 0 && N > 0 && K > 0, SH_ERR_INVALID_ARG, "sh_linear_bwd_data: bad argument");
+    SH_REQUIRE(sh_mma_mode_valid(mma_mode), SH_ERR_INVALID_ARG, "sh_linear_bwd_data: unknown mma_mode %d", mma_mode);
     {
-        const LSPlan pl = plan_stream(M, K, N);
+        const bool x3 = lin_x3(mma_mode) && N % 32 == 0;
+        const LSPlan pl = plan_stream(M, K, N, x3 ? 32 : 16);
         if (pl.ok && aligned16(dy, weight, dx)) {
             LSParams s{};
             s.a = dy; s.w = weight; s.bias = nullptr; s.out = dx; s.M = M; s.N = N; s.K = K;
-            return run_stream<false>(s, pl, K, workspace, workspace_bytes, static_cast<hipStream_t>(stream), "linear_bwd_data");
+            return run_stream<false>(s, pl, K, workspace, workspace_bytes, static_cast<hipStream_t>(stream), "linear_bwd_data", x3);
         }
     }
     SGParams p{};                                   // dx(m,k) = sum_n dy(m,n) W(n,k)
@@ -822,8 +990,9 @@ int sh_linear_bwd_data(const float* dy, const float* weight, float* dx, int M, i
 }
 
 int sh_linear_bwd_wgt(const float* dy, const float* x, float* dW, float* dbias, int M, int N, int K, void* workspace,
-                      size_t workspace_bytes, sh_stream_t stream) {
+                      size_t workspace_bytes, int mma_mode, sh_stream_t stream) {
     SH_REQUIRE(dy && x && dW && M > 0 && N > 0 && K > 0, SH_ERR_INVALID_ARG, "sh_linear_bwd_wgt: bad argument");
+    SH_REQUIRE(sh_mma_mode_valid(mma_mode), SH_ERR_INVALID_ARG, "sh_linear_bwd_wgt: unknown mma_mode %d", mma_mode);
     hipStream_t st = static_cast<hipStream_t>(stream);
     static const int stream_on = sh_env_int("SH_LIN_STREAM", 1, 0, 1);
     if (stream_on && M <= 64 && N % 64 == 0 && K % 64 == 0 && aligned16(dy, x, dW)) {
@@ -835,17 +1004,22 @@ int sh_linear_bwd_wgt(const float* dy, const float* x, float* dW, float* dbias, 
         if (dma_on) {
             static bool attr_set = false;
             if (!attr_set) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bwd_wgt_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        160 * 1024) != hipSuccess) {
-                    (void)hipGetLastError();
-                    sh_set_error("linear_bwd_wgt: cannot raise the dynamic LDS limit to %d bytes", LWD_LDS);
-                    return SH_ERR_LAUNCH;
-                }
+                for (const void* k : {reinterpret_cast<const void*>(linear_bwd_wgt_dma_kernel<false>), reinterpret_cast<const void*>(linear_bwd_wgt_dma_kernel<true>)})
+                    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                        (void)hipGetLastError();
+                        sh_set_error("linear_bwd_wgt: cannot raise the dynamic LDS limit to %d bytes", LWD_LDS);
+                        return SH_ERR_LAUNCH;
+                    }
                 attr_set = true;
             }
             const int wgs = (N / 64) * sh_cdiv(K / 64, 4);
-            ShProfScope ps(st, "linear_bwd_wgt_dma_kernel|M=%d N=%d K=%d", M, N, K);
-            SH_LAUNCH_PS(ps, linear_bwd_wgt_dma_kernel, dim3(wgs), dim3(LTHREADS), LWD_LDS, st, s);
+            if (lin_x3(mma_mode)) {
+                ShProfScope ps(st, "linear_bwd_wgt_x3_kernel|M=%d N=%d K=%d", M, N, K);
+                SH_LAUNCH_PS(ps, linear_bwd_wgt_dma_kernel<true>, dim3(wgs), dim3(LTHREADS), LWD_LDS, st, s);
+            } else {
+                ShProfScope ps(st, "linear_bwd_wgt_dma_kernel|M=%d N=%d K=%d", M, N, K);
+                SH_LAUNCH_PS(ps, linear_bwd_wgt_dma_kernel<false>, dim3(wgs), dim3(LTHREADS), LWD_LDS, st, s);
+            }
         } else {
             ShProfScope ps(st, "linear_bwd_wgt_stream_kernel|M=%d N=%d K=%d", M, N, K);
             SH_LAUNCH_PS(ps, linear_bwd_wgt_stream_kernel, dim3(sh_cdiv(items, 4)), dim3(LTHREADS), 0, st, s);

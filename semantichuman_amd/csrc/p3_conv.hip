@@ -318,9 +318,10 @@ constexpr int P3S_NT = 4, P3S_KC = 4;
 // RT vertices per wave share every weight fragment read: with one vertex a fragment (1 KiB of LDS) feeds 6 MFMAs = 96 cycles
 // of one SIMD, i.e. the four SIMDs ask for exactly the 128 bytes / clock LDS delivers - matrix pipe and LDS co-limited; with
 // two, half of that.  RT = 2 runs 8 waves per workgroup (two per SIMD, up to 256 VGPRs each), RT = 1 sixteen.
-template <int RT, bool BWD, int NP>
+template <int RT, bool BWD, int NP, int NT = P3S_NT>
 __global__ __launch_bounds__(1024 / RT) void conv_p3s_kernel(const P3Params p) {
-    constexpr int NT = P3S_NT, D = P3S_KC, WAVES = 16 / RT, WF = 48 / WAVES;      // WF: fragments of a chunk this wave fetches
+    constexpr int D = P3S_KC, WAVES = 16 / RT, WF = P3S_KC * NT * 3 / WAVES;      // WF: fragments of a chunk this wave fetches
+    static_assert(WF * WAVES == P3S_KC * NT * 3, "a chunk's fragments must divide evenly over the waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u32x4* Wl = reinterpret_cast<u32x4*>(smem);                   // [2][KC][NT][3][64]
     constexpr int CHUNK_PIECES = P3S_KC * NT * 192;               // 16-byte pieces per chunk buffer
@@ -563,17 +564,24 @@ inline P3Geom p3_geom(int S, int Cg, int Nout) {
     while (r.nt > 1 && (long)g.nks * r.nt * 3 > 150) { r.nt >>= 1; r.nsplit <<= 1; }
     return r;
 }
-// the streaming form: K in whole chunks, gathered channels in 32s, at least one full slice of 64 output channels
+// the streaming form: gathered channels in 32s; whole slices of 64 output channels, or 32 output channels (two tiles)
 inline bool p3s_shape_ok(int S, int Cg, int Nout) {
     static const int on = sh_env_int("SH_P3_STREAM", 1, 0, 1);
-    if (!on || Cg % 32 || Nout % 64) return false;
+    static const int pad_on = sh_env_int("SH_P3S_PAD", 1, 0, 1), nt2_on = sh_env_int("SH_P3S_NT2", 1, 0, 1);
+    if (!on || Cg % 32 || !(Nout % 64 == 0 || (nt2_on && Nout == 32))) return false;
     const ShFragGeom g = sh_frag_geom(S, Cg, Nout);
-    return g.nks % P3S_KC == 0 && g.nt_tot % P3S_NT == 0;
+    return (pad_on || g.nks % P3S_KC == 0) && (Nout == 32 || g.nt_tot % P3S_NT == 0);
 }
 inline bool p3_resident_ok(int S, int Cg, int Nout) {
     const P3Geom g = p3_geom(S, Cg, Nout);
     static const int max_split = sh_env_int("SH_P3_MAX_SPLIT", 1, 1, 8);      // output-channel slices re-gather the input
     return (long)g.nks * g.nt * 3 <= 150 && g.nsplit <= max_split;
+}
+// k-steps of a layer's three-plane fragment buffer: sh_frag_geom's, rounded up to whole chunks where the weight is streamed
+inline int p3_nks(int S, int Cg, int Nout) {
+    const ShFragGeom g = sh_frag_geom(S, Cg, Nout);
+    if (p3_resident_ok(S, Cg, Nout) || !p3s_shape_ok(S, Cg, Nout)) return g.nks;
+    return (g.nks + P3S_KC - 1) / P3S_KC * P3S_KC;
 }
 inline bool p3_shape_ok(int B, int S, int Cg, int Nout) {
     if (B <= 0 || B % 16 || S <= 0 || S > 64 || Nout % 4) return false;
@@ -581,11 +589,11 @@ inline bool p3_shape_ok(int B, int S, int Cg, int Nout) {
     return p3_resident_ok(S, Cg, Nout) || p3s_shape_ok(S, Cg, Nout);
 }
 
-template <int RT, bool BWD, int NP>
+template <int RT, bool BWD, int NP, int NT = P3S_NT>
 int launch_p3s(P3Params& p, hipStream_t st) {
-    auto kern = conv_p3s_kernel<RT, BWD, NP>;
+    auto kern = conv_p3s_kernel<RT, BWD, NP, NT>;
     constexpr int WAVES = 16 / RT;
-    const size_t smem = (size_t)2 * P3S_KC * P3S_NT * 3072;
+    const size_t smem = (size_t)2 * P3S_KC * NT * 3072;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
@@ -595,7 +603,7 @@ int launch_p3s(P3Params& p, hipStream_t st) {
         }
         attr_set = true;
     }
-    p.nsplit = p.nt_tot / P3S_NT;
+    p.nsplit = p.nt_tot / NT;
     p.n_vg = sh_cdiv(p.R, RT);
     const long tiles = (long)p.n_vg * (p.B / 16);
     SH_REQUIRE(tiles < (1L << 30), SH_ERR_UNSUPPORTED, "conv_p3s: %ld work items", tiles);
@@ -606,8 +614,8 @@ int launch_p3s(P3Params& p, hipStream_t st) {
     if (groups < 8) groups = 8;
     groups = (groups + 7) / 8 * 8;
     const int grid = (int)groups * p.nsplit;
-    ShProfScope ps(st, "conv_p3s_kernel<%d, %s, %d>|R=%d B=%d K=%d N=%d grid=%dx%d", RT, BWD ? "true" : "false", NP, p.R, p.B, p.S * p.Cg,
-                   p.Nout, grid, WAVES * 64);
+    ShProfScope ps(st, "conv_p3s_kernel<%d, %s, %d, %d>|R=%d B=%d K=%d N=%d grid=%dx%d", RT, BWD ? "true" : "false", NP, NT, p.R, p.B,
+                   p.S * p.Cg, p.Nout, grid, WAVES * 64);
     SH_LAUNCH_PS(ps, kern, dim3(grid), dim3(WAVES * 64), smem, st, p);
     SH_CHECK_LAUNCH("conv_p3s");
     g_p3_launches.fetch_add(1, std::memory_order_relaxed);
@@ -616,6 +624,7 @@ int launch_p3s(P3Params& p, hipStream_t st) {
 template <bool BWD, int NP>
 int dispatch_p3s(P3Params& p, hipStream_t st) {
     static const int rt = sh_env_int("SH_P3S_RT", 2, 1, 2);
+    if (p.nt_tot == 2) return launch_p3s<2, BWD, NP, 2>(p, st);          // 32 output channels: two tiles, two vertices per wave
     return rt == 2 ? launch_p3s<2, BWD, NP>(p, st) : launch_p3s<1, BWD, NP>(p, st);
 }
 
@@ -692,6 +701,7 @@ int dispatch_p3(P3Params& p, hipStream_t st) {
                ((p.y_sv | p.y_sb | p.yv_sv | p.yv_sb) & 3) == 0, SH_ERR_INVALID_ARG, "conv_p3: tensors must be 16-byte aligned with strides %% 4 == 0");
     static const int np = sh_env_int("SH_P3_NP", 6, 6, 9);
     if (!p3_resident_ok(p.S, p.Cg, p.Nout)) {
+        p.nks = p3_nks(p.S, p.Cg, p.Nout);                     // whole chunks (the fragments past K are zeros)
         SH_REQUIRE(!p.xf, SH_ERR_UNSUPPORTED, "conv_p3: the weight-streaming form takes imaged rows only (sh_spiral_conv_p3_kind() == 2)");
         return np == 9 ? dispatch_p3s<BWD, 9>(p, st) : dispatch_p3s<BWD, 6>(p, st);
     }
@@ -732,7 +742,7 @@ int sh_to_p3(const float* x, int64_t x_sv, int64_t x_sb, void* planes, int B, in
 size_t sh_conv_wfrag3_bytes(int S, int Cg, int Nout) {
     if (S <= 0 || Cg <= 0 || Nout <= 0) return 0;
     const ShFragGeom g = sh_frag_geom(S, Cg, Nout);
-    return (size_t)g.nks * g.nt_tot * 3072;
+    return (size_t)p3_nks(S, Cg, Nout) * g.nt_tot * 3072;
 }
 
 int sh_conv_wfrag3_prep_multi(int n_layers, const float* const* weight, void* const* wfrag3, const int* S, const int* Cin,
@@ -752,9 +762,10 @@ int sh_conv_wfrag3_prep_multi(int n_layers, const float* const* weight, void* co
             SH_REQUIRE(Cg % 8 == 0, SH_ERR_UNSUPPORTED, "sh_conv_wfrag3_prep_multi: %d gathered channels", Cg);
             const ShFragGeom g = transpose[k] ? sh_frag_geom(S[k], Cout[k], Cin[k]) : sh_frag_geom(S[k], Cin[k], Cout[k]);
             a.w[i] = weight[k]; a.out[i] = static_cast<u32x4*>(wfrag3[k]);
-            a.S[i] = S[k]; a.Cin[i] = Cin[k]; a.Cout[i] = Cout[k]; a.tr[i] = transpose[k] ? 1 : 0; a.nks[i] = g.nks; a.nt_tot[i] = g.nt_tot;
+            const int nks = transpose[k] ? p3_nks(S[k], Cout[k], Cin[k]) : p3_nks(S[k], Cin[k], Cout[k]);
+            a.S[i] = S[k]; a.Cin[i] = Cin[k]; a.Cout[i] = Cout[k]; a.tr[i] = transpose[k] ? 1 : 0; a.nks[i] = nks; a.nt_tot[i] = g.nt_tot;
             a.block0[i] = blocks;
-            blocks += (g.nks * g.nt_tot * 64 + 255) / 256;
+            blocks += (nks * g.nt_tot * 64 + 255) / 256;
         }
         a.block0[a.nd] = blocks;
         ShProfScope ps(st, "wfrag3_prep_kernel|layers=%d", a.nd);

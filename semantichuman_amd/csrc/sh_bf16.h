@@ -17,7 +17,7 @@ __device__ __forceinline__ f32x4 sh_from_bf16x4(bf16x4 v) { return (f32x4){(floa
 
 // EXACT split of eight fp32 numbers into three bf16 terms each, x = h + m + l (h = rne_bf16(x), m = rne_bf16(x - h),
 // l = x - h - m: 8 + 8 + 8 significand bits; both subtractions are exact in fp32), packed as MFMA operand pieces - the
-// bf16x3 form of the fp32 matrix products (include/sh_kernels.h, sh_set_f32_mma_mode).  ~44 VALU operations.
+// bf16x3 form of the fp32 matrix products (include/sh_kernels.h, enum sh_mma_mode: an argument of every entry point whose kernel choice depends on it).  ~44 VALU operations.
 __device__ __forceinline__ void sh_split3(const f32x4 a, const f32x4 b, u32x4& h, u32x4& m, u32x4& l) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

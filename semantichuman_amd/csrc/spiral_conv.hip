@@ -567,7 +567,7 @@ __global__ __launch_bounds__(NTHREADS) void gather_gemm_direct_kernel(const GGPa
 }
 
 // ------------------------------------------------------------------------------------------
-// bf16x3 form of the direct kernel (sh_set_f32_mma_mode(SH_MMA_SPLIT3); Cg % 8 == 0).  Every fp32 operand is written as an
+// bf16x3 form of the direct kernel (mma_mode SH_MMA_SPLIT3; Cg % 8 == 0).  Every fp32 operand is written as an
 // EXACT sum of three bf16 numbers, x = h + m + l (h = rne_bf16(x), m = rne_bf16(x - h), l = x - h - m: 8 + 8 + 8 significand
 // bits), and a product row is evaluated as the six leading terms of (Wh + Wm + Wl)(Xh + Xm + Xl) -
 //     Wh Xh + (Wh Xm + Wm Xh) + (Wh Xl + Wl Xh + Wm Xm)
@@ -989,7 +989,7 @@ int dispatch_gg(GGParams& p, hipStream_t st) {
         p.s0 = s1; p.pass = 2;
         return run(p.S - s1);
     }
-    // bf16x3 form (sh_set_f32_mma_mode): up to four channel tiles per workgroup, the rest split over workgroups
+    // bf16x3 form (mma_mode SH_MMA_SPLIT3): up to four channel tiles per workgroup, the rest split over workgroups
     static const int s3_min_nt = sh_env_int("SH_S3_MIN_NT", 4, 1, 8);      // layers with fewer channel tiles keep the exact form (no gain there)
     if (sh_f32_mma_mode() != SH_MMA_EXACT && vec4 && p.vec_out && !c3 && p.Cg % 8 == 0 && nt >= s3_min_nt) {
         static const int s3_nt = sh_env_int("SH_S3_NT", 4, 1, 8), s3_rt = sh_env_int("SH_S3_RT", 0, 0, 2);
@@ -1449,6 +1449,19 @@ __device__ __forceinline__ void ws_presum_tail(const WSParams& p) {
     }
 }
 
+// the part of slab rc an item with column group cg owns (all output channels of this launch x its 64 columns; the bias sums
+// with cg == 0), zeroed - for an active item without vertices
+__device__ __forceinline__ void ws_zero_slab(const WSParams& p, int rc, int cg, int lane) {
+    float* slab = p.slab + (long)rc * p.slab_stride;
+    const int co_end = min(p.Cout, p.co0 + 128);
+    const int c_lo = p.Cin == 3 ? 48 * cg : 64 * cg, c_hi = min(p.K, c_lo + (p.Cin == 3 ? 48 : 64));      // (3-channel inputs: 16 quads = 48 columns)
+    const int w = c_hi - c_lo;
+    if (w > 0)
+        for (int i = lane; i < (co_end - p.co0) * w; i += 64) slab[(long)(p.co0 + i / w) * p.K + c_lo + i % w] = 0.f;
+    if (cg == 0)
+        for (int co = p.co0 + lane; co < co_end; co += 64) p.slab[p.bias_off + (long)rc * p.Cout + co] = 0.f;
+}
+
 // work item of a wave: (slab index rc, column group cg, first batch entry, vertices v_begin + vl * v_step for vl < nv)
 struct WSItem { bool active; int rc, cg, b0, v_begin, v_step, nv; };
 __device__ __forceinline__ WSItem ws_item(const WSParams& p, int wave) {
@@ -1498,7 +1511,10 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_stream_kernel(const WSParams p
         Tl[i] = (int)((unsigned)p.table[(long)(v_begin + vl * v_step) * S + j] * (unsigned)(C3 ? p.x_sv : p.x_sv >> 2));
     }
     __syncthreads();
-    if (!wi.active) return;           // (an active item whose vertex range is empty still owns a slab: it writes zeros)
+    if (nv <= 0) {                    // nothing to sum; an ACTIVE item whose vertex range is empty still owns a slab: zeros
+        if (wi.active) ws_zero_slab(p, rc, cg, lane);
+        return;                       // (a separate exit, so that the main path below stays the straight-line code it was: with the
+    }                                 //  prefetch inside an `if` the four-tile instance ran 25 % slower)
 
     const int la = lane & 15, kq = lane >> 4;
     const int k0 = cg * 64 + 4 * la;
@@ -1564,10 +1580,8 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_stream_kernel(const WSParams p
         }
     };
 
-    if (nv > 0) {
 #pragma unroll
-        for (int d = 0; d < DEPTH - 1; ++d) load_v(d, gr[d], pr[d]);
-    }
+    for (int d = 0; d < DEPTH - 1; ++d) load_v(d, gr[d], pr[d]);
     for (int vl = 0; vl < nv; vl += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
@@ -1702,14 +1716,19 @@ WGPlan plan_wgrad(int B, int R, int S, int Cin, int Cout) {
         if (xg_on && (w.n_btiles == 1 || w.n_btiles == 2 || w.n_btiles == 4 || w.n_btiles == 8) && Cout > 3) {
             const int G = 8 / w.n_btiles;
             const int Vg = sh_cdiv(R, G);
-            // chunks per XCD: the item target (one wave per SIMD = 128 items per XCD of 32 CUs) and the slab budget decide
-            long cpg_t = items_target / 8 / w.ncg;
-            if (cpg_t * 8 > cap) cpg_t = cap / 8;
-            int cpg = (int)cpg_t;
-            if (cpg < 1) cpg = 1;
-            if (cpg > Vg) cpg = Vg;
-            const int vcap2 = 2048 / S > 0 ? 2048 / S : 1;
-            if (sh_cdiv(Vg, cpg) > vcap2) cpg = sh_cdiv(Vg, vcap2);      // table lines of a wave: <= 8 KiB of LDS
+            // chunks per XCD: whole "rounds" of the item target (one wave per SIMD = items_target / 8 items per XCD), as many rounds
+            // as the general plan above settled on (table cap, slab budget), more if a chunk's table lines would not fit
+            const long per_xcd = items_target / 8 > 0 ? items_target / 8 : 1;
+            long rounds = ((long)w.ncg * w.n_btiles * w.nvc + items_target / 2) / items_target;
+            if (rounds < 1) rounds = 1;
+            const int vcap2 = 2048 / S > 0 ? 2048 / S : 1;          // table lines of a wave: <= 8 KiB of LDS
+            int cpg = 1;
+            for (;; ++rounds) {
+                cpg = (int)(rounds * per_xcd / w.ncg);
+                if (cpg < 1) cpg = 1;
+                if (cpg >= Vg) { cpg = Vg; break; }
+                if (sh_cdiv(Vg, cpg) <= vcap2) break;
+            }
             w.xg_G = G; w.xg_cpg = cpg; w.xg_Vg = Vg;
             w.vpc = sh_cdiv(Vg, cpg);
             w.nvc = cpg * G;
@@ -1734,7 +1753,7 @@ int launch_ws(const WSParams& p, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Weight gradient in the bf16x3 form (sh_set_f32_mma_mode(SH_MMA_SPLIT3); Cin % 4 == 0, batch % 16 == 0, >= 2 output-channel
+// Weight gradient in the bf16x3 form (mma_mode SH_MMA_SPLIT3; Cin % 4 == 0, batch % 16 == 0, >= 2 output-channel
 // tiles).  Same work items, slabs and output mapping as wgrad_stream_kernel; the reduction runs in steps of 32 rows = two
 // vertices x 16 batch entries on v_mfma_f32_16x16x32_bf16: lane (a = lane & 15, kb = lane >> 4) loads the quads
 // x[nbr(v + (kb >> 1), s_a)][b0 + 8 (kb & 1) + j][c_a .. c_a+3], j = 0..7 - its eight reduction rows of the four gathered
@@ -1756,7 +1775,10 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_split3_kernel(const WSParams p
         Tl[i] = p.table[(long)(v_begin + vl * v_step) * S + j];
     }
     __syncthreads();
-    if (!wi.active) return;           // (an active item whose vertex range is empty still owns a slab: it writes zeros)
+    if (nv <= 0) {                    // as wgrad_stream_kernel
+        if (wi.active) ws_zero_slab(p, rc, cg, lane);
+        return;
+    }
 
     const int la = lane & 15, kb = lane >> 4;
     const int k0 = cg * 64 + 4 * la;
@@ -1828,7 +1850,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_split3_kernel(const WSParams p
         }
     };
 
-    if (nv > 0) load_step(0, g4[0], pr[0]);
+    load_step(0, g4[0], pr[0]);
     for (int vl = 0; vl < nv; vl += 4) {
         load_step(vl + 2, g4[1], pr[1]);
         __builtin_amdgcn_sched_barrier(0);                       // prefetch loads stay ahead of the MFMAs

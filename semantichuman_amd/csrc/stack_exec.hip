@@ -15,6 +15,26 @@ inline int out_rows(const sh_stack_step& s) { return s.kind == 0 ? s.R : s.m_row
 inline bool is_last_step(int i, int n) { return i == n - 1; }
 inline int in_rows(const sh_stack_step& s) { return s.kind == 0 ? s.n_in : s.m_cols; }
 
+// Every tensor a step gathers from is addressed with 32-bit offsets: element offsets in the fp32 conv kernels, row offsets
+// pre-multiplied by the row stride in 16-byte units in the plane convs (csrc/p3_conv.hip: tv[]) and the streaming weight
+// gradients (Tl[]).  2^32 ELEMENTS per tensor is the tightest of the three (16 GiB of fp32, 24 GiB of planes against the 64 GiB
+// the pre-multiplied forms reach), so that is what is refused here - with a message, not with wrapped gather addresses.
+int check_tensor_sizes(int n, const sh_stack_step* st, int rows0, int c0, int B, const char* what) {
+    long rows = rows0;
+    int c = c0;
+    for (int i = 0; i <= n; ++i) {
+        long extra = 0;                                       // pre-summed rows behind a conv step's gradient rows
+        if (i > 0 && st[i - 1].kind == 0) extra = (long)st[i - 1].n1 + st[i - 1].n2;
+        SH_REQUIRE((rows + extra) * (long)B * c < (1L << 32), SH_ERR_UNSUPPORTED,
+                   "%s: the tensor %s step %d has %ld rows x %d batch entries x %d channels >= 2^32 elements - split the batch", what,
+                   i < n ? "entering" : "leaving", i < n ? i : n - 1, rows + extra, B, c);
+        if (i == n) break;
+        rows = st[i].kind == 0 ? st[i].R : (st[i].extend ? (long)st[i].m_cols + st[i].m_rows : st[i].m_rows);
+        if (st[i].kind == 0) c = st[i].cout;
+    }
+    return SH_OK;
+}
+
 int check_steps(int n, const sh_stack_step* st, int c0, const char* what) {
     SH_REQUIRE(n > 0 && st, SH_ERR_INVALID_ARG, "%s: no steps", what);
     int c = c0;
@@ -65,6 +85,7 @@ int sh_stack_forward(int n_steps, const sh_stack_step* steps, const float* x, in
                      void* const* planes, const void* const* wfrag3, sh_stream_t stream) {
     int rc = check_steps(n_steps, steps, c0, "sh_stack_forward");
     if (rc != SH_OK) return rc;
+    if (B > 0 && (rc = check_tensor_sizes(n_steps, steps, rows0, c0, B, "sh_stack_forward")) != SH_OK) return rc;
     SH_REQUIRE(x && weights && outs && B > 0, SH_ERR_INVALID_ARG, "sh_stack_forward: null pointer or empty batch");
     SH_REQUIRE(sh_mma_mode_valid(mma_mode), SH_ERR_INVALID_ARG, "sh_stack_forward: unknown mma_mode %d", mma_mode);
     const P3Ctx pc{n_steps, B, mma_mode, steps, planes, wfrag3};
@@ -112,6 +133,7 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
                       void* const* gin_planes, void* dpre_last_planes, const void* const* wfrag3_t, sh_stream_t stream) {
     int rc = check_steps(n_steps, steps, c0, "sh_stack_backward");
     if (rc != SH_OK) return rc;
+    if (B > 0 && (rc = check_tensor_sizes(n_steps, steps, rows0, c0, B, "sh_stack_backward")) != SH_OK) return rc;
     SH_REQUIRE(x && acts && g && weights && gin && dW && B > 0, SH_ERR_INVALID_ARG, "sh_stack_backward: null pointer or empty batch");
     SH_REQUIRE(n_steps <= 64, SH_ERR_UNSUPPORTED, "sh_stack_backward: more than 64 steps");
     SH_REQUIRE(sh_mma_mode_valid(mma_mode), SH_ERR_INVALID_ARG, "sh_stack_backward: unknown mma_mode %d", mma_mode);
@@ -313,6 +335,7 @@ int sh_stack_forward_bf16(int n_steps, const sh_stack_step* steps, const void* x
                           void* const* outs, int out_dtype, int out_layout, sh_stream_t stream) {
     int rc = check_steps(n_steps, steps, c0, "sh_stack_forward_bf16");
     if (rc != SH_OK) return rc;
+    if (B > 0 && (rc = check_tensor_sizes(n_steps, steps, rows0, c0, B, "sh_stack_forward_bf16")) != SH_OK) return rc;
     SH_REQUIRE(x && weights && outs && wfrag && B > 0, SH_ERR_INVALID_ARG, "sh_stack_forward_bf16: null pointer or empty batch");
     SH_REQUIRE(n_steps <= 64, SH_ERR_UNSUPPORTED, "sh_stack_forward_bf16: more than 64 steps");
     {
@@ -369,6 +392,7 @@ int sh_stack_backward_bf16(int n_steps, const sh_stack_step* steps, const void* 
                            sh_stream_t stream) {
     int rc = check_steps(n_steps, steps, c0, "sh_stack_backward_bf16");
     if (rc != SH_OK) return rc;
+    if (B > 0 && (rc = check_tensor_sizes(n_steps, steps, rows0, c0, B, "sh_stack_backward_bf16")) != SH_OK) return rc;
     SH_REQUIRE(x && acts && g && weights && gin && dW && B > 0, SH_ERR_INVALID_ARG, "sh_stack_backward_bf16: null pointer or empty batch");
     SH_REQUIRE(n_steps <= 64, SH_ERR_UNSUPPORTED, "sh_stack_backward_bf16: more than 64 steps");
     const int last = n_steps - 1;

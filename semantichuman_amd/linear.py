@@ -14,19 +14,21 @@ from . import ops
 class _LatentLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
+        from . import _lib
         x = x.contiguous()
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return ops.linear_fwd(x, weight.contiguous(), bias)
+        ctx.mma = _lib.get_f32_mma_mode()          # the node's arithmetic form: backward (autograd's thread, later) keeps it
+        return ops.linear_fwd(x, weight.contiguous(), bias, ctx.mma)
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = ops.linear_bwd_data(dy, weight) if ctx.needs_input_grad[0] else None
+        dx = ops.linear_bwd_data(dy, weight, ctx.mma) if ctx.needs_input_grad[0] else None
         dW = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dW, db = ops.linear_bwd_wgt(dy, x, want_bias=ctx.has_bias and ctx.needs_input_grad[2])
+            dW, db = ops.linear_bwd_wgt(dy, x, want_bias=ctx.has_bias and ctx.needs_input_grad[2], mma=ctx.mma)
         return dx, dW, db
 
 

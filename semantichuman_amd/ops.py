@@ -180,36 +180,37 @@ def _check2d(*ts):
                                "no CPU path" % (t.device, t.dtype, tuple(t.shape)))
 
 
-def linear_fwd(x, weight, bias):
-    """y = x @ weight.T + bias for x [M,K], weight [N,K] (nn.Linear layout)."""
+def linear_fwd(x, weight, bias, mma=None):
+    """y = x @ weight.T + bias for x [M,K], weight [N,K] (nn.Linear layout).  mma: arithmetic form of the products (None = the
+    caller's default, _lib.get_f32_mma_mode())."""
     _check2d(x, weight, bias)
     M, K = x.shape
     N = weight.shape[0]
     assert weight.shape[1] == K
     y = torch.empty((M, N), dtype=torch.float32, device=x.device)
     ws, nb = _linear_ws(M, N, K, x.device)
-    check(_lib.load().sh_linear_fwd(ptr(x), ptr(weight), ptr(bias), ptr(y), M, N, K, ptr(ws), nb, stream_ptr()), "sh_linear_fwd")
+    check(_lib.load().sh_linear_fwd(ptr(x), ptr(weight), ptr(bias), ptr(y), M, N, K, ptr(ws), nb, _lib.mma_id(mma), stream_ptr()), "sh_linear_fwd")
     return y
 
 
-def linear_bwd_data(dy, weight):
+def linear_bwd_data(dy, weight, mma=None):
     _check2d(dy, weight)
     M, N = dy.shape
     K = weight.shape[1]
     dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
     ws, nb = _linear_ws(M, N, K, dy.device)
-    check(_lib.load().sh_linear_bwd_data(ptr(dy), ptr(weight), ptr(dx), M, N, K, ptr(ws), nb, stream_ptr()), "sh_linear_bwd_data")
+    check(_lib.load().sh_linear_bwd_data(ptr(dy), ptr(weight), ptr(dx), M, N, K, ptr(ws), nb, _lib.mma_id(mma), stream_ptr()), "sh_linear_bwd_data")
     return dx
 
 
-def linear_bwd_wgt(dy, x, want_bias=True):
+def linear_bwd_wgt(dy, x, want_bias=True, mma=None):
     _check2d(dy, x)
     M, N = dy.shape
     K = x.shape[1]
     dW = torch.empty((N, K), dtype=torch.float32, device=dy.device)
     db = torch.empty((N,), dtype=torch.float32, device=dy.device) if want_bias else None
     ws, nb = _linear_ws(M, N, K, dy.device)
-    check(_lib.load().sh_linear_bwd_wgt(ptr(dy), ptr(x), ptr(dW), ptr(db), M, N, K, ptr(ws), nb, stream_ptr()), "sh_linear_bwd_wgt")
+    check(_lib.load().sh_linear_bwd_wgt(ptr(dy), ptr(x), ptr(dW), ptr(db), M, N, K, ptr(ws), nb, _lib.mma_id(mma), stream_ptr()), "sh_linear_bwd_wgt")
     return dW, db
 
 

@@ -397,7 +397,10 @@ class Stack:
         planes_p = wf3_p = None
         if mma == "planes3" and B % 16 == 0 and plan["wf3_total"]:
             planes, wf3, wbase = self._p3_prepare(plan, weights, with_backward, x.device)
-            p3 = (planes, wf3, wbase)
+            # what the backward pass needs of this: the weight fragments.  The image arena of the forward activations (6 bytes per
+            # element) is NOT kept - nothing in sh_stack_backward reads it, the launches above are ordered on the stream, and the
+            # backward pass's own image arena can take the memory
+            p3 = (None, wf3, wbase)
             pl = (plan["pl_off"] + np.uint64(planes.data_ptr())) * plan["pl_mask"]
             wf = (plan["wf3_off"] + np.uint64(wf3.data_ptr() + wbase)) * plan["wf3_mask"]
             planes_p, wf3_p = pl.ctypes.data, wf.ctypes.data

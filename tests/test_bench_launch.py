@@ -88,3 +88,88 @@ def test_all_attempts_failing_gives_a_nonzero_status():
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def _tagged_processes(tag):
+    """PIDs of live processes whose environment carries SH_BENCH_TEST_TAG=<tag> (the launcher, its supervisors, their ranks)."""
+    out = []
+    needle = ("SH_BENCH_TEST_TAG=%s" % tag).encode()
+    for d in os.listdir("/proc"):
+        if not d.isdigit():
+            continue
+        try:
+            with open("/proc/%s/environ" % d, "rb") as f:
+                if needle in f.read().split(b"\0"):
+                    with open("/proc/%s/stat" % d) as g:
+                        if g.read().rsplit(")", 1)[1].split()[0] != "Z":
+                            out.append(int(d))
+        except OSError:
+            continue
+    return out
+
+
+def test_terminated_launcher_leaves_no_rank_behind(tmp_path):
+    """a launcher that is terminated (the driver's `timeout`, torch.distributed.run after a rank failure) must not
+    orphan rank processes - on a GPU box they would sit in a collective holding the device.  Two ranks hang after the
+    rendezvous; the launcher gets SIGTERM; every process of the job (launcher -> supervisors -> ranks) must be gone, and the
+    supervisors' marker directory with it."""
+    import signal
+    import time
+    import uuid
+    tag = uuid.uuid4().hex
+    env = dict(_env(), SH_BENCH_TEST_RANK_HANG="*:*", SH_BENCH_TEST_TAG=tag, TMPDIR=str(tmp_path))
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                         stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    try:
+        t0 = time.time()
+        while time.time() - t0 < 120 and len(_tagged_processes(tag)) < 5:      # launcher + 2 supervisors + 2 ranks
+            time.sleep(0.2)
+        assert len(_tagged_processes(tag)) >= 5, _tagged_processes(tag)
+        time.sleep(2.0)                                                      # let the ranks reach the rendezvous
+        p.send_signal(signal.SIGTERM)
+        p.wait(60)
+        t0 = time.time()
+        while time.time() - t0 < 30 and _tagged_processes(tag):
+            time.sleep(0.2)
+        assert _tagged_processes(tag) == []
+        assert not [d for d in os.listdir(tmp_path) if d.startswith("sh_bench_")], os.listdir(tmp_path)
+    finally:
+        for pid in _tagged_processes(tag):
+            try:
+                os.kill(pid, signal.SIGKILL)
+            except OSError:
+                pass
+
+
+def test_killed_supervisor_takes_its_rank_along(tmp_path):
+    """... and a supervisor that is SIGKILLed (no handler, no finally) still does not leave its rank: the child asked the
+    kernel for SIGKILL on its parent's death (PR_SET_PDEATHSIG) before it would touch a GPU."""
+    import signal
+    import time
+    import uuid
+    tag = uuid.uuid4().hex
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(_env(), SH_BENCH_TEST_RANK_HANG="*:*", SH_BENCH_TEST_TAG=tag, TMPDIR=str(tmp_path), WORLD_SIZE="2", RANK="1", LOCAL_RANK="1",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sup = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    try:
+        t0 = time.time()
+        while time.time() - t0 < 120 and len(_tagged_processes(tag)) < 2:      # the supervisor and its rank
+            time.sleep(0.2)
+        assert len(_tagged_processes(tag)) == 2
+        time.sleep(3.0)                                                      # the rank has set PR_SET_PDEATHSIG by now
+        sup.kill()
+        sup.wait(30)
+        t0 = time.time()
+        while time.time() - t0 < 30 and _tagged_processes(tag):
+            time.sleep(0.2)
+        assert _tagged_processes(tag) == []
+    finally:
+        for pid in _tagged_processes(tag):
+            try:
+                os.kill(pid, signal.SIGKILL)
+            except OSError:
+                pass

@@ -152,3 +152,47 @@ def test_stack_step_selects_the_plane_kernels():
         _lib.set_f32_mma_mode(was)
     assert counts["exact"] == 0
     assert counts["planes3"] == 14, counts          # 7 forward + 7 backward-data launches (every conv but the 3-channel sides)
+
+
+@pytest.mark.parametrize("adversarial", [False, True])
+@pytest.mark.parametrize("mnk", [(64, 256, 55296), (64, 55296, 256), (16, 256, 55296), (48, 1024, 4096)])
+def test_latent_fc_bf16x3_error_against_float64(mnk, adversarial):
+    """The same gate for the latent FCs (models.py:130,144; round 5: csrc/linear.hip runs their six GEMMs in the bf16x3 form when
+    the caller's form is split3 / planes3 - both fp32 operands split exactly into three bf16 terms in registers, six partial
+    products on v_mfma_f32_16x16x32_bf16, fp32 accumulation): forward, input gradient, weight gradient and bias gradient against
+    a float64 evaluation, max-abs error <= 1.5 x the exact fp32 MFMA kernels' + one fp32 ulp of the result's scale - on
+    training-scale operands and on adversarial ones (six decades of dynamic range, cancelling sums of 55 296 terms)."""
+    from semantichuman_amd import _lib, ops
+    M, N, K = mnk
+    g = torch.Generator().manual_seed(M + N + K + (7 if adversarial else 0))
+    if adversarial:
+        mag = lambda *s: torch.pow(10.0, 6 * torch.rand(*s, generator=g) - 3)                     # noqa: E731
+        x = torch.randn(M, K, generator=g) * mag(M, K)
+        W = torch.randn(N, K, generator=g) * mag(N, K) / K ** 0.5
+        dy = torch.randn(M, N, generator=g) * mag(M, N)
+        x[:, 1::2] = -x[:, 0::2] * (1 + 1e-3 * torch.randn(M, K // 2, generator=g))                # sums that cancel
+    else:
+        x = torch.randn(M, K, generator=g)
+        W = torch.randn(N, K, generator=g) / K ** 0.5
+        dy = torch.randn(M, N, generator=g) * 1e-3
+    b = torch.randn(N, generator=g)
+    ref = {"y": x.double() @ W.double().T + b.double(), "dx": dy.double() @ W.double(), "dW": dy.double().T @ x.double(),
+           "db": dy.double().sum(0)}
+    d = dev()
+    xd, Wd, bd, dyd = (t.to(d) for t in (x, W, b, dy))
+    err = {}
+    for form in ("exact", "planes3"):
+        _lib.profile_enable(True)
+        out = {"y": ops.linear_fwd(xd, Wd, bd, form), "dx": ops.linear_bwd_data(dyd, Wd, form)}
+        out["dW"], out["db"] = ops.linear_bwd_wgt(dyd, xd, True, form)
+        torch.cuda.synchronize()
+        names = [n for n, _, _ in _lib.profile_records_by_kernel()]
+        _lib.profile_enable(False)
+        assert sum(1 for n in names if "_x3_" in n) == (3 if form == "planes3" else 0), names      # the kernels under test really ran
+        err[form] = {k: float((out[k].double().cpu() - ref[k]).abs().max()) for k in ref}
+    for k in ref:
+        scale = float(ref[k].abs().max())
+        assert err["planes3"][k] <= 1.5 * err["exact"][k] + 2.0 ** -23 * scale, (k, err["planes3"][k], err["exact"][k], scale)
+        assert err["exact"][k] <= 2e-5 * scale, (k, err["exact"][k], scale)
+    print("FC %s %s: " % (mnk, "adversarial" if adversarial else "training-scale") +
+          "  ".join("%s %.2e / %.2e" % (k, err["planes3"][k] / float(ref[k].abs().max()), err["exact"][k] / float(ref[k].abs().max())) for k in ref))
