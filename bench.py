@@ -661,7 +661,10 @@ def roofline_f32(recs, model, B, nprof, verts):
     def line(k):
         a = agg[k["kernel"]]
         traffic, traffic_note = measured_traffic(k["kernel"], workload_tag(verts, B, "f32", mma))
-        base = {"kernel": k["kernel"], "traffic": traffic, "traffic_unit": traffic_note, "avg_launch_ms": k["avg_ms"],
+        base = {"kernel": k["kernel"], "traffic": traffic, "traffic_unit": traffic_note,
+                # what the launch really moved per second (PMC bytes / this run's HIP-event time): how close the kernel is to what
+                # the memory system delivers, next to `achieved`, which only counts the bytes the algorithm needs
+                "traffic_gbps": (traffic / (k["avg_ms"] * 1e-3) / 1e9) if traffic else None, "avg_launch_ms": k["avg_ms"],
                 "launches_per_step": k["launches_per_step"], "ms_per_step": k["ms_per_step"], "f32_mma": mma,
                 "algorithmic_bytes_per_launch": (a["bytes"] / a["n"]) if a["matched"] == a["n"] else None}
         # FLOPs / byte of the launch decides the roof: below the ridge of the pipe it runs on it is an HBM line

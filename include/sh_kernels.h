@@ -241,10 +241,13 @@ typedef struct sh_stack_step {
  * outs[i] (sh_p3_bytes of the buffer's rows - a step that appends shares its predecessor's buffer AND image - or NULL: the
  * step that gathers it keeps the SPLIT3 kernels); wfrag3[i] = three-plane weight fragments of conv step i, forward operand
  * (sh_conv_wfrag3_prep_multi, transpose 0), already converted from the CURRENT weights.  A conv step whose input has an
- * image and whose shape sh_spiral_conv_p3_ok() takes runs sh_spiral_conv_fwd_p3; images are written by their producers. */
+ * image and whose shape sh_spiral_conv_p3_ok() takes runs sh_spiral_conv_fwd_p3; images are written by their producers.
+ * keep_fp32: 1 = every step writes its fp32 output (a backward pass reads them); 0 = forward only: rows that the next plane
+ * conv gathers through their image alone are written as the image alone (outs[i] of such a step is then partly or wholly
+ * unwritten; the last step's output is always fp32). */
 SH_API int sh_stack_forward(int n_steps, const sh_stack_step* steps, const float* x, int x_layout, int rows0, int c0, int B,
                             const float* const* weights, const float* const* biases, float* const* outs, int out_layout,
-                            int mma_mode, void* const* planes, const void* const* wfrag3, sh_stream_t stream);
+                            int mma_mode, void* const* planes, const void* const* wfrag3, int keep_fp32, sh_stream_t stream);
 
 /* acts[i]: what sh_stack_forward wrote to outs[i].  g: gradient w.r.t. the stack output (out_layout).
  * gin[i]: gradient w.r.t. the INPUT of step i - for i >= 1 vertex-major with (n1 + n2 of step i-1, if that is a
@@ -613,7 +616,8 @@ SH_API int sh_spiral_conv_p3_kind(int B, int S, int Cg, int Nout);
  * really ran or the SPLIT3 kernels served the call (batch not a multiple of 16, shapes sh_spiral_conv_p3_ok() refuses):
  * tests/conftest.py reports the [planes3] instance of a test that never moved this counter as skipped, not passed. */
 SH_API int64_t sh_p3_launch_count(void);
-/* sh_spmm that also writes the plane image of the rows it produces (y_planes: image of row 0 of y; NULL = plain sh_spmm) */
+/* sh_spmm that also writes the plane image of the rows it produces (y_planes: image of row 0 of y; NULL = plain sh_spmm);
+ * y == NULL with y_planes: the image alone (y_sv / y_sb still describe the vertex-major tensor the image belongs to) */
 SH_API int sh_spmm_p3(const int32_t* rowptr, const int32_t* col, const float* val, const float* x, int64_t x_sv, int64_t x_sb,
                       float* y, int64_t y_sv, int64_t y_sb, void* y_planes, const float* yprev, int64_t yp_sv, int64_t yp_sb,
                       int act_prev, int zero_row, int B, int rows, int C, sh_stream_t stream);

@@ -37,7 +37,7 @@ SIGNATURES = {
     "sh_act_backward": (c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _P]),
     "sh_act_backward_tr": (c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "sh_spmm": (c_int, [_P, _P, _P, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _P]),
-    "sh_stack_forward": (c_int, [_I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "sh_stack_forward": (c_int, [_I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _I, _P]),
     "sh_stack_backward": (c_int, [_I, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "sh_linear_workspace": (c_size_t, [_I, _I, _I]),
     "sh_linear_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, c_size_t, _I, _P]),

@@ -368,6 +368,10 @@ __global__ __launch_bounds__(LTHREADS) void linear_fwd_dma_kernel(const LSParams
     const int ng = item % p.groups, sp = item / p.groups;
     const int n0 = ng * 64, k_begin = sp * p.range;
     const int nst = (min(p.K, k_begin + p.range) - k_begin) >> 5;          // stages of 32 k
+    // batches of more than 64 rows (round 5: config 5's decode runs the decoder FC at 1024): blockIdx.y = the 64-row chunk - the
+    // weight is streamed once per chunk, from the Infinity Cache after the first (56.6 MB of 256)
+    const int m_lo = 64 * (int)blockIdx.y, m_n = min(64, p.M - m_lo);
+    const float* pa = p.a + (long)m_lo * p.K;
     const int lr = lane & 15, kq = lane >> 4;
     typedef __attribute__((address_space(3))) char* lptr_t;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_t)smem);
@@ -388,7 +392,7 @@ __global__ __launch_bounds__(LTHREADS) void linear_fwd_dma_kernel(const LSParams
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int r = 8 * (2 * wave + j) + drow, piece = (lane & 7) ^ ((r >> 1) & 7);
-        xsrc[j] = p.a + (long)min(r, p.M - 1) * p.K + k_begin + 4 * piece;
+        xsrc[j] = pa + (long)min(r, m_n - 1) * p.K + k_begin + 4 * piece;
     }
     auto issue = [&](int st) {
         const unsigned slot = lds0 + (unsigned)((st % 3) * LFD_STAGE);
@@ -446,11 +450,11 @@ __global__ __launch_bounds__(LTHREADS) void linear_fwd_dma_kernel(const LSParams
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    // lane holds y[m = 16 mt + lr][n0 + 16 nt + 4 kq .. +3]
+    // lane holds y[m = m_lo + 16 mt + lr][n0 + 16 nt + 4 kq .. +3]
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int m = 16 * mt + lr;
-        if (m >= p.M) continue;
+        if (16 * mt + lr >= m_n) continue;
+        const int m = m_lo + 16 * mt + lr;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const int n = n0 + 16 * nt + 4 * kq;
@@ -770,10 +774,12 @@ __global__ __launch_bounds__(LTHREADS) void linear_bwd_wgt_dma_kernel(const LSPa
 
 // plan of the streaming forms: enough items for one wave per SIMD (1024), reduction ranges multiples of 16
 struct LSPlan { bool ok; int range, nsplit, groups; };
-LSPlan plan_stream(int M, int out_cols, int red_len, int gran = 16) {        // gran: the reduction steps of the kernel (bf16x3 forms: 32)
+LSPlan plan_stream(int M, int out_cols, int red_len, int gran = 16, bool chunked = false) {   // gran: reduction steps of the kernel (bf16x3 forms: 32)
     LSPlan pl{false, red_len, 1, out_cols / 64};
     static const int on = sh_env_int("SH_LIN_STREAM", 1, 0, 1);
-    if (!on || M > 64 || out_cols % 64 != 0 || red_len % gran != 0) return pl;
+    // chunked: the forward LDS-DMA kernel takes any batch as 64-row chunks (gridDim.y) when the reduction is not split
+    const bool big_ok = chunked && red_len < 1024 && red_len % 32 == 0 && (out_cols / 64) % 4 == 0;
+    if (!on || (M > 64 && !big_ok) || out_cols % 64 != 0 || red_len % gran != 0) return pl;
     pl.ok = true;
     static const int items = sh_env_int("SH_LIN_ITEMS", 1024, 64, 1 << 20);
     if (pl.groups < items / 2 && red_len >= 1024) {
@@ -853,7 +859,8 @@ int run_stream(LSParams& p, const LSPlan& pl, int cols, void* ws, size_t ws_byte
         SH_REQUIRE(ws && ws_bytes >= (size_t)p.nsplit * p.M * cols * sizeof(float), SH_ERR_WORKSPACE, "%s: workspace too small", what);
         p.slab = static_cast<float*>(ws);
     }
-    const int items = p.groups * p.nsplit, grid = sh_cdiv(items, 4), mt = sh_cdiv(p.M, 16);
+    const int items = p.groups * p.nsplit, grid = sh_cdiv(items, 4), mchunks = sh_cdiv(p.M, 64), mt = p.M > 64 ? 4 : sh_cdiv(p.M, 16);
+    SH_REQUIRE(mchunks == 1 || (FWD && p.nsplit == 1), SH_ERR_UNSUPPORTED, "%s: more than 64 rows need the unsplit forward form", what);
     {
         ShProfScope ps(st, "%s<%d>|M=%d N=%d K=%d split=%d", FWD ? "linear_fwd_stream_kernel" : "linear_bwd_data_stream_kernel", mt, p.M,
                        p.N, p.K, p.nsplit);
@@ -862,6 +869,7 @@ int run_stream(LSParams& p, const LSPlan& pl, int cols, void* ws, size_t ws_byte
     else SH_LAUNCH_PS(ps, linear_bwd_data_stream_kernel<MTV>, dim3(grid), dim3(LTHREADS), 0, st, p)
         static const int dma_on = sh_env_int("SH_LIN_DMA", 1, 0, 1);
         const bool dma = FWD && dma_on && p.K % 32 == 0 && p.range % 32 == 0 && p.groups % 4 == 0;
+        SH_REQUIRE(mchunks == 1 || dma, SH_ERR_UNSUPPORTED, "%s: more than 64 rows need the LDS-DMA forward form (SH_LIN_DMA=1)", what);
         if (x3 && !FWD) {
             snprintf(ps.name, sizeof ps.name, "linear_bwd_data_x3_kernel<%d>|M=%d N=%d K=%d split=%d", mt, p.M, p.N, p.K, p.nsplit);
             if (mt == 1) SH_LAUNCH_PS(ps, linear_bwd_data_x3_kernel<1>, dim3(grid), dim3(LTHREADS), 0, st, p);
@@ -882,10 +890,10 @@ int run_stream(LSParams& p, const LSPlan& pl, int cols, void* ws, size_t ws_byte
                 attr3_set = true;
             }
             snprintf(ps.name, sizeof ps.name, "linear_fwd_x3_kernel<%d>|M=%d N=%d K=%d split=%d", mt, p.M, p.N, p.K, p.nsplit);
-            if (mt == 1) SH_LAUNCH_PS(ps, (linear_fwd_dma_kernel<1, true>), dim3(grid), dim3(LTHREADS), LFD_LDS, st, p);
-            else if (mt == 2) SH_LAUNCH_PS(ps, (linear_fwd_dma_kernel<2, true>), dim3(grid), dim3(LTHREADS), LFD_LDS, st, p);
-            else if (mt == 3) SH_LAUNCH_PS(ps, (linear_fwd_dma_kernel<3, true>), dim3(grid), dim3(LTHREADS), LFD_LDS, st, p);
-            else SH_LAUNCH_PS(ps, (linear_fwd_dma_kernel<4, true>), dim3(grid), dim3(LTHREADS), LFD_LDS, st, p);
+            if (mt == 1) SH_LAUNCH_PS(ps, (linear_fwd_dma_kernel<1, true>), dim3(grid, mchunks), dim3(LTHREADS), LFD_LDS, st, p);
+            else if (mt == 2) SH_LAUNCH_PS(ps, (linear_fwd_dma_kernel<2, true>), dim3(grid, mchunks), dim3(LTHREADS), LFD_LDS, st, p);
+            else if (mt == 3) SH_LAUNCH_PS(ps, (linear_fwd_dma_kernel<3, true>), dim3(grid, mchunks), dim3(LTHREADS), LFD_LDS, st, p);
+            else SH_LAUNCH_PS(ps, (linear_fwd_dma_kernel<4, true>), dim3(grid, mchunks), dim3(LTHREADS), LFD_LDS, st, p);
         } else if (dma) {
             static bool attr_set = false;
             if (!attr_set) {
@@ -900,10 +908,10 @@ int run_stream(LSParams& p, const LSPlan& pl, int cols, void* ws, size_t ws_byte
                 attr_set = true;
             }
             snprintf(ps.name, sizeof ps.name, "linear_fwd_dma_kernel<%d>|M=%d N=%d K=%d split=%d", mt, p.M, p.N, p.K, p.nsplit);
-            if (mt == 1) SH_LAUNCH_PS(ps, linear_fwd_dma_kernel<1>, dim3(grid), dim3(LTHREADS), LFD_LDS, st, p);
-            else if (mt == 2) SH_LAUNCH_PS(ps, linear_fwd_dma_kernel<2>, dim3(grid), dim3(LTHREADS), LFD_LDS, st, p);
-            else if (mt == 3) SH_LAUNCH_PS(ps, linear_fwd_dma_kernel<3>, dim3(grid), dim3(LTHREADS), LFD_LDS, st, p);
-            else SH_LAUNCH_PS(ps, linear_fwd_dma_kernel<4>, dim3(grid), dim3(LTHREADS), LFD_LDS, st, p);
+            if (mt == 1) SH_LAUNCH_PS(ps, linear_fwd_dma_kernel<1>, dim3(grid, mchunks), dim3(LTHREADS), LFD_LDS, st, p);
+            else if (mt == 2) SH_LAUNCH_PS(ps, linear_fwd_dma_kernel<2>, dim3(grid, mchunks), dim3(LTHREADS), LFD_LDS, st, p);
+            else if (mt == 3) SH_LAUNCH_PS(ps, linear_fwd_dma_kernel<3>, dim3(grid, mchunks), dim3(LTHREADS), LFD_LDS, st, p);
+            else SH_LAUNCH_PS(ps, linear_fwd_dma_kernel<4>, dim3(grid, mchunks), dim3(LTHREADS), LFD_LDS, st, p);
         } else if (mt == 1) { SH_LS_CASE(1); } else if (mt == 2) { SH_LS_CASE(2); } else if (mt == 3) { SH_LS_CASE(3); } else { SH_LS_CASE(4); }
 #undef SH_LS_CASE
     }
@@ -953,7 +961,8 @@ int sh_linear_fwd(const float* x, const float* weight, const float* bias, float*
     {
         // bf16x3 form: the LDS-DMA kernel's shapes (32-wide stages, four column groups per workgroup); anything else keeps fp32 MFMA
         const bool x3 = lin_x3(mma_mode) && K % 32 == 0 && (N / 64) % 4 == 0;
-        const LSPlan pl = plan_stream(M, N, K, x3 ? 32 : 16);
+        static const int chunk_on = sh_env_int("SH_LIN_CHUNKED", 1, 0, 1);
+        const LSPlan pl = plan_stream(M, N, K, x3 ? 32 : 16, chunk_on && M > 64);
         if (pl.ok && aligned16(x, weight, y) && (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0)) {
             LSParams s{};
             s.a = x; s.w = weight; s.bias = bias; s.out = y; s.M = M; s.N = N; s.K = K;

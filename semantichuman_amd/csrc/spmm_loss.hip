@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void spmm_kernel(const int* __restrict__ rowpt
                     for (int k = 0; k < 4; ++k) acc[k] *= sh_act_grad_from_out(yv[k], act);
                 }
                 if (zero) acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-                *reinterpret_cast<f32x4*>(y + yo) = acc;
+                if (!P3 || y) *reinterpret_cast<f32x4*>(y + yo) = acc;        // (P3: the image alone when nobody reads the fp32 rows)
                 if constexpr (P3) {
                     u32x2 h, m, l;
                     sh_split3_quad(acc, h, m, l);
@@ -78,6 +78,66 @@ __global__ __launch_bounds__(256) void spmm_kernel(const int* __restrict__ rowpt
                 y[yo] = zero ? 0.f : acc;
             }
         }
+    }
+}
+
+// The image-writing form with EIGHT channels per thread (round 5): a thread's result is one whole 16-byte piece of each plane
+// (the quad form above writes 8-byte halves: two store instructions per piece, each touching half of every line), its fp32
+// row segment two 16-byte stores; the sums are the quad form's, entry for entry (bitwise the same rows and image).
+__global__ __launch_bounds__(256) void spmm_p3x8_kernel(const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ val,
+                                                        const float* __restrict__ x, long x_sv, long x_sb, float* __restrict__ y, long y_sv,
+                                                        long y_sb, const float* __restrict__ yprev, long yp_sv, long yp_sb, int act, int zero_row,
+                                                        int B, int rows, int C, char* __restrict__ img, long img_vb, long img_bgb) {
+    const int CW = C >> 3;
+    const int per_row = B * CW;
+    const int parts = (per_row + 255) >> 8;
+    const long items = (long)rows * parts;
+    const bool c16 = C == 16;
+    const int pb = c16 ? 512 : 1024;
+    for (long it = blockIdx.x; it < items; it += gridDim.x) {
+        const int r = (int)(it / parts), part = (int)(it - (long)r * parts);
+        const int e0 = rowptr[r], e1 = rowptr[r + 1];
+        const int j = part * 256 + threadIdx.x;
+        if (j >= per_row) continue;
+        const int b = j / CW, co = 8 * (j - b * CW);
+        const long xo = (long)b * x_sb + co;
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+        int e = e0;
+        for (; e + 1 < e1; e += 2) {                         // two entries = four independent 16-byte loads in flight
+            const float* s0 = x + (long)col[e] * x_sv + xo;
+            const float* s1 = x + (long)col[e + 1] * x_sv + xo;
+            const f32x4 p0 = *reinterpret_cast<const f32x4*>(s0), p1 = *reinterpret_cast<const f32x4*>(s0 + 4);
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(s1), q1 = *reinterpret_cast<const f32x4*>(s1 + 4);
+            const float w0 = val[e], w1 = val[e + 1];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a0[k] = fmaf(w1, q0[k], fmaf(w0, p0[k], a0[k])); a1[k] = fmaf(w1, q1[k], fmaf(w0, p1[k], a1[k])); }
+        }
+        if (e < e1) {
+            const float* s0 = x + (long)col[e] * x_sv + xo;
+            const f32x4 p0 = *reinterpret_cast<const f32x4*>(s0), p1 = *reinterpret_cast<const f32x4*>(s0 + 4);
+            const float w0 = val[e];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a0[k] = fmaf(w0, p0[k], a0[k]); a1[k] = fmaf(w0, p1[k], a1[k]); }
+        }
+        if (yprev) {
+            const float* yp = yprev + (long)r * yp_sv + (long)b * yp_sb + co;
+            const f32x4 y0 = *reinterpret_cast<const f32x4*>(yp), y1 = *reinterpret_cast<const f32x4*>(yp + 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a0[k] *= sh_act_grad_from_out(y0[k], act); a1[k] *= sh_act_grad_from_out(y1[k], act); }
+        }
+        if (r == zero_row) { a0 = (f32x4){0.f, 0.f, 0.f, 0.f}; a1 = a0; }
+        if (y) {
+            float* d = y + (long)r * y_sv + (long)b * y_sb + co;
+            *reinterpret_cast<f32x4*>(d) = a0;
+            *reinterpret_cast<f32x4*>(d + 4) = a1;
+        }
+        u32x4 h, m, l;
+        sh_split3(a0, a1, h, m, l);
+        char* d = img + (long)r * img_vb + (long)(b >> 4) * img_bgb +
+                  (c16 ? ((co >> 3) * 16 + (b & 15)) * 16 : (co >> 5) * 3072 + (((co & 31) >> 3) * 16 + (b & 15)) * 16);
+        *reinterpret_cast<u32x4*>(d) = h;
+        *reinterpret_cast<u32x4*>(d + pb) = m;
+        *reinterpret_cast<u32x4*>(d + 2 * pb) = l;
     }
 }
 
@@ -328,7 +388,7 @@ int sh_spmm(const int32_t* rowptr, const int32_t* col, const float* val, const f
 int sh_spmm_p3(const int32_t* rowptr, const int32_t* col, const float* val, const float* x, int64_t x_sv, int64_t x_sb, float* y,
                int64_t y_sv, int64_t y_sb, void* y_planes, const float* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row,
                int B, int rows, int C, sh_stream_t stream) {
-    SH_REQUIRE(rowptr && col && val && x && y, SH_ERR_INVALID_ARG, "sh_spmm: null pointer");
+    SH_REQUIRE(rowptr && col && val && x && (y || y_planes), SH_ERR_INVALID_ARG, "sh_spmm: null pointer");
     SH_REQUIRE(B > 0 && rows > 0 && C > 0, SH_ERR_INVALID_ARG, "sh_spmm: non-positive size");
     SH_REQUIRE(act_prev >= SH_ACT_IDENTITY && act_prev <= SH_ACT_TANH, SH_ERR_INVALID_ARG, "sh_spmm: unknown activation %d", act_prev);
     const bool vec = (C % 4 == 0) && (x_sv % 4 == 0) && (x_sb % 4 == 0) && (y_sv % 4 == 0) && (y_sb % 4 == 0) &&
@@ -343,6 +403,16 @@ int sh_spmm_p3(const int32_t* rowptr, const int32_t* col, const float* val, cons
                    "sh_spmm_p3: B=%d C=%d has no plane image (vertex-major y; B %% 16 == 0; C == 16 or C %% 32 == 0; 16-byte aligned tensors)", B, C);
         const long bgb = C == 16 ? 1536 : (long)(C / 32) * 3072;
         ShProfScope ps(st, "spmm_kernel<true, p3>|rows=%d B=%d C=%d", rows, B, C);
+        // measured (profiles/r05_spmm_x8.txt): the eight-channel form wins on wide rows (C = 128: 396 -> 286 us at batch 1024, 19.1 -> 18.1
+        // at 64; C = 64 at batch 1024: 156 -> 138) and loses 1-7 % on the 32-channel levels: 0 = never, 1 = that rule, 2 = always
+        static const int x8_mode = sh_env_int("SH_SPMM_P3X8", 1, 0, 2);
+        const bool x8 = x8_mode == 2 || (x8_mode == 1 && (C >= 128 || (C == 64 && B >= 256)));
+        if (x8) {
+            const long items8 = (long)rows * (((long)B * (C / 8) + 255) / 256);
+            const int grid8 = (int)(items8 < grid_cap ? items8 : grid_cap);
+            SH_LAUNCH_PS(ps, spmm_p3x8_kernel, dim3(grid8), dim3(256), 0, st, rowptr, col, val, x, x_sv, x_sb, y, y_sv, y_sb, yprev, yp_sv, yp_sb,
+                         act_prev, zero_row, B, rows, C, static_cast<char*>(y_planes), bgb * (B / 16), bgb);
+        } else
         SH_LAUNCH_PS(ps, (spmm_kernel<true, true>), dim3(grid), dim3(256), 0, st, rowptr, col, val, x, x_sv, x_sb, y, y_sv, y_sb,
                      yprev, yp_sv, yp_sb, act_prev, zero_row, B, rows, C, static_cast<char*>(y_planes), bgb * (B / 16), bgb);
         SH_CHECK_LAUNCH("spmm");

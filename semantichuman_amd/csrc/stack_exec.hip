@@ -82,7 +82,7 @@ extern "C" {
 
 int sh_stack_forward(int n_steps, const sh_stack_step* steps, const float* x, int x_layout, int rows0, int c0, int B,
                      const float* const* weights, const float* const* biases, float* const* outs, int out_layout, int mma_mode,
-                     void* const* planes, const void* const* wfrag3, sh_stream_t stream) {
+                     void* const* planes, const void* const* wfrag3, int keep_fp32, sh_stream_t stream) {
     int rc = check_steps(n_steps, steps, c0, "sh_stack_forward");
     if (rc != SH_OK) return rc;
     if (B > 0 && (rc = check_tensor_sizes(n_steps, steps, rows0, c0, B, "sh_stack_forward")) != SH_OK) return rc;
@@ -101,10 +101,15 @@ int sh_stack_forward(int n_steps, const sh_stack_step* steps, const float* x, in
         const int cons = i < n_steps - 1 ? consumer_conv(pc, i) : -1;
         void* img = (cons >= 0 && planes && planes[i] && mma_mode == SH_MMA_PLANES3 && wfrag3 && wfrag3[cons] &&
                      sh_spiral_conv_p3_ok(B, steps[cons].S, steps[cons].cin, steps[cons].cout) && sh_p3_bytes(1, B, co)) ? planes[i] : nullptr;
+        // forward only (keep_fp32 == 0: no backward pass will read this pass's activations): rows that are gathered through
+        // their plane image alone are written as the image alone - a re-sampling step in front of a plane conv, a plane conv
+        // directly in front of another (6 instead of 10 bytes per element; BASELINE config 5's decode)
+        const bool img_only = !keep_fp32 && img && cons >= 0 && p3_fwd(pc, cons, true);
         if (s.kind == 0) {
             if (p3_fwd(pc, i, cl.sb == c && cl.sv == (long)B * c)) {
-                rc = sh_spiral_conv_fwd_p3(planes[i - 1], s.table, wfrag3[i], biases ? biases[s.param] : nullptr, outs[i], ol.sv, ol.sb, img, B,
-                                           s.R, s.S, s.cin, s.cout, s.act, s.zero_row, stream);
+                const bool direct = img_only && cons == i + 1;      // (through a folded up-sampling the fp32 rows feed the blend)
+                rc = sh_spiral_conv_fwd_p3(planes[i - 1], s.table, wfrag3[i], biases ? biases[s.param] : nullptr, direct ? nullptr : outs[i], ol.sv,
+                                           ol.sb, img, B, s.R, s.S, s.cin, s.cout, s.act, s.zero_row, stream);
             } else {
                 rc = sh_spiral_conv_fwd_img(cur, cl.sv, cl.sb, s.table, weights[s.param], biases ? biases[s.param] : nullptr, outs[i],
                                             ol.sv, ol.sb, img, B, s.R, s.S, s.cin, s.cout, s.act, s.zero_row, mma_mode, stream);
@@ -113,11 +118,11 @@ int sh_stack_forward(int n_steps, const sh_stack_step* steps, const float* x, in
             SH_REQUIRE(i > 0 && !is_last_step(i, n_steps) && outs[i] == outs[i - 1] && cl.sb == c, SH_ERR_INVALID_ARG,
                        "sh_stack_forward: step %d appends to its input, which must be the vertex-major output buffer of step %d", i, i - 1);
             SH_REQUIRE(!planes || planes[i] == planes[i - 1], SH_ERR_INVALID_ARG, "sh_stack_forward: step %d appends to its input: same image buffer", i);
-            float* dst = outs[i] + (long)s.m_cols * cl.sv;
+            float* dst = img_only ? nullptr : outs[i] + (long)s.m_cols * cl.sv;
             rc = sh_spmm_p3(s.m.rowptr, s.m.col, s.m.val, cur, cl.sv, cl.sb, dst, cl.sv, cl.sb,
                             img ? static_cast<char*>(img) + sh_p3_bytes(s.m_cols, B, c) : nullptr, nullptr, 0, 0, 0, -1, B, s.m_rows, c, stream);
         } else {
-            rc = sh_spmm_p3(s.m.rowptr, s.m.col, s.m.val, cur, cl.sv, cl.sb, outs[i], ol.sv, ol.sb, img, nullptr, 0, 0, 0, -1, B,
+            rc = sh_spmm_p3(s.m.rowptr, s.m.col, s.m.val, cur, cl.sv, cl.sb, img_only ? nullptr : outs[i], ol.sv, ol.sb, img, nullptr, 0, 0, 0, -1, B,
                             s.m_rows, c, stream);
         }
         if (rc != SH_OK) return rc;

@@ -406,7 +406,8 @@ class Stack:
             planes_p, wf3_p = pl.ctypes.data, wf.ctypes.data
         _lib.check(_lib.load().sh_stack_forward(n, self._native_steps(), _lib.ptr(x), _LAYOUT_ID[in_layout], rows0, c0, B,
                                                 self._ptr_array(weights), self._ptr_array(biases), outs.ctypes.data,
-                                                _LAYOUT_ID[out_layout], _lib.mma_id(mma), planes_p, wf3_p, _lib.stream_ptr()),
+                                                _LAYOUT_ID[out_layout], _lib.mma_id(mma), planes_p, wf3_p, 1 if with_backward else 0,
+                                                _lib.stream_ptr()),
                    "sh_stack_forward")
         return out, arena, p3
 

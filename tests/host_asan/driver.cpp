@@ -86,7 +86,7 @@ int main() {
             }
             void* planes[4] = {img0, img0, nullptr, nullptr};
             rc = sh_stack_forward(4, st, reinterpret_cast<const float*>(x), 0, L0.n_in, L0.cin, B, W, bias, reinterpret_cast<float* const*>(outs), 1, mma,
-                                  planes, wf3, nullptr);
+                                  planes, wf3, 1, nullptr);
         }
         if (rc) { printf("forward rc=%d\n", rc); break; }
         // ---- backward buffers

@@ -522,15 +522,15 @@ def test_c_abi_error_contract():
                                     ctypes.c_size_t(16), 2, 9, 3, 4, 4, 0, st)
     assert rc == -3 and b"workspace" in lib.sh_last_error()
     # whole-stack entry points: empty step table, channel mismatch between consecutive steps, missing output buffer
-    assert lib.sh_stack_forward(0, None, _lib.ptr(x), 1, 9, 4, 2, None, None, None, 1, 0, None, None, st) == -1
+    assert lib.sh_stack_forward(0, None, _lib.ptr(x), 1, 9, 4, 2, None, None, None, 1, 0, None, None, 1, st) == -1
     steps = (_lib.StackStep * 1)()
     steps[0].kind, steps[0].param, steps[0].table = 0, 0, table.data_ptr()
     steps[0].R, steps[0].S, steps[0].n_in, steps[0].cin, steps[0].cout, steps[0].act, steps[0].zero_row = 9, 3, 9, 8, 4, 2, 8
     wp, outs = (ctypes.c_void_p * 1)(w.data_ptr()), (ctypes.c_void_p * 1)(0)
-    assert lib.sh_stack_forward(1, steps, _lib.ptr(x), 1, 9, 4, 2, wp, None, outs, 1, 0, None, None, st) == -1
+    assert lib.sh_stack_forward(1, steps, _lib.ptr(x), 1, 9, 4, 2, wp, None, outs, 1, 0, None, None, 1, st) == -1
     assert b"channels" in lib.sh_last_error()
     steps[0].cin = 4
-    assert lib.sh_stack_forward(1, steps, _lib.ptr(x), 1, 9, 4, 2, wp, None, outs, 1, 0, None, None, st) == -1
+    assert lib.sh_stack_forward(1, steps, _lib.ptr(x), 1, 9, 4, 2, wp, None, outs, 1, 0, None, None, 1, st) == -1
     assert b"output buffer" in lib.sh_last_error()
     # the typed wrappers raise
     with pytest.raises(RuntimeError, match="status -2"):             # a spiral longer than the kernels' 64-entry table lines

@@ -27,8 +27,10 @@ def run(latents=100000, batch=1024, dev=None, template=None):
     m = sh.SpiralAutoencoder(FE, FD, 256, h.sizes, h.spiral_sizes, h.spirals, h.D, h.U, dev)
     z = torch.randn(latents, 256, generator=torch.Generator().manual_seed(0)).to(dev)
     with torch.no_grad():
-        for _ in range(5):                        # warm-up: the allocator's blocks for the arenas of a batch, first touches
-            m.decode(z[:batch])
+        keep = None
+        for _ in range(5):                        # warm-up: the allocator's blocks for the arenas of a batch, first touches -
+            keep = m.decode(z[:batch])            # with the previous batch's output still alive, as in the timed loop below
+                                                  # (round 4's window paid one 60 ms hipMalloc for that second output block)
         if latents % batch:
             m.decode(z[:latents % batch])         # ... and for the ragged last batch
         torch.cuda.synchronize()
