@@ -639,7 +639,7 @@ def roofline_f32(recs, model, B, nprof, verts):
     PEAK_X3 = PEAK_BF16_MFMA_TFLOPS / 6.0
 
     def is_x3(name):
-        return "split3" in name or name.startswith("conv_p3")
+        return "split3" in name or name.startswith("conv_p3") or "_x3_" in name
     kernels = []
     for name, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
         e = {"kernel": name, "launches_per_step": a["n"] / nprof, "avg_ms": a["ms"] / a["n"], "ms_per_step": a["ms"] / nprof}
@@ -650,6 +650,9 @@ def roofline_f32(recs, model, B, nprof, verts):
                 e["peak_tflops"] = peak
                 e["frac"] = e["tflops"] / peak
             e["gbps_algorithmic"] = a["bytes"] / (a["ms"] * 1e-3) / 1e9
+            if "frac" not in e:                                   # streaming kernels: against HBM
+                e["peak_gbps"] = PEAK_HBM_GBS
+                e["frac"] = e["gbps_algorithmic"] / PEAK_HBM_GBS
         kernels.append(e)
     fam = {}
     for k in kernels:
