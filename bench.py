@@ -191,9 +191,22 @@ def measured_traffic(kernel, workload):
     strip = lambda e: {k: v for k, v in e.items() if k != "SH_F32_MMA"}      # noqa: E731 - the arithmetic form is part of the workload tag
     if strip(meta.get("env", {})) != strip(_lib.env_overrides()):
         return None, "PMC profile %s was taken with other SH_* switches (%s)" % (name, meta.get("env"))
-    if kernel not in pmc:
+    # the library's profiler names a launch by what it does; rocprofv3 by the kernel instantiation(s) that did it
+    alias = {"spmm_kernel<true, p3>": ["spmm_kernel<true, true>", "spmm_p3x8_kernel"],
+             "linear_bwd_wgt_x3_kernel": ["linear_bwd_wgt_dma_kernel<true>"], "linear_bwd_wgt_dma_kernel": ["linear_bwd_wgt_dma_kernel<false>"]}
+    m = __import__("re").match(r"linear_fwd_x3_kernel<(\d+)>$", kernel)
+    if m:
+        alias[kernel] = ["linear_fwd_dma_kernel<%s, true>" % m.group(1)]
+    m = __import__("re").match(r"linear_fwd_dma_kernel<(\d+)>$", kernel)
+    if m:
+        alias[kernel] = ["linear_fwd_dma_kernel<%s, false>" % m.group(1), kernel]
+    names = [k for k in alias.get(kernel, [kernel]) if k in pmc]
+    if not names:
         return None, "kernel not in %s" % name
-    return pmc[kernel]["hbm_bytes_per_launch"], "bytes/launch, rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE (profiles/%s: same workload, library build and switches)" % name
+    n = sum(pmc[k]["launches_profiled"] for k in names)
+    byt = sum(pmc[k]["hbm_bytes_per_launch"] * pmc[k]["launches_profiled"] for k in names) / n
+    return byt, "bytes/launch, rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE (profiles/%s%s: same workload, library build and switches)" % (
+        name, "" if names == [kernel] else " as " + " + ".join(names))
 
 
 def step_work(model, B, dtype):
@@ -555,6 +568,8 @@ def roofline_bf16(recs, model, B, nprof, verts):
     from semantichuman_amd import _lib
     result = {}
     work = bf16_work_table(model, B)
+    hbm = hbm_work_table(model, B)                      # fp32 bytes; the bf16 re-sampling launches move half of them
+    seen = {}
     agg = {}
     for name, shape, ms in recs:
         a = agg.setdefault(name, {"n": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "matched": 0})
@@ -562,18 +577,26 @@ def roofline_bf16(recs, model, B, nprof, verts):
         key = parse_tag(name, shape)
         if key in work:
             a["flops"] += work[key][0]; a["bytes"] += work[key][1]; a["matched"] += 1
+        elif name.startswith("spmm_bf16_kernel"):
+            f = dict(kv.split("=") for kv in shape.split() if "=" in kv)
+            hk = ("spmm", int(f.get("rows", -1)), int(f.get("C", -1)))
+            if hk in hbm:
+                k = seen.get(hk, 0)
+                seen[hk] = k + 1
+                a["bytes"] += 0.5 * hbm[hk][k % len(hbm[hk])]; a["matched"] += 1
     kernels = []
     for name, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
         e = {"kernel": name, "launches_per_step": a["n"] / nprof, "avg_ms": a["ms"] / a["n"], "ms_per_step": a["ms"] / nprof}
         if a["matched"] == a["n"] and a["n"]:
             e["gbps"] = a["bytes"] / (a["ms"] * 1e-3) / 1e9
-            e["tflops"] = a["flops"] / (a["ms"] * 1e-3) / 1e12
+            if a["flops"] > 0:
+                e["tflops"] = a["flops"] / (a["ms"] * 1e-3) / 1e12
         kernels.append(e)
     fam = {}
     for k in kernels:
         f = fam.setdefault(k["kernel"].split("<")[0].split("|")[0], 0.0)
         fam[k["kernel"].split("<")[0].split("|")[0]] = f + k["ms_per_step"]
-    conv = [k for k in kernels if "gbps" in k]
+    conv = [k for k in kernels if "tflops" in k]
     dom = conv[0] if conv else kernels[0]
     a = agg[dom["kernel"]]
     # bf16: ridge of the chip ~ 2.5 PF / 8 TB/s = 300 FLOP/B, these layers have 30-250 FLOP/B -> HBM roof
@@ -593,6 +616,11 @@ def roofline_bf16(recs, model, B, nprof, verts):
         line = {"bound": "hbm", "kernel": top["kernel"], "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None,
                 "traffic": None, "avg_launch_ms": top["avg_ms"], "launches_per_step": top["launches_per_step"],
                 "ms_per_step": top["ms_per_step"]}
+        if "gbps" in top:                                     # a streaming kernel priced by hbm_work_table (re-sampling)
+            ta = agg[top["kernel"]]
+            tr, tn = measured_traffic(top["kernel"], workload_tag(verts, B, "bf16"))
+            line.update(achieved=top["gbps"], frac=top["gbps"] / PEAK_HBM_GBS, algorithmic_bytes_per_launch=ta["bytes"] / ta["n"], traffic=tr,
+                        traffic_unit=tn, note="algorithmic bytes (outputs written once + distinct inputs read once, bf16) of its launches / their HIP-event time")
         if top["kernel"].startswith("adam_kernel"):
             n_par = sum(p.numel() for p in model.parameters())
             byt = (7 * 4.0 + 2.0) * n_par                     # p, g, m, v read; p, m, v written; bf16 copy written
