@@ -735,23 +735,31 @@ def collective_block(reducer, world, rank, dev, backend):
     """World size, the device every rank runs on, and what the step's gradient messages cost when nothing else runs: each
     message size of the reducer all-reduced 5 times (after 2 warm-ups) between HIP events; bus bandwidth by the ring
     formula 2 (n - 1) / n x bytes / time.  Every rank calls this (collectives inside)."""
+    on_gpu = torch.device(dev).type == "cuda"          # (the dry run times the same block over gloo with host tensors)
     ids = [None] * dist.get_world_size()
-    dist.all_gather_object(ids, {"rank": rank, "device": torch.cuda.current_device(), "name": torch.cuda.get_device_name(),
-                                 "pid": os.getpid()})
+    dist.all_gather_object(ids, {"rank": rank, "device": torch.cuda.current_device() if on_gpu else "cpu",
+                                 "name": torch.cuda.get_device_name() if on_gpu else "host", "pid": os.getpid()})
     msgs = []
     for b in reducer.buckets:
         nbytes = b.numel * (2 if (b.inplace and reducer.large_dtype is not None and reducer.large_dtype.itemsize == 2) else 4)
         buf = torch.zeros(nbytes // 4, dtype=torch.float32, device=dev)
         for _ in range(2):
             dist.all_reduce(buf)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            dist.all_reduce(buf)
-        e1.record()
-        torch.cuda.synchronize()
-        t = torch.tensor([e0.elapsed_time(e1) / 5.0], dtype=torch.float64, device=dev)
+        if on_gpu:
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                dist.all_reduce(buf)
+            e1.record()
+            torch.cuda.synchronize()
+            ms1 = e0.elapsed_time(e1) / 5.0
+        else:
+            t0 = time.perf_counter()
+            for _ in range(5):
+                dist.all_reduce(buf)
+            ms1 = 1e3 * (time.perf_counter() - t0) / 5.0
+        t = torch.tensor([ms1], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ms = float(t.item())
         n = dist.get_world_size()
@@ -1058,8 +1066,14 @@ def dry_run(args, world, rank):
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    coll = None
+    if world > 1:                                       # the `collective` block of an N > 1 line, exercised end to end over gloo
+        import types
+        stand_in = types.SimpleNamespace(buckets=[types.SimpleNamespace(numel=1 << 16, inplace=True), types.SimpleNamespace(numel=1 << 12, inplace=False)],
+                                         large_dtype=None, avg=False, overlap=True)
+        coll = collective_block(stand_in, world, rank, torch.device("cpu"), "gloo")
     if rank == 0:
-        print(json.dumps({"metric": "training meshes/sec at 6890 verts, batch=%d" % args.batch, "value": None, "unit": "meshes/s",
+        print(json.dumps({"collective": coll, "metric": "training meshes/sec at 6890 verts, batch=%d" % args.batch, "value": None, "unit": "meshes/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(1, args.steps),
                           "dry_run": True, "config": {"global_batch": world * args.batch, "parallelism": "dp%d" % world,
                                                      "launch": "dry run (%s)" % os.environ.get("SH_BENCH_ATTEMPT_NAME", "single process") + attempt_note()}}))

@@ -29,6 +29,11 @@ def test_self_launch_two_ranks():
     assert r.returncode == 0, r.stderr
     res = _one_json_line(r.stdout)
     assert res["n_gpus"] == 2 and res["steps"] == 3 and res["config"]["global_batch"] == 128 and res["dry_run"]
+    # the N > 1 line's `collective` block: world size as the process group sees it, one entry per rank, every gradient message timed
+    # with its ring bus bandwidth (the same code path an RCCL run takes, here over gloo with host tensors)
+    c = res["collective"]
+    assert c["world_size"] == 2 and sorted(r["rank"] for r in c["ranks"]) == [0, 1] and len({r["pid"] for r in c["ranks"]}) == 2
+    assert len(c["messages"]) == 2 and all(m["ms"] > 0 and m["bus_gbps"] > 0 and m["bytes"] > 0 for m in c["messages"])
 
 
 def test_under_torch_distributed_run():
