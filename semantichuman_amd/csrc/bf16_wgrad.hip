@@ -33,7 +33,7 @@ __device__ __forceinline__ u32x4 bw_pack(const bw_f3& u, const bw_f3& v) {
 template <bool XC3, bool PC3>
 __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const BWParams p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * TG_IMG_BYTES];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = sh_wave_id();
     int bid = blockIdx.x;
     const int qt = bid % p.n_qt; bid /= p.n_qt;
     const int pt = bid % p.n_pt; const int split = bid / p.n_pt;

@@ -263,7 +263,7 @@ struct LSParams {
 // forward: y[m][n] = sum_k x[m][k] W[n][k].  Item = (64 output columns, k range); both operands contiguous in k.
 template <int MT>
 __global__ __launch_bounds__(LTHREADS) void linear_fwd_stream_kernel(const LSParams p) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = sh_wave_id();
     const int item = sh_xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
     if (item >= p.groups * p.nsplit) return;
     const int ng = item % p.groups, sp = item / p.groups;
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(LTHREADS) void linear_fwd_dma_kernel(const LSParams
 // {nb + 4 rr' + e} and produces the columns {k0 + 4 a' + t}.  dy quads run along n: element e pairs with weight row e.
 template <int MT>
 __global__ __launch_bounds__(LTHREADS) void linear_bwd_data_stream_kernel(const LSParams p) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = sh_wave_id();
     const int item = sh_xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
     if (item >= p.groups * p.nsplit) return;
     const int kg = item % p.groups, sp = item / p.groups;
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(LTHREADS) void linear_bwd_data_stream_kernel(const 
 // per 32 rows against 16 MT x 2 of 32 in the fp32 form, behind 4 + MT splits.  Same items, slabs and output mapping.
 template <int MT>
 __global__ __launch_bounds__(LTHREADS) void linear_bwd_data_x3_kernel(const LSParams p) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = sh_wave_id();
     const int item = sh_xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
     if (item >= p.groups * p.nsplit) return;
     const int kg = item % p.groups, sp = item / p.groups;
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(LTHREADS) void linear_bwd_data_x3_kernel(const LSPa
 // x[m0+rr][k0+4a..]; MFMA (t', t) produces dW[n0 + 4 i + t'][k0 + 4 j + t] - one pair of loads feeds 16 MFMAs.
 // (A 16 x 256 tile with 1 KiB-contiguous writes was measured slower: 39 / 48 us against 38 / 40 us.)
 __global__ __launch_bounds__(LTHREADS) void linear_bwd_wgt_stream_kernel(const LSParams p) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = sh_wave_id();
     const int item = sh_xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
     const int ktiles = p.K >> 6;
     if (item >= (p.N >> 6) * ktiles) return;

@@ -98,6 +98,21 @@ __device__ __forceinline__ int sh_xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
 }
 
+// The index of a wave in its workgroup as a SCALAR (readfirstlane of threadIdx.x >> 6, which is uniform over a wave by
+// construction - hipcc does not know).  Work-item decoding, loop bounds and branches derived from it are then uniform values:
+// real branches and SALU arithmetic instead of predicated VALU code.  Round 5, measured kernel by kernel (profiles/
+// r05_kernel_experiments.txt); -DSH_SCALAR_WAVE=0 builds the old form.
+#ifndef SH_SCALAR_WAVE
+#define SH_SCALAR_WAVE 1
+#endif
+__device__ __forceinline__ int sh_wave_id() {
+#if SH_SCALAR_WAVE
+    return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#else
+    return (int)(threadIdx.x >> 6);
+#endif
+}
+
 __device__ __forceinline__ float sh_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -828,7 +828,7 @@ int launch_ggd(const GGParams& p_in, int nblocks128 /* workgroups if the tiles h
 template <int S>
 __global__ __launch_bounds__(256) void conv_out3_linewise_kernel(const GGParams p) {
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wave = sh_wave_id();
     const int cq = lane & 3, bl = lane >> 2;
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
     const int nw = (int)(gridDim.x >> 3) * 4;                          // waves per XCD (the grid is a multiple of 8)
@@ -1493,11 +1493,21 @@ __device__ __forceinline__ WSItem ws_item(const WSParams& p, int wave) {
 }
 
 // C3: Cin == 3, columns counted in zero-padded quads (k' = 4 s + c), dwordx3 gathers, scalar slab stores.
-template <int COT, int NG, int DEPTH, bool FULL, bool C3 = false>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// ILV (round 5): the COT channel tiles of a wave are INTERLEAVED - lane la's B operands are the channels co0 + COT la + b instead
+// of co0 + 16 b + la - so its COT gradient values of a row are contiguous and arrive by ONE load of 4 COT bytes (COT = 8: two
+// 16-byte loads) instead of COT 4-byte loads: NG instead of NG x COT gradient loads (and their address arithmetic) per vertex.
+// Only which output channel an accumulator belongs to changes (the slab stores below); needs all 16 COT channels of the launch.
+template <int COT, int NG, int DEPTH, bool FULL, bool C3 = false, bool ILV = false>
 __global__ __launch_bounds__(NTHREADS) void wgrad_stream_kernel(const WSParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if ((int)blockIdx.x >= p.grid_main) { ws_presum_tail(p); return; }    // tail job (whole workgroups; before any barrier)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    // the wave index as a SCALAR (round 5): the item, its column group and loop bounds are then uniform values - real branches
+    // instead of predicated code (the bias sums of the cg == 0 items were executed, masked, by every wave): the four-tile launches
+    // 82.5 -> 75 and 30.2 -> 28 us
+    const int wave = sh_wave_id();
     int* Tl = reinterpret_cast<int*>(smem) + wave * p.vpc * p.S;          // this wave's table lines
     const WSItem wi = ws_item(p, wave);
     const int rc = wi.rc, cg = wi.cg, b0 = wi.b0, v_begin = wi.v_begin, v_step = wi.v_step, nv = wi.nv;
@@ -1532,7 +1542,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_stream_kernel(const WSParams p
     const float* pb = p.dpre + (long)v_begin * p.dp_sv;
     int pco[COT];
 #pragma unroll
-    for (int b = 0; b < COT; ++b) pco[b] = min(p.co0 + 16 * b + la, p.Cout - 1);      // channels past Cout: duplicate, never stored
+    for (int b = 0; b < COT; ++b) pco[b] = ILV ? p.co0 + COT * la + b : min(p.co0 + 16 * b + la, p.Cout - 1);      // channels past Cout: duplicate, never stored
     // loop-invariant parts of the addresses, formed once: x column + batch entry, dpre batch entry
     const float* xg[NG];
     long pbo[NG];
@@ -1549,9 +1559,21 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_stream_kernel(const WSParams p
 #pragma unroll
         for (int g = 0; g < NG; ++g) g4[g] = C3 ? sh_ld3(xg[g] + goff) : *reinterpret_cast<const f32x4*>(xg[g] + goff);
 #pragma unroll
-        for (int g = 0; g < NG; ++g)
+        for (int g = 0; g < NG; ++g) {
+            if constexpr (ILV && COT == 2) {
+                const f32x2 v = *reinterpret_cast<const f32x2*>(psrc + pbo[g] + pco[0]);
+                pp[g][0] = v[0]; pp[g][1] = v[1];
+            } else if constexpr (ILV && COT >= 4) {
 #pragma unroll
-            for (int b = 0; b < COT; ++b) pp[g][b] = psrc[pbo[g] + pco[b]];
+                for (int q = 0; q < COT / 4; ++q) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(psrc + pbo[g] + pco[0] + 4 * q);
+                    pp[g][4 * q] = v[0]; pp[g][4 * q + 1] = v[1]; pp[g][4 * q + 2] = v[2]; pp[g][4 * q + 3] = v[3];
+                }
+            } else {
+#pragma unroll
+                for (int b = 0; b < COT; ++b) pp[g][b] = psrc[pbo[g] + pco[b]];
+            }
+        }
     };
 
     f32x4 acc[4][COT];
@@ -1582,6 +1604,12 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_stream_kernel(const WSParams p
 
 #pragma unroll
     for (int d = 0; d < DEPTH - 1; ++d) load_v(d, gr[d], pr[d]);
+    // (Round 5, measured and put back: the steps as straight-line whole rounds + a separate partial round - no `if` per step, so
+    // that hipcc's s_waitcnt insertion stops draining every load at the top of each step (it merges the "previous step ran" and
+    // "was skipped" paths there: `s_waitcnt vmcnt(3) .. vmcnt(0)` in front of each step's address arithmetic).  The counted waits
+    // came out as intended (vmcnt(16) with 24 loads in flight) and every launch got SLOWER - 74 -> 80, 43 -> 48, 84 -> 88 us, the
+    // eight-tile instance spilled - : one vertex of prefetch distance already covers the L2 latency here, and the compiler's
+    // freer schedule moved loads in between the MFMAs.  profiles/r05_kernel_experiments.txt.)
     for (int vl = 0; vl < nv; vl += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
@@ -1596,7 +1624,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_stream_kernel(const WSParams p
     float* slab = p.slab + (long)rc * p.slab_stride;
 #pragma unroll
     for (int b = 0; b < COT; ++b) {
-        const int co = p.co0 + 16 * b + la;
+        const int co = ILV ? pco[b] : p.co0 + 16 * b + la;
         if (co >= p.Cout) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1618,7 +1646,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_stream_kernel(const WSParams p
             float v = bs[b];
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
-            const int co = p.co0 + 16 * b + la;
+            const int co = ILV ? pco[b] : p.co0 + 16 * b + la;
             if (kq == 0 && co < p.Cout) p.slab[p.bias_off + (long)rc * p.Cout + co] = v;
         }
     }
@@ -1746,6 +1774,20 @@ int launch_ws(const WSParams& p, hipStream_t st) {
     const bool c3 = p.Cin == 3;
     ShProfScope ps(st, "wgrad_stream_kernel<%d, %d, %d, %s, %s>|R=%d B=%d K=%d N=%d grid=%d presum=%d", COT, NG, DEPTH, FULL ? "true" : "false",
                    c3 ? "true" : "false", p.R, p.B, p.K, p.Cout, p.grid_main, p.tail_blocks ? p.tail_rows : 0);
+    // interleaved channel tiles (one gradient load per batch group instead of COT): all 16 COT channels of the launch exist and
+    // a lane's COT values are COT-float aligned
+    static const int ilv_on = sh_env_int("SH_WS_ILV", 1, 0, 1);
+    const bool ilv = ilv_on && COT >= 2 && !c3 && p.Cout - p.co0 >= 16 * COT && p.dp_sb % COT == 0 && p.dp_sv % COT == 0 &&
+                     (reinterpret_cast<uintptr_t>(p.dpre) & 15) == 0;
+    if constexpr (COT >= 2) {
+        if (ilv) {
+            snprintf(ps.name, sizeof ps.name, "wgrad_stream_kernel<%d, %d, %d, %s, ilv>|R=%d B=%d K=%d N=%d grid=%d presum=%d", COT, NG, DEPTH,
+                     FULL ? "true" : "false", p.R, p.B, p.K, p.Cout, p.grid_main, p.tail_blocks ? p.tail_rows : 0);
+            SH_LAUNCH_PS(ps, (wgrad_stream_kernel<COT, NG, DEPTH, FULL, false, true>), dim3(grid), dim3(NTHREADS), smem, st, p);
+            SH_CHECK_LAUNCH("wgrad_stream");
+            return SH_OK;
+        }
+    }
     if (c3) SH_LAUNCH_PS(ps, (wgrad_stream_kernel<COT, NG, DEPTH, FULL, true>), dim3(grid), dim3(NTHREADS), smem, st, p);
     else SH_LAUNCH_PS(ps, (wgrad_stream_kernel<COT, NG, DEPTH, FULL, false>), dim3(grid), dim3(NTHREADS), smem, st, p);
     SH_CHECK_LAUNCH("wgrad_stream");
@@ -1765,7 +1807,7 @@ template <int COT>
 __global__ __launch_bounds__(NTHREADS) void wgrad_split3_kernel(const WSParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if ((int)blockIdx.x >= p.grid_main) { ws_presum_tail(p); return; }    // tail job (whole workgroups; before any barrier)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = sh_wave_id();
     int* Tl = reinterpret_cast<int*>(smem) + wave * p.vpc * p.S;
     const WSItem wi = ws_item(p, wave);                          // (log2TB == 4: a slice of 16 batch entries)
     const int rc = wi.rc, cg = wi.cg, b0 = wi.b0, v_begin = wi.v_begin, v_step = wi.v_step, nv = wi.nv;

@@ -1,0 +1,12 @@
+#!/bin/bash
+O=gpurun_out/r05e13; rm -rf $O; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
+timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_headline.py tests/test_configs.py -q -m gpu -x > $O/tests.txt 2>&1; tail -3 $O/tests.txt | cut -c1-250
+for rep in 1 2; do for v in 1 0; do
+  SH_WS_ILV=$v SH_F32_MMA=planes3 timeout 300 python tools/layer_report.py 64 > $O/layer_ilv${v}_$rep.txt 2>&1
+  echo "--- ilv=$v rep $rep"; grep -h "wgrad_stream\|total" $O/layer_ilv${v}_$rep.txt | awk '{print $0} /wgrad_stream/ {s+=$(NF-1)} END {print "wgrad_stream sum", s}'
+done; done
+for v in 1 0; do
+  SH_WS_ILV=$v SH_F32_MMA=planes3 timeout 300 python tools/layer_report.py 32 tests/golden/template27554.npz f32 > $O/layer_c4_ilv$v.txt 2>&1
+  echo "--- c4 ilv=$v"; grep -h "wgrad_stream\|total" $O/layer_c4_ilv$v.txt | awk '{print $0} /wgrad_stream/ {s+=$(NF-1)} END {print "wgrad_stream sum", s}'
+done
