@@ -200,6 +200,8 @@ def measured_traffic(kernel, workload):
     m = __import__("re").match(r"linear_fwd_dma_kernel<(\d+)>$", kernel)
     if m:
         alias[kernel] = ["linear_fwd_dma_kernel<%s, false>" % m.group(1), kernel]
+    if kernel.endswith(", ilv>"):                               # the interleaved-tile instance of the streaming weight gradient
+        alias[kernel] = [kernel[:-len(", ilv>")] + ", false, true>"]
     names = [k for k in alias.get(kernel, [kernel]) if k in pmc]
     if not names:
         return None, "kernel not in %s" % name
