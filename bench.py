@@ -951,7 +951,10 @@ def supervise_rank(argv):
 def _supervise_attempts(argv, rank, world, job, child):
     import subprocess
     import threading
-    timeout = float(os.environ.get("SH_BENCH_ATTEMPT_TIMEOUT", "900"))
+    timeout_all = float(os.environ.get("SH_BENCH_ATTEMPT_TIMEOUT", "900"))
+    # the first attempt (the step as ONE hipGraph with the RCCL all-reduces inside) has never run with more than one rank on
+    # hardware: if it hangs instead of failing, give up on it sooner - a whole N > 1 attempt is ~1-3 minutes (import, build, 60 steps)
+    timeout_graph = float(os.environ.get("SH_BENCH_GRAPH_ATTEMPT_TIMEOUT", str(min(timeout_all, 420.0))))
     grace = float(os.environ.get("SH_BENCH_FAIL_GRACE", "20"))
     attempts = [a for a in ATTEMPTS if not (a[0] == "graph" and os.environ.get("SH_BENCH_DP_GRAPH", "1") == "0")]
     history, rc = [], 1
@@ -966,6 +969,7 @@ def _supervise_attempts(argv, rank, world, job, child):
         return None
 
     for k, (name, extra) in enumerate(attempts):
+        timeout = timeout_graph if name == "graph" else timeout_all
         base = os.path.join(job, "attempt%d" % k)
         env = dict(os.environ, SH_BENCH_ATTEMPT=str(k), SH_BENCH_ATTEMPT_NAME=name, SH_BENCH_ATTEMPT_HISTORY="; ".join(history), **extra)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
