@@ -469,6 +469,65 @@ __global__ __launch_bounds__(LTHREADS) void linear_fwd_dma_kernel(const LSParams
     }
 }
 
+// Forward for LARGE batches and a short reduction (round 5: BASELINE config 5 decodes 1024 latents through fc_latent_dec, 55 296 x
+// 256), bf16x3 form.  The chunked DMA kernel above re-splits every weight tile once per 64-row chunk of the batch (16 times at
+// 1024) and ran at 94 TF.  Here a workgroup owns 64 output columns for the WHOLE batch: its weight tile [64][K] is split ONCE
+// into three-plane MFMA fragments resident in LDS (K / 32 x 12 KiB: K <= 384), then its eight waves walk the batch in passes
+// of 128 rows - a wave's 16 rows arrive straight from global memory (two 16-byte loads per lane and k-step: whole 128-byte
+// lines; the activations are L2-resident), are split in registers (one split per 24 MFMAs) and multiplied against the four
+// column tiles' fragments.
+constexpr int LFW_WAVES = 8;
+__global__ __launch_bounds__(LFW_WAVES * 64) void linear_fwd_wide_x3_kernel(const LSParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u32x4* Wl = reinterpret_cast<u32x4*>(smem);                       // [K / 32][4 tiles][3 planes][64 lanes]
+    const int lane = threadIdx.x & 63, wave = sh_wave_id();
+    const int n0 = sh_xcd_remap(blockIdx.x, gridDim.x) * 64;
+    const int nks = p.K >> 5;
+    const int lr = lane & 15, kq = lane >> 4;
+    for (int f = wave; f < nks * 4; f += LFW_WAVES) {                  // fragment (k-step ks, column tile nt): split once
+        const int ks = f >> 2, nt = f & 3;
+        const float* src = p.w + (long)(n0 + 16 * nt + lr) * p.K + 32 * ks + 8 * kq;
+        u32x4 h, m, l;
+        sh_split3(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4), h, m, l);
+        u32x4* d = Wl + (long)f * 192 + lane;
+        d[0] = h; d[64] = m; d[128] = l;
+    }
+    __syncthreads();
+    // (measured and not kept, gpurun_out/r05e22: a whole pass of activation loads issued a pass ahead - 255 us; two row tiles per
+    // wave so that a fragment read feeds 12 MFMAs - 281 us, it spills; non-temporal stores - slower: the 64-byte pieces of a
+    // row's four column tiles merge in L2 only with ordinary stores.  This form: 238 us against 312 for the chunked kernel.)
+    for (int m0 = 16 * wave; m0 < p.M; m0 += 16 * LFW_WAVES) {
+        const int mrow = m0 + lr;
+        const float* xr = p.a + (long)min(mrow, p.M - 1) * p.K + 8 * kq;
+        f32x4 acc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 xa = *reinterpret_cast<const f32x4*>(xr), xb = *reinterpret_cast<const f32x4*>(xr + 4);
+        for (int ks = 0; ks < nks; ++ks) {
+            const int kn = ks + 1 < nks ? ks + 1 : ks;
+            const f32x4 na = *reinterpret_cast<const f32x4*>(xr + 32 * kn), nb = *reinterpret_cast<const f32x4*>(xr + 32 * kn + 4);
+            const LinX3 xs = lin_split(xa, xb);
+            const u32x4* wk = Wl + (long)ks * 4 * 192 + lane;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const u32x4 r0 = wk[nt * 192], r1 = wk[nt * 192 + 64], r2 = wk[nt * 192 + 128];
+                acc[nt] = lin_x3_mma(__builtin_bit_cast(bf16x8, r0), __builtin_bit_cast(bf16x8, r1), __builtin_bit_cast(bf16x8, r2), xs.h, xs.m,
+                                     xs.l, acc[nt]);
+            }
+            xa = na; xb = nb;
+        }
+        if (mrow < p.M) {                                               // lane holds y[mrow][n0 + 16 nt + 4 kq .. +3]
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int n = n0 + 16 * nt + 4 * kq;
+                f32x4 v = acc[nt];
+                if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                *reinterpret_cast<f32x4*>(p.out + (long)mrow * p.N + n) = v;
+            }
+        }
+    }
+}
+
 // backward-data: dx[m][k] = sum_n dy[m][n] W[n][k].  Item = (64 output columns k, n range).  The weight quad runs along
 // the OUTPUT index: lane (a, rr) loads W[nb + 4 rr + e][k0 + 4 a ..+3] for e = 0..3; MFMA (e, t) reduces over the four rows
 // {nb + 4 rr' + e} and produces the columns {k0 + 4 a' + t}.  dy quads run along n: element e pairs with weight row e.
@@ -958,6 +1017,31 @@ int sh_linear_fwd(const float* x, const float* weight, const float* bias, float*
                   size_t workspace_bytes, int mma_mode, sh_stream_t stream) {
     SH_REQUIRE(x && weight && y && M > 0 && N > 0 && K > 0, SH_ERR_INVALID_ARG, "sh_linear_fwd: bad argument");
     SH_REQUIRE(sh_mma_mode_valid(mma_mode), SH_ERR_INVALID_ARG, "sh_linear_fwd: unknown mma_mode %d", mma_mode);
+    if (lin_x3(mma_mode) && M > 64 && K % 32 == 0 && K <= 384 && N % 64 == 0 && aligned16(x, weight, y) &&
+        (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0)) {
+        // large batch, short reduction: the weight tile split once per workgroup (linear_fwd_wide_x3_kernel)
+        static const int wide_on = sh_env_int("SH_LIN_WIDE", 1, 0, 1);
+        if (wide_on) {
+            hipStream_t st = static_cast<hipStream_t>(stream);
+            const size_t smem = (size_t)(K / 32) * 4 * 3072;
+            static bool attr_set = false;
+            if (!attr_set) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_fwd_wide_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        160 * 1024) != hipSuccess) {
+                    (void)hipGetLastError();
+                    sh_set_error("linear_fwd: cannot raise the dynamic LDS limit to %zu bytes", smem);
+                    return SH_ERR_LAUNCH;
+                }
+                attr_set = true;
+            }
+            LSParams s{};
+            s.a = x; s.w = weight; s.bias = bias; s.out = y; s.M = M; s.N = N; s.K = K;
+            ShProfScope ps(st, "linear_fwd_wide_x3_kernel|M=%d N=%d K=%d", M, N, K);
+            SH_LAUNCH_PS(ps, linear_fwd_wide_x3_kernel, dim3(N / 64), dim3(LFW_WAVES * 64), smem, st, s);
+            SH_CHECK_LAUNCH("linear_fwd_wide");
+            return SH_OK;
+        }
+    }
     {
         // bf16x3 form: the LDS-DMA kernel's shapes (32-wide stages, four column groups per workgroup); anything else keeps fp32 MFMA
         const bool x3 = lin_x3(mma_mode) && K % 32 == 0 && (N / 64) % 4 == 0;

@@ -64,10 +64,20 @@ struct P3Ctx {
     void* const* planes;              // forward: per step, image buffer of outs[i] (NULL: none)
     const void* const* wfrag3;        // per conv step: forward operand (sh_stack_forward) / backward-data operand (sh_stack_backward)
 };
+// does conv step j's FORWARD pass take the plane kernel for this batch?  The kernels' shape test, and one measured rule: a layer with
+// <= 16 output channels (one channel tile: 6 MFMAs per gathered 3-KiB fragment) loses to the exact staged kernel once the batch is
+// large - per 64 meshes, dec3 (6891 rows, K = 320 -> 16): plane 50.6 / 58.1 / 63.4 / 65.4 / 67.9 us at batch 64 / 128 / 256 / 512 / 1024,
+// exact 68.8 / 66.6 / 63.4 / 60.4 / 56.5 (profiles/r05_decode_batch_sweep.txt).  SH_P3_N16_MAXB: the largest batch at which such a layer
+// still runs the plane kernel.
+inline bool p3_step_shape_ok(int B, const sh_stack_step& s) {
+    static const int n16_maxb = sh_env_int("SH_P3_N16_MAXB", 256, 0, 1 << 30);
+    if (s.cout <= 16 && B > n16_maxb) return false;
+    return sh_spiral_conv_p3_ok(B, s.S, s.cin, s.cout) != 0;
+}
 inline bool p3_fwd(const P3Ctx& c, int i, bool in_vm) {
     const sh_stack_step& s = c.st[i];
     return c.mode == SH_MMA_PLANES3 && s.kind == 0 && i > 0 && in_vm && c.planes && c.planes[i - 1] && c.wfrag3 && c.wfrag3[i] &&
-           sh_spiral_conv_p3_ok(c.B, s.S, s.cin, s.cout);
+           p3_step_shape_ok(c.B, s);
 }
 // the conv step that gathers the buffer step i writes (through a folded up-sampling that appends to it), or -1
 inline int consumer_conv(const P3Ctx& c, int i) {
@@ -100,7 +110,7 @@ int sh_stack_forward(int n_steps, const sh_stack_step* steps, const float* x, in
         // does a three-plane conv gather the buffer this step writes?  then its image is written with it
         const int cons = i < n_steps - 1 ? consumer_conv(pc, i) : -1;
         void* img = (cons >= 0 && planes && planes[i] && mma_mode == SH_MMA_PLANES3 && wfrag3 && wfrag3[cons] &&
-                     sh_spiral_conv_p3_ok(B, steps[cons].S, steps[cons].cin, steps[cons].cout) && sh_p3_bytes(1, B, co)) ? planes[i] : nullptr;
+                     p3_step_shape_ok(B, steps[cons]) && sh_p3_bytes(1, B, co)) ? planes[i] : nullptr;
         // forward only (keep_fp32 == 0: no backward pass will read this pass's activations): rows that are gathered through
         // their plane image alone are written as the image alone - a re-sampling step in front of a plane conv, a plane conv
         // directly in front of another (6 instead of 10 bytes per element; BASELINE config 5's decode)

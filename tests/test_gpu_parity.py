@@ -235,11 +235,13 @@ def test_spmm_vs_dense(golden_dir):
 
 
 @pytest.mark.parametrize("mnk", [(64, 256, 55296), (64, 55296, 256), (4, 16, 1536), (3, 1536, 16), (5, 7, 13), (130, 70, 4100),
-                                 (1, 8, 136), (64, 8, 2176), (20, 128, 2048), (3, 64, 4096), (33, 320, 256), (48, 192, 1088)])
+                                 (1, 8, 136), (64, 8, 2176), (20, 128, 2048), (3, 64, 4096), (33, 320, 256), (48, 192, 1088),
+                                 (200, 640, 256), (1024, 1280, 256), (130, 128, 96), (65, 64, 384)])
 def test_latent_linear_vs_torch(mnk):
     """y = x W^T + b and its gradients (the latent FCs, models.py:130,144) - ragged sizes, the
-    split-reduction path (K = 55296, 4100), the wide-output path (N = 55296), and batches of 3 / 20 / 33 / 48 rows through
-    the streaming kernels (masked 16-row tiles)."""
+    split-reduction path (K = 55296, 4100), the wide-output path (N = 55296), batches of 3 / 20 / 33 / 48 rows through
+    the streaming kernels (masked 16-row tiles), and batches of 65 / 130 / 200 / 1024 rows with a short reduction (K <= 384: the
+    large-batch forward of the split forms, linear_fwd_wide_x3_kernel; config 5's decode)."""
     from semantichuman_amd.linear import latent_linear
     M, N, K = mnk
     rs = np.random.RandomState(M + N + K)
