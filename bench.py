@@ -194,10 +194,11 @@ def measured_traffic(kernel, workload):
     # the library's profiler names a launch by what it does; rocprofv3 by the kernel instantiation(s) that did it
     alias = {"spmm_kernel<true, p3>": ["spmm_kernel<true, true>", "spmm_p3x8_kernel"],
              "linear_bwd_wgt_x3_kernel": ["linear_bwd_wgt_dma_kernel<true>"], "linear_bwd_wgt_dma_kernel": ["linear_bwd_wgt_dma_kernel<false>"]}
-    m = __import__("re").match(r"linear_fwd_x3_kernel<(\d+)>$", kernel)
+    import re
+    m = re.match(r"linear_fwd_x3_kernel<(\d+)>$", kernel)
     if m:
         alias[kernel] = ["linear_fwd_dma_kernel<%s, true>" % m.group(1)]
-    m = __import__("re").match(r"linear_fwd_dma_kernel<(\d+)>$", kernel)
+    m = re.match(r"linear_fwd_dma_kernel<(\d+)>$", kernel)
     if m:
         alias[kernel] = ["linear_fwd_dma_kernel<%s, false>" % m.group(1), kernel]
     if kernel.endswith(", ilv>"):                               # the interleaved-tile instance of the streaming weight gradient
