@@ -889,6 +889,19 @@ def _touch(path, text=""):
     os.replace(tmp, path)                                  # atomic: a reader never sees a half-written file
 
 
+def mark_phase(name):
+    """A rank tells its supervisor how far it is (SH_BENCH_PHASE_FILE, set by the supervisor): 'rendezvous' -> 'built' -> 'warm'
+    -> 'timed'.  Everything after the rendezvous is seconds of work, so the supervisor treats a phase that lasts longer than
+    SH_BENCH_PHASE_TIMEOUT as a hang (a collective that never completes) without waiting for the whole-attempt limit, which has
+    to cover a cold `import torch` on a fresh box."""
+    path = os.environ.get("SH_BENCH_PHASE_FILE")
+    if path:
+        try:
+            _touch(path, name)
+        except OSError:
+            pass
+
+
 def supervise_rank(argv):
     """The launcher's rank process (RANK / WORLD_SIZE set, SH_BENCH_ATTEMPT not): runs the attempts of ATTEMPTS in order
     until one succeeds on rank 0; returns the exit status.  Coordination between the supervisors of one node is a
@@ -957,6 +970,8 @@ def _supervise_attempts(argv, rank, world, job, child):
     # hardware: if it hangs instead of failing, give up on it sooner - a whole N > 1 attempt is ~1-3 minutes (import, build, 60 steps)
     timeout_graph = float(os.environ.get("SH_BENCH_GRAPH_ATTEMPT_TIMEOUT", str(min(timeout_all, 420.0))))
     grace = float(os.environ.get("SH_BENCH_FAIL_GRACE", "20"))
+    # ... and once a rank is past the rendezvous (mark_phase), no single phase of it is more than seconds of work
+    phase_timeout = float(os.environ.get("SH_BENCH_PHASE_TIMEOUT", "150"))
     attempts = [a for a in ATTEMPTS if not (a[0] == "graph" and os.environ.get("SH_BENCH_DP_GRAPH", "1") == "0")]
     history, rc = [], 1
 
@@ -974,6 +989,7 @@ def _supervise_attempts(argv, rank, world, job, child):
         base = os.path.join(job, "attempt%d" % k)
         env = dict(os.environ, SH_BENCH_ATTEMPT=str(k), SH_BENCH_ATTEMPT_NAME=name, SH_BENCH_ATTEMPT_HISTORY="; ".join(history), **extra)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env["SH_BENCH_PHASE_FILE"] = phase_file = base + ".phase.%d" % rank
         if k > 0:                                           # fresh rendezvous: the first one's store holds the dead attempt's keys
             if rank == 0:
                 _touch(base + ".port", str(_free_port()))
@@ -996,6 +1012,8 @@ def _supervise_attempts(argv, rank, world, job, child):
                 killed = "attempt declared failed by rank 0"
             elif time.time() - t0 > timeout:
                 killed = "no result after %.0f s" % timeout
+            elif _phase_age(phase_file) > phase_timeout:
+                killed = "no progress for %.0f s after phase '%s'" % (phase_timeout, open(phase_file).read().strip())
             elif rank == 0:
                 if first_fail is None and any(f.startswith("attempt%d.rankfail." % k) for f in os.listdir(job)):
                     first_fail = time.time()
@@ -1017,8 +1035,8 @@ def _supervise_attempts(argv, rank, world, job, child):
             ok = st == 0 and not killed and any(l.startswith("{") for l in lines)
             _touch(base + (".ok" if ok else ".failed"), killed or "rc=%s" % st)
         else:
-            if st != 0 and not killed:
-                _touch(base + ".rankfail.%d" % rank, "rc=%s" % st)
+            if (st != 0 and not killed) or (killed and not os.path.exists(base + ".failed")):
+                _touch(base + ".rankfail.%d" % rank, killed or "rc=%s" % st)     # (also a hang this supervisor ended itself)
             verdict = wait_for([base + ".ok", base + ".failed"], timeout + grace + 30)
             ok = verdict is not None and verdict.endswith(".ok")
             if verdict is None:
@@ -1033,6 +1051,15 @@ def _supervise_attempts(argv, rank, world, job, child):
         history.append("%s: %s" % (name, killed or "rc=%s" % st))
         print("bench.py[supervisor %d]: attempt %d (%s) failed: %s" % (rank, k, name, history[-1]), file=sys.stderr)
     return rc
+
+
+def _phase_age(path):
+    try:
+        if open(path).read().strip() == "timed":               # the collectives are behind it; what follows (profiles, report) is host work
+            return -1.0
+        return time.time() - os.stat(path).st_mtime
+    except OSError:
+        return -1.0                                            # not past the rendezvous yet: only the whole-attempt limit applies
 
 
 def attempt_note():
@@ -1061,8 +1088,10 @@ def dry_run(args, world, rank):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")
+        mark_phase("rendezvous")
         injected_rank_failure(rank)
         dist.barrier()
+    mark_phase("warm")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         pass
@@ -1172,6 +1201,7 @@ def main():
         else:
             torch.cuda.set_device(dev_index)
             dist.init_process_group(backend)                                               # safe mode: created by the first collective
+        mark_phase("rendezvous")
         injected_rank_failure(rank)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -1210,6 +1240,7 @@ def main():
     data = torch.from_numpy(synthetic.synth_batch(h.verts, n_data, seed=100 + rank)).to(dev)
     test = torch.from_numpy(synthetic.synth_batch(h.verts, B, seed=7)).to(dev)
 
+    mark_phase("built")
     xin = torch.empty((B, h.sizes[0] + 1, 3), dtype=torch.float32, device=dev)
     last = {}                                     # the step's loss tensor (a fixed address inside the graph's pool when captured)
     unit = torch.ones((), dtype=torch.float32, device=dev)   # d loss / d loss, made once instead of one fill launch per step
@@ -1305,11 +1336,13 @@ def main():
         else:
             one_step()
 
+    mark_phase("captured" if graph is not None else "eager")
     for i in range(args.warmup):
         step(i)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    mark_phase("warm")
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
@@ -1321,6 +1354,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    mark_phase("timed")
     final_loss = float(last["loss"].item())
 
     with torch.no_grad():

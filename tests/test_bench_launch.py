@@ -86,6 +86,24 @@ def test_retry_under_torch_distributed_run_rank0_failure():
     assert "attempt 1 'eager'" in res["config"]["launch"]
 
 
+def test_hung_attempt_is_cut_short_by_the_progress_watchdog():
+    """A rank that HANGS after the rendezvous (a collective that never completes - the failure mode a first multi-GPU run of
+    the hipGraph-with-RCCL attempt could have) is not waited for until the whole-attempt limit (which has to cover a cold import
+    on a fresh box): every phase after the rendezvous is seconds of work, so its supervisor gives up after
+    SH_BENCH_PHASE_TIMEOUT without progress and the job goes on with the next mode."""
+    import time
+    env = dict(_env(), SH_BENCH_TEST_RANK_HANG="0:1", SH_BENCH_PHASE_TIMEOUT="3", SH_BENCH_FAIL_GRACE="1", SH_BENCH_ATTEMPT_TIMEOUT="600",
+               SH_BENCH_GRAPH_ATTEMPT_TIMEOUT="600")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert time.time() - t0 < 200
+    res = _one_json_line(r.stdout)
+    assert "attempt 1 'eager'" in res["config"]["launch"], res["config"]["launch"]
+    assert "no progress for 3 s after phase 'rendezvous'" in r.stderr, r.stderr
+
+
 def test_all_attempts_failing_gives_a_nonzero_status():
     env = dict(_retry_env("0:1"), SH_BENCH_DP_GRAPH="0")     # attempts: eager (index 0, fails), eager-safe (index 1)
     env["SH_BENCH_TEST_RANK_FAIL"] = "*:1"
