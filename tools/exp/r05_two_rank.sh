@@ -7,9 +7,12 @@ SH_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-ba
 echo "rc=$?"
 SH_BENCH_BACKEND=gloo SH_BENCH_TEST_RANK_FAIL=0:1 SH_BENCH_FAIL_GRACE=3 python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-roofline > $O/r05_two_rank_retry.json 2> $O/r05_two_rank_retry.err
 echo "rc=$?"
+# ... and with a rank that HANGS after the rendezvous in the first attempt: the progress watchdog ends it, the next attempt reports
+SH_BENCH_BACKEND=gloo SH_BENCH_TEST_RANK_HANG=0:1 SH_BENCH_PHASE_TIMEOUT=20 SH_BENCH_FAIL_GRACE=3 python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-roofline > $O/r05_two_rank_hang.json 2> $O/r05_two_rank_hang.err
+echo "rc=$?"
 python - <<'PY'
 import json
-for f in ("gpurun_out/r05_two_rank_gloo.json", "gpurun_out/r05_two_rank_retry.json"):
+for f in ("gpurun_out/r05_two_rank_gloo.json", "gpurun_out/r05_two_rank_retry.json", "gpurun_out/r05_two_rank_hang.json"):
     try:
         r = json.loads([l for l in open(f) if l.startswith("{")][-1])
         print(f, r["n_gpus"], round(r["ms_per_step"], 3), r["config"]["launch"], r.get("collective", {}).get("world_size"),
@@ -17,4 +20,4 @@ for f in ("gpurun_out/r05_two_rank_gloo.json", "gpurun_out/r05_two_rank_retry.js
     except Exception as e:
         print(f, "ERR", e)
 PY
-grep -h supervisor $O/r05_two_rank_retry.err | head -4
+grep -h supervisor $O/r05_two_rank_retry.err $O/r05_two_rank_hang.err | head -8
