@@ -193,7 +193,8 @@ def measured_traffic(kernel, workload):
         return None, "PMC profile %s was taken with other SH_* switches (%s)" % (name, meta.get("env"))
     # the library's profiler names a launch by what it does; rocprofv3 by the kernel instantiation(s) that did it
     alias = {"spmm_kernel<true, p3>": ["spmm_kernel<true, true>", "spmm_p3x8_kernel"],
-             "linear_bwd_wgt_x3_kernel": ["linear_bwd_wgt_dma_kernel<true>"], "linear_bwd_wgt_dma_kernel": ["linear_bwd_wgt_dma_kernel<false>"]}
+             "linear_bwd_wgt_x3_kernel": ["linear_bwd_wgt_dma_kernel<true, false>"], "linear_bwd_wgt_dma_kernel": ["linear_bwd_wgt_dma_kernel<false, false>"],
+             "linear_bwd_wgt_adam_x3_kernel": ["linear_bwd_wgt_dma_kernel<true, true>"], "linear_bwd_wgt_adam_kernel": ["linear_bwd_wgt_dma_kernel<false, true>"]}
     import re
     m = re.match(r"linear_fwd_x3_kernel<(\d+)>$", kernel)
     if m:
@@ -307,7 +308,8 @@ def hbm_work_table(model, B):
       ("spmm", rows, C) -> [bytes per launch, ...] in the order a step issues launches with that key: every output element
           written once + every DISTINCT input row read once, 4 bytes per element (the plane images a producer also writes in
           the planes3 form are overhead of that form, not algorithm);
-      ("adam",) -> 7 fp32 streams per parameter."""
+      ("adam",) -> 7 fp32 streams per parameter (all of them; a launch whose tag carries numel= is priced by that count instead:
+          with the latent FCs' update applied inside their weight-gradient kernels the multi-tensor launch only holds the rest)."""
     import numpy as np
     out = {}
 
@@ -346,14 +348,15 @@ def parse_tag_hbm(name, shape):
         if fam == "spmm_kernel":
             return ("spmm", int(f["rows"]), int(f["C"]))
         if fam == "adam_kernel":
-            return ("adam",)
+            return ("adam", int(f["numel"])) if "numel" in f else ("adam",)
     except (KeyError, ValueError):
         return None
     return None
 
 
 def parse_tag_linear(name, shape):
-    """(flops, bytes) of a latent-FC launch from its tag (M = batch, N x K weight), or None."""
+    """(flops, bytes) of a latent-FC launch from its tag (M = batch, N x K weight), or None.  A weight-gradient launch that applies
+    Adam to its tile (linear_bwd_wgt_adam*) reads the weight and its two moments and writes them back: six weight-sized streams."""
     if not name.startswith("linear_"):
         return None
     f = dict(kv.split("=") for kv in shape.split() if "=" in kv)
@@ -361,10 +364,10 @@ def parse_tag_linear(name, shape):
         M, N, K = int(f["M"]), int(f["N"]), int(f["K"])
     except (KeyError, ValueError):
         return None
-    return 2.0 * M * N * K, 4.0 * (N * K + M * K + M * N)
+    return 2.0 * M * N * K, 4.0 * ((6 if "_adam" in name else 1) * N * K + M * K + M * N)
 
 
-def replayed_training(sh, h, B, dtype, dev, steps, warmup, n_data=None, seed=100):
+def replayed_training(sh, h, B, dtype, dev, steps, warmup, n_data=None, seed=100, fused_update=True):
     """One more training configuration measured the way the headline is: model on hierarchy `h`, batch B, kernels in
     `dtype`; forward + loss + backward + Adam captured into one hipGraph; `steps` timed replays (batch copy-in included)
     after `warmup`.  Returns (result dict, model, init_state, data) - used by the `secondary` block."""
@@ -375,6 +378,8 @@ def replayed_training(sh, h, B, dtype, dev, steps, warmup, n_data=None, seed=100
         model.set_compute_dtype(torch.bfloat16)
     init_state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     optim = sh.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-5)
+    if dtype == "f32" and fused_update:
+        optim.fuse_linear_weight_gradients([model.fc_latent_enc, model.fc_latent_dec])
     ft = sh.FaceTables(h.faces, h.sizes[0] + 1, dev)
     n_data = n_data or 4 * B
     data = torch.from_numpy(synthetic.synth_batch(h.verts, n_data, seed=seed)).to(dev)
@@ -425,6 +430,7 @@ def replayed_training(sh, h, B, dtype, dev, steps, warmup, n_data=None, seed=100
            "whole_step": whole_step_block(model, B, dtype, dt, _lib.get_f32_mma_mode() if dtype == "f32" else None)}
     if dtype == "f32":
         res["f32_mma"] = _lib.get_f32_mma_mode()
+        res["adam"] = "latent FCs updated inside their weight-gradient kernels" if fused_update else "multi-tensor kernel"
     del graph
     return res, model, init_state, data, ft
 
@@ -498,7 +504,7 @@ def secondary_block(sh, h, B, dev, init_state, data, test, ft, cpu_l2_mm, args):
 
     def config4_leg():
         h4 = load_hierarchy(os.path.join(ROOT, "tests", "golden", "template27554.npz"))
-        res, model, _, d4, ft4 = replayed_training(sh, h4, 32, "f32", dev, steps, warm, n_data=64)
+        res, model, _, d4, ft4 = replayed_training(sh, h4, 32, "f32", dev, steps, warm, n_data=64, fused_update=not args.no_fused_update)
         res.update(f32_roofline_of(model, d4[:32], ft4, 32, h4.sizes[0]))
         del model
         res["config"] = "BASELINE configs[3]: 27 554 vertices, spiral length 18, batch 32, fp32"
@@ -529,7 +535,7 @@ def secondary_block(sh, h, B, dev, init_state, data, test, ft, cpu_l2_mm, args):
             was = _lib.get_f32_mma_mode()
             _lib.set_f32_mma_mode(other)
             try:
-                res, model, _, _, _ = replayed_training(sh, h, B, "f32", dev, steps, warm)
+                res, model, _, _, _ = replayed_training(sh, h, B, "f32", dev, steps, warm, fused_update=not args.no_fused_update)
             finally:
                 _lib.set_f32_mma_mode(was)
             del model
@@ -662,6 +668,8 @@ def roofline_f32(recs, model, B, nprof, verts):
             a["flops"] += work[key]["flops"]; a["bytes"] += work[key]["bytes"]; a["matched"] += 1
         elif lin is not None:
             a["flops"] += lin[0]; a["bytes"] += lin[1]; a["matched"] += 1
+        elif hk is not None and hk[0] == "adam" and len(hk) == 2:
+            a["bytes"] += 28.0 * hk[1]; a["matched"] += 1; a["hbm"] += 1
         elif hk in hbm:
             lst = hbm[hk]
             k = seen.get(hk, 0)
@@ -1129,6 +1137,8 @@ def main():
                     "each timed as 20 replayed steps after the headline's timed region)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured hipGraph")
     ap.add_argument("--adam", choices=["hip", "torch"], default="hip", help="library Adam kernel, or torch's fused capturable Adam")
+    ap.add_argument("--no-fused-update", action="store_true", help="fp32, one GPU: write the latent FCs' weight gradients and let the multi-tensor Adam "
+                    "read them back, instead of applying the update inside the weight-gradient kernel (the default; same bits)")
     ap.add_argument("--adam-overlap", action="store_true", help="update the big parameters on a side stream underneath backward (measured: no gain, the GPU is already saturated)")
     ap.add_argument("--grad-comm", choices=["fp32", "bf16"], default="fp32",
                     help="N > 1: type of the two large gradient messages (bf16 halves the xGMI bytes; fp32 is the measured default)")
@@ -1233,8 +1243,15 @@ def main():
         optim = sh.optim.Adam(opt_params, lr=1e-3, weight_decay=5e-5)
         if world == 1 and args.adam_overlap:
             optim.overlap_backward()              # the two latent FCs (99 % of the parameters) update underneath the encoder backward
+        # one GPU: nothing consumes the latent FCs' weight gradients but Adam, so the kernel that computes a tile of them applies
+        # the update to that tile (sh_linear_bwd_wgt_adam; bit-identical, tests/test_optim.py) - 8 of 32 bytes per weight never move.
+        # With a gradient all-reduce in between (N > 1) the gradients have to exist: the ordinary two-kernel form.
+        fused_update = reducer is None and args.dtype == "f32" and not args.no_fused_update and not args.adam_overlap
+        if fused_update:
+            optim.fuse_linear_weight_gradients([model.fc_latent_enc, model.fc_latent_dec])
     else:
         optim = torch.optim.Adam(opt_params, lr=1e-3, weight_decay=5e-5, capturable=True, fused=True)
+        fused_update = False
 
     n_data = 16 * B                               # resident synthetic set, disjoint per rank
     data = torch.from_numpy(synthetic.synth_batch(h.verts, n_data, seed=100 + rank)).to(dev)
@@ -1381,6 +1398,8 @@ def main():
                    "launch": (("hipGraph replay" + (" (RCCL all-reduces inside the graph)" if reducer else "")) if graph is not None
                               else (graph_note or "eager")) + (" safe mode (SH_BENCH_DP_SAFE)" if safe and reducer else "") +
                              (" [sharded update of the large parameters: reduce-scatter / all-gather]" if shard_opt else "") + attempt_note(),
+                   "adam": ("library kernel; the two latent FCs' update applied inside their weight-gradient kernels (sh_linear_bwd_wgt_adam)"
+                            if fused_update else ("library multi-tensor kernel" if args.adam == "hip" else "torch fused capturable")),
                    **({"gradient_messages": "%.1f MB %s all-reduce per step" % (
                        sum(b.numel * (2 if (b.inplace and args.grad_comm == "bf16") else 4) for b in reducer.buckets) / 1e6,
                        "bf16 (large) + fp32" if args.grad_comm == "bf16" else "fp32")} if reducer else {})},

@@ -287,6 +287,21 @@ SH_API int sh_linear_bwd_data(const float* dy, const float* weight, float* dx, i
                        void* workspace, size_t workspace_bytes, int mma_mode, sh_stream_t stream);
 SH_API int sh_linear_bwd_wgt(const float* dy, const float* x, float* dW, float* dbias, int M, int N, int K,
                       void* workspace, size_t workspace_bytes, int mma_mode, sh_stream_t stream);
+/* Weight gradient of a latent FC with torch.optim.Adam's update applied to it in the same kernel (round 5): every 64 x 64 tile of
+ * dW = dy^T . x is, instead of being stored, used as the gradient `g` of sh_adam_step's update of the same tile of `weight`,
+ * `exp_avg` and `exp_avg_sq` (in place; coefficients from the DEVICE scalars `step` = updates applied so far and `lr`, so the
+ * launch is replayable in a hipGraph).  Bit-identical to sh_linear_bwd_wgt followed by sh_adam_step on that tensor (one shared
+ * update function), without writing and re-reading the gradient: 24 instead of 32 bytes of HBM traffic per weight.  `step` is
+ * NOT advanced here (every workgroup reads it): the caller advances it once the launch is queued - sh_adam_bump.  dbias as in
+ * sh_linear_bwd_wgt (the bias keeps its ordinary gradient).  Served shapes: sh_linear_bwd_wgt_adam_ok (M <= 64, N and K
+ * multiples of 64; SH_LIN_WGT_ADAM=0 makes it answer 0); others return SH_ERR_UNSUPPORTED and nothing is launched.
+ * Replaces, for one parameter, the pair reference `loss.backward()` (models.py:130 / :144 autograd of nn.Linear) +
+ * `optimizer.step()` (train_funcs.py:391-392, 509-510).  Only valid when nothing else consumes that gradient between backward
+ * and step (no all-reduce, clipping or accumulation over several backward passes). */
+SH_API int sh_linear_bwd_wgt_adam_ok(int M, int N, int K);
+SH_API int sh_linear_bwd_wgt_adam(const float* dy, const float* x, float* weight, float* exp_avg, float* exp_avg_sq, const float* step,
+                           const float* lr, double beta1, double beta2, double eps, double weight_decay, float* dbias, int M,
+                           int N, int K, int mma_mode, sh_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Grouped (ragged) dense layers: the 3 x 17 per-part nn.Linear layers of SpiralAutoencoder_multiz_partkps
@@ -433,11 +448,15 @@ SH_API int sh_gather_meshes(const float* src, int64_t row_elems, const int64_t* 
  * params / grads / exp_avg / exp_avg_sq / steps / numel are HOST arrays of length n_tensors holding
  * DEVICE pointers (steps[i]: one float, the number of updates applied so far) and element counts;
  * `lr` is a DEVICE scalar, so a captured launch follows learning-rate schedules and step counts
- * without re-capture.
+ * without re-capture.  An entry with numel[i] == 0 only advances steps[i] (its other pointers are not read): a parameter whose
+ * update was applied by sh_linear_bwd_wgt_adam during backward.
  */
 SH_API int sh_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                  float* const* exp_avg_sq, float* const* steps, const int64_t* numel, const float* lr,
                  double beta1, double beta2, double eps, double weight_decay, sh_stream_t stream);
+/* steps[i][0] += 1 for i < n_tensors (HOST array of DEVICE pointers): the step counts of parameters whose update was applied by
+ * sh_linear_bwd_wgt_adam during backward. */
+SH_API int sh_adam_bump(int n_tensors, float* const* steps, sh_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * The small loss terms of the semantic loop as kernels.  x tensors are [B] meshes of rows of 3 floats,

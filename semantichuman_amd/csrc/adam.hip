@@ -5,6 +5,7 @@
 // changes from step to step (learning rate, step counts) is read from DEVICE memory, which keeps
 // the launch replayable inside a hipGraph.
 #include "sh_bf16.h"
+#include "sh_adam.h"
 
 #include <math.h>
 
@@ -29,17 +30,6 @@ struct AdamArgs {
     float w1, b2, w2, eps, wd;    // (float)(1 - beta1), (float)beta2, (float)(1 - beta2)
 };
 
-__device__ __forceinline__ void adam_update(float& p, float g, float& m, float& v, float w, float beta2, float w2, float eps, float wd,
-                                            float step_size, float bc2_sqrt) {
-#pragma clang fp contract(off)      // same rounding on the 16-byte and the scalar path (no call-site dependent FMA fusion)
-    if (wd != 0.f) g += wd * p;                                   // coupled L2 (torch.optim.Adam, not AdamW)
-    const float d = g - m;
-    m = w < 0.5f ? m + w * d : g - d * (1.f - w);                 // lerp(m, g, 1 - beta1)
-    v = beta2 * v + w2 * g * g;
-    const float denom = sqrtf(v) / bc2_sqrt + eps;
-    p -= step_size * m / denom;
-}
-
 __global__ __launch_bounds__(ANT) void adam_kernel(const AdamArgs a) {
     __shared__ float sh[2];
     int t = 0;
@@ -47,10 +37,7 @@ __global__ __launch_bounds__(ANT) void adam_kernel(const AdamArgs a) {
     const long base = (long)((int)blockIdx.x - a.blk_start[t]) * ACH;
     const long n = a.n[t];
     if (threadIdx.x == 0) {
-        const double step = (double)a.step[t][0] + 1.0;           // this update's 1-based index
-        const double bc1 = 1.0 - pow(a.beta1, step), bc2 = 1.0 - pow(a.beta2, step);
-        sh[0] = (float)((double)a.lr[0] / bc1);
-        sh[1] = (float)sqrt(bc2);
+        sh_adam_coeffs(a.beta1, a.beta2, a.step[t][0], a.lr[0], sh[0], sh[1]);
     }
     __syncthreads();
     const float step_size = sh[0], bc2_sqrt = sh[1];
@@ -95,11 +82,24 @@ __global__ __launch_bounds__(ANT) void adam_kernel(const AdamArgs a) {
             }
         }
     } else {
-        for (long o = base + threadIdx.x; o < n && o < base + ACH; o += ANT) {
-            float pp = p[o], mm = m[o], vv = v[o];
-            adam_update(pp, g[o], mm, vv, a.w1, a.b2, a.w2, a.eps, a.wd, step_size, bc2_sqrt);
-            p[o] = pp; m[o] = mm; v[o] = vv;
-            if (sw) sw[o] = (__bf16)pp;
+        // ragged or unaligned end of a tensor (and every tensor smaller than a workgroup's 4096 elements: biases, the thin convs):
+        // all of a thread's elements are requested before the first is used - one memory round trip, not sixteen in sequence
+        constexpr int PER = ACH / ANT;
+        float pp[PER], mm[PER], vv[PER], gg[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const long o = base + threadIdx.x + (long)i * ANT;
+            const bool ok = o < n;
+            pp[i] = ok ? p[o] : 0.f; mm[i] = ok ? m[o] : 0.f; vv[i] = ok ? v[o] : 0.f; gg[i] = ok ? g[o] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const long o = base + threadIdx.x + (long)i * ANT;
+            if (o < n) {
+                adam_update(pp[i], gg[i], mm[i], vv[i], a.w1, a.b2, a.w2, a.eps, a.wd, step_size, bc2_sqrt);
+                p[o] = pp[i]; m[o] = mm[i]; v[o] = vv[i];
+                if (sw) sw[o] = (__bf16)pp[i];
+            }
         }
     }
 }
@@ -129,8 +129,9 @@ static int adam_impl(int n_tensors, float* const* params, const float* const* gr
         long blocks = 0;
         for (int i = 0; i < a.nt; ++i) {
             const int k = t0 + i;
-            SH_REQUIRE(params[k] && grads[k] && exp_avg[k] && exp_avg_sq[k] && steps[k] && numel[k] > 0, SH_ERR_INVALID_ARG,
-                       "sh_adam_step: tensor %d has a null pointer or no elements", k);
+            // numel == 0: a parameter whose update was applied elsewhere (sh_linear_bwd_wgt_adam) - only its step count advances
+            SH_REQUIRE(steps[k] && numel[k] >= 0 && (numel[k] == 0 || (params[k] && grads[k] && exp_avg[k] && exp_avg_sq[k])), SH_ERR_INVALID_ARG,
+                       "sh_adam_step: tensor %d has a null pointer or a negative element count", k);
             a.p[i] = params[k]; a.g[i] = grads[k]; a.m[i] = exp_avg[k]; a.v[i] = exp_avg_sq[k]; a.step[i] = steps[k];
             a.shadow[i] = shadow ? static_cast<__bf16*>(shadow[k]) : nullptr;
             SH_REQUIRE(!a.shadow[i] || (reinterpret_cast<uintptr_t>(a.shadow[i]) & 7) == 0, SH_ERR_INVALID_ARG, "sh_adam_step_bf16: shadow %d misaligned", k);
@@ -143,12 +144,32 @@ static int adam_impl(int n_tensors, float* const* params, const float* const* gr
         a.nontemporal = nontemporal;
         a.lr = lr; a.beta1 = beta1; a.beta2 = beta2;
         a.w1 = (float)(1.0 - beta1); a.b2 = (float)beta2; a.w2 = (float)(1.0 - beta2); a.eps = (float)eps; a.wd = (float)weight_decay;
-        {
-            ShProfScope ps(st, "adam_kernel|tensors=%d blocks=%ld", a.nt, blocks);
+        if (blocks > 0) {
+            long numel_sum = 0;
+            for (int i = 0; i < a.nt; ++i) numel_sum += a.n[i];
+            ShProfScope ps(st, "adam_kernel|tensors=%d blocks=%ld numel=%ld", a.nt, blocks, numel_sum);
             SH_LAUNCH_PS(ps, adam_kernel, dim3((unsigned)blocks), dim3(ANT), 0, st, a);
         }
         hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(64), 0, st, a);
         SH_CHECK_LAUNCH("adam_step");
+    }
+    return SH_OK;
+}
+
+int sh_adam_bump(int n_tensors, float* const* steps, sh_stream_t stream) {
+    SH_REQUIRE(n_tensors >= 0, SH_ERR_INVALID_ARG, "sh_adam_bump: negative tensor count");
+    if (n_tensors == 0) return SH_OK;
+    SH_REQUIRE(steps, SH_ERR_INVALID_ARG, "sh_adam_bump: null pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int t0 = 0; t0 < n_tensors; t0 += AT) {
+        AdamArgs a{};
+        a.nt = n_tensors - t0 < AT ? n_tensors - t0 : AT;
+        for (int i = 0; i < a.nt; ++i) {
+            SH_REQUIRE(steps[t0 + i], SH_ERR_INVALID_ARG, "sh_adam_bump: tensor %d has a null step pointer", t0 + i);
+            a.step[i] = steps[t0 + i];
+        }
+        hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(64), 0, st, a);
+        SH_CHECK_LAUNCH("adam_bump");
     }
     return SH_OK;
 }

@@ -14,6 +14,7 @@
 // v_mfma_f32_16x16x4_f32, optional split of the reduction over workgroups with partial slabs
 // summed in a fixed order by a second kernel (deterministic, no atomics).
 #include "sh_bf16.h"
+#include "sh_adam.h"
 
 #include <type_traits>
 
@@ -258,6 +259,10 @@ struct LSParams {
     float* dbias;        // weight-gradient kernel: column sums of dy (bias gradient) or null
     int M, N, K;
     int range, nsplit, groups;     // reduction range per split (multiple of 16), #splits, #64-wide output groups
+    // weight-gradient kernel with the Adam update applied to the tile (sh_linear_bwd_wgt_adam): `out` is the PARAMETER
+    float* am;           // exp_avg
+    float* av;           // exp_avg_sq
+    ShAdamHyper ad;
 };
 
 // forward: y[m][n] = sum_k x[m][k] W[n][k].  Item = (64 output columns, k range); both operands contiguous in k.
@@ -735,9 +740,14 @@ __global__ __launch_bounds__(LTHREADS) void linear_bwd_wgt_stream_kernel(const L
 // X3 (round 5): steps of 32 reduction rows on v_mfma_f32_16x16x32_bf16; a lane's eight rows are m = 32 s + 4 j + rr (j = 0..7; rows
 // 4 apart, so that the four row groups of a read keep their different swizzles: no bank conflicts), element tn / tk of its eight
 // dy / x quads split exactly into three bf16 terms: 16 x 6 MFMAs of 16 cycles per 32 rows against 8 x 16 of 32.
+// ADAM (round 5): the tile is not written as a gradient; it is the `g` of torch.optim.Adam's update of the same tile of the parameter
+// (p.out), exp_avg (p.am) and exp_avg_sq (p.av), applied here with adam.hip's own update function: the same bits as "store dW, then
+// sh_adam_step", without the 2 x 4 bytes per weight of writing and re-reading the gradient.  The step's coefficients (two double
+// pow) are computed by every wave while its tile loads are in flight.
 constexpr int LWD_TILE = 16 * 1024, LWD_LDS = 5 * LWD_TILE;
-template <bool X3 = false>
-__global__ __launch_bounds__(LTHREADS) void linear_bwd_wgt_dma_kernel(const LSParams p) {
+template <bool X3 = false, bool ADAM = false>
+__global__ __launch_bounds__(LTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))      // 80 KiB of LDS: two workgroups per CU, 256 registers each
+void linear_bwd_wgt_dma_kernel(const LSParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -766,6 +776,8 @@ __global__ __launch_bounds__(LTHREADS) void linear_bwd_wgt_dma_kernel(const LSPa
         const int row = 4 * ins + (lane >> 4);
         dma16(p.w + (long)min(row, p.M - 1) * p.K + k0 + 4 * piece, lds0 + (unsigned)((1 + wave) * LWD_TILE + ins * 1024));
     }
+    float step_size = 0.f, bc2_sqrt = 1.f;
+    if constexpr (ADAM) sh_adam_coeffs(p.ad.beta1, p.ad.beta2, p.ad.step[0], p.ad.lr[0], step_size, bc2_sqrt);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (!active) return;
@@ -779,6 +791,18 @@ __global__ __launch_bounds__(LTHREADS) void linear_bwd_wgt_dma_kernel(const LSPa
     const bool own_bias = kt == 0 && p.dbias != nullptr;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     const int roff = rr * 256 + ((la ^ (rr << 2)) << 4);               // row (4 s + rr): (row & 3) == rr
+    // ADAM: weight / exp_avg / exp_avg_sq of tile rows (tn, jj = 0..3), two sets: the first is requested here, underneath the products
+    f32x4 apf[ADAM ? 2 : 1][4][3];
+    auto adam_load = [&](int tn, int buf) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const long o = (long)(n0 + 16 * rr + 4 * jj + tn) * p.K + k0 + 4 * la;
+            apf[buf][jj][0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.out + o));
+            apf[buf][jj][1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.am + o));
+            apf[buf][jj][2] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.av + o));
+        }
+    };
+    if constexpr (ADAM) adam_load(0, 0);
     if constexpr (X3) {
         const int nst32 = (p.M + 31) >> 5;
         for (int s = 0; s < nst32; ++s) {
@@ -822,6 +846,26 @@ __global__ __launch_bounds__(LTHREADS) void linear_bwd_wgt_dma_kernel(const LSPa
         }
         if (rr == 0) *reinterpret_cast<f32x4*>(p.dbias + n0 + 4 * la) = bsum;
     }
+    if constexpr (ADAM) {
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {                                // four rows of the tile at a time, the next four in flight
+            if (tn + 1 < 4) adam_load(tn + 1, (tn + 1) & 1);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const long o = (long)(n0 + 16 * rr + 4 * jj + tn) * p.K + k0 + 4 * la;
+                f32x4 pp = apf[tn & 1][jj][0], mm = apf[tn & 1][jj][1], vv = apf[tn & 1][jj][2];
+#pragma unroll
+                for (int tk = 0; tk < 4; ++tk) {
+                    float p1 = pp[tk], m1 = mm[tk], v1 = vv[tk];
+                    adam_update(p1, acc[tn][tk][jj], m1, v1, p.ad.w1, p.ad.b2, p.ad.w2, p.ad.eps, p.ad.wd, step_size, bc2_sqrt);
+                    pp[tk] = p1; mm[tk] = m1; vv[tk] = v1;
+                }
+                *reinterpret_cast<f32x4*>(p.out + o) = pp;               // the parameter is read by the next forward pass: keep it cached
+                __builtin_nontemporal_store(mm, reinterpret_cast<f32x4*>(p.am + o));
+                __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(p.av + o));
+            }
+        }
+    } else {
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
@@ -829,6 +873,7 @@ __global__ __launch_bounds__(LTHREADS) void linear_bwd_wgt_dma_kernel(const LSPa
             float* dst = p.out + (long)(n0 + 16 * rr + 4 * jj + tn) * p.K + k0 + 4 * la;
             __builtin_nontemporal_store((f32x4){acc[tn][0][jj], acc[tn][1][jj], acc[tn][2][jj], acc[tn][3][jj]}, reinterpret_cast<f32x4*>(dst));
         }
+    }
 }
 
 // plan of the streaming forms: enough items for one wave per SIMD (1024), reduction ranges multiples of 16
@@ -1082,6 +1127,22 @@ int sh_linear_bwd_data(const float* dy, const float* weight, float* dx, int M, i
     return run_gemm(p, workspace, workspace_bytes, static_cast<hipStream_t>(stream), "linear_bwd_data");
 }
 
+// the LDS-DMA weight-gradient kernels need 80 KiB of dynamic LDS: raise the limit once
+static bool wgt_dma_attr() {
+    static bool attr_set = false;
+    if (!attr_set) {
+        for (const void* k : {reinterpret_cast<const void*>(linear_bwd_wgt_dma_kernel<false>), reinterpret_cast<const void*>(linear_bwd_wgt_dma_kernel<true>),
+                              reinterpret_cast<const void*>(linear_bwd_wgt_dma_kernel<false, true>), reinterpret_cast<const void*>(linear_bwd_wgt_dma_kernel<true, true>)})
+            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                (void)hipGetLastError();
+                sh_set_error("linear_bwd_wgt: cannot raise the dynamic LDS limit to %d bytes", LWD_LDS);
+                return false;
+            }
+        attr_set = true;
+    }
+    return true;
+}
+
 int sh_linear_bwd_wgt(const float* dy, const float* x, float* dW, float* dbias, int M, int N, int K, void* workspace,
                       size_t workspace_bytes, int mma_mode, sh_stream_t stream) {
     SH_REQUIRE(dy && x && dW && M > 0 && N > 0 && K > 0, SH_ERR_INVALID_ARG, "sh_linear_bwd_wgt: bad argument");
@@ -1095,16 +1156,7 @@ int sh_linear_bwd_wgt(const float* dy, const float* x, float* dW, float* dbias, 
         const int items = (N / 64) * (K / 64);
         static const int dma_on = sh_env_int("SH_LIN_WGT_DMA", 1, 0, 1);
         if (dma_on) {
-            static bool attr_set = false;
-            if (!attr_set) {
-                for (const void* k : {reinterpret_cast<const void*>(linear_bwd_wgt_dma_kernel<false>), reinterpret_cast<const void*>(linear_bwd_wgt_dma_kernel<true>)})
-                    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-                        (void)hipGetLastError();
-                        sh_set_error("linear_bwd_wgt: cannot raise the dynamic LDS limit to %d bytes", LWD_LDS);
-                        return SH_ERR_LAUNCH;
-                    }
-                attr_set = true;
-            }
+            if (!wgt_dma_attr()) return SH_ERR_LAUNCH;
             const int wgs = (N / 64) * sh_cdiv(K / 64, 4);
             if (lin_x3(mma_mode)) {
                 ShProfScope ps(st, "linear_bwd_wgt_x3_kernel|M=%d N=%d K=%d", M, N, K);
@@ -1132,6 +1184,43 @@ int sh_linear_bwd_wgt(const float* dy, const float* x, float* dW, float* dbias, 
         hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)sh_cdiv(N, 256)), dim3(256), 0, st, dy, M, N, dbias);
         SH_CHECK_LAUNCH("colsum");
     }
+    return SH_OK;
+}
+
+int sh_linear_bwd_wgt_adam_ok(int M, int N, int K) {
+    static const int on = sh_env_int("SH_LIN_WGT_ADAM", 1, 0, 1);
+    return on && M > 0 && M <= 64 && N > 0 && K > 0 && N % 64 == 0 && K % 64 == 0;
+}
+
+int sh_linear_bwd_wgt_adam(const float* dy, const float* x, float* weight, float* exp_avg, float* exp_avg_sq, const float* step,
+                           const float* lr, double beta1, double beta2, double eps, double weight_decay, float* dbias, int M, int N, int K,
+                           int mma_mode, sh_stream_t stream) {
+    SH_REQUIRE(dy && x && weight && exp_avg && exp_avg_sq && step && lr && M > 0 && N > 0 && K > 0, SH_ERR_INVALID_ARG,
+               "sh_linear_bwd_wgt_adam: bad argument");
+    SH_REQUIRE(sh_mma_mode_valid(mma_mode), SH_ERR_INVALID_ARG, "sh_linear_bwd_wgt_adam: unknown mma_mode %d", mma_mode);
+    SH_REQUIRE(beta1 >= 0 && beta1 < 1 && beta2 >= 0 && beta2 < 1 && eps >= 0 && weight_decay >= 0, SH_ERR_INVALID_ARG,
+               "sh_linear_bwd_wgt_adam: hyper-parameter out of range");
+    SH_REQUIRE(sh_linear_bwd_wgt_adam_ok(M, N, K) && aligned16(dy, x, weight) && aligned16(exp_avg, exp_avg_sq, weight), SH_ERR_UNSUPPORTED,
+               "sh_linear_bwd_wgt_adam: M=%d N=%d K=%d is not served by the tile kernel (M <= 64, N and K multiples of 64, 16-byte aligned "
+               "tensors): use sh_linear_bwd_wgt + sh_adam_step", M, N, K);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!wgt_dma_attr()) return SH_ERR_LAUNCH;
+    LSParams s{};
+    s.a = dy; s.w = x; s.out = weight; s.M = M; s.N = N; s.K = K;
+    s.am = exp_avg; s.av = exp_avg_sq;
+    s.ad.lr = lr; s.ad.step = step; s.ad.beta1 = beta1; s.ad.beta2 = beta2;
+    s.ad.w1 = (float)(1.0 - beta1); s.ad.b2 = (float)beta2; s.ad.w2 = (float)(1.0 - beta2); s.ad.eps = (float)eps; s.ad.wd = (float)weight_decay;
+    s.dbias = (dbias && (reinterpret_cast<uintptr_t>(dbias) & 15) == 0) ? dbias : nullptr;
+    const int wgs = (N / 64) * sh_cdiv(K / 64, 4);
+    if (lin_x3(mma_mode)) {
+        ShProfScope ps(st, "linear_bwd_wgt_adam_x3_kernel|M=%d N=%d K=%d", M, N, K);
+        SH_LAUNCH_PS(ps, (linear_bwd_wgt_dma_kernel<true, true>), dim3(wgs), dim3(LTHREADS), LWD_LDS, st, s);
+    } else {
+        ShProfScope ps(st, "linear_bwd_wgt_adam_kernel|M=%d N=%d K=%d", M, N, K);
+        SH_LAUNCH_PS(ps, (linear_bwd_wgt_dma_kernel<false, true>), dim3(wgs), dim3(LTHREADS), LWD_LDS, st, s);
+    }
+    if (dbias && !s.dbias) hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)sh_cdiv(N, 256)), dim3(256), 0, st, dy, M, N, dbias);
+    SH_CHECK_LAUNCH("linear_bwd_wgt_adam");
     return SH_OK;
 }
 

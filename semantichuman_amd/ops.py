@@ -214,6 +214,26 @@ def linear_bwd_wgt(dy, x, want_bias=True, mma=None):
     return dW, db
 
 
+def linear_bwd_wgt_adam_ok(M, N, K):
+    return bool(_lib.load().sh_linear_bwd_wgt_adam_ok(int(M), int(N), int(K)))
+
+
+def linear_bwd_wgt_adam(dy, x, weight, exp_avg, exp_avg_sq, step, lr, betas, eps, weight_decay, want_bias=True, mma=None):
+    """dW = dy^T x used as the gradient of Adam's update of `weight` / `exp_avg` / `exp_avg_sq`, in place, in the kernel that
+    computes it (sh_linear_bwd_wgt_adam); returns the bias gradient (or None).  `step` is not advanced (sh_adam_bump)."""
+    _check2d(dy, x)
+    M, N = dy.shape
+    K = x.shape[1]
+    for t in (weight, exp_avg, exp_avg_sq):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == (N, K)):
+            raise RuntimeError("linear_bwd_wgt_adam: weight / exp_avg / exp_avg_sq must be contiguous fp32 [%d, %d] HIP tensors" % (N, K))
+    db = torch.empty((N,), dtype=torch.float32, device=dy.device) if want_bias else None
+    check(_lib.load().sh_linear_bwd_wgt_adam(ptr(dy), ptr(x), ptr(weight), ptr(exp_avg), ptr(exp_avg_sq), ptr(step), ptr(lr), float(betas[0]),
+                                             float(betas[1]), float(eps), float(weight_decay), ptr(db), M, N, K, _lib.mma_id(mma), stream_ptr()),
+          "sh_linear_bwd_wgt_adam")
+    return db
+
+
 def _glin_args(x_off, y_off, N, K):
     import ctypes
     G = len(N)

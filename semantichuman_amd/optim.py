@@ -39,6 +39,8 @@ class Adam(torch.optim.Optimizer):
         self._early = set()          # parameters already updated during this backward
         self._hooks = []
         self._side = None
+        self._fused = []             # weak references to weights updated inside their weight-gradient kernel
+        self._fused_done = []        # ... those that were, during this backward: step() advances their step counts
 
     # ---------------------------------------------------------------------------------- internals
     def _state_of(self, p):
@@ -74,10 +76,12 @@ class Adam(torch.optim.Optimizer):
             if ps:
                 self._lr_tensor(group, ps[0].device)
 
-    def _apply(self, group, params):
+    def _apply(self, group, params, bump_only=()):
         params = [p for p in params if p.grad is not None]
-        if not params:
+        if not params and not bump_only:
             return
+        n_upd = len(params)
+        params = params + list(bump_only)      # (updated inside their weight-gradient kernel: only their step counts advance)
         n = len(params)
         arr = lambda: (ctypes.c_void_p * n)()                      # noqa: E731
         P, G, M, V, S, N = arr(), arr(), arr(), arr(), arr(), (ctypes.c_int64 * n)()
@@ -85,6 +89,9 @@ class Adam(torch.optim.Optimizer):
         from . import shadow
         keep = []
         for i, p in enumerate(params):
+            if i >= n_upd:
+                S[i], N[i] = self.state[p]["step"].data_ptr(), 0
+                continue
             g = p.grad
             if g.is_sparse or g.dtype != torch.float32 or g.device != p.device:
                 raise RuntimeError("semantichuman_amd.optim.Adam needs dense fp32 gradients on the parameter's device")
@@ -130,6 +137,46 @@ class Adam(torch.optim.Optimizer):
             self._apply(group, [p])
         self._early.add(id(p))
 
+    # ---------------------------------------------------------------------------------- update inside the weight-gradient kernel
+    def fuse_linear_weight_gradients(self, modules):
+        """For the weights of the given `nn.Linear` modules that run on `latent_linear` (the autoencoder's two latent FCs: 99 %
+        of its parameters), let the kernel that computes a tile of the weight gradient apply this optimizer's update to the same
+        tile of the weight and its two moments (sh_linear_bwd_wgt_adam) instead of writing the gradient for `step()` to read
+        back: 24 instead of 32 bytes of HBM traffic per weight and step, the same bits.  `weight.grad` is then never
+        materialised (it stays None); `step()` updates everything else and advances the fused parameters' step counts.
+        As with `overlap_backward`: only when nothing else consumes the gradients between backward and step (no all-reduce,
+        no clipping, one backward per step).  Shapes the kernel does not serve (batch > 64, sizes that are not multiples of 64),
+        the bf16 path and parameters that already hold a `.grad` fall back to the ordinary gradient + `step()`."""
+        import weakref
+        from . import linear
+        for mod in modules:
+            w = mod.weight
+            group = next((g for g in self.param_groups if any(q is w for q in g["params"])), None)
+            if group is None:
+                raise ValueError("fuse_linear_weight_gradients: a module's weight is not a parameter of this optimizer")
+            if not (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 2):
+                raise RuntimeError("fuse_linear_weight_gradients: contiguous 2-D fp32 HIP weights only")
+            linear._FUSED_UPDATE[w.data_ptr()] = (weakref.ref(w), lambda p, dy, x, want_bias, mma, g=group: self._fused_update(g, p, dy, x, want_bias, mma))
+            self._fused.append(weakref.ref(w))
+        return self
+
+    def remove_fusion(self):
+        from . import linear
+        for r in self._fused:
+            w = r()
+            if w is not None:
+                linear._FUSED_UPDATE.pop(w.data_ptr(), None)
+        self._fused = []
+
+    @torch.no_grad()
+    def _fused_update(self, group, p, dy, x, want_bias, mma):
+        from . import ops
+        st = self._state_of(p)
+        db = ops.linear_bwd_wgt_adam(dy, x, p, st["exp_avg"], st["exp_avg_sq"], st["step"], self._lr_tensor(group, p.device), group["betas"],
+                                     group["eps"], group["weight_decay"], want_bias=want_bias, mma=mma)
+        self._fused_done.append(p)
+        return db
+
     # ---------------------------------------------------------------------------------- torch.optim API
     @torch.no_grad()
     def step(self, closure=None):
@@ -140,6 +187,8 @@ class Adam(torch.optim.Optimizer):
         if self._early:
             torch.cuda.current_stream(self._side.device).wait_stream(self._side)   # join: early updates are part of this step
         for group in self.param_groups:
-            self._apply(group, [p for p in group["params"] if id(p) not in self._early])
+            fused = [p for p in self._fused_done if any(q is p for q in group["params"])]
+            self._apply(group, [p for p in group["params"] if id(p) not in self._early], bump_only=fused)
         self._early.clear()
+        self._fused_done = []
         return loss

@@ -70,6 +70,10 @@ def test_streaming_launches_are_priced(model):
             assert any(v == pytest.approx(want) for v in t[key]), key
     assert bench.parse_tag_hbm("spmm_kernel<true, p3>", "rows=863 B=64 C=128") == ("spmm", 863, 128)
     assert bench.parse_tag_hbm("adam_kernel", "tensors=22 blocks=100") == ("adam",)
+    assert bench.parse_tag_hbm("adam_kernel", "tensors=24 blocks=90 numel=237000") == ("adam", 237000)
+    # the weight-gradient launch that applies Adam to its tile: six weight-sized streams instead of one
+    assert bench.parse_tag_linear("linear_bwd_wgt_adam_x3_kernel", "M=64 N=256 K=55296")[1] == 4.0 * (6 * 256 * 55296 + 64 * 55296 + 64 * 256)
+    assert bench.parse_tag_linear("linear_bwd_wgt_x3_kernel", "M=64 N=256 K=55296")[1] == 4.0 * (256 * 55296 + 64 * 55296 + 64 * 256)
     assert bench.parse_tag_linear("linear_fwd_x3_kernel<4>", "M=64 N=256 K=55296 split=247")[0] == 2.0 * 64 * 256 * 55296
     assert bench.parse_tag_f32("conv_p3s_kernel<2, true, 6, 4>", "R=863 B=64 K=512 N=128 grid=256x512") == ("bwd", 863, 512, 128)
     assert bench.parse_tag_f32("wgrad_stream_kernel<2, 4, 3, true, ilv>", "R=3446 B=64 K=352 N=32 grid=256 presum=4495") == ("wgt", 3446, 352, 32)

@@ -141,3 +141,100 @@ def test_hip_adam_captured_step_follows_steplr_through_sync_lr():
         assert opt.param_groups[0]["lr"] == pytest.approx(1e-3 * 0.5 ** 4)
     for p, q in zip(*outs):
         assert torch.equal(p, q)
+
+
+# ------------------------------------------------------------------------------ Adam applied inside the FC weight-gradient kernel
+def _fc_case(dev, M, N, K, seed):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g)                    # noqa: E731
+    return (r(M, N) * 1e-2).to(dev), r(M, K).to(dev), (r(N, K) * 0.05).to(dev), (r(N, K) * 1e-3).to(dev), (r(N, K) ** 2 * 1e-6).to(dev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["exact", "planes3"])
+@pytest.mark.parametrize("M,N,K", [(64, 256, 640), (64, 1280, 256), (16, 128, 192), (37, 192, 64)])
+def test_fused_weight_gradient_adam_is_bitwise_the_two_kernel_form(form, M, N, K):
+    """sh_linear_bwd_wgt_adam == sh_linear_bwd_wgt, then sh_adam_step on that tensor: the same bits in the weight and both moments,
+    the same bias gradient; the step count is left to the caller (sh_adam_bump)."""
+    from semantichuman_amd import ops
+    dev = torch.device("cuda:0")
+    dy, x, w, m, v = _fc_case(dev, M, N, K, 5)
+    assert ops.linear_bwd_wgt_adam_ok(M, N, K)
+    lr = torch.full((), 1e-3, device=dev)
+    # the two-kernel form through the library's own optimizer (steps already applied: 3)
+    p_ref = w.clone().requires_grad_(True)
+    opt = sh.optim.Adam([p_ref], lr=1e-3, weight_decay=5e-5)
+    st = opt._state_of(p_ref)
+    st["step"].fill_(3.0); st["exp_avg"].copy_(m); st["exp_avg_sq"].copy_(v)
+    p_ref.grad, db_ref = ops.linear_bwd_wgt(dy, x, want_bias=True, mma=form)
+    opt.step()
+    # the fused form
+    p, m1, v1, step = w.clone(), m.clone(), v.clone(), torch.full((), 3.0, device=dev)
+    db = ops.linear_bwd_wgt_adam(dy, x, p, m1, v1, step, lr, (0.9, 0.999), 1e-8, 5e-5, want_bias=True, mma=form)
+    torch.cuda.synchronize()
+    assert float(step) == 3.0 and float(st["step"]) == 4.0
+    assert torch.equal(p, p_ref.detach()) and torch.equal(m1, st["exp_avg"]) and torch.equal(v1, st["exp_avg_sq"])
+    assert torch.equal(db, db_ref)
+    assert not torch.equal(p, w)                                     # it did move
+
+
+@pytest.mark.gpu
+def test_fused_weight_gradient_adam_refuses_what_it_does_not_serve():
+    from semantichuman_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    assert not ops.linear_bwd_wgt_adam_ok(128, 256, 640) and not ops.linear_bwd_wgt_adam_ok(64, 200, 640)
+    dy, x, w, m, v = _fc_case(dev, 128, 256, 640, 1)
+    w0 = w.clone()
+    with pytest.raises(RuntimeError, match="not served"):
+        ops.linear_bwd_wgt_adam(dy, x, w, m, v, torch.zeros((), device=dev), torch.full((), 1e-3, device=dev), (0.9, 0.999), 1e-8, 0.0)
+    torch.cuda.synchronize()
+    assert torch.equal(w, w0)                                        # nothing was launched
+    assert _lib.load().sh_linear_bwd_wgt_adam(None, None, None, None, None, None, None, 0.9, 0.999, 1e-8, 0.0, None, 64, 64, 64, 0, None) != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["exact", "planes3"])
+@pytest.mark.parametrize("batch", [16, 8])
+def test_training_steps_with_the_update_fused_into_backward(golden_dir, form, batch):
+    """Three training steps of the small autoencoder with `fuse_linear_weight_gradients` on its two latent FCs against the same
+    steps without: every parameter, moment and step count bitwise equal; the FC weights never hold a `.grad`.  (batch 8: fewer
+    reduction rows than one 32-row step of the bf16x3 kernel - the zero-filled rows must not change a bit.)"""
+    import os
+    from semantichuman_amd import _lib, synthetic
+    from semantichuman_amd.hierarchy import load_hierarchy
+    dev = torch.device("cuda:0")
+    h = load_hierarchy(os.path.join(golden_dir, "template6890.npz"))
+    FE = [[3, 16, 32, 64, 128], [[], [], [], [], []]]
+    FD = [[128, 64, 32, 32, 16], [[], [], [], [], 3]]
+    was = _lib.get_f32_mma_mode()
+    _lib.set_f32_mma_mode(form)
+    try:
+        runs = []
+        for fuse in (False, True):
+            torch.manual_seed(3)
+            model = sh.SpiralAutoencoder(FE, FD, 256, h.sizes, h.spiral_sizes, h.spirals, h.D, h.U, dev)
+            opt = sh.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-5)
+            if fuse:
+                opt.fuse_linear_weight_gradients([model.fc_latent_enc, model.fc_latent_dec])
+            ft = sh.FaceTables(h.faces, h.sizes[0] + 1, dev)
+            x = torch.from_numpy(synthetic.synth_batch(h.verts, batch, seed=11)).to(dev)
+            for _ in range(3):
+                opt.zero_grad(set_to_none=True)
+                xh, _ = model(x)
+                loss, _ = sh.recon_loss(xh, x, ft, 1e-2)
+                loss.backward()
+                if fuse:
+                    assert model.fc_latent_enc.weight.grad is None and model.fc_latent_dec.weight.grad is None
+                    assert model.fc_latent_enc.bias.grad is not None
+                opt.step()
+            torch.cuda.synchronize()
+            runs.append((model, opt, float(loss.detach())))
+            opt.remove_fusion()
+        (ma, oa, la), (mb, ob, lb) = runs
+        assert la == lb
+        for (k, p), (_, q) in zip(ma.named_parameters(), mb.named_parameters()):
+            assert torch.equal(p, q), k
+            assert float(oa.state[p]["step"]) == float(ob.state[q]["step"]) == 3.0, k
+            assert torch.equal(oa.state[p]["exp_avg"], ob.state[q]["exp_avg"]) and torch.equal(oa.state[p]["exp_avg_sq"], ob.state[q]["exp_avg_sq"]), k
+    finally:
+        _lib.set_f32_mma_mode(was)
