@@ -378,7 +378,7 @@ def replayed_training(sh, h, B, dtype, dev, steps, warmup, n_data=None, seed=100
         model.set_compute_dtype(torch.bfloat16)
     init_state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     optim = sh.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-5)
-    if dtype == "f32" and fused_update:
+    if fused_update:
         optim.fuse_linear_weight_gradients([model.fc_latent_enc, model.fc_latent_dec])
     ft = sh.FaceTables(h.faces, h.sizes[0] + 1, dev)
     n_data = n_data or 4 * B
@@ -430,7 +430,7 @@ def replayed_training(sh, h, B, dtype, dev, steps, warmup, n_data=None, seed=100
            "whole_step": whole_step_block(model, B, dtype, dt, _lib.get_f32_mma_mode() if dtype == "f32" else None)}
     if dtype == "f32":
         res["f32_mma"] = _lib.get_f32_mma_mode()
-        res["adam"] = "latent FCs updated inside their weight-gradient kernels" if fused_update else "multi-tensor kernel"
+    res["adam"] = "latent FCs updated inside their weight-gradient kernels" if fused_update else "multi-tensor kernel"
     del graph
     return res, model, init_state, data, ft
 
@@ -454,7 +454,7 @@ def secondary_block(sh, h, B, dev, init_state, data, test, ft, cpu_l2_mm, args):
         torch.cuda.empty_cache()
 
     def bf16_leg():
-        res, model, init16, d16, ft16 = replayed_training(sh, h, B, "bf16", dev, steps, warm)
+        res, model, init16, d16, ft16 = replayed_training(sh, h, B, "bf16", dev, steps, warm, fused_update=not args.no_fused_update)
         # roofline of its dominant kernel against HBM: per-launch HIP events of 3 eagerly launched steps
         opt = sh.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-5)
         x = d16[:B]
@@ -1137,7 +1137,7 @@ def main():
                     "each timed as 20 replayed steps after the headline's timed region)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured hipGraph")
     ap.add_argument("--adam", choices=["hip", "torch"], default="hip", help="library Adam kernel, or torch's fused capturable Adam")
-    ap.add_argument("--no-fused-update", action="store_true", help="fp32, one GPU: write the latent FCs' weight gradients and let the multi-tensor Adam "
+    ap.add_argument("--no-fused-update", action="store_true", help="one GPU: write the latent FCs' weight gradients and let the multi-tensor Adam "
                     "read them back, instead of applying the update inside the weight-gradient kernel (the default; same bits)")
     ap.add_argument("--adam-overlap", action="store_true", help="update the big parameters on a side stream underneath backward (measured: no gain, the GPU is already saturated)")
     ap.add_argument("--grad-comm", choices=["fp32", "bf16"], default="fp32",
@@ -1246,7 +1246,7 @@ def main():
         # one GPU: nothing consumes the latent FCs' weight gradients but Adam, so the kernel that computes a tile of them applies
         # the update to that tile (sh_linear_bwd_wgt_adam; bit-identical, tests/test_optim.py) - 8 of 32 bytes per weight never move.
         # With a gradient all-reduce in between (N > 1) the gradients have to exist: the ordinary two-kernel form.
-        fused_update = reducer is None and args.dtype == "f32" and not args.no_fused_update and not args.adam_overlap
+        fused_update = reducer is None and not args.no_fused_update and not args.adam_overlap
         if fused_update:
             optim.fuse_linear_weight_gradients([model.fc_latent_enc, model.fc_latent_dec])
     else:

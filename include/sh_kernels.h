@@ -292,16 +292,19 @@ SH_API int sh_linear_bwd_wgt(const float* dy, const float* x, float* dW, float* 
  * `exp_avg` and `exp_avg_sq` (in place; coefficients from the DEVICE scalars `step` = updates applied so far and `lr`, so the
  * launch is replayable in a hipGraph).  Bit-identical to sh_linear_bwd_wgt followed by sh_adam_step on that tensor (one shared
  * update function), without writing and re-reading the gradient: 24 instead of 32 bytes of HBM traffic per weight.  `step` is
- * NOT advanced here (every workgroup reads it): the caller advances it once the launch is queued - sh_adam_bump.  dbias as in
+ * NOT advanced here (every workgroup reads it): the caller advances it once the launch is queued (sh_adam_bump, or a numel == 0 entry of sh_adam_step).  dbias as in
  * sh_linear_bwd_wgt (the bias keeps its ordinary gradient).  Served shapes: sh_linear_bwd_wgt_adam_ok (M <= 64, N and K
  * multiples of 64; SH_LIN_WGT_ADAM=0 makes it answer 0); others return SH_ERR_UNSUPPORTED and nothing is launched.
  * Replaces, for one parameter, the pair reference `loss.backward()` (models.py:130 / :144 autograd of nn.Linear) +
  * `optimizer.step()` (train_funcs.py:391-392, 509-510).  Only valid when nothing else consumes that gradient between backward
- * and step (no all-reduce, clipping or accumulation over several backward passes). */
+ * and step (no all-reduce, clipping or accumulation over several backward passes).
+ * dy / x carry an element type (enum sh_dtype, declared below): bf16 operands (the bf16 path's layer, sh_linear_bwd_wgt_bf16) are
+ * widened to fp32 in the kernel and multiplied on the fp32 MFMA - exact products of bf16 values, fp32 accumulation; `weight_bf16`,
+ * if not NULL, is the bf16 working copy of the weight and is rewritten with the update (as sh_adam_step_bf16 does). */
 SH_API int sh_linear_bwd_wgt_adam_ok(int M, int N, int K);
-SH_API int sh_linear_bwd_wgt_adam(const float* dy, const float* x, float* weight, float* exp_avg, float* exp_avg_sq, const float* step,
-                           const float* lr, double beta1, double beta2, double eps, double weight_decay, float* dbias, int M,
-                           int N, int K, int mma_mode, sh_stream_t stream);
+SH_API int sh_linear_bwd_wgt_adam(const void* dy, int dy_dtype, const void* x, int x_dtype, float* weight, void* weight_bf16, float* exp_avg,
+                           float* exp_avg_sq, const float* step, const float* lr, double beta1, double beta2, double eps,
+                           double weight_decay, float* dbias, int M, int N, int K, int mma_mode, sh_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Grouped (ragged) dense layers: the 3 x 17 per-part nn.Linear layers of SpiralAutoencoder_multiz_partkps

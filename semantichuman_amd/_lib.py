@@ -44,7 +44,7 @@ SIGNATURES = {
     "sh_linear_bwd_data": (c_int, [_P, _P, _P, _I, _I, _I, _P, c_size_t, _I, _P]),
     "sh_linear_bwd_wgt": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, c_size_t, _I, _P]),
     "sh_linear_bwd_wgt_adam_ok": (c_int, [_I, _I, _I]),
-    "sh_linear_bwd_wgt_adam": (c_int, [_P] * 7 + [ctypes.c_double] * 4 + [_P, _I, _I, _I, _I, _P]),
+    "sh_linear_bwd_wgt_adam": (c_int, [_P, _I, _P, _I] + [_P] * 6 + [ctypes.c_double] * 4 + [_P, _I, _I, _I, _I, _P]),
     "sh_adam_bump": (c_int, [_I, _P, _P]),
     "sh_grouped_linear_fwd": (c_int, [_I, _P, _L, _P, _P, _P, _P, _L, _P, _I, _P, _P, _P]),
     "sh_grouped_linear_bwd_data": (c_int, [_I, _P, _L, _P, _P, _P, _L, _P, _I, _P, _P, _P]),

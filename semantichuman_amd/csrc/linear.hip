@@ -262,6 +262,7 @@ struct LSParams {
     // weight-gradient kernel with the Adam update applied to the tile (sh_linear_bwd_wgt_adam): `out` is the PARAMETER
     float* am;           // exp_avg
     float* av;           // exp_avg_sq
+    __bf16* shadow;      // bf16 working copy of the parameter (the bf16 path's latent FCs), rewritten with the update, or null
     ShAdamHyper ad;
 };
 
@@ -744,8 +745,11 @@ __global__ __launch_bounds__(LTHREADS) void linear_bwd_wgt_stream_kernel(const L
 // (p.out), exp_avg (p.am) and exp_avg_sq (p.av), applied here with adam.hip's own update function: the same bits as "store dW, then
 // sh_adam_step", without the 2 x 4 bytes per weight of writing and re-reading the gradient.  The step's coefficients (two double
 // pow) are computed by every wave while its tile loads are in flight.
+// A16 / W16: dy / x is a bf16 tensor (the bf16 path's layer): its tile is read with ordinary 16-byte loads, widened to fp32 (exact) in
+// registers and written into the same LDS layout; the products are the fp32 MFMA's (a product of two bf16 values is exact in fp32:
+// what the bf16 MFMA computes, in another summation order).
 constexpr int LWD_TILE = 16 * 1024, LWD_LDS = 5 * LWD_TILE;
-template <bool X3 = false, bool ADAM = false>
+template <bool X3 = false, bool ADAM = false, bool A16 = false, bool W16 = false>
 __global__ __launch_bounds__(LTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))      // 80 KiB of LDS: two workgroups per CU, 256 registers each
 void linear_bwd_wgt_dma_kernel(const LSParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -766,15 +770,39 @@ void linear_bwd_wgt_dma_kernel(const LSParams p) {
     };
     // instruction i of a tile: rows 4 i .. 4 i + 3; lane -> row 4 i + (lane >> 4), slot lane & 15 holds piece slot ^ ((row & 3) << 2)
     const int piece = (lane & 15) ^ ((lane >> 4) << 2);
+    // a bf16 tile row is 8 pieces of 8 elements: lane -> (row, piece j); elements 8 j .. 8 j + 7 are fp32 pieces 2 j and 2 j + 1 of the row
+    auto stage16 = [&](const __bf16* src, long ld, int col0, int row, int j, char* tile) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + (long)min(row, p.M - 1) * ld + col0 + 8 * j);
+        char* d = tile + (row >> 2) * 1024 + (row & 3) * 256;
+        const int sw = (row & 3) << 2;
+        *reinterpret_cast<f32x4*>(d + (((2 * j) ^ sw) << 4)) = (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+        *reinterpret_cast<f32x4*>(d + (((2 * j + 1) ^ sw) << 4)) = (f32x4){(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+    };
+    if constexpr (A16) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {                                 // this wave's quarter (16 rows x 8 pieces) of the shared dy tile
+            const int q = 64 * i + lane;
+            stage16(reinterpret_cast<const __bf16*>(p.a), p.N, n0, 16 * wave + (q >> 3), q & 7, smem);
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {                                     // this wave's quarter of the shared dy tile
         const int ins = 4 * wave + i, row = 4 * ins + (lane >> 4);
         dma16(p.a + (long)min(row, p.M - 1) * p.N + n0 + 4 * piece, lds0 + (unsigned)(ins * 1024));
     }
+    }
+    if constexpr (W16) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {                                 // its own x tile: 64 rows x 8 pieces
+            const int q = 64 * i + lane;
+            stage16(reinterpret_cast<const __bf16*>(p.w), p.K, k0, q >> 3, q & 7, smem + (1 + wave) * LWD_TILE);
+        }
+    } else {
 #pragma unroll
     for (int ins = 0; ins < 16; ++ins) {                              // its own x tile
         const int row = 4 * ins + (lane >> 4);
         dma16(p.w + (long)min(row, p.M - 1) * p.K + k0 + 4 * piece, lds0 + (unsigned)((1 + wave) * LWD_TILE + ins * 1024));
+    }
     }
     float step_size = 0.f, bc2_sqrt = 1.f;
     if constexpr (ADAM) sh_adam_coeffs(p.ad.beta1, p.ad.beta2, p.ad.step[0], p.ad.lr[0], step_size, bc2_sqrt);
@@ -861,6 +889,7 @@ void linear_bwd_wgt_dma_kernel(const LSParams p) {
                     pp[tk] = p1; mm[tk] = m1; vv[tk] = v1;
                 }
                 *reinterpret_cast<f32x4*>(p.out + o) = pp;               // the parameter is read by the next forward pass: keep it cached
+                if (p.shadow) *reinterpret_cast<bf16x4*>(p.shadow + o) = sh_to_bf16x4(pp);
                 __builtin_nontemporal_store(mm, reinterpret_cast<f32x4*>(p.am + o));
                 __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(p.av + o));
             }
@@ -1132,7 +1161,10 @@ static bool wgt_dma_attr() {
     static bool attr_set = false;
     if (!attr_set) {
         for (const void* k : {reinterpret_cast<const void*>(linear_bwd_wgt_dma_kernel<false>), reinterpret_cast<const void*>(linear_bwd_wgt_dma_kernel<true>),
-                              reinterpret_cast<const void*>(linear_bwd_wgt_dma_kernel<false, true>), reinterpret_cast<const void*>(linear_bwd_wgt_dma_kernel<true, true>)})
+                              reinterpret_cast<const void*>(linear_bwd_wgt_dma_kernel<false, true>), reinterpret_cast<const void*>(linear_bwd_wgt_dma_kernel<true, true>),
+                              reinterpret_cast<const void*>(linear_bwd_wgt_dma_kernel<false, true, true, false>),
+                              reinterpret_cast<const void*>(linear_bwd_wgt_dma_kernel<false, true, false, true>),
+                              reinterpret_cast<const void*>(linear_bwd_wgt_dma_kernel<false, true, true, true>)})
             if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
                 (void)hipGetLastError();
                 sh_set_error("linear_bwd_wgt: cannot raise the dynamic LDS limit to %d bytes", LWD_LDS);
@@ -1192,34 +1224,45 @@ int sh_linear_bwd_wgt_adam_ok(int M, int N, int K) {
     return on && M > 0 && M <= 64 && N > 0 && K > 0 && N % 64 == 0 && K % 64 == 0;
 }
 
-int sh_linear_bwd_wgt_adam(const float* dy, const float* x, float* weight, float* exp_avg, float* exp_avg_sq, const float* step,
-                           const float* lr, double beta1, double beta2, double eps, double weight_decay, float* dbias, int M, int N, int K,
-                           int mma_mode, sh_stream_t stream) {
+int sh_linear_bwd_wgt_adam(const void* dy, int dy_dtype, const void* x, int x_dtype, float* weight, void* weight_bf16, float* exp_avg,
+                           float* exp_avg_sq, const float* step, const float* lr, double beta1, double beta2, double eps, double weight_decay,
+                           float* dbias, int M, int N, int K, int mma_mode, sh_stream_t stream) {
     SH_REQUIRE(dy && x && weight && exp_avg && exp_avg_sq && step && lr && M > 0 && N > 0 && K > 0, SH_ERR_INVALID_ARG,
                "sh_linear_bwd_wgt_adam: bad argument");
     SH_REQUIRE(sh_mma_mode_valid(mma_mode), SH_ERR_INVALID_ARG, "sh_linear_bwd_wgt_adam: unknown mma_mode %d", mma_mode);
+    SH_REQUIRE((dy_dtype == SH_DTYPE_F32 || dy_dtype == SH_DTYPE_BF16) && (x_dtype == SH_DTYPE_F32 || x_dtype == SH_DTYPE_BF16), SH_ERR_INVALID_ARG,
+               "sh_linear_bwd_wgt_adam: unknown element type");
     SH_REQUIRE(beta1 >= 0 && beta1 < 1 && beta2 >= 0 && beta2 < 1 && eps >= 0 && weight_decay >= 0, SH_ERR_INVALID_ARG,
                "sh_linear_bwd_wgt_adam: hyper-parameter out of range");
-    SH_REQUIRE(sh_linear_bwd_wgt_adam_ok(M, N, K) && aligned16(dy, x, weight) && aligned16(exp_avg, exp_avg_sq, weight), SH_ERR_UNSUPPORTED,
+    SH_REQUIRE(sh_linear_bwd_wgt_adam_ok(M, N, K) && aligned16(dy, x, weight) && aligned16(exp_avg, exp_avg_sq, weight) &&
+               (reinterpret_cast<uintptr_t>(weight_bf16) & 7) == 0, SH_ERR_UNSUPPORTED,
                "sh_linear_bwd_wgt_adam: M=%d N=%d K=%d is not served by the tile kernel (M <= 64, N and K multiples of 64, 16-byte aligned "
                "tensors): use sh_linear_bwd_wgt + sh_adam_step", M, N, K);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (!wgt_dma_attr()) return SH_ERR_LAUNCH;
     LSParams s{};
-    s.a = dy; s.w = x; s.out = weight; s.M = M; s.N = N; s.K = K;
-    s.am = exp_avg; s.av = exp_avg_sq;
+    s.a = static_cast<const float*>(dy); s.w = static_cast<const float*>(x); s.out = weight; s.M = M; s.N = N; s.K = K;
+    s.am = exp_avg; s.av = exp_avg_sq; s.shadow = static_cast<__bf16*>(weight_bf16);
     s.ad.lr = lr; s.ad.step = step; s.ad.beta1 = beta1; s.ad.beta2 = beta2;
     s.ad.w1 = (float)(1.0 - beta1); s.ad.b2 = (float)beta2; s.ad.w2 = (float)(1.0 - beta2); s.ad.eps = (float)eps; s.ad.wd = (float)weight_decay;
+    const bool a16 = dy_dtype == SH_DTYPE_BF16, w16 = x_dtype == SH_DTYPE_BF16;
+    // the bias gradient is summed from the dy tile in LDS, whatever it was loaded from
     s.dbias = (dbias && (reinterpret_cast<uintptr_t>(dbias) & 15) == 0) ? dbias : nullptr;
+    SH_REQUIRE(!dbias || s.dbias || !a16, SH_ERR_UNSUPPORTED, "sh_linear_bwd_wgt_adam: a bf16 dy needs a 16-byte aligned dbias");
     const int wgs = (N / 64) * sh_cdiv(K / 64, 4);
-    if (lin_x3(mma_mode)) {
+    if (a16 || w16) {                                  // bf16 operands: their products are exact on the fp32 MFMA
+        ShProfScope ps(st, "linear_bwd_wgt_adam_kernel|M=%d N=%d K=%d dy=%s x=%s", M, N, K, a16 ? "bf16" : "f32", w16 ? "bf16" : "f32");
+        if (a16 && w16) SH_LAUNCH_PS(ps, (linear_bwd_wgt_dma_kernel<false, true, true, true>), dim3(wgs), dim3(LTHREADS), LWD_LDS, st, s);
+        else if (a16)   SH_LAUNCH_PS(ps, (linear_bwd_wgt_dma_kernel<false, true, true, false>), dim3(wgs), dim3(LTHREADS), LWD_LDS, st, s);
+        else            SH_LAUNCH_PS(ps, (linear_bwd_wgt_dma_kernel<false, true, false, true>), dim3(wgs), dim3(LTHREADS), LWD_LDS, st, s);
+    } else if (lin_x3(mma_mode)) {
         ShProfScope ps(st, "linear_bwd_wgt_adam_x3_kernel|M=%d N=%d K=%d", M, N, K);
         SH_LAUNCH_PS(ps, (linear_bwd_wgt_dma_kernel<true, true>), dim3(wgs), dim3(LTHREADS), LWD_LDS, st, s);
     } else {
         ShProfScope ps(st, "linear_bwd_wgt_adam_kernel|M=%d N=%d K=%d", M, N, K);
         SH_LAUNCH_PS(ps, (linear_bwd_wgt_dma_kernel<false, true>), dim3(wgs), dim3(LTHREADS), LWD_LDS, st, s);
     }
-    if (dbias && !s.dbias) hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)sh_cdiv(N, 256)), dim3(256), 0, st, dy, M, N, dbias);
+    if (dbias && !s.dbias) hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)sh_cdiv(N, 256)), dim3(256), 0, st, static_cast<const float*>(dy), M, N, dbias);
     SH_CHECK_LAUNCH("linear_bwd_wgt_adam");
     return SH_OK;
 }

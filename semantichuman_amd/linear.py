@@ -29,13 +29,11 @@ class _LatentLinear(torch.autograd.Function):
         dW = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             want_bias = ctx.has_bias and ctx.needs_input_grad[2]
-            fused = _FUSED_UPDATE.get(weight.data_ptr()) if ctx.needs_input_grad[1] else None
-            param = fused[0]() if fused is not None else None
-            if param is not None and param.data_ptr() == weight.data_ptr() and param.shape == weight.shape and param.grad is None and \
-                    weight.is_contiguous() and ops.linear_bwd_wgt_adam_ok(dy.shape[0], dy.shape[1], x.shape[1]):
+            param = _fused_param(weight, dy, x) if ctx.needs_input_grad[1] else None
+            if param is not None:
                 # the optimizer asked for this parameter's update to be applied by the kernel that computes its gradient
                 # (optim.Adam.fuse_linear_weight_gradients): no dW is materialised, `weight.grad` stays None
-                db = fused[1](param, dy, x, want_bias, ctx.mma)
+                db = _FUSED_UPDATE[weight.data_ptr()][1](param, dy, x, want_bias, ctx.mma)
             else:
                 dW, db = ops.linear_bwd_wgt(dy, x, want_bias=want_bias, mma=ctx.mma)
         return dx, dW, db
@@ -44,6 +42,16 @@ class _LatentLinear(torch.autograd.Function):
 # weight.data_ptr() -> (weakref to the parameter, callable(weight, dy, x, want_bias, mma) -> dbias): registered by
 # semantichuman_amd.optim.Adam.fuse_linear_weight_gradients, consulted by the backward pass above
 _FUSED_UPDATE = {}
+
+
+def _fused_param(weight, dy, x):
+    """The registered parameter behind `weight` if this backward may apply its update in the weight-gradient kernel, else None."""
+    fused = _FUSED_UPDATE.get(weight.data_ptr())
+    param = fused[0]() if fused is not None else None
+    if param is not None and param.data_ptr() == weight.data_ptr() and param.shape == weight.shape and param.grad is None and \
+            weight.is_contiguous() and ops.linear_bwd_wgt_adam_ok(dy.shape[0], dy.shape[1], x.shape[1]):
+        return param
+    return None
 
 
 def latent_linear(x: torch.Tensor, weight: torch.Tensor, bias) -> torch.Tensor:
@@ -73,7 +81,12 @@ class _LatentLinearBF16(torch.autograd.Function):
         dx = ops.linear_bwd_data_bf16(dy, shadow.get(weight), x.dtype) if ctx.needs_input_grad[0] else None
         dW = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dW, db = ops.linear_bwd_wgt_bf16(dy, x, want_bias=ctx.has_bias and ctx.needs_input_grad[2])
+            want_bias = ctx.has_bias and ctx.needs_input_grad[2]
+            param = _fused_param(weight, dy, x) if ctx.needs_input_grad[1] else None
+            if param is not None:                          # (see _LatentLinear.backward) - the bf16 working copy is rewritten too
+                db = _FUSED_UPDATE[weight.data_ptr()][1](param, dy, x, want_bias, None)
+            else:
+                dW, db = ops.linear_bwd_wgt_bf16(dy, x, want_bias=want_bias)
         return dx, dW, db, None
 
 

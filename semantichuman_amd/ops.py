@@ -218,19 +218,25 @@ def linear_bwd_wgt_adam_ok(M, N, K):
     return bool(_lib.load().sh_linear_bwd_wgt_adam_ok(int(M), int(N), int(K)))
 
 
-def linear_bwd_wgt_adam(dy, x, weight, exp_avg, exp_avg_sq, step, lr, betas, eps, weight_decay, want_bias=True, mma=None):
+def linear_bwd_wgt_adam(dy, x, weight, exp_avg, exp_avg_sq, step, lr, betas, eps, weight_decay, want_bias=True, mma=None, weight_bf16=None):
     """dW = dy^T x used as the gradient of Adam's update of `weight` / `exp_avg` / `exp_avg_sq`, in place, in the kernel that
-    computes it (sh_linear_bwd_wgt_adam); returns the bias gradient (or None).  `step` is not advanced (sh_adam_bump)."""
-    _check2d(dy, x)
+    computes it (sh_linear_bwd_wgt_adam); returns the bias gradient (or None).  `step` is not advanced (sh_adam_step with a
+    zero-length entry, or sh_adam_bump).  dy / x: fp32 or bf16; `weight_bf16`: the bf16 working copy to rewrite, or None."""
+    for t in (dy, x):
+        if not (t.is_cuda and t.dim() == 2 and t.is_contiguous() and t.dtype in (torch.float32, torch.bfloat16)):
+            raise RuntimeError("linear_bwd_wgt_adam: dy / x must be contiguous 2-D fp32 or bf16 HIP tensors")
     M, N = dy.shape
     K = x.shape[1]
     for t in (weight, exp_avg, exp_avg_sq):
         if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == (N, K)):
             raise RuntimeError("linear_bwd_wgt_adam: weight / exp_avg / exp_avg_sq must be contiguous fp32 [%d, %d] HIP tensors" % (N, K))
+    if weight_bf16 is not None and not (weight_bf16.dtype == torch.bfloat16 and weight_bf16.is_contiguous() and tuple(weight_bf16.shape) == (N, K)):
+        raise RuntimeError("linear_bwd_wgt_adam: the bf16 working copy must be a contiguous bf16 [%d, %d] tensor" % (N, K))
     db = torch.empty((N,), dtype=torch.float32, device=dy.device) if want_bias else None
-    check(_lib.load().sh_linear_bwd_wgt_adam(ptr(dy), ptr(x), ptr(weight), ptr(exp_avg), ptr(exp_avg_sq), ptr(step), ptr(lr), float(betas[0]),
-                                             float(betas[1]), float(eps), float(weight_decay), ptr(db), M, N, K, _lib.mma_id(mma), stream_ptr()),
-          "sh_linear_bwd_wgt_adam")
+    did = lambda t: 1 if t.dtype == torch.bfloat16 else 0               # noqa: E731 - enum sh_dtype
+    check(_lib.load().sh_linear_bwd_wgt_adam(ptr(dy), did(dy), ptr(x), did(x), ptr(weight), ptr(weight_bf16), ptr(exp_avg), ptr(exp_avg_sq),
+                                             ptr(step), ptr(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), ptr(db),
+                                             M, N, K, _lib.mma_id(mma), stream_ptr()), "sh_linear_bwd_wgt_adam")
     return db
 
 

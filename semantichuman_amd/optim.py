@@ -170,10 +170,10 @@ class Adam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def _fused_update(self, group, p, dy, x, want_bias, mma):
-        from . import ops
+        from . import ops, shadow
         st = self._state_of(p)
         db = ops.linear_bwd_wgt_adam(dy, x, p, st["exp_avg"], st["exp_avg_sq"], st["step"], self._lr_tensor(group, p.device), group["betas"],
-                                     group["eps"], group["weight_decay"], want_bias=want_bias, mma=mma)
+                                     group["eps"], group["weight_decay"], want_bias=want_bias, mma=mma, weight_bf16=shadow.lookup(p))
         self._fused_done.append(p)
         return db
 

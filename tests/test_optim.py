@@ -189,7 +189,7 @@ def test_fused_weight_gradient_adam_refuses_what_it_does_not_serve():
         ops.linear_bwd_wgt_adam(dy, x, w, m, v, torch.zeros((), device=dev), torch.full((), 1e-3, device=dev), (0.9, 0.999), 1e-8, 0.0)
     torch.cuda.synchronize()
     assert torch.equal(w, w0)                                        # nothing was launched
-    assert _lib.load().sh_linear_bwd_wgt_adam(None, None, None, None, None, None, None, 0.9, 0.999, 1e-8, 0.0, None, 64, 64, 64, 0, None) != 0
+    assert _lib.load().sh_linear_bwd_wgt_adam(None, 0, None, 0, None, None, None, None, None, None, 0.9, 0.999, 1e-8, 0.0, None, 64, 64, 64, 0, None) != 0
 
 
 @pytest.mark.gpu
@@ -238,3 +238,83 @@ def test_training_steps_with_the_update_fused_into_backward(golden_dir, form, ba
             assert torch.equal(oa.state[p]["exp_avg"], ob.state[q]["exp_avg"]) and torch.equal(oa.state[p]["exp_avg_sq"], ob.state[q]["exp_avg_sq"]), k
     finally:
         _lib.set_f32_mma_mode(was)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dy16,x16", [(True, False), (False, True), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(64, 256, 640), (24, 1280, 256)])
+def test_fused_weight_gradient_adam_with_bf16_operands(dy16, x16, M, N, K):
+    """The bf16 path's layer: bf16 dy and / or x are widened in the kernel and multiplied on the fp32 MFMA - exact products, so the
+    result equals the fp32-operand kernel run on the widened tensors BITWISE; the bf16 working copy is the rounded new weight."""
+    from semantichuman_amd import ops
+    dev = torch.device("cuda:0")
+    dy, x, w, m, v = _fc_case(dev, M, N, K, 9)
+    dy_in = dy.bfloat16() if dy16 else dy
+    x_in = x.bfloat16() if x16 else x
+    lr = torch.full((), 1e-3, device=dev)
+    step = torch.full((), 2.0, device=dev)
+    pa, ma, va = w.clone(), m.clone(), v.clone()
+    dba = ops.linear_bwd_wgt_adam(dy_in.float(), x_in.float(), pa, ma, va, step, lr, (0.9, 0.999), 1e-8, 5e-5, want_bias=True, mma="exact")
+    pb, mb, vb = w.clone(), m.clone(), v.clone()
+    w16 = torch.zeros((N, K), dtype=torch.bfloat16, device=dev)
+    dbb = ops.linear_bwd_wgt_adam(dy_in, x_in, pb, mb, vb, step, lr, (0.9, 0.999), 1e-8, 5e-5, want_bias=True, mma="exact", weight_bf16=w16)
+    torch.cuda.synchronize()
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb) and torch.equal(dba, dbb)
+    assert torch.equal(w16, pb.bfloat16())
+    # ... and the gradient behind it is the bf16 layer's (sh_linear_bwd_wgt_bf16) or better: that kernel ROUNDS an fp32 operand to bf16
+    # on load, this one multiplies it as it is
+    dW, db = ops.linear_bwd_wgt_bf16(dy_in, x_in, want_bias=True)
+    ref16 = dy_in.bfloat16().double().t() @ x_in.bfloat16().double()
+    assert float((dW.double() - ref16).abs().max()) <= 2e-6 * float(ref16.abs().max()) + 1e-9
+    ref = dy_in.double().t() @ x_in.double()
+    g = (mb - 0.9 * m) / 0.1 - 5e-5 * w                      # the gradient the fused kernel used, recovered from exp_avg
+    assert float((g.double() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+    np.testing.assert_allclose(dbb.cpu().numpy(), dy_in.double().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-7)      # (column sums of dy as it is,
+    np.testing.assert_allclose(db.cpu().numpy(), dy_in.bfloat16().double().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-7)   # ... of dy rounded)
+
+
+@pytest.mark.gpu
+def test_bf16_training_steps_with_the_update_fused_into_backward(golden_dir):
+    """The bf16 path with the latent FCs' update inside their weight-gradient kernels: three steps track the unfused bf16 run (the
+    gradients differ in summation order only), no FC weight ever holds a `.grad`, and the bf16 working copies stay the rounded
+    masters - what the next forward pass reads."""
+    import os
+    from semantichuman_amd import shadow, synthetic
+    from semantichuman_amd.hierarchy import load_hierarchy
+    dev = torch.device("cuda:0")
+    h = load_hierarchy(os.path.join(golden_dir, "template6890.npz"))
+    FE = [[3, 16, 32, 64, 128], [[], [], [], [], []]]
+    FD = [[128, 64, 32, 32, 16], [[], [], [], [], 3]]
+    runs = []
+    for fuse in (False, True):
+        torch.manual_seed(3)
+        model = sh.SpiralAutoencoder(FE, FD, 256, h.sizes, h.spiral_sizes, h.spirals, h.D, h.U, dev)
+        model.set_compute_dtype(torch.bfloat16)
+        opt = sh.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-5)
+        if fuse:
+            opt.fuse_linear_weight_gradients([model.fc_latent_enc, model.fc_latent_dec])
+        ft = sh.FaceTables(h.faces, h.sizes[0] + 1, dev)
+        x = torch.from_numpy(synthetic.synth_batch(h.verts, 16, seed=11)).to(dev)
+        losses = []
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            xh, _ = model(x)
+            loss, _ = sh.recon_loss(xh.float(), x, ft, 1e-2)
+            loss.backward()
+            if fuse:
+                assert model.fc_latent_enc.weight.grad is None and model.fc_latent_dec.weight.grad is None
+            opt.step()
+            losses.append(float(loss.detach()))
+        torch.cuda.synchronize()
+        for fc in (model.fc_latent_enc, model.fc_latent_dec):
+            w16 = shadow.lookup(fc.weight)
+            assert w16 is not None and torch.equal(w16, fc.weight.detach().bfloat16())
+            assert float(opt.state[fc.weight]["step"]) == 3.0
+        runs.append((model, losses))
+        opt.remove_fusion()
+    (ma, la), (mb, lb) = runs
+    assert la[0] == lb[0]                                      # the first forward pass is the same computation
+    np.testing.assert_allclose(la, lb, rtol=2e-3)
+    for (k, p), (_, q) in zip(ma.named_parameters(), mb.named_parameters()):
+        d = (p.detach() - q.detach()).abs()
+        assert float(d.max()) <= 3 * 2.1e-3 and float(d.mean()) <= 2e-5, (k, float(d.max()), float(d.mean()))

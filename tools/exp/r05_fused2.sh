@@ -1,0 +1,3 @@
+#!/bin/bash
+cd "$(dirname "$0")/../.."
+timeout 900 python -m pytest tests/test_optim.py -q -m gpu 2>&1 | tail -4
