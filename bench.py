@@ -193,8 +193,11 @@ def measured_traffic(kernel, workload):
         return None, "PMC profile %s was taken with other SH_* switches (%s)" % (name, meta.get("env"))
     # the library's profiler names a launch by what it does; rocprofv3 by the kernel instantiation(s) that did it
     alias = {"spmm_kernel<true, p3>": ["spmm_kernel<true, true>", "spmm_p3x8_kernel"],
-             "linear_bwd_wgt_x3_kernel": ["linear_bwd_wgt_dma_kernel<true, false>"], "linear_bwd_wgt_dma_kernel": ["linear_bwd_wgt_dma_kernel<false, false>"],
-             "linear_bwd_wgt_adam_x3_kernel": ["linear_bwd_wgt_dma_kernel<true, true>"], "linear_bwd_wgt_adam_kernel": ["linear_bwd_wgt_dma_kernel<false, true>"]}
+             "linear_bwd_wgt_x3_kernel": ["linear_bwd_wgt_dma_kernel<true, false, false, false>"],
+             "linear_bwd_wgt_dma_kernel": ["linear_bwd_wgt_dma_kernel<false, false, false, false>"],
+             "linear_bwd_wgt_adam_x3_kernel": ["linear_bwd_wgt_dma_kernel<true, true, false, false>"],
+             "linear_bwd_wgt_adam_kernel": ["linear_bwd_wgt_dma_kernel<false, true, false, false>", "linear_bwd_wgt_dma_kernel<false, true, true, false>",
+                                            "linear_bwd_wgt_dma_kernel<false, true, false, true>", "linear_bwd_wgt_dma_kernel<false, true, true, true>"]}
     import re
     m = re.match(r"linear_fwd_x3_kernel<(\d+)>$", kernel)
     if m:
@@ -630,6 +633,21 @@ def roofline_bf16(recs, model, B, nprof, verts):
             tr, tn = measured_traffic(top["kernel"], workload_tag(verts, B, "bf16"))
             line.update(achieved=top["gbps"], frac=top["gbps"] / PEAK_HBM_GBS, algorithmic_bytes_per_launch=ta["bytes"] / ta["n"], traffic=tr,
                         traffic_unit=tn, note="algorithmic bytes (outputs written once + distinct inputs read once, bf16) of its launches / their HIP-event time")
+        if top["kernel"].startswith("linear_bwd_wgt_adam"):
+            # the two latent FCs' weight gradients with Adam applied to the tile: weight, exp_avg, exp_avg_sq read and written
+            # (24 B / weight), the bf16 working copy written (2 B), dy and x read
+            byt = 0.0
+            for name, shape, _ in recs:
+                if name == top["kernel"]:
+                    f = dict(kv.split("=") for kv in shape.split() if "=" in kv)
+                    M, N, K = int(f["M"]), int(f["N"]), int(f["K"])
+                    byt += 26.0 * N * K + (2.0 if f.get("dy") == "bf16" else 4.0) * M * N + (2.0 if f.get("x") == "bf16" else 4.0) * M * K
+            byt /= nprof
+            tr, tn = measured_traffic(top["kernel"], workload_tag(verts, B, "bf16"))
+            line.update(achieved=byt / (top["ms_per_step"] * 1e-3) / 1e9, algorithmic_bytes_per_step=byt, traffic=tr, traffic_unit=tn,
+                        note="latent-FC weight gradients with the Adam update of the same tile inside (sh_linear_bwd_wgt_adam): "
+                             "3 fp32 streams read + written, the bf16 working copy written; no gradient is materialised")
+            line["frac"] = line["achieved"] / PEAK_HBM_GBS
         if top["kernel"].startswith("adam_kernel"):
             n_par = sum(p.numel() for p in model.parameters())
             byt = (7 * 4.0 + 2.0) * n_par                     # p, g, m, v read; p, m, v written; bf16 copy written

@@ -318,3 +318,35 @@ def test_bf16_training_steps_with_the_update_fused_into_backward(golden_dir):
     for (k, p), (_, q) in zip(ma.named_parameters(), mb.named_parameters()):
         d = (p.detach() - q.detach()).abs()
         assert float(d.max()) <= 3 * 2.1e-3 and float(d.mean()) <= 2e-5, (k, float(d.max()), float(d.mean()))
+
+
+@pytest.mark.gpu
+def test_fused_update_registration_rules():
+    """`fuse_linear_weight_gradients`: only weights this optimizer owns; a parameter that already holds a `.grad` (accumulation
+    over several backward passes, `zero_grad(set_to_none=False)`) keeps the ordinary gradient path; `remove_fusion` undoes it."""
+    from semantichuman_amd import linear
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    fc = torch.nn.Linear(256, 128).to(dev)
+    other = torch.nn.Linear(256, 128).to(dev)
+    opt = sh.optim.Adam(fc.parameters(), lr=1e-3)
+    with pytest.raises(ValueError, match="not a parameter of this optimizer"):
+        opt.fuse_linear_weight_gradients([other])
+    opt.fuse_linear_weight_gradients([fc])
+    x = torch.randn(32, 256, device=dev)
+    w0 = fc.weight.detach().clone()
+    linear.latent_linear(x, fc.weight, fc.bias).sum().backward()
+    assert fc.weight.grad is None and fc.bias.grad is not None and not torch.equal(fc.weight.detach(), w0)     # updated in backward
+    opt.step()
+    assert float(opt.state[fc.weight]["step"]) == 1.0 and float(opt.state[fc.bias]["step"]) == 1.0
+    # a gradient that already exists: the ordinary path accumulates into it and step() applies it
+    fc.weight.grad = torch.zeros_like(fc.weight)
+    w1 = fc.weight.detach().clone()
+    linear.latent_linear(x, fc.weight, fc.bias).sum().backward()
+    assert torch.equal(fc.weight.detach(), w1) and float(fc.weight.grad.abs().max()) > 0
+    opt.step()
+    assert float(opt.state[fc.weight]["step"]) == 2.0 and not torch.equal(fc.weight.detach(), w1)
+    opt.remove_fusion()
+    opt.zero_grad(set_to_none=True)
+    linear.latent_linear(x, fc.weight, fc.bias).sum().backward()
+    assert fc.weight.grad is not None

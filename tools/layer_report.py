@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-launch timing of one training step (library HIP events), with shapes and achieved TFLOP/s.
+"""Per-launch timing of one training step - forward, loss, backward, Adam - (library HIP events), with shapes and achieved TFLOP/s.
 Run on the GPU box:  python tools/layer_report.py [batch] [template.npz] [f32|bf16]"""
 import os
 import re
@@ -28,10 +28,19 @@ ft = sh.FaceTables(h.faces, h.sizes[0] + 1, dev)
 x = torch.from_numpy(synthetic.synth_batch(h.verts, B, seed=1)).to(dev)
 
 
+# the step bench.py replays: fused reconstruction loss, Adam with the latent FCs' update inside their weight-gradient kernels
+# (SH_LAYER_REPORT_TWO_KERNEL_ADAM=1: gradients written, multi-tensor Adam for everything)
+opt = sh.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-5)
+if os.environ.get("SH_LAYER_REPORT_TWO_KERNEL_ADAM", "0") == "0":
+    opt.fuse_linear_weight_gradients([model.fc_latent_enc, model.fc_latent_dec])
+
+
 def step():
-    model.zero_grad(set_to_none=True)
+    opt.zero_grad(set_to_none=True)
     xh, _ = model(x)
-    (sh.l1_loss(x, xh) + 1e-2 * sh.edge_ratio_loss(xh, x, ft)).backward()
+    loss, _ = sh.recon_loss(xh, x, ft, 1e-2)
+    loss.backward()
+    opt.step()
 
 
 for _ in range(3):

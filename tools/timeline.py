@@ -12,6 +12,8 @@ def main():
     # a step starts with the copy of the batch into the graph's input (the only kernel outside the graph), found by the
     # first-layer kernel's name: gather_gemm_kernel<1, true, false, true, true> (Cin = 3 forward) runs once per step
     marks = [i for i, k in enumerate(ks) if "gather_gemm_kernel<1, true, false, true, true>" in k[2] or "conv_in3" in k[2]]
+    if len(marks) < back + 1:                               # the bf16 path: its weight-fragment preparation opens every step
+        marks = [i for i, k in enumerate(ks) if "wfrag_prep_kernel" in k[2]]
     if len(marks) < back + 1:
         print("not enough steps in the trace")
         return
