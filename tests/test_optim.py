@@ -176,6 +176,16 @@ def test_fused_weight_gradient_adam_is_bitwise_the_two_kernel_form(form, M, N, K
     assert torch.equal(p, p_ref.detach()) and torch.equal(m1, st["exp_avg"]) and torch.equal(v1, st["exp_avg_sq"])
     assert torch.equal(db, db_ref)
     assert not torch.equal(p, w)                                     # it did move
+    # the caller's half of the contract: advancing the step count (sh_adam_bump, or a zero-length entry of sh_adam_step)
+    import ctypes
+    from semantichuman_amd import _lib
+    S = (ctypes.c_void_p * 1)(step.data_ptr())
+    _lib.check(_lib.load().sh_adam_bump(1, S, _lib.stream_ptr()), "sh_adam_bump")
+    P0 = (ctypes.c_void_p * 1)()
+    N0 = (ctypes.c_int64 * 1)(0)
+    _lib.check(_lib.load().sh_adam_step(1, P0, P0, P0, P0, S, N0, _lib.ptr(lr), 0.9, 0.999, 1e-8, 5e-5, _lib.stream_ptr()), "sh_adam_step")
+    torch.cuda.synchronize()
+    assert float(step) == 5.0
 
 
 @pytest.mark.gpu
