@@ -47,6 +47,17 @@ cp $(find $O/prof_f32 -name "*kernel_stats.csv" | head -1) $O/rocprof_kernel_sta
 cp $(find $O/prof_ex -name "*kernel_stats.csv" | head -1) $O/rocprof_kernel_stats_f32_exact.csv 2>/dev/null
 cp $(find $O/prof_bf16 -name "*kernel_stats.csv" | head -1) $O/rocprof_kernel_stats_bf16.csv 2>/dev/null
 rm -rf $O/prof_f32 $O/prof_bf16 $O/prof_ex
+# the latent FCs' update inside their weight-gradient kernels: the kernel against the pair it replaces, the step with / without it
+timeout 300 python tools/fc_adam_probe.py planes3 2>/dev/null | grep -v amdgpu.ids > $O/fc_adam_probe.txt
+timeout 300 python tools/fc_adam_probe.py exact 2>/dev/null | grep -v amdgpu.ids >> $O/fc_adam_probe.txt
+timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-roofline --no-fused-update > $O/bench_f32_two_kernel_adam.json 2>/dev/null
+timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-roofline --no-fused-update --dtype bf16 > $O/bench_bf16_two_kernel_adam.json 2>/dev/null
+# one replayed step as a timeline (rocprofv3 kernel trace of the bench command)
+for d in f32 bf16; do
+  timeout 600 rocprofv3 --kernel-trace -d $O/tr_$d -o t --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-roofline --dtype $d > $O/bench_${d}_trace_run.json 2>/dev/null
+  python3 tools/timeline.py $(find $O/tr_$d -name "*kernel_trace.csv" | head -1) > $O/timeline_$d.txt
+  rm -rf $O/tr_$d
+done
 ls $O | head -60
 python - <<'PY'
 import json,glob
