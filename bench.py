@@ -901,8 +901,11 @@ def _stop_processes(procs, grace=15.0):
 # it), and under torch.distributed.run a dead rank ends the job.  So the process the launcher started never touches the
 # GPU: it starts the real rank as a CHILD (subprocess: never an exec from a GPU process), and when an attempt fails on any
 # rank, all supervisors start FRESH children for the next attempt on a fresh rendezvous port.
+# Round 5: the eager mode goes first.  In a world of one rank on RCCL the replayed graph is no faster than the eager step (1.724
+# against 1.708 ms, tools/exp/r05_dp_modes.sh: the host is not what paces a 1.7-ms step), and a graph with RCCL nodes is the only
+# mode here that has never run with more than one rank and could hang rather than fail.  SH_BENCH_DP_GRAPH=1 puts it first again.
 ATTEMPTS = (
-    ("graph", {}),                                                           # the step as one hipGraph, RCCL inside
+    ("graph", {"SH_BENCH_DP_GRAPH": "1"}),                                   # the step as one hipGraph, RCCL inside (opt-in)
     ("eager", {"SH_BENCH_DP_GRAPH": "0"}),                                   # the same step, launched eagerly
     ("eager-safe", {"SH_BENCH_DP_GRAPH": "0", "SH_BENCH_DP_SAFE": "1"}),     # + lazy communicator, no stream priority, all-reduce
 )                                                                            #   (sum of pre-scaled gradients) after backward
@@ -992,13 +995,13 @@ def _supervise_attempts(argv, rank, world, job, child):
     import subprocess
     import threading
     timeout_all = float(os.environ.get("SH_BENCH_ATTEMPT_TIMEOUT", "900"))
-    # the first attempt (the step as ONE hipGraph with the RCCL all-reduces inside) has never run with more than one rank on
-    # hardware: if it hangs instead of failing, give up on it sooner - a whole N > 1 attempt is ~1-3 minutes (import, build, 60 steps)
+    # the graph attempt (opt-in: the step as ONE hipGraph with the RCCL all-reduces inside) has never run with more than one rank
+    # on hardware: if it hangs instead of failing, give up on it sooner - a whole N > 1 attempt is ~1-3 minutes (import, build, 60 steps)
     timeout_graph = float(os.environ.get("SH_BENCH_GRAPH_ATTEMPT_TIMEOUT", str(min(timeout_all, 420.0))))
     grace = float(os.environ.get("SH_BENCH_FAIL_GRACE", "20"))
     # ... and once a rank is past the rendezvous (mark_phase), no single phase of it is more than seconds of work
     phase_timeout = float(os.environ.get("SH_BENCH_PHASE_TIMEOUT", "150"))
-    attempts = [a for a in ATTEMPTS if not (a[0] == "graph" and os.environ.get("SH_BENCH_DP_GRAPH", "1") == "0")]
+    attempts = [a for a in ATTEMPTS if a[0] != "graph" or os.environ.get("SH_BENCH_DP_GRAPH", "0") == "1"]
     history, rc = [], 1
 
     def wait_for(paths, limit):

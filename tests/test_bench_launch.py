@@ -59,7 +59,7 @@ def _retry_env(spec, **kw):
 
 
 def test_failed_attempt_is_retried_with_fresh_children():
-    """A rank that dies in the first attempt (the hipGraph-with-RCCL mode on a real node) must not end the job: every rank's
+    """A rank that dies in the first attempt must not end the job: every rank's
     GPU-free supervisor starts a FRESH child for the next, more conservative mode on a fresh rendezvous port; rank 0 prints
     exactly one JSON line - the successful attempt's - and says in config.launch what happened before."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0"],
@@ -67,8 +67,8 @@ def test_failed_attempt_is_retried_with_fresh_children():
     assert r.returncode == 0, r.stderr
     res = _one_json_line(r.stdout)
     assert res["n_gpus"] == 2
-    assert "attempt 1 'eager'" in res["config"]["launch"] and "graph: " in res["config"]["launch"], res["config"]["launch"]
-    assert "attempt 0 (graph) failed" in r.stderr
+    assert "attempt 1 'eager-safe'" in res["config"]["launch"] and "eager: " in res["config"]["launch"], res["config"]["launch"]
+    assert "attempt 0 (eager) failed" in r.stderr
 
 
 def test_retry_under_torch_distributed_run_rank0_failure():
@@ -83,7 +83,7 @@ def test_retry_under_torch_distributed_run_rank0_failure():
                         "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     res = _one_json_line(r.stdout)
-    assert "attempt 1 'eager'" in res["config"]["launch"]
+    assert "attempt 1 'eager-safe'" in res["config"]["launch"]
 
 
 def test_hung_attempt_is_cut_short_by_the_progress_watchdog():
@@ -100,12 +100,23 @@ def test_hung_attempt_is_cut_short_by_the_progress_watchdog():
     assert r.returncode == 0, r.stderr
     assert time.time() - t0 < 200
     res = _one_json_line(r.stdout)
-    assert "attempt 1 'eager'" in res["config"]["launch"], res["config"]["launch"]
+    assert "attempt 1 'eager-safe'" in res["config"]["launch"], res["config"]["launch"]
     assert "no progress for 3 s after phase 'rendezvous'" in r.stderr, r.stderr
 
 
+def test_graph_attempt_is_opt_in_and_then_goes_first():
+    """SH_BENCH_DP_GRAPH=1 puts the hipGraph-with-RCCL mode in front of the other two (default since round 5: eager first - the
+    graph is no faster in a world of one and is the mode that could hang)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0"],
+                       env=_retry_env("0:1", SH_BENCH_DP_GRAPH="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    res = _one_json_line(r.stdout)
+    assert "attempt 1 'eager'" in res["config"]["launch"] and "graph: " in res["config"]["launch"], res["config"]["launch"]
+    assert "attempt 0 (graph) failed" in r.stderr
+
+
 def test_all_attempts_failing_gives_a_nonzero_status():
-    env = dict(_retry_env("0:1"), SH_BENCH_DP_GRAPH="0")     # attempts: eager (index 0, fails), eager-safe (index 1)
+    env = _retry_env("0:1")                                  # attempts: eager (index 0, fails), eager-safe (index 1)
     env["SH_BENCH_TEST_RANK_FAIL"] = "*:1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env=env, capture_output=True, text=True, timeout=300)
