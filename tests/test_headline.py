@@ -57,7 +57,7 @@ def case(request, golden_dir):
     opt.step()
     w1 = {n: p.detach().clone() for n, p in om.named_parameters()}
     del om, opt
-    return dict(tpl=tpl, B=B, h=h, x=x, sd0=sd0, x_hat=xo.detach(), z=zo.detach(), rec=float(rec), edge=float(edge), grads=grads, w1=w1)
+    return dict(tpl=tpl, B=B, h=h, x=x, sd0=sd0, x_hat=xo.detach(), z=zo.detach(), rec=float(rec.detach()), edge=float(edge.detach()), grads=grads, w1=w1)
 
 
 def close(got, ref, tol, what, floor=0.0):
@@ -125,6 +125,53 @@ def test_full_training_step_vs_oracle(case, form, record_property):
             assert float(d.mean()) <= 2e-6, (name, float(d.mean()))
         record_property("rel_err", {"x_hat": e_x, "z": e_z, "worst_grad": worst})
         print("%s B=%d %s: x_hat %.2e z %.2e worst grad %.2e plane launches %d" % (case["tpl"], B, form, e_x, e_z, worst, n_p3))
+    finally:
+        _lib.profile_enable(False)
+        _lib.set_f32_mma_mode(was)
+
+
+@pytest.mark.parametrize("form", ["exact", "planes3"])
+def test_the_benchs_own_step_vs_oracle(case, form):
+    """The step exactly as bench.py issues it - the fused reconstruction loss, Adam with the two latent FCs' update applied
+    inside their weight-gradient kernels (no FC weight gradient is ever materialised) - against the oracle's weights after one
+    `loss.backward(); optimizer.step()` (train_funcs.py:383-392), with the post-Adam criterion of the test above; the profiler
+    must show that the fused kernels are what ran."""
+    import semantichuman_amd as sh
+    from semantichuman_amd import _lib
+    dev = torch.device("cuda:0")
+    h, B = case["h"], case["B"]
+    was = _lib.get_f32_mma_mode()
+    _lib.set_f32_mma_mode(form)
+    try:
+        m = sh.SpiralAutoencoder(FE, FD, 256, h.sizes, h.spiral_sizes, h.spirals, h.D, h.U, dev)
+        m.load_state_dict(case["sd0"])
+        opt = sh.optim.Adam(m.parameters(), lr=LR, weight_decay=WD)
+        opt.fuse_linear_weight_gradients([m.fc_latent_enc, m.fc_latent_dec])
+        ft = sh.FaceTables(h.faces, h.sizes[0] + 1, dev)
+        x = case["x"].to(dev)
+        _lib.profile_enable(True)
+        opt.zero_grad(set_to_none=True)
+        x_hat, _ = m(x)
+        loss, parts = sh.recon_loss(x_hat, x, ft, EDGE_W)
+        loss.backward()
+        opt.step()
+        torch.cuda.synchronize()
+        names = [n for n, _, _ in _lib.profile_records_by_kernel()]
+        _lib.profile_enable(False)
+        assert sum(1 for n in names if n.startswith("linear_bwd_wgt_adam")) == 2, sorted(set(names))
+        assert not any(n.startswith(("linear_bwd_wgt_x3", "linear_bwd_wgt_dma", "linear_bwd_wgt_stream")) for n in names)
+        assert m.fc_latent_enc.weight.grad is None and m.fc_latent_dec.weight.grad is None
+        assert float(parts[0]) == pytest.approx(case["rec"], rel=1e-5) and float(parts[1]) == pytest.approx(case["edge"], rel=1e-5)
+        for name, prm in m.named_parameters():
+            g, w1 = case["grads"][name], case["w1"][name]
+            d = (prm.detach().cpu() - w1).abs()
+            big = g.abs() >= 100 * GRAD_TOL * float(g.abs().max())
+            assert float(d.max()) <= 2 * LR * 1.05, name
+            if bool(big.any()):
+                assert float(d[big].max()) <= 5e-6 + 1e-6 * float(w1.abs().max()), (name, float(d[big].max()))
+            assert float(d.mean()) <= 2e-6, (name, float(d.mean()))
+            assert float(opt.state[prm]["step"]) == 1.0, name
+        opt.remove_fusion()
     finally:
         _lib.profile_enable(False)
         _lib.set_f32_mma_mode(was)
