@@ -51,7 +51,7 @@ def spiral_conv(x, spiral_adj, weight, bias, activation="elu"):
     gathered = x[:, nbr.reshape(-1), :]                     # negative index wraps to row N
     gathered = gathered.reshape(B * N1, S * C)
     out = ACTIVATIONS[activation](F.linear(gathered, weight, bias)).reshape(B, N1, -1)
-    keep = torch.ones(1, N1, 1, dtype=x.dtype)
+    keep = torch.ones(1, N1, 1, dtype=x.dtype, device=x.device)
     keep[0, N1 - 1, 0] = 0
     return out * keep
 
