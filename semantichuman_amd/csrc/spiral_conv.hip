@@ -1317,15 +1317,40 @@ constexpr int MR_MAX = 32;
 struct MultiReduce {
     const float* slab[MR_MAX]; long stride[MR_MAX]; long n[MR_MAX]; float* out[MR_MAX];
     int nslab[MR_MAX]; int block0[MR_MAX]; int nd;
+    unsigned vec_mask;                  // bit d: entry d is reduced four outputs per thread (16-byte loads: 1 KiB of a slab per workgroup)
 };
+// One workgroup = 64 (or, four per thread, 256) outputs x 16 slab phases.  Per output the sum is the same in both forms and in
+// every launch: phase ry takes slabs ry, ry + 16, ... in groups of four ((a + b) + (c + e)), then the 16 phases are added in order.
 __global__ __launch_bounds__(1024) void slab_reduce_multi_kernel(const MultiReduce m) {
-    __shared__ float red[16][64];
+    __shared__ f32x4 red[16][64];
     int d = 0;
     while (d + 1 < m.nd && m.block0[d + 1] <= (int)blockIdx.x) ++d;
     const float* __restrict__ slab = m.slab[d];
     const long stride = m.stride[d], n = m.n[d];
     const int nslab = m.nslab[d];
     const int ox = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    if ((m.vec_mask >> d) & 1u) {                         // round 5: n, stride multiples of 4, 16-byte aligned slabs and output
+        const long i = ((long)(blockIdx.x - m.block0[d]) * 64 + ox) * 4;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        if (i < n) {
+            int r = ry;
+            for (; r + 48 < nslab; r += 64) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(slab + (long)r * stride + i), b = *reinterpret_cast<const f32x4*>(slab + (long)(r + 16) * stride + i);
+                const f32x4 c = *reinterpret_cast<const f32x4*>(slab + (long)(r + 32) * stride + i), e = *reinterpret_cast<const f32x4*>(slab + (long)(r + 48) * stride + i);
+                s += (a + b) + (c + e);
+            }
+            for (; r < nslab; r += 16) s += *reinterpret_cast<const f32x4*>(slab + (long)r * stride + i);
+        }
+        red[ry][ox] = s;
+        __syncthreads();
+        if (ry == 0 && i < n) {
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += red[k][ox];
+            *reinterpret_cast<f32x4*>(m.out[d] + i) = t;
+        }
+        return;
+    }
     const long i = (long)(blockIdx.x - m.block0[d]) * 64 + ox;
     float s = 0.f;
     if (i < n) {
@@ -1337,12 +1362,12 @@ __global__ __launch_bounds__(1024) void slab_reduce_multi_kernel(const MultiRedu
         }
         for (; r < nslab; r += 16) s += slab[(long)r * stride + i];
     }
-    red[ry][ox] = s;
+    red[ry][ox][0] = s;
     __syncthreads();
     if (ry == 0 && i < n) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) t += red[k][ox];
+        for (int k = 0; k < 16; ++k) t += red[k][ox][0];
         m.out[d][i] = t;
     }
 }
@@ -2278,7 +2303,16 @@ static int reduce_multi_impl(int n_layers, const void* const* workspaces, float*
         const long stride = (long)Cout[i] * S[i] * Cin[i];
         const float* slab = static_cast<const float*>(workspaces[i]);
         m.slab[nd] = slab; m.stride[nd] = stride; m.nslab[nd] = nrc; m.n[nd] = stride; m.out[nd] = dW[i]; m.block0[nd] = blocks;
-        blocks += (int)((stride + 63) / 64); ++nd;
+        // measured (tools/exp/r05_quick.sh): four outputs per thread win where a workgroup has many slabs to walk (27 554 vertices, 720-760
+        // slabs: 33.0 / 22.2 -> 24.5 / 16.5 us) and in the bf16 plan (10.1 / 10.3 -> 9.2 / 9.8), and lose on the headline's 256 slabs (13.4 /
+        // 16.8 -> 14.6 / 18.6: a quarter of the workgroups, each as long): 1 = that rule, 0 = never, 2 = always
+        static const int vec_on = sh_env_int("SH_SLAB_REDUCE_VEC", 1, 0, 2);
+        if ((vec_on == 2 || (vec_on == 1 && (nrc >= 512 || bf16_plan))) && stride % 4 == 0 && ((reinterpret_cast<uintptr_t>(slab) | reinterpret_cast<uintptr_t>(dW[i])) & 15) == 0) {
+            m.vec_mask |= 1u << nd;
+            blocks += (int)((stride / 4 + 63) / 64);
+        } else
+            blocks += (int)((stride + 63) / 64);
+        ++nd;
         if (dbias[i]) {
             m.slab[nd] = slab + (long)nrc * stride; m.stride[nd] = Cout[i]; m.nslab[nd] = nrc; m.n[nd] = Cout[i];
             m.out[nd] = dbias[i]; m.block0[nd] = blocks;
