@@ -33,6 +33,19 @@ def test_constructor_validation():
         opt.step()
 
 
+def test_fused_update_registration_is_refused_on_the_host():
+    """`fuse_linear_weight_gradients` is a HIP-kernel feature: CPU parameters are refused at registration (there is no CPU path to fall
+    into), and a module whose weight the optimizer does not own is a ValueError."""
+    fc, other = torch.nn.Linear(64, 64), torch.nn.Linear(64, 64)
+    opt = sh.optim.Adam(fc.parameters(), lr=1e-3)
+    with pytest.raises(RuntimeError, match="HIP weights only"):
+        opt.fuse_linear_weight_gradients([fc])
+    with pytest.raises(ValueError, match="not a parameter of this optimizer"):
+        opt.fuse_linear_weight_gradients([other])
+    from semantichuman_amd import linear
+    assert fc.weight.data_ptr() not in linear._FUSED_UPDATE
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("wd", [0.0, 5e-5])
 def test_hip_adam_matches_torch_adam(wd):
