@@ -1,9 +1,6 @@
 #!/bin/bash
 cd "$(dirname "$0")/../.."
-rep() { SH_F32_MMA=planes3 timeout 300 python tools/layer_report.py 64 2>/dev/null | grep -E "^gather_gemm<1|conv_out3|wgrad_thin|total" | awk '{printf "%s %s | ", $1, $(NF-1)} END {print ""}'; }
-echo "default: $(rep)"
-for v in 4 8 32 64; do echo "SH_GG_TB=$v: $(SH_GG_TB=$v rep)"; done
-for v in 256 512 1536 3072; do echo "SH_GG_FILL=$v: $(SH_GG_FILL=$v rep)"; done
-for v in 1 2; do echo "SH_GG_RT=$v: $(SH_GG_RT=$v rep)"; done
-for v in 32 128 256; do echo "SH_OUT3_WG_PER_XCD=$v: $(SH_OUT3_WG_PER_XCD=$v rep)"; done
-echo "default: $(rep)"
+O=gpurun_out/r05n2; rm -rf $O; mkdir -p $O
+( time timeout 900 python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-roofline > $O/n2.json 2>$O/n2.err ) 2> $O/n2.time; echo "rc=$?"
+tail -3 $O/n2.time; grep -c "^{" $O/n2.json; grep -h "supervisor\|Error\|error" $O/n2.err | cut -c1-200 | head -12
+ps aux | grep -c "[b]ench.py"
