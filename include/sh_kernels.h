@@ -671,6 +671,18 @@ SH_API int sh_spiral_conv_bwd_data_p3(const void* dprep, int dpre_zero_row, cons
                                       int64_t dx_sb, void* dxp, const float* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev,
                                       int zero_row, int B, int n_in, int S, int Cin, int Cout, sh_stream_t stream);
 
+/* Weight gradient of a spiral conv in the three-plane form (csrc/wgrad_p3.hip, round 6; autograd of reference models.py:45,
+ * dW = dpre^T . gather(x)): both operands given as their plane images - x_planes = image of the layer's input ([n_in] rows,
+ * what its forward plane conv gathered), dpre_planes = image of the pre-activation gradient (rows [0, R) are read) - six
+ * bf16 partial products per fp32 product, fp32 accumulation, the arithmetic of sh_spiral_conv_fwd_p3.  Writes partial slabs
+ * (dW and dbias) into workspace, in the layout and for the deferred reduction of sh_spiral_conv_bwd_wgt(dW == NULL):
+ * sh_spiral_conv_bwd_wgt_reduce_multi_p3.  .._p3_ok: 1 when the kernel takes the shape (batch % 32 == 0, Cin 16 or a multiple
+ * of 32, Cout a multiple of 32); otherwise the caller keeps sh_spiral_conv_bwd_wgt. */
+SH_API int sh_spiral_conv_bwd_wgt_p3_ok(int B, int R, int S, int Cin, int Cout);
+SH_API size_t sh_spiral_conv_bwd_wgt_p3_workspace(int B, int R, int S, int Cin, int Cout);
+SH_API int sh_spiral_conv_bwd_wgt_p3(const void* dpre_planes, const void* x_planes, const int32_t* table, void* workspace,
+                                     size_t workspace_bytes, int B, int R, int S, int Cin, int Cout, sh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -750,7 +750,9 @@ __global__ __launch_bounds__(LTHREADS) void linear_bwd_wgt_stream_kernel(const L
 // what the bf16 MFMA computes, in another summation order).
 constexpr int LWD_TILE = 16 * 1024, LWD_LDS = 5 * LWD_TILE;
 template <bool X3 = false, bool ADAM = false, bool A16 = false, bool W16 = false>
-__global__ __launch_bounds__(LTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))      // 80 KiB of LDS: two workgroups per CU, 256 registers each
+// (80 KiB of LDS: two workgroups per CU.  The Adam / bf16x3 instances are pinned to that occupancy - 256 registers each, measured
+// with the fused update, profiles/r05_fc_adam_probe.txt; the plain fp32 instance keeps the compiler's own choice: ADVICE r5)
+__global__ __launch_bounds__(LTHREADS) __attribute__((amdgpu_waves_per_eu((X3 || ADAM) ? 2 : 1, (X3 || ADAM) ? 2 : 8)))
 void linear_bwd_wgt_dma_kernel(const LSParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -911,7 +913,9 @@ LSPlan plan_stream(int M, int out_cols, int red_len, int gran = 16, bool chunked
     LSPlan pl{false, red_len, 1, out_cols / 64};
     static const int on = sh_env_int("SH_LIN_STREAM", 1, 0, 1);
     // chunked: the forward LDS-DMA kernel takes any batch as 64-row chunks (gridDim.y) when the reduction is not split
-    const bool big_ok = chunked && red_len < 1024 && red_len % 32 == 0 && (out_cols / 64) % 4 == 0;
+    // (only with the LDS-DMA forward kernel enabled - under SH_LIN_DMA=0 a batch above 64 rows keeps the skinny GEMM: ADVICE r5)
+    static const int dma_on = sh_env_int("SH_LIN_DMA", 1, 0, 1);
+    const bool big_ok = chunked && dma_on && red_len < 1024 && red_len % 32 == 0 && (out_cols / 64) % 4 == 0;
     if (!on || (M > 64 && !big_ok) || out_cols % 64 != 0 || red_len % gran != 0) return pl;
     pl.ok = true;
     static const int items = sh_env_int("SH_LIN_ITEMS", 1024, 64, 1 << 20);

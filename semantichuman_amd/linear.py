@@ -33,25 +33,39 @@ class _LatentLinear(torch.autograd.Function):
             if param is not None:
                 # the optimizer asked for this parameter's update to be applied by the kernel that computes its gradient
                 # (optim.Adam.fuse_linear_weight_gradients): no dW is materialised, `weight.grad` stays None
-                db = _FUSED_UPDATE[weight.data_ptr()][1](param, dy, x, want_bias, ctx.mma)
+                db = _fused_apply(param, dy, x, want_bias, ctx.mma)
             else:
                 dW, db = ops.linear_bwd_wgt(dy, x, want_bias=want_bias, mma=ctx.mma)
         return dx, dW, db
 
 
-# weight.data_ptr() -> (weakref to the parameter, callable(weight, dy, x, want_bias, mma) -> dbias): registered by
-# semantichuman_amd.optim.Adam.fuse_linear_weight_gradients, consulted by the backward pass above
+# weight.data_ptr() -> (weakref to the parameter, weakref to the optimizer that owns its update, index of its param group):
+# registered by semantichuman_amd.optim.Adam.fuse_linear_weight_gradients, consulted by the backward pass above.  Both references
+# are weak: an entry whose parameter or optimizer is gone is dropped at the next lookup and the layer is back on the ordinary
+# gradient + step() path.  With an entry, backward ITSELF updates the weight (see that method's docstring for what follows).
 _FUSED_UPDATE = {}
 
 
 def _fused_param(weight, dy, x):
     """The registered parameter behind `weight` if this backward may apply its update in the weight-gradient kernel, else None."""
-    fused = _FUSED_UPDATE.get(weight.data_ptr())
-    param = fused[0]() if fused is not None else None
-    if param is not None and param.data_ptr() == weight.data_ptr() and param.shape == weight.shape and param.grad is None and \
-            weight.is_contiguous() and ops.linear_bwd_wgt_adam_ok(dy.shape[0], dy.shape[1], x.shape[1]):
+    key = weight.data_ptr()
+    fused = _FUSED_UPDATE.get(key)
+    if fused is None:
+        return None
+    param, opt = fused[0](), fused[1]()
+    if param is None or opt is None:                   # the parameter or its optimizer died: a stale entry
+        _FUSED_UPDATE.pop(key, None)
+        return None
+    if param.data_ptr() == key and param.shape == weight.shape and param.grad is None and weight.is_contiguous() and \
+            ops.linear_bwd_wgt_adam_ok(dy.shape[0], dy.shape[1], x.shape[1]):
         return param
     return None
+
+
+def _fused_apply(param, dy, x, want_bias, mma):
+    _, opt_ref, gi = _FUSED_UPDATE[param.data_ptr()]
+    opt = opt_ref()
+    return opt._fused_update(opt.param_groups[gi], param, dy, x, want_bias, mma)
 
 
 def latent_linear(x: torch.Tensor, weight: torch.Tensor, bias) -> torch.Tensor:
@@ -84,7 +98,7 @@ class _LatentLinearBF16(torch.autograd.Function):
             want_bias = ctx.has_bias and ctx.needs_input_grad[2]
             param = _fused_param(weight, dy, x) if ctx.needs_input_grad[1] else None
             if param is not None:                          # (see _LatentLinear.backward) - the bf16 working copy is rewritten too
-                db = _FUSED_UPDATE[weight.data_ptr()][1](param, dy, x, want_bias, None)
+                db = _fused_apply(param, dy, x, want_bias, None)
             else:
                 dW, db = ops.linear_bwd_wgt_bf16(dy, x, want_bias=want_bias)
         return dx, dW, db, None

@@ -41,6 +41,35 @@ class Adam(torch.optim.Optimizer):
         self._side = None
         self._fused = []             # weak references to weights updated inside their weight-gradient kernel
         self._fused_done = []        # ... those that were, during this backward: step() advances their step counts
+        self._release_foreign_fusions()
+
+    def _release_foreign_fusions(self):
+        """A new optimizer over parameters whose update ANOTHER optimizer applies inside their weight-gradient kernel replaces
+        that optimizer: its registrations are dropped, or it would keep updating those weights during backward - with its own
+        moments and a step count nobody advances - while this optimizer finds no gradient to apply."""
+        import warnings
+        from . import linear
+        for group in self.param_groups:
+            for p in group["params"]:
+                ent = linear._FUSED_UPDATE.get(p.data_ptr()) if p.is_cuda else None
+                if ent is None or ent[0]() is not p:
+                    continue
+                other = ent[1]()
+                if other is not None and other is not self:
+                    warnings.warn("semantichuman_amd.optim.Adam: a parameter of this optimizer was registered for the fused weight-"
+                                  "gradient update of another optimizer; that registration is removed (call "
+                                  "fuse_linear_weight_gradients on the new optimizer to fuse again)", stacklevel=3)
+                    other._drop_fusion_of(p)
+                linear._FUSED_UPDATE.pop(p.data_ptr(), None)
+
+    def _drop_fusion_of(self, p):
+        self._fused = [r for r in self._fused if r() is not None and r() is not p]
+
+    def __del__(self):
+        try:
+            self.remove_fusion()
+        except Exception:          # interpreter shutdown: modules may be gone
+            pass
 
     # ---------------------------------------------------------------------------------- internals
     def _state_of(self, p):
@@ -144,9 +173,19 @@ class Adam(torch.optim.Optimizer):
         tile of the weight and its two moments (sh_linear_bwd_wgt_adam) instead of writing the gradient for `step()` to read
         back: 24 instead of 32 bytes of HBM traffic per weight and step, the same bits.  `weight.grad` is then never
         materialised (it stays None); `step()` updates everything else and advances the fused parameters' step counts.
-        As with `overlap_backward`: only when nothing else consumes the gradients between backward and step (no all-reduce,
-        no clipping, one backward per step).  Shapes the kernel does not serve (batch > 64, sizes that are not multiples of 64),
-        the bf16 path and parameters that already hold a `.grad` fall back to the ordinary gradient + `step()`."""
+
+        **`backward()` itself then MUTATES these weights and their moments** - so, as with `overlap_backward`: only when
+        nothing else consumes the gradients between backward and step (no all-reduce, no clipping) and with exactly ONE
+        backward per `step()`.  A second backward through a fused layer before `step()` (gradient accumulation) raises a
+        RuntimeError instead of applying a second update with the same bias-correction step; a `step()` that the caller skips
+        (NaN guard, GradScaler) cannot undo the update backward already applied - do not fuse under such a policy.
+        Shapes the kernel does not serve (batch > 64, sizes that are not multiples of 64) and parameters that already hold a
+        `.grad` fall back to the ordinary gradient + `step()`.  On the bf16 compute path the same kernel runs: the bf16
+        operand tiles are widened to fp32 on their way into LDS and multiplied on the fp32 MFMA (products of bf16 values are
+        exact there), the bf16 working copy is rewritten with the update - close to, not bit-identical with,
+        `linear_bwd_wgt_bf16` followed by `sh_adam_step_bf16` (tests/test_bf16.py has the tolerance test).
+        The registry entry holds this optimizer weakly and is dropped when the optimizer dies, when `remove_fusion()` is
+        called, or when another `optim.Adam` is constructed over the same parameter."""
         import weakref
         from . import linear
         for mod in modules:
@@ -156,21 +195,33 @@ class Adam(torch.optim.Optimizer):
                 raise ValueError("fuse_linear_weight_gradients: a module's weight is not a parameter of this optimizer")
             if not (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 2):
                 raise RuntimeError("fuse_linear_weight_gradients: contiguous 2-D fp32 HIP weights only")
-            linear._FUSED_UPDATE[w.data_ptr()] = (weakref.ref(w), lambda p, dy, x, want_bias, mma, g=group: self._fused_update(g, p, dy, x, want_bias, mma))
-            self._fused.append(weakref.ref(w))
+            prev = linear._FUSED_UPDATE.get(w.data_ptr())
+            if prev is not None and prev[0]() is w and prev[1]() not in (None, self):
+                prev[1]()._drop_fusion_of(w)
+            linear._FUSED_UPDATE[w.data_ptr()] = (weakref.ref(w), weakref.ref(self), self.param_groups.index(group))
+            if not any(r() is w for r in self._fused):
+                self._fused.append(weakref.ref(w))
         return self
 
     def remove_fusion(self):
         from . import linear
         for r in self._fused:
             w = r()
-            if w is not None:
+            if w is None:
+                continue
+            ent = linear._FUSED_UPDATE.get(w.data_ptr())
+            if ent is not None and ent[1]() in (None, self):       # (never another optimizer's registration)
                 linear._FUSED_UPDATE.pop(w.data_ptr(), None)
         self._fused = []
+        self._fused_done = []
 
     @torch.no_grad()
     def _fused_update(self, group, p, dy, x, want_bias, mma):
         from . import ops, shadow
+        if any(q is p for q in self._fused_done):
+            raise RuntimeError("semantichuman_amd.optim.Adam: second backward through a layer whose update is fused into its weight-"
+                               "gradient kernel before step() - backward itself applies the update there, so gradient accumulation "
+                               "is not possible; call remove_fusion() to accumulate")
         st = self._state_of(p)
         db = ops.linear_bwd_wgt_adam(dy, x, p, st["exp_avg"], st["exp_avg_sq"], st["step"], self._lr_tensor(group, p.device), group["betas"],
                                      group["eps"], group["weight_decay"], want_bias=want_bias, mma=mma, weight_bf16=shadow.lookup(p))
