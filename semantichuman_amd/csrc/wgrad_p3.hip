@@ -14,10 +14,15 @@
 // The reduction index is (vertex, batch) - in the images the index ACROSS lanes, where the matrix instruction wants it inside
 // a lane's eight values - so every operand block takes the hardware transpose on its way from LDS (ds_read_b64_tr_b16), as
 // in the bf16 path's LDS-DMA weight gradient (bf16_wgrad.hip).  What the image layout buys: one LDS-DMA instruction
-// (global_load_lds_dwordx4, lane l -> LDS base + 16 l) moves one "TR block" = 32 reduction rows (two 16-batch groups of one
-// vertex) x 16 channels of one plane = two contiguous 512-byte pieces of HBM/L2 into exactly the [32 r][16 idx] image the
-// transposed read wants (lane l = 2 r + half fetches piece (2 cb + half) * 16 + (r & 15) of batch group r >> 4): whole
-// 128-byte lines, no staging registers, no ds_write, conflict-free reads.
+// (global_load_lds_dwordx4, lane l -> LDS base + 16 l) copies one whole 1-KiB fragment - 16 batch entries x 32 channels of one
+// plane, CONTIGUOUS in memory, four consecutive lanes on 64 consecutive bytes (eight full lines per instruction; the vector L1
+// serves a quad of lanes that touches two lines as two accesses: the first form of this kernel, which had lane 2 r + half
+// fetch piece `half` of row r, ran at 2.2 accesses per 64 bytes) - into LDS as it is; no staging registers, no ds_write.  The
+// transposed read of a 16-channel block then takes, per lane, 8 bytes of the piece (8-channel group kb, batch entry b): the
+// 32 reduction rows of a matrix instruction are the 16 batch entries of two fragments (batch groups 2 bp and 2 bp + 1 of one
+// vertex).  Bank conflicts: the two 8-channel groups of a 16-channel block are 256 bytes = all 64 banks apart, so the copy
+// swaps the upper and lower eight batch entries of every ODD group (lane l fetches piece l ^ 8 when l & 16: still 64
+// contiguous bytes per quad of lanes) and the reads undo it - conflict-free.
 //
 // A WAVE owns an output tile - QF gathered 32-column groups (a 32-channel fragment of one spiral position; two positions of a
 // 16-channel image) x PT 16-channel tiles of dpre - over a contiguous range of stages (one stage = one vertex x 32 batch
@@ -39,28 +44,44 @@ struct WP3Params {
     float* slab; long slab_stride, bias_off;   // [nslab][Cout * K], then [nslab][Cout]
     int B, R, S, Cin, Cout, K;
     int nxg;                                   // gathered 32-column groups: S * Cin / 32, or ceil(S / 2) for 16-channel images
-    int n_qg, n_pt, nsplit, nslab, n_items;
+    int n_qg, n_pt, sgx, nslab, n_items;       // sgx: workgroups (slabs) per XCD and tile
+    int xsplit, dnt;                           // xsplit: one batch pair per XCD; dnt: non-temporal dpre loads
     long n_stages;
 };
 
 constexpr int WP_BLK = 1024;                   // one TR block: [32 r][16 idx] bf16
 constexpr int WP_GRP = 6 * WP_BLK;             // a group: two 16-column halves x three planes
-constexpr int WP_G = 5;                        // ring slots per wave
-constexpr int WP_TBL_INTS = 2048;              // table lines a wave may hold
-constexpr int WP_WAVE_LDS = WP_G * WP_GRP + WP_TBL_INTS * 4;
+#ifndef WP_G
+#define WP_G 6                                 // ring slots per wave: G - 1 groups (30 KiB) requested ahead
+#endif
+constexpr int WP_TBL_INTS = 1024;              // source offsets a wave may hold (stages x (1 + its column groups))
+constexpr int WP_WAVE_LDS = WP_G * WP_GRP + WP_TBL_INTS * 4;      // 40 KiB: four waves = the CU's 160 KiB
 
-// transposed fragment of one TR block: lane (i = lane & 15, g = lane >> 4) receives r = {4g..4g+3} u {16+4g..16+4g+3} of idx i
-__device__ __forceinline__ bf16x8 wp_frag(const char* blk, int lane) {
+// transposed operand fragment: lane (i = lane & 15, g = lane >> 4) receives channel i of batch entries {4g..4g+3} of the
+// fragment at LDS byte address `lo` (batch group 2 bp) and of the one at `hi` (batch group 2 bp + 1) - its eight reduction rows.
+// Fragment image in LDS: [8-channel group kb][batch entry b ^ (8 (kb & 1))][8 bf16]; the lane-dependent part of the address
+// (wp_lane_part: 8-channel group p >> 1 of the block, batch entry 4g + q, half p & 1) is formed once per group by the caller,
+// everything else is an immediate offset of the read.
+__device__ __forceinline__ unsigned wp_lane_part(int lane) {
     const int g = lane >> 4, l16 = lane & 15, q = l16 >> 2, p = l16 & 3;
-    const char* a = blk + (4 * g + q) * 32 + p * 8;
+    return (unsigned)((p >> 1) * 256 + (((4 * g + q) ^ ((p >> 1) << 3)) << 4) + (p & 1) * 8);
+}
+__device__ __forceinline__ bf16x8 wp_frag(unsigned lo, unsigned hi) {
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 16 * 32));
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)lo);
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)hi);
     typedef short s16x8 __attribute__((ext_vector_type(8)));
-    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     return *reinterpret_cast<const bf16x8*>(&v);
 }
 
+// Work assignment.  XCD x (= blockIdx & 7: workgroups are dealt round-robin) owns ONE batch pair (x % nbp, nbp = B / 32) and a
+// contiguous vertex range, and its C = 4 sgx waves per tile walk that range TOGETHER: wave c takes vertices lo + c, lo + c + C, ...
+// The kernel is a gather stream whose traffic beyond L2 is what it waits for (PMC: L2 hit rate 71 %, 157 MB fetched for 84 MB
+// of images at 3446 rows x 352 columns, ~4 TB/s of HBM / Infinity-Cache traffic under a 37-us launch), so what an XCD's 4 MiB L2
+// must hold between two uses of a gathered row decides: with this order it is the images of ~two rings of the mesh for ONE
+// batch pair (6 KiB per row) plus the dpre rows streamed past them in the meantime.  (A contiguous block of stages per wave
+// has every wave on a different part of the mesh; both batch pairs per XCD double the bytes between two uses.)
 template <int QF, int PT, bool XC16>
 __global__ __launch_bounds__(256) void wgrad_p3_kernel(const WP3Params p) {
     static_assert(PT % 2 == 0, "dpre channels come in 32-channel fragments");
@@ -70,80 +91,100 @@ __global__ __launch_bounds__(256) void wgrad_p3_kernel(const WP3Params p) {
     const int wave = sh_wave_id();
     char* ring = smem + wave * WP_WAVE_LDS;
     int* Tl = reinterpret_cast<int*>(ring + G * WP_GRP);
-    // XCD-contiguous item order: an XCD works through a contiguous range of row chunks, all column groups of a chunk side by side
-    int it = sh_xcd_remap((int)blockIdx.x, (int)gridDim.x);
-    const int qg = it % p.n_qg; it /= p.n_qg;
-    const int pt = it % p.n_pt; const int sgroup = it / p.n_pt;
-    const int split = sgroup * 4 + wave;
-    const long st0 = (long)split * p.n_stages / p.nsplit, st1 = (long)(split + 1) * p.n_stages / p.nsplit;
-    const int nst = split < p.nsplit ? (int)(st1 - st0) : 0;
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int tiles = p.n_qg * p.n_pt;
+    const int tile = local % tiles, sgl = local / tiles;
+    const int qg = tile % p.n_qg, pt = tile / p.n_qg;
+    const int sgroup = xcd * p.sgx + sgl;
+    const int C = 4 * p.sgx, c = sgl * 4 + wave;
     const int S = p.S, nbp = p.B >> 5;
-    const int v_first = (int)(st0 / nbp);
-    if (nst > 0) {   // this wave's table lines -> LDS, pre-multiplied by the image's row stride in 16-byte units
-        const int v_last = (int)((st0 + nst - 1) / nbp);
-        const int n = (v_last - v_first + 1) * S;
-        for (int i = lane; i < n; i += 64) Tl[i] = (int)((unsigned)p.table[(long)v_first * S + i] * (unsigned)(p.x_vb >> 4));
-    }
-    // per gathered group: spiral position(s) and byte offset of its channel group inside a (row, batch group)
+    // stage n of this wave = stage S0 + c + n C of the XCD's list.  xsplit (8 % nbp == 0): the XCD owns ONE batch pair
+    // (xcd % nbp) and a contiguous vertex range - its list is that range's vertices; otherwise (vertex, batch pair) pairs in order
+    const bool xsplit = p.xsplit != 0;
+    int S0, S1;
+    if (xsplit) { const int Gx = 8 / nbp, gx = xcd / nbp; S0 = (int)((long)gx * p.R / Gx); S1 = (int)((long)(gx + 1) * p.R / Gx); }
+    else { S0 = (int)((long)xcd * p.n_stages / 8); S1 = (int)((long)(xcd + 1) * p.n_stages / 8); }
+    const int nst = c < S1 - S0 ? (S1 - S0 - c + C - 1) / C : 0;
+    // this wave's source offsets -> LDS, all in 16-byte units (32 bits reach 64 GiB): per stage n (vertex v, batch pair bp)
+    //   Tl[n * NE + 0]         dpre:  v * d_vb + 2 bp * d_bgb
+    //   Tl[n * NE + 1 + k * H + hb]  gathered group k (16-channel images: its half hb): table[v][position] * x_vb + 2 bp * x_bgb +
+    //                          the offset of its 32-channel group       (groups past the end: a duplicate of the last, never stored)
+    // so a group's source address is ONE LDS read away and the loop holds no division
+    constexpr int H = XC16 ? 2 : 1, NE = 1 + QF * H;
     const int f0 = qg * QF;
-    int s_of[QF][2], cgo[QF];
-#pragma unroll
-    for (int k = 0; k < QF; ++k) {
-        const int f = f0 + k < p.nxg ? f0 + k : p.nxg - 1;                  // groups past the end: a duplicate, never stored
-        if (XC16) {
-            s_of[k][0] = 2 * f < S ? 2 * f : S - 1; s_of[k][1] = 2 * f + 1 < S ? 2 * f + 1 : S - 1; cgo[k] = 0;
+    for (int i = lane; i < nst * NE; i += 64) {
+        const int n = i / NE, e = i - n * NE;
+        const int sn = S0 + c + n * C;
+        const int v = xsplit ? sn : sn / nbp, bp = xsplit ? xcd % nbp : sn - v * nbp;
+        unsigned val;
+        if (e == 0) {
+            val = (unsigned)v * (unsigned)(p.d_vb >> 4) + (unsigned)(2 * bp) * (unsigned)(p.d_bgb >> 4);
         } else {
-            const int ncg = p.Cin >> 5;
-            s_of[k][0] = s_of[k][1] = f / ncg; cgo[k] = (f % ncg) * 3072;
+            const int k = (e - 1) / H, hb = (e - 1) - k * H;
+            const int f = f0 + k < p.nxg ? f0 + k : p.nxg - 1;
+            int sp, off16;
+            if (XC16) { sp = 2 * f + hb < S ? 2 * f + hb : S - 1; off16 = 0; }
+            else { const int ncg = p.Cin >> 5; sp = f / ncg; off16 = (f - sp * ncg) * 192; }
+            val = (unsigned)p.table[(long)v * S + sp] * (unsigned)(p.x_vb >> 4) + (unsigned)(2 * bp) * (unsigned)(p.x_bgb >> 4) + (unsigned)off16;
         }
+        Tl[i] = (int)val;
     }
-    // lane l = 2 r + half: reduction row r (batch group r >> 4, entry r & 15), 8-channel piece `half` of a 16-channel block
-    const int r = lane >> 1, half = lane & 1;
-    const long lo_x = (long)(r >> 4) * p.x_bgb + (long)((half * 16 + (r & 15)) * 16);
-    const long lo_d = (long)(r >> 4) * p.d_bgb + (long)((half * 16 + (r & 15)) * 16);
+    // which 16-byte piece of a 1-KiB instruction this lane copies (see the header): l, with the low / high eight batch entries of
+    // every odd 8-channel group swapped (16-channel images: a 512-byte plane has two groups: the same rule)
+    const long lane_off = (long)((lane ^ ((lane >> 1) & 8)) << 4);
     typedef __attribute__((address_space(3))) char* lptr_t;
     auto dma16 = [](const char* gsrc, unsigned lds_dst) {
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory", "m0");
     };
+    auto dma16nt = [](const char* gsrc, unsigned lds_dst) {                 // streamed once: do not displace the gathered rows in L2
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" : : "v"(gsrc), "s"(lds_dst) : "memory", "m0");
+    };
     const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_t)ring);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // the table lines are in LDS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // the offsets are in LDS
 
-    // issue side: (local vertex, batch pair) of the stage whose groups are being requested; advanced when a stage's last group went out
-    int iss_v = 0, iss_bp = (int)(st0 - (long)v_first * nbp), iss_st = 0, issued = 0;
+    // issue side: the stage whose groups are being requested; advanced when a stage's last group went out
+    int iss_n = 0, issued = 0;
+    const char* xbase = p.xp + lane_off;
+    const char* dbase = p.dp + (long)(pt * NGD) * 3072 + lane_off;
     auto issue = [&](auto JJ) {
         constexpr int jj = decltype(JJ)::value;
         const unsigned slot = ring_lds + (unsigned)((issued % G) * WP_GRP);
-        if constexpr (jj < NGD) {
-            const char* base = p.dp + (long)(v_first + iss_v) * p.d_vb + (long)(2 * iss_bp) * p.d_bgb + (long)(pt * NGD + jj) * 3072 + lo_d;
+        if constexpr (jj < NGD) {                                           // fragments (batch group 2 bp + bgi, plane pl) of 32 dpre channels
+            const unsigned o = (unsigned)__builtin_amdgcn_readfirstlane(Tl[iss_n * NE]);
+            const char* base = dbase + ((unsigned long)o << 4) + jj * 3072;
+            if (p.dnt) {
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
+                for (int bgi = 0; bgi < 2; ++bgi)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) dma16(base + cb * 512 + pl * 1024, slot + (unsigned)((cb * 3 + pl) * WP_BLK));
+                    for (int pl = 0; pl < 3; ++pl) dma16nt(base + bgi * p.d_bgb + pl * 1024, slot + (unsigned)((bgi * 3 + pl) * WP_BLK));
+            } else {
+#pragma unroll
+                for (int bgi = 0; bgi < 2; ++bgi)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) dma16(base + bgi * p.d_bgb + pl * 1024, slot + (unsigned)((bgi * 3 + pl) * WP_BLK));
+            }
         } else {
             constexpr int k = jj - NGD;
-            if constexpr (XC16) {
+            if constexpr (XC16) {                                           // per half: 3072 contiguous bytes = (bg, plane) x 512
 #pragma unroll
                 for (int hb = 0; hb < 2; ++hb) {
-                    const unsigned row = (unsigned)__builtin_amdgcn_readfirstlane(Tl[iss_v * S + s_of[k][hb]]);
-                    const char* base = p.xp + ((unsigned long)row << 4) + (long)(2 * iss_bp) * p.x_bgb + lo_x;
+                    const unsigned o = (unsigned)__builtin_amdgcn_readfirstlane(Tl[iss_n * NE + 1 + k * 2 + hb]);
+                    const char* base = xbase + ((unsigned long)o << 4);
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) dma16(base + pl * 512, slot + (unsigned)((hb * 3 + pl) * WP_BLK));
+                    for (int i = 0; i < 3; ++i) dma16(base + i * 1024, slot + (unsigned)((hb * 3 + i) * WP_BLK));
                 }
             } else {
-                const unsigned row = (unsigned)__builtin_amdgcn_readfirstlane(Tl[iss_v * S + s_of[k][0]]);
-                const char* base = p.xp + ((unsigned long)row << 4) + (long)(2 * iss_bp) * p.x_bgb + cgo[k] + lo_x;
+                const unsigned o = (unsigned)__builtin_amdgcn_readfirstlane(Tl[iss_n * NE + 1 + k]);
+                const char* base = xbase + ((unsigned long)o << 4);
 #pragma unroll
-                for (int cb = 0; cb < 2; ++cb)
+                for (int bgi = 0; bgi < 2; ++bgi)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) dma16(base + cb * 512 + pl * 1024, slot + (unsigned)((cb * 3 + pl) * WP_BLK));
+                    for (int pl = 0; pl < 3; ++pl) dma16(base + bgi * p.x_bgb + pl * 1024, slot + (unsigned)((bgi * 3 + pl) * WP_BLK));
             }
         }
         ++issued;
         if constexpr (jj == NG - 1) {                                       // the stage is out: next one (the last one again past the end)
-            if (iss_st + 1 < nst) {
-                ++iss_st;
-                if (++iss_bp == nbp) { iss_bp = 0; ++iss_v; }
-            }
+            if (iss_n + 1 < nst) ++iss_n;
         }
     };
 
@@ -159,46 +200,75 @@ __global__ __launch_bounds__(256) void wgrad_p3_kernel(const WP3Params p) {
     const bf16x8 ones = {(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f};
     const bool want_bias = qg == 0;
     bf16x8 fb[PT][3];
+    // Operand fragments are read from LDS ONE GROUP AHEAD (one wave per SIMD: nothing else would hide the LDS round trip in front
+    // of every group's products): fr[b] holds the six fragments - two 16-channel blocks x three planes - of a group, whatever its
+    // kind; the group being multiplied and the one being read alternate between the two sets (a stage with an odd number of
+    // groups ends with one register copy of the set, so that the parity is a compile-time constant).
+    bf16x8 fr[2][2][3];
+    const unsigned lane_part = wp_lane_part(lane);
+    auto read_group = [&](unsigned slot_lds, bf16x8 (&f)[2][3]) {
+        unsigned vb = slot_lds + lane_part;
+        asm volatile("" : "+v"(vb));                                        // ONE address register per group; the rest are immediates
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                if constexpr (XC16) {
+                    // (a gathered 16-channel group: half hb = [bg 0: h m l][bg 1: h m l] x 512 bytes, a plane = one block)
+                    f[hb][pl] = wp_frag(vb + hb * 3 * WP_BLK + pl * 512, vb + hb * 3 * WP_BLK + pl * 512 + 1536);
+                } else {
+                    f[hb][pl] = wp_frag(vb + pl * WP_BLK + hb * 512, vb + (3 + pl) * WP_BLK + hb * 512);
+                }
+            }
+    };
+    // dpre fragments always have the 32-channel layout
+    auto read_dgroup = [&](unsigned slot_lds, bf16x8 (&f)[2][3]) {
+        unsigned vb = slot_lds + lane_part;
+        asm volatile("" : "+v"(vb));
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) f[cb][pl] = wp_frag(vb + pl * WP_BLK + cb * 512, vb + (3 + pl) * WP_BLK + cb * 512);
+    };
 
-    auto consume = [&](auto J, const char* slot) {
+    auto multiply = [&](auto J, const bf16x8 (&f)[2][3]) {
         constexpr int j0 = decltype(J)::value;
         if constexpr (j0 < NGD) {
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) fb[2 * j0 + cb][pl] = wp_frag(slot + (cb * 3 + pl) * WP_BLK, lane);
+                for (int pl = 0; pl < 3; ++pl) fb[2 * j0 + cb][pl] = f[cb][pl];
             if (want_bias) {                                                // column sums of the dpre tile: ones^T . (Dl + Dm + Dh)
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb) {
-                    f32x4 c = accb[2 * j0 + cb];
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fb[2 * j0 + cb][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fb[2 * j0 + cb][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fb[2 * j0 + cb][0], c, 0, 0, 0);
-                    accb[2 * j0 + cb] = c;
+                    f32x4 cc = accb[2 * j0 + cb];
+                    cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, f[cb][2], cc, 0, 0, 0);
+                    cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, f[cb][1], cc, 0, 0, 0);
+                    cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, f[cb][0], cc, 0, 0, 0);
+                    accb[2 * j0 + cb] = cc;
                 }
             }
         } else {
             constexpr int k = j0 - NGD;
 #pragma unroll
-            for (int hb = 0; hb < 2; ++hb) {
-                const bf16x8 xh = wp_frag(slot + (hb * 3 + 0) * WP_BLK, lane), xm = wp_frag(slot + (hb * 3 + 1) * WP_BLK, lane),
-                             xl = wp_frag(slot + (hb * 3 + 2) * WP_BLK, lane);
+            for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
                 for (int j = 0; j < PT; ++j) {
-                    f32x4 c = acc[k][hb][j];                                // smallest terms first, one dependent chain (the fast form: DESIGN 4e)
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, fb[j][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, fb[j][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, fb[j][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, fb[j][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, fb[j][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, fb[j][0], c, 0, 0, 0);
-                    acc[k][hb][j] = c;
+                    f32x4 cc = acc[k][hb][j];                               // smallest terms first, one dependent chain (the fast form: DESIGN 4e)
+                    cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[hb][2], fb[j][0], cc, 0, 0, 0);
+                    cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[hb][0], fb[j][2], cc, 0, 0, 0);
+                    cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[hb][1], fb[j][1], cc, 0, 0, 0);
+                    cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[hb][1], fb[j][0], cc, 0, 0, 0);
+                    cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[hb][0], fb[j][1], cc, 0, 0, 0);
+                    cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[hb][0], fb[j][0], cc, 0, 0, 0);
+                    acc[k][hb][j] = cc;
                 }
-            }
         }
     };
 
-    // flat group sequence t = stage * NG + j; group t lives in slot t % G; groups t+1 .. t+G-2 are in flight while t is read
+    // flat group sequence t = stage * NG + j; group t lives in slot t % G.  Iteration t: group t + 1 has landed -> its fragments
+    // into the idle register set; group t + G - 1 requested into the slot group t - 1 was read from (an iteration ago); the
+    // products of group t.  Groups t + 2 .. t + G - 1 are in flight meanwhile.
     auto prologue = [&](auto self, auto D) -> void {
         constexpr int d = decltype(D)::value;
         if constexpr (d < G - 1) {
@@ -206,25 +276,40 @@ __global__ __launch_bounds__(256) void wgrad_p3_kernel(const WP3Params p) {
             self(self, std::integral_constant<int, d + 1>{});
         }
     };
-    if (nst > 0) prologue(prologue, std::integral_constant<int, 0>{});
     int t = 0;
-    auto stage_groups = [&](auto self, auto J) -> void {
-        constexpr int j = decltype(J)::value;
+    if (nst > 0) {
+        prologue(prologue, std::integral_constant<int, 0>{});
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((G - 2) * 6) : "memory");
+        read_dgroup(ring_lds, fr[0]);                                        // group 0 is a dpre group
+    }
+    auto stage_groups = [&](auto self, auto J, auto PAR) -> void {
+        constexpr int j = decltype(J)::value, par = decltype(PAR)::value;
         if constexpr (j < NG) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((G - 2) * 6) : "memory");
-            issue(std::integral_constant<int, (j + G - 1) % NG>{});          // group t + G - 1 into the slot group t - 1 was read from
-            consume(J, ring + (t % G) * WP_GRP);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // this slot's reads are done before a later DMA may overwrite it
+            constexpr int cur = (j + par) & 1, jn = (j + 1) % NG;
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((G - 3) * 6) : "memory");
+            const unsigned nslot = ring_lds + (unsigned)(((t + 1) % G) * WP_GRP);
+            if constexpr (jn < NGD) read_dgroup(nslot, fr[cur ^ 1]);
+            else read_group(nslot, fr[cur ^ 1]);
+            issue(std::integral_constant<int, (j + G - 1) % NG>{});
+            multiply(J, fr[cur]);
             ++t;
-            self(self, std::integral_constant<int, j + 1>{});
+            self(self, std::integral_constant<int, j + 1>{}, PAR);
         }
     };
-    for (int st = 0; st < nst; ++st) stage_groups(stage_groups, std::integral_constant<int, 0>{});
+    for (int st = 0; st < nst; ++st) {
+        stage_groups(stage_groups, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        if constexpr (NG % 2 != 0) {                                         // the next stage's first group was read into set 1: every stage starts on set 0
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) fr[0][hb][pl] = fr[1][hb][pl];
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // the clamped tail loads still write this wave's LDS
     __syncthreads();                                                         // every wave is done with its ring: reuse it for the sum
 
-    // four waves -> one slab: passes of up to 16 tiles per wave (64 KiB for the four)
-    constexpr int NT = QF * 2 * PT, TPP = 16, NPASS = (NT + TPP - 1) / TPP;
+    // four waves -> one slab: passes of up to 32 tiles per wave (128 KiB for the four)
+    constexpr int NT = QF * 2 * PT, TPP = 32, NPASS = (NT + TPP - 1) / TPP;
     float* red = reinterpret_cast<float*>(smem);
     float* slab = p.slab + (long)sgroup * p.slab_stride;
 #pragma unroll
@@ -237,14 +322,14 @@ __global__ __launch_bounds__(256) void wgrad_p3_kernel(const WP3Params p) {
             for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
                 for (int j = 0; j < PT; ++j) {
-                    const int tile = (k * 2 + hb) * PT + j;
-                    if (tile / TPP == ps) *reinterpret_cast<f32x4*>(mine + (tile % TPP) * 256 + lane * 4) = acc[k][hb][j];
+                    const int tl = (k * 2 + hb) * PT + j;
+                    if (tl / TPP == ps) *reinterpret_cast<f32x4*>(mine + (tl % TPP) * 256 + lane * 4) = acc[k][hb][j];
                 }
         __syncthreads();
         const int ntile = NT - ps * TPP < TPP ? NT - ps * TPP : TPP;
         for (int e = threadIdx.x; e < ntile * 64; e += 256) {
-            const int tile = ps * TPP + (e >> 6), l = e & 63;
-            const int k = tile / (2 * PT), hb = (tile / PT) & 1, j = tile % PT;
+            const int tl = ps * TPP + (e >> 6), l = e & 63;
+            const int k = tl / (2 * PT), hb = (tl / PT) & 1, j = tl % PT;
             const f32x4 v = ((*reinterpret_cast<const f32x4*>(red + e * 4) + *reinterpret_cast<const f32x4*>(red + WAVE_F + e * 4)) +
                              *reinterpret_cast<const f32x4*>(red + 2 * WAVE_F + e * 4)) + *reinterpret_cast<const f32x4*>(red + 3 * WAVE_F + e * 4);
             const int f = f0 + k;
@@ -268,7 +353,10 @@ __global__ __launch_bounds__(256) void wgrad_p3_kernel(const WP3Params p) {
     }
 }
 
-struct WP3Plan { int ok, qf, pt, xc16, nxg, n_qg, n_pt, nslab, nsplit; long n_stages; };
+// column groups per wave the kernel is built for (PT = 2: <= 16, PT = 4: <= 8: 256 accumulator registers)
+constexpr int WP_QF2[] = {4, 6, 8, 9, 11, 12, 16}, WP_QF4[] = {4, 6, 8};
+
+struct WP3Plan { int ok, qf, pt, xc16, nxg, n_qg, n_pt, sgx, nslab, xsplit; long n_stages; };
 WP3Plan plan_wp3(int B, int R, int S, int Cin, int Cout) {
     WP3Plan w{};
     if (B <= 0 || B % 32 != 0 || R <= 0 || S <= 0) return w;
@@ -276,31 +364,45 @@ WP3Plan plan_wp3(int B, int R, int S, int Cin, int Cout) {
     w.xc16 = Cin == 16;
     w.nxg = w.xc16 ? (S + 1) / 2 : S * (Cin / 32);
     w.pt = Cout % 64 == 0 ? 4 : 2;
-    static const int qf_env = sh_env_int("SH_WP3_QF", 4, 2, 4);
-    w.qf = qf_env == 3 ? 4 : qf_env;
-    if (w.nxg <= 2) w.qf = 2;
-    w.n_qg = sh_cdiv(w.nxg, w.qf);
     w.n_pt = Cout / (16 * w.pt);
     w.n_stages = (long)R * (B / 32);
-    // one workgroup (~152 KiB of LDS) per CU: tiles x slabs <= 256
+    // Column groups per wave (QF), out of the widths the kernel is built for: one workgroup (160 KiB of LDS) per CU, so
+    // 8 XCDs x tiles x sgx <= 256 workgroups; a wave's time is its stage count x the groups of a stage (dpre + QF gathered),
+    // and with only a handful of stages per wave the rounding of that count decides (1724 rows x 16 groups: 3.4 stages of 17
+    // groups per wave = 4 x 17, or split in two column groups 6.7 stages of 9 = 7 x 9).  Minimise it; ties: the wider group
+    // (dpre is re-read once per column group).
     static const int wg_target = sh_env_int("SH_WP3_BLOCKS", 256, 8, 1 << 16);
     static const int slab_mb = sh_env_int("SH_WP3_SLAB_MB", 32, 1, 4096);
-    const long tiles = (long)w.n_qg * w.n_pt;
-    long ns = wg_target / tiles;
-    const long cap = ((long)slab_mb << 20) / ((long)Cout * S * Cin * 4);
-    if (ns > cap) ns = cap;
-    if (ns > w.n_stages / (4 * 4)) ns = w.n_stages / (4 * 4);               // >= 4 stages per wave
-    if (ns < 1) ns = 1;
-    // a wave's table lines must fit its LDS area
+    static const int q_force = sh_env_int("SH_WP3_QF", 0, 0, 16);
+    const long cap = (((long)slab_mb << 20) / ((long)Cout * S * Cin * 4)) / 8;
+    static const int xsplit_on = sh_env_int("SH_WP3_XSPLIT", 1, 0, 1);
     const int nbp = B / 32;
-    for (;; ++ns) {
-        const long sps = (w.n_stages + 4 * ns - 1) / (4 * ns);
-        if (((sps + nbp - 1) / nbp + 2) * S <= WP_TBL_INTS) break;
-        if (ns > w.n_stages) return w;
-    }
-    w.nslab = (int)ns;
-    w.nsplit = (int)(4 * ns < w.n_stages ? 4 * ns : w.n_stages);
-    w.nslab = sh_cdiv(w.nsplit, 4);
+    w.xsplit = xsplit_on && 8 % nbp == 0;
+    const long per_xcd = w.xsplit ? ((long)R + 8 / nbp - 1) / (8 / nbp) : (w.n_stages + 7) / 8;
+    const int ngd = w.pt / 2;
+    long best = -1, sgx = 1;
+    auto consider = [&](int q) {
+        if (q_force && q != q_force) return;
+        const int n_qg = sh_cdiv(w.nxg, q);
+        if (q > w.nxg && q != (w.pt == 2 ? WP_QF2[0] : WP_QF4[0])) return;       // wider than the layer: only the narrowest form
+        const long tiles = (long)n_qg * w.n_pt;
+        long sg = wg_target / (8 * tiles);
+        if (sg > cap) sg = cap;
+        if (sg < 1) sg = 1;
+        for (;; ++sg) {                                                         // a wave's source offsets must fit its LDS area
+            const long nst = (per_xcd + 4 * sg - 1) / (4 * sg);
+            if (nst * (1 + q * (w.xc16 ? 2 : 1)) <= WP_TBL_INTS) break;
+            if (sg > per_xcd) return;
+        }
+        const long rounds = (8 * tiles * sg + wg_target - 1) / wg_target;        // more workgroups than CUs: they run in turns
+        const long cost = rounds * ((per_xcd + 4 * sg - 1) / (4 * sg)) * (ngd + q);
+        if (best < 0 || cost < best || (cost == best && q > w.qf)) { best = cost; w.qf = q; w.n_qg = n_qg; sgx = sg; }
+    };
+    if (w.pt == 2) { for (int q : WP_QF2) consider(q); }
+    else { for (int q : WP_QF4) consider(q); }
+    if (best < 0) return w;
+    w.sgx = (int)sgx;
+    w.nslab = 8 * w.sgx;
     w.ok = 1;
     return w;
 }
@@ -318,11 +420,33 @@ int launch_wp3(const WP3Params& p, hipStream_t st) {
         }
         attr_set = true;
     }
-    ShProfScope ps(st, "wgrad_p3_kernel<%d, %d, %s>|R=%d B=%d K=%d N=%d grid=%d split=%d", QF, PT, XC16 ? "true" : "false", p.R, p.B, p.K, p.Cout,
-                   p.n_items, p.nsplit);
+    ShProfScope ps(st, "wgrad_p3_kernel<%d, %d, %s>|R=%d B=%d K=%d N=%d grid=%d", QF, PT, XC16 ? "true" : "false", p.R, p.B, p.K, p.Cout, p.n_items);
     SH_LAUNCH_PS(ps, kern, dim3(p.n_items), dim3(256), smem, st, p);
     SH_CHECK_LAUNCH("wgrad_p3");
     return SH_OK;
+}
+
+template <int PT, bool XC16>
+int dispatch_wp3(int qf, const WP3Params& p, hipStream_t st) {
+    if constexpr (PT == 2) {
+        switch (qf) {
+            case 4: return launch_wp3<4, 2, XC16>(p, st);
+            case 6: return launch_wp3<6, 2, XC16>(p, st);
+            case 8: return launch_wp3<8, 2, XC16>(p, st);
+            case 9: return launch_wp3<9, 2, XC16>(p, st);
+            case 11: return launch_wp3<11, 2, XC16>(p, st);
+            case 12: return launch_wp3<12, 2, XC16>(p, st);
+            case 16: return launch_wp3<16, 2, XC16>(p, st);
+        }
+    } else {
+        switch (qf) {
+            case 4: return launch_wp3<4, 4, XC16>(p, st);
+            case 6: return launch_wp3<6, 4, XC16>(p, st);
+            case 8: return launch_wp3<8, 4, XC16>(p, st);
+        }
+    }
+    sh_set_error("wgrad_p3: no kernel for %d column groups x %d channel tiles", qf, PT);
+    return SH_ERR_UNSUPPORTED;
 }
 
 }  // namespace
@@ -363,13 +487,14 @@ int sh_spiral_conv_bwd_wgt_p3(const void* dpre_planes, const void* x_planes, con
     p.table = table; p.slab = static_cast<float*>(workspace);
     p.B = B; p.R = R; p.S = S; p.Cin = Cin; p.Cout = Cout; p.K = S * Cin;
     p.slab_stride = (long)Cout * p.K; p.bias_off = (long)w.nslab * p.slab_stride;
-    p.nxg = w.nxg; p.n_qg = w.n_qg; p.n_pt = w.n_pt; p.nsplit = w.nsplit; p.nslab = w.nslab; p.n_stages = w.n_stages;
+    p.nxg = w.nxg; p.n_qg = w.n_qg; p.n_pt = w.n_pt; p.sgx = w.sgx; p.nslab = w.nslab; p.n_stages = w.n_stages;
     p.n_items = w.n_qg * w.n_pt * w.nslab;
+    p.xsplit = w.xsplit;
+    static const int dnt = sh_env_int("SH_WP3_DNT", 0, 0, 1);
+    p.dnt = dnt;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (w.xc16) return w.pt == 4 ? (w.qf == 4 ? launch_wp3<4, 4, true>(p, st) : launch_wp3<2, 4, true>(p, st))
-                                 : (w.qf == 4 ? launch_wp3<4, 2, true>(p, st) : launch_wp3<2, 2, true>(p, st));
-    return w.pt == 4 ? (w.qf == 4 ? launch_wp3<4, 4, false>(p, st) : launch_wp3<2, 4, false>(p, st))
-                     : (w.qf == 4 ? launch_wp3<4, 2, false>(p, st) : launch_wp3<2, 2, false>(p, st));
+    if (w.xc16) return w.pt == 4 ? dispatch_wp3<4, true>(w.qf, p, st) : dispatch_wp3<2, true>(w.qf, p, st);
+    return w.pt == 4 ? dispatch_wp3<4, false>(w.qf, p, st) : dispatch_wp3<2, false>(w.qf, p, st);
 }
 
 }  // extern "C"

@@ -40,7 +40,7 @@ def wgrad_p3(dp_img, x_img, table, B, R, S, cin, cout):
     return dW, db, ws, nb
 
 
-def probe_layers(B=64, tpl=None, adversarial=False, reps=1, seed=1):
+def probe_layers(B=64, tpl=None, adversarial=False, reps=1, seed=1, local_table=False):
     tpl = tpl or os.path.join(ROOT, "tests", "golden", "template6890.npz")
     dev = torch.device("cuda:0")
     lib = _lib.load()
@@ -57,6 +57,8 @@ def probe_layers(B=64, tpl=None, adversarial=False, reps=1, seed=1):
                     continue
                 R, S, cin, cout, n_in = st.R, st.S, st.cin, st.cout, st.n_in
                 table = st.dev["table"]
+                if local_table:       # experiment: perfect locality - vertex v gathers rows v, v + 1, ... (what would a local numbering buy?)
+                    table = ((torch.arange(R, device=dev)[:, None] + torch.arange(S, device=dev)[None, :]) % n_in).to(torch.int32).contiguous()
                 x = rnd((n_in, B, cin), dev, adversarial, gen)
                 dp = rnd((R, B, cout), dev, adversarial, gen)
                 dp[st.zero_row] = 0
@@ -106,7 +108,7 @@ def main():
         if f.startswith("--reps="):
             reps = int(f.split("=")[1])
     print("%-30s %-22s %-22s %s" % ("layer", "dW err exact / p3", "dbias err exact / p3", "us exact / p3 (slabs)"))
-    for r in probe_layers(B, tpl, "--adversarial" in flags, reps):
+    for r in probe_layers(B, tpl, "--adversarial" in flags, reps, local_table="--local-table" in flags):
         if r["ok"]:
             print("%-30s %.2e %.2e    %.2e %.2e    %6.1f %6.1f (%d)" % (r["name"], r["err"]["exact"], r["err"]["p3"], r["errb"]["exact"],
                                                                        r["errb"]["p3"], r["us"]["exact"], r["us"]["p3"], r["nslab"]), flush=True)
