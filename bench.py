@@ -95,7 +95,7 @@ def parse_tag_f32(name, shape):
             return ("fwd", int(f["R"]), int(f["K"]), int(f["N"]))
         if fam.startswith("gather_gemm_"):                 # direct / split3 / coalesced forms: <NT, BWD, ...>
             return ("bwd" if targs[1] == "true" else "fwd", int(f["R"]), int(f["K"]), int(f["N"]))
-        if fam in ("wgrad_stream_kernel", "wgrad_kernel", "wgrad_split3_kernel"):
+        if fam in ("wgrad_stream_kernel", "wgrad_kernel", "wgrad_split3_kernel", "wgrad_p3_kernel"):
             return ("wgt", int(f["R"]), int(f["K"]), int(f["N"]))
         if fam == "wgrad_thin_kernel":
             if "pass" in f and f["pass"].split("/")[0] != f["pass"].split("/")[1]:     # an earlier launch of a multi-pass layer: priced with the last
@@ -254,7 +254,7 @@ def matrix_pipe_split(model, B, dtype, mma):
     """Algorithmic matrix FLOPs of one training step by the pipe that executes them, and the time they need at the dense peaks
     (one `frac_mfma` against the fp32 peak mis-states a step whose conv products run on the bf16 pipe at six
     instruction FLOPs per algorithmic FLOP).  planes3: forward / backward-data of every conv step the plane kernels take run on
-    v_mfma_f32_16x16x32_bf16 (x6), weight gradients and latent FCs on v_mfma_f32_16x16x4_f32; exact: everything on the fp32
+    v_mfma_f32_16x16x32_bf16 (x6), as do (round 6) the weight gradients whose two images exist; the other weight gradients and the latent FCs on v_mfma_f32_16x16x4_f32; exact: everything on the fp32
     pipe; bf16: everything on the bf16 pipe (x1).  (split3 partitions by tile count inside the library: not split here.)"""
     from semantichuman_amd import _lib
     lib = _lib.load()
@@ -273,8 +273,11 @@ def matrix_pipe_split(model, B, dtype, mma):
             p3 = mma == "planes3" and B % 16 == 0
             fwd_p3 = p3 and i > 0 and bool(lib.sh_spiral_conv_p3_ok(B, st.S, st.cin, st.cout))
             bwd_p3 = p3 and has_bwd and bool(lib.sh_spiral_conv_p3_ok(B, st.S, st.cout, st.cin))
-            b16 += (f if fwd_p3 else 0.0) + (f if bwd_p3 else 0.0)
-            f32 += (0.0 if fwd_p3 else f) + ((0.0 if bwd_p3 else f) if has_bwd else 0.0) + f
+            # round 6: the weight gradient of a step whose both images exist runs on the bf16 pipe too (csrc/wgrad_p3.hip)
+            wgt_p3 = (fwd_p3 and bwd_p3 and os.environ.get("SH_P3_WGRAD", "1") != "0" and
+                      bool(lib.sh_spiral_conv_bwd_wgt_p3_ok(B, st.R, st.S, st.cin, st.cout)))
+            b16 += (f if fwd_p3 else 0.0) + (f if bwd_p3 else 0.0) + (f if wgt_p3 else 0.0)
+            f32 += (0.0 if fwd_p3 else f) + ((0.0 if bwd_p3 else f) if has_bwd else 0.0) + (0.0 if wgt_p3 else f)
     fc = sum(3 * 2.0 * B * m.in_features * m.out_features for m in (model.fc_latent_enc, model.fc_latent_dec))
     if dtype == "bf16":
         b16 += fc
@@ -702,7 +705,7 @@ def roofline_f32(recs, model, B, nprof, verts):
     PEAK_X3 = PEAK_BF16_MFMA_TFLOPS / 6.0
 
     def is_x3(name):
-        return "split3" in name or name.startswith("conv_p3") or "_x3_" in name
+        return "split3" in name or name.startswith(("conv_p3", "wgrad_p3")) or "_x3_" in name
     kernels = []
     for name, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
         e = {"kernel": name, "launches_per_step": a["n"] / nprof, "avg_ms": a["ms"] / a["n"], "ms_per_step": a["ms"] / nprof}

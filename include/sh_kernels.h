@@ -259,13 +259,17 @@ SH_API int sh_stack_forward(int n_steps, const sh_stack_step* steps, const float
  * Three-plane form (SH_MMA_PLANES3; otherwise ignored, may be NULL): gin_planes[i] / dpre_last_planes = buffers for the plane
  * images of gin[i] / dpre_last (all rows, the pre-summed ones included; NULL = that conv step's backward-data pass keeps the
  * SPLIT3 kernels), wfrag3_t[i] = fragments of conv step i's backward-data operand (transpose 1); weight_t[i] may be NULL for
- * a step that runs sh_spiral_conv_bwd_data_p3. */
+ * a step that runs sh_spiral_conv_bwd_data_p3.  in_planes (round 6; may be NULL): in_planes[i] = the plane image of the INPUT
+ * of conv step i - what sh_stack_forward wrote to planes[i - 1], kept alive by the caller - or NULL; with it, the image of its
+ * gradient rows and a workspace of at least sh_spiral_conv_bwd_wgt_p3_workspace() bytes, a step whose shape
+ * sh_spiral_conv_bwd_wgt_p3_ok() takes computes its WEIGHT gradient from the two images (sh_spiral_conv_bwd_wgt_p3_presum)
+ * instead of from the fp32 tensors (sh_spiral_conv_bwd_wgt_presum). */
 SH_API int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, int x_layout, int rows0, int c0, int B,
                              const float* const* acts, const float* g, int out_layout, const float* const* weights,
                              float* const* gin, float* dpre_last, float* const* weight_t, void* const* workspace,
                              const size_t* workspace_bytes, float* const* dW, float* const* dbias, int need_x_grad,
                              int mma_mode, void* const* gin_planes, void* dpre_last_planes, const void* const* wfrag3_t,
-                             sh_stream_t stream);
+                             const void* const* in_planes, sh_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense layers with one tiny and one huge dimension: the latent nn.Linear pair fc_latent_enc /
@@ -682,6 +686,20 @@ SH_API int sh_spiral_conv_bwd_wgt_p3_ok(int B, int R, int S, int Cin, int Cout);
 SH_API size_t sh_spiral_conv_bwd_wgt_p3_workspace(int B, int R, int S, int Cin, int Cout);
 SH_API int sh_spiral_conv_bwd_wgt_p3(const void* dpre_planes, const void* x_planes, const int32_t* table, void* workspace,
                                      size_t workspace_bytes, int B, int R, int S, int Cin, int Cout, sh_stream_t stream);
+/* The same launch also carrying a pre-sum job, as sh_spiral_conv_bwd_wgt_presum does for the fp32 kernels: sum_out[r] = sum_e
+ * sum_val[e] * dpre[sum_col[e]] for r < sum_rows over the FP32 gradient rows dpre (element strides dp_sv, dp_sb; sum_out has the
+ * same strides; sum_out_planes != NULL: also the image of those rows) - sh_spmm's sums bit for bit, run by tail workgroups of
+ * the launch (or, for rows that do not take 16-byte accesses, by sh_spmm_p3 in front of it).  sum_rows == 0: no job. */
+SH_API int sh_spiral_conv_bwd_wgt_p3_presum(const void* dpre_planes, const void* x_planes, const int32_t* table, void* workspace,
+                                            size_t workspace_bytes, const float* dpre, int64_t dp_sv, int64_t dp_sb,
+                                            const int32_t* sum_rowptr, const int32_t* sum_col, const float* sum_val, float* sum_out,
+                                            void* sum_out_planes, int sum_rows, int B, int R, int S, int Cin, int Cout,
+                                            sh_stream_t stream);
+/* sh_spiral_conv_bwd_wgt_reduce_multi over layers whose slabs were written under different plans: kinds[i] = 0 the fp32 plan
+ * (sh_spiral_conv_bwd_wgt*, the thin-layer kernel), 1 the bf16 plan, 2 the three-plane plan (sh_spiral_conv_bwd_wgt_p3*). */
+SH_API int sh_spiral_conv_bwd_wgt_reduce_multi_kinds(int n_layers, const void* const* workspaces, float* const* dW, float* const* dbias,
+                                                     const int* B, const int* R, const int* S, const int* Cin, const int* Cout,
+                                                     const int* kinds, sh_stream_t stream);
 
 #ifdef __cplusplus
 }

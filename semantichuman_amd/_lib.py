@@ -38,7 +38,7 @@ SIGNATURES = {
     "sh_act_backward_tr": (c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "sh_spmm": (c_int, [_P, _P, _P, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _P]),
     "sh_stack_forward": (c_int, [_I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _I, _P]),
-    "sh_stack_backward": (c_int, [_I, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "sh_stack_backward": (c_int, [_I, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "sh_linear_workspace": (c_size_t, [_I, _I, _I]),
     "sh_linear_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, c_size_t, _I, _P]),
     "sh_linear_bwd_data": (c_int, [_P, _P, _P, _I, _I, _I, _P, c_size_t, _I, _P]),
@@ -113,6 +113,8 @@ SIGNATURES = {
     "sh_spiral_conv_bwd_wgt_p3_ok": (c_int, [_I, _I, _I, _I, _I]),
     "sh_spiral_conv_bwd_wgt_p3_workspace": (c_size_t, [_I, _I, _I, _I, _I]),
     "sh_spiral_conv_bwd_wgt_p3": (c_int, [_P, _P, _P, _P, c_size_t, _I, _I, _I, _I, _I, _P]),
+    "sh_spiral_conv_bwd_wgt_p3_presum": (c_int, [_P, _P, _P, _P, c_size_t, _P, _L, _L, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "sh_spiral_conv_bwd_wgt_reduce_multi_kinds": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 DTYPE_IDS = {"float32": 0, "bfloat16": 1}
 

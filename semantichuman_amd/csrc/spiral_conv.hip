@@ -27,6 +27,7 @@
 #include <type_traits>
 
 int sh_wgrad_bf16_nsplit(int B, int R, int S, int Cin, int Cout);      // csrc/bf16_wgrad.hip
+int sh_wgrad_p3_nslab(int B, int R, int S, int Cin, int Cout);         // csrc/wgrad_p3.hip
 
 namespace {
 
@@ -2292,14 +2293,20 @@ int sh_spiral_conv_bwd_wgt_presum(const float* dpre, int64_t dp_sv, int64_t dp_s
 }
 
 static int reduce_multi_impl(int n_layers, const void* const* workspaces, float* const* dW, float* const* dbias, const int* B,
-                             const int* R, const int* S, const int* Cin, const int* Cout, bool bf16_plan, sh_stream_t stream) {
+                             const int* R, const int* S, const int* Cin, const int* Cout, bool bf16_plan_all, sh_stream_t stream,
+                             const int* kinds = nullptr) {
     SH_REQUIRE(n_layers > 0 && 2 * n_layers <= MR_MAX && workspaces && dW && dbias && B && R && S && Cin && Cout,
                SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_wgt_reduce_multi: bad argument (at most %d layers)", MR_MAX / 2);
     MultiReduce m{};
     int nd = 0, blocks = 0;
     for (int i = 0; i < n_layers; ++i) {
         SH_REQUIRE(workspaces[i] && dW[i], SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_wgt_reduce_multi: null pointer in layer %d", i);
-        const int nrc = bf16_plan ? sh_wgrad_bf16_nsplit(B[i], R[i], S[i], Cin[i], Cout[i]) : plan_wgrad(B[i], R[i], S[i], Cin[i], Cout[i]).nrc;
+        const int kind = kinds ? kinds[i] : (bf16_plan_all ? 1 : 0);
+        SH_REQUIRE(kind >= 0 && kind <= 2, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_wgt_reduce_multi: unknown plan kind %d of layer %d", kind, i);
+        const bool bf16_plan = kind == 1;                      // (slab-walk form below; the three-plane plan has the fp32 plan's slab counts)
+        const int nrc = kind == 1 ? sh_wgrad_bf16_nsplit(B[i], R[i], S[i], Cin[i], Cout[i])
+                        : kind == 2 ? sh_wgrad_p3_nslab(B[i], R[i], S[i], Cin[i], Cout[i]) : plan_wgrad(B[i], R[i], S[i], Cin[i], Cout[i]).nrc;
+        SH_REQUIRE(nrc > 0, SH_ERR_UNSUPPORTED, "sh_spiral_conv_bwd_wgt_reduce_multi: layer %d has no plan of kind %d", i, kind);
         const long stride = (long)Cout[i] * S[i] * Cin[i];
         const float* slab = static_cast<const float*>(workspaces[i]);
         m.slab[nd] = slab; m.stride[nd] = stride; m.nslab[nd] = nrc; m.n[nd] = stride; m.out[nd] = dW[i]; m.block0[nd] = blocks;
@@ -2331,6 +2338,13 @@ int sh_spiral_conv_bwd_wgt_reduce_multi(int n_layers, const void* const* workspa
                                         const int* B, const int* R, const int* S, const int* Cin, const int* Cout,
                                         sh_stream_t stream) {
     return reduce_multi_impl(n_layers, workspaces, dW, dbias, B, R, S, Cin, Cout, false, stream);
+}
+
+int sh_spiral_conv_bwd_wgt_reduce_multi_kinds(int n_layers, const void* const* workspaces, float* const* dW, float* const* dbias,
+                                              const int* B, const int* R, const int* S, const int* Cin, const int* Cout,
+                                              const int* kinds, sh_stream_t stream) {
+    SH_REQUIRE(kinds, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_wgt_reduce_multi_kinds: no kinds");
+    return reduce_multi_impl(n_layers, workspaces, dW, dbias, B, R, S, Cin, Cout, false, stream, kinds);
 }
 
 int sh_spiral_conv_bwd_wgt_reduce_multi_bf16(int n_layers, const void* const* workspaces, float* const* dW, float* const* dbias,

@@ -145,7 +145,8 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
                       const float* const* acts, const float* g, int out_layout, const float* const* weights,
                       float* const* gin, float* dpre_last, float* const* weight_t, void* const* workspace,
                       const size_t* workspace_bytes, float* const* dW, float* const* dbias, int need_x_grad, int mma_mode,
-                      void* const* gin_planes, void* dpre_last_planes, const void* const* wfrag3_t, sh_stream_t stream) {
+                      void* const* gin_planes, void* dpre_last_planes, const void* const* wfrag3_t, const void* const* in_planes,
+                      sh_stream_t stream) {
     int rc = check_steps(n_steps, steps, c0, "sh_stack_backward");
     if (rc != SH_OK) return rc;
     if (B > 0 && (rc = check_tensor_sizes(n_steps, steps, rows0, c0, B, "sh_stack_backward")) != SH_OK) return rc;
@@ -212,8 +213,12 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
             cur = g; cl = lay(out_layout, s.m_rows, B, cin_of[last]);
         }
     }
-    const void* job_ws[64]; float* job_dW[64]; float* job_db[64]; int jB[64], jR[64], jS[64], jCi[64], jCo[64];
+    const void* job_ws[64]; float* job_dW[64]; float* job_db[64]; int jB[64], jR[64], jS[64], jCi[64], jCo[64], jK[64];
     int njobs = 0;
+    // three-plane WEIGHT GRADIENT (csrc/wgrad_p3.hip, round 6): conv step i takes it when the caller kept the image of the step's
+    // input alive (in_planes[i] = what sh_stack_forward wrote to planes[i - 1]), the image of its pre-activation gradient exists
+    // (the step's backward-data pass gathers it) and the kernel takes the shape; SH_P3_WGRAD=0: the exact fp32 MFMA kernels everywhere
+    static const int p3_wgrad_on = sh_env_int("SH_P3_WGRAD", 1, 0, 1);
     for (int i = last; i >= 0; --i) {
         const sh_stack_step& s = steps[i];
         const bool want_in = i > 0 || need_x_grad;
@@ -255,19 +260,33 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
                                 pimg0 ? pimg0 + sh_p3_bytes(s.R, B, s.cout) : nullptr, nullptr, 0, 0, 0, -1, B, s.n1, s.cout, stream);
                 if (rc != SH_OK) return rc;
             }
+            const bool p3w = p3 && p3_wgrad_on && i > 0 && in_planes && in_planes[i] && il.sb == s.cin && il.sv == (long)B * s.cin &&
+                             sh_spiral_conv_bwd_wgt_p3_ok(B, s.R, s.S, s.cin, s.cout) &&
+                             workspace_bytes[i] >= sh_spiral_conv_bwd_wgt_p3_workspace(B, s.R, s.S, s.cin, s.cout);
             if (!thin) {
                 const sh_csr_ref& lm = s.n2 ? s.sum2 : s.sum1;
                 const int ln = ride ? (s.n2 ? s.n2 : s.n1) : 0;
                 float* lout = mut0 + (long)(s.R + (s.n2 ? s.n1 : 0)) * cl.sv;
-                rc = sh_spiral_conv_bwd_wgt_presum(cur, cl.sv, cl.sb, inp, il.sv, il.sb, s.table, nullptr, nullptr, workspace[i],
-                                                   workspace_bytes[i], ln ? lm.rowptr : nullptr, ln ? lm.col : nullptr,
-                                                   ln ? lm.val : nullptr, ln ? lout : nullptr,
-                                                   (ln && pimg0) ? pimg0 + sh_p3_bytes(s.R + (s.n2 ? s.n1 : 0), B, s.cout) : nullptr, ln, B, s.R,
-                                                   s.S, s.cin, s.cout, mma_mode, stream);
+                void* limg = (ln && pimg0) ? pimg0 + sh_p3_bytes(s.R + (s.n2 ? s.n1 : 0), B, s.cout) : nullptr;
+                if (p3w) {
+                    if (!cur_img_done) {                       // the gradient rows' image, unless their producer wrote it
+                        rc = sh_to_p3(cur, cl.sv, cl.sb, cur_img, B, s.R, s.cout, stream);
+                        if (rc != SH_OK) return rc;
+                        cur_img_done = true;
+                    }
+                    rc = sh_spiral_conv_bwd_wgt_p3_presum(cur_img, in_planes[i], s.table, workspace[i], workspace_bytes[i], cur, cl.sv, cl.sb,
+                                                          ln ? lm.rowptr : nullptr, ln ? lm.col : nullptr, ln ? lm.val : nullptr,
+                                                          ln ? lout : nullptr, limg, ln, B, s.R, s.S, s.cin, s.cout, stream);
+                } else {
+                    rc = sh_spiral_conv_bwd_wgt_presum(cur, cl.sv, cl.sb, inp, il.sv, il.sb, s.table, nullptr, nullptr, workspace[i],
+                                                       workspace_bytes[i], ln ? lm.rowptr : nullptr, ln ? lm.col : nullptr,
+                                                       ln ? lm.val : nullptr, ln ? lout : nullptr, limg, ln, B, s.R, s.S, s.cin, s.cout, mma_mode,
+                                                       stream);
+                }
                 if (rc != SH_OK) return rc;
             }
             job_ws[njobs] = workspace[i]; job_dW[njobs] = dW[s.param]; job_db[njobs] = dbias ? dbias[s.param] : nullptr;
-            jB[njobs] = B; jR[njobs] = s.R; jS[njobs] = s.S; jCi[njobs] = s.cin; jCo[njobs] = s.cout;
+            jB[njobs] = B; jR[njobs] = s.R; jS[njobs] = s.S; jCi[njobs] = s.cin; jCo[njobs] = s.cout; jK[njobs] = p3w ? 2 : 0;
             SH_REQUIRE(job_dW[njobs], SH_ERR_INVALID_ARG, "sh_stack_backward: no dW buffer for parameter %d", s.param);
             ++njobs;
             if (want_in) {
@@ -332,7 +351,7 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
     }
     for (int k = 0; k < njobs; k += 16) {
         const int n = njobs - k < 16 ? njobs - k : 16;
-        rc = sh_spiral_conv_bwd_wgt_reduce_multi(n, job_ws + k, job_dW + k, job_db + k, jB + k, jR + k, jS + k, jCi + k, jCo + k, stream);
+        rc = sh_spiral_conv_bwd_wgt_reduce_multi_kinds(n, job_ws + k, job_dW + k, job_db + k, jB + k, jR + k, jS + k, jCi + k, jCo + k, jK + k, stream);
         if (rc != SH_OK) return rc;
     }
     return SH_OK;

@@ -46,6 +46,14 @@ struct WP3Params {
     int nxg;                                   // gathered 32-column groups: S * Cin / 32, or ceil(S / 2) for 16-channel images
     int n_qg, n_pt, sgx, nslab, n_items;       // sgx: workgroups (slabs) per XCD and tile
     int xsplit, dnt;                           // xsplit: one batch pair per XCD; dnt: non-temporal dpre loads
+    // tail job (sh_spiral_conv_bwd_wgt_p3_presum): workgroups n_items .. n_items + tail_blocks - 1 of the launch fill the pre-summed
+    // rows the layer's backward-data pass reads through its transposed table - y[r] = sum_e val[e] dpre[col[e]] over the FP32
+    // gradient rows, sh_spmm's arithmetic entry for entry (the rider of wgrad_stream_kernel, spiral_conv.hip)
+    const float* df; long df_sv, df_sb;        // fp32 dpre, element strides of (row, batch entry)
+    int tail_blocks, tail_rows;
+    const int* tail_rowptr; const int* tail_col; const float* tail_val;
+    float* tail_y;                             // same strides as df
+    char* tail_img; long tail_img_vb, tail_img_bgb;   // three-plane image of the tail rows, or NULL
     long n_stages;
 };
 
@@ -75,6 +83,80 @@ __device__ __forceinline__ bf16x8 wp_frag(unsigned lo, unsigned hi) {
     return *reinterpret_cast<const bf16x8*>(&v);
 }
 
+// The tail job.  A tail workgroup only starts when a main workgroup has left its CU (every workgroup of the launch is allotted the
+// 160 KiB of LDS), so it runs ALONE there, four waves per CU: what it needs is loads in flight per thread, not occupancy - each
+// thread works on four output pieces (four (row, 256-element part) items) at once, up to four entries of each requested before
+// the first sum.  Per element: acc = fma(val[e], dpre[col[e]], acc) in entry order - sh_spmm's / ws_presum_tail's sum, bit for bit.
+__device__ __forceinline__ void wp_presum_tail(const WP3Params& p) {
+    const int CW = p.Cout >> 2, per_row = p.B * CW;
+    const int parts = (per_row + 255) >> 8;
+    const long items = (long)p.tail_rows * parts;
+    const long stride = p.tail_blocks;
+    for (long it0 = (long)blockIdx.x - p.n_items; it0 < items; it0 += 4 * stride) {
+        int rr[4], e0[4], cnt[4];
+        long xo[4];
+        bool ok[4];
+        f32x4 xv[4][4];
+        float wv[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long it = it0 + u * stride;
+            const bool live = it < items;                                       // uniform
+            const long itc = live ? it : 0;
+            const int r = (int)(itc / parts), part = (int)(itc - (long)r * parts);
+            rr[u] = r;
+            e0[u] = p.tail_rowptr[r];
+            cnt[u] = live ? p.tail_rowptr[r + 1] - e0[u] : 0;
+            const int j = part * 256 + (int)threadIdx.x;
+            ok[u] = live && j < per_row;
+            const int jc = j < per_row ? j : 0;
+            const int b = jc / CW, co = 4 * (jc - b * CW);
+            xo[u] = (long)b * p.df_sb + co;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k < cnt[u]) {                                               // uniform
+                    xv[u][k] = *reinterpret_cast<const f32x4*>(p.df + (long)p.tail_col[e0[u] + k] * p.df_sv + xo[u]);
+                    wv[u][k] = p.tail_val[e0[u] + k];
+                }
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (cnt[u] <= 0 && !(it0 + u * stride < items)) continue;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k < cnt[u]) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q] = fmaf(wv[u][k], xv[u][k][q], acc[q]);
+                }
+            }
+            for (int e = e0[u] + 4; e < e0[u] + cnt[u]; ++e) {                  // long lists: the rest, one entry at a time
+                const f32x4 x1 = *reinterpret_cast<const f32x4*>(p.df + (long)p.tail_col[e] * p.df_sv + xo[u]);
+                const float w1 = p.tail_val[e];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = fmaf(w1, x1[q], acc[q]);
+            }
+            if (!ok[u]) continue;
+            *reinterpret_cast<f32x4*>(p.tail_y + (long)rr[u] * p.df_sv + xo[u]) = acc;
+            if (p.tail_img) {                                                   // the image of the row just written, as spmm_kernel<true, true>
+                u32x2 h, m, l;
+                sh_split3_quad(acc, h, m, l);
+                const int b = (int)(xo[u] / p.df_sb), co = (int)(xo[u] - (long)b * p.df_sb);
+                const bool c16 = p.Cout == 16;
+                char* d = p.tail_img + (long)rr[u] * p.tail_img_vb + (long)(b >> 4) * p.tail_img_bgb +
+                          (c16 ? ((co >> 3) * 16 + (b & 15)) * 16 : (co >> 5) * 3072 + (((co & 31) >> 3) * 16 + (b & 15)) * 16) + ((co >> 2) & 1) * 8;
+                const int pb = c16 ? 512 : 1024;
+                *reinterpret_cast<u32x2*>(d) = h;
+                *reinterpret_cast<u32x2*>(d + pb) = m;
+                *reinterpret_cast<u32x2*>(d + 2 * pb) = l;
+            }
+        }
+    }
+}
+
 // Work assignment.  XCD x (= blockIdx & 7: workgroups are dealt round-robin) owns ONE batch pair (x % nbp, nbp = B / 32) and a
 // contiguous vertex range, and its C = 4 sgx waves per tile walk that range TOGETHER: wave c takes vertices lo + c, lo + c + C, ...
 // The kernel is a gather stream whose traffic beyond L2 is what it waits for (PMC: L2 hit rate 71 %, 157 MB fetched for 84 MB
@@ -87,6 +169,7 @@ __global__ __launch_bounds__(256) void wgrad_p3_kernel(const WP3Params p) {
     static_assert(PT % 2 == 0, "dpre channels come in 32-channel fragments");
     constexpr int NGD = PT / 2, NG = NGD + QF, G = WP_G;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x >= p.n_items) { wp_presum_tail(p); return; }        // tail job (whole workgroups; before any barrier)
     const int lane = threadIdx.x & 63;
     const int wave = sh_wave_id();
     char* ring = smem + wave * WP_WAVE_LDS;
@@ -420,8 +503,9 @@ int launch_wp3(const WP3Params& p, hipStream_t st) {
         }
         attr_set = true;
     }
-    ShProfScope ps(st, "wgrad_p3_kernel<%d, %d, %s>|R=%d B=%d K=%d N=%d grid=%d", QF, PT, XC16 ? "true" : "false", p.R, p.B, p.K, p.Cout, p.n_items);
-    SH_LAUNCH_PS(ps, kern, dim3(p.n_items), dim3(256), smem, st, p);
+    ShProfScope ps(st, "wgrad_p3_kernel<%d, %d, %s>|R=%d B=%d K=%d N=%d grid=%d presum=%d", QF, PT, XC16 ? "true" : "false", p.R, p.B, p.K, p.Cout,
+                   p.n_items, p.tail_blocks ? p.tail_rows : 0);
+    SH_LAUNCH_PS(ps, kern, dim3(p.n_items + p.tail_blocks), dim3(256), smem, st, p);
     SH_CHECK_LAUNCH("wgrad_p3");
     return SH_OK;
 }
@@ -469,7 +553,17 @@ size_t sh_spiral_conv_bwd_wgt_p3_workspace(int B, int R, int S, int Cin, int Cou
 
 int sh_spiral_conv_bwd_wgt_p3(const void* dpre_planes, const void* x_planes, const int32_t* table, void* workspace, size_t workspace_bytes,
                               int B, int R, int S, int Cin, int Cout, sh_stream_t stream) {
+    return sh_spiral_conv_bwd_wgt_p3_presum(dpre_planes, x_planes, table, workspace, workspace_bytes, nullptr, 0, 0, nullptr, nullptr, nullptr,
+                                            nullptr, nullptr, 0, B, R, S, Cin, Cout, stream);
+}
+
+int sh_spiral_conv_bwd_wgt_p3_presum(const void* dpre_planes, const void* x_planes, const int32_t* table, void* workspace,
+                                     size_t workspace_bytes, const float* dpre, int64_t dp_sv, int64_t dp_sb, const int32_t* sum_rowptr,
+                                     const int32_t* sum_col, const float* sum_val, float* sum_out, void* sum_out_planes, int sum_rows, int B,
+                                     int R, int S, int Cin, int Cout, sh_stream_t stream) {
     SH_REQUIRE(dpre_planes && x_planes && table && workspace, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_wgt_p3: null pointer");
+    SH_REQUIRE(sum_rows == 0 || (sum_rows > 0 && dpre && sum_rowptr && sum_col && sum_val && sum_out), SH_ERR_INVALID_ARG,
+               "sh_spiral_conv_bwd_wgt_p3_presum: incomplete pre-sum job");
     const WP3Plan w = plan_wp3(B, R, S, Cin, Cout);
     SH_REQUIRE(w.ok, SH_ERR_UNSUPPORTED,
                "sh_spiral_conv_bwd_wgt_p3: B=%d S=%d Cin=%d Cout=%d is not taken (batch %% 32 == 0; Cin 16 or %% 32 == 0; Cout %% 32 == 0)", B, S,
@@ -492,6 +586,30 @@ int sh_spiral_conv_bwd_wgt_p3(const void* dpre_planes, const void* x_planes, con
     p.xsplit = w.xsplit;
     static const int dnt = sh_env_int("SH_WP3_DNT", 0, 0, 1);
     p.dnt = dnt;
+    if (sum_rows > 0) {
+        // the pre-sum job: tail workgroups of this launch (SH_WP3_TAIL=1) when its rows take 16-byte accesses, else a launch of its own
+        static const int tail_on = sh_env_int("SH_WP3_TAIL", 1, 0, 1), tail_cap = sh_env_int("SH_WP3_TAIL_BLOCKS", 256, 1, 1 << 16);
+        const bool sum_vec = (Cout % 4 == 0) && (dp_sv % 4 == 0) && (dp_sb % 4 == 0) &&
+                             ((reinterpret_cast<uintptr_t>(dpre) | reinterpret_cast<uintptr_t>(sum_out)) % 16 == 0);
+        if (tail_on && sum_vec) {
+            const long items = (long)sum_rows * (((long)B * (Cout / 4) + 255) / 256);
+            const long want = (items + 3) / 4;
+            p.tail_blocks = (int)(want < tail_cap ? want : tail_cap);
+            p.df = dpre; p.df_sv = dp_sv; p.df_sb = dp_sb;
+            p.tail_rows = sum_rows; p.tail_rowptr = sum_rowptr; p.tail_col = sum_col; p.tail_val = sum_val; p.tail_y = sum_out;
+            if (sum_out_planes) {
+                SH_REQUIRE(dp_sb == Cout && dp_sv == (int64_t)B * Cout && sh_p3_bytes(1, B, Cout) && (reinterpret_cast<uintptr_t>(sum_out_planes) & 15) == 0,
+                           SH_ERR_UNSUPPORTED, "sh_spiral_conv_bwd_wgt_p3_presum: B=%d Cout=%d has no plane image", B, Cout);
+                p.tail_img = static_cast<char*>(sum_out_planes);
+                p.tail_img_bgb = (long)(Cout / 32) * 3072;
+                p.tail_img_vb = p.tail_img_bgb * (B / 16);
+            }
+        } else {
+            const int rc = sh_spmm_p3(sum_rowptr, sum_col, sum_val, dpre, dp_sv, dp_sb, sum_out, dp_sv, dp_sb, sum_out_planes, nullptr, 0, 0, 0, -1, B,
+                                      sum_rows, Cout, stream);
+            if (rc != SH_OK) return rc;
+        }
+    }
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (w.xc16) return w.pt == 4 ? dispatch_wp3<4, true>(w.qf, p, st) : dispatch_wp3<2, true>(w.qf, p, st);
     return w.pt == 4 ? dispatch_wp3<4, false>(w.qf, p, st) : dispatch_wp3<2, false>(w.qf, p, st);

@@ -39,6 +39,9 @@ from .mesh_ops import CSR, TransposedTable
 # one library call per stack and direction (csrc/stack_exec.hip); 0 = the call-by-call Python sequencing below
 NATIVE = os.environ.get("SH_STACK_NATIVE", "1") != "0"
 _LAYOUT_ID = {"vm": 0, "bm": 1}
+# the library's own switch (csrc/stack_exec.hip reads it once): with the exact weight-gradient kernels nothing reads the forward
+# images during the backward pass, so they are not kept
+_P3_WGRAD = os.environ.get("SH_P3_WGRAD", "1").strip() != "0"
 _ALIGN = 64                       # floats: every carved buffer starts 256-byte aligned (16-byte vector accesses)
 
 
@@ -292,7 +295,9 @@ class Stack:
                 continue
             wt_off[i], wt_mask[i] = o, 1
             o += _round(st.cin * st.S * st.cout)
-            nb = int(lib.sh_spiral_conv_bwd_wgt_workspace(B, st.R, st.S, st.cin, st.cout))
+            # (room for either plan of the step's partial slabs: the fp32 kernels' or the three-plane weight gradient's)
+            nb = max(int(lib.sh_spiral_conv_bwd_wgt_workspace(B, st.R, st.S, st.cin, st.cout)),
+                     int(lib.sh_spiral_conv_bwd_wgt_p3_workspace(B, st.R, st.S, st.cin, st.cout)))
             ws_off[i], ws_mask[i], ws_bytes[i] = o, 1, nb
             o += _round((nb + 3) // 4)
         b_total = o
@@ -397,10 +402,10 @@ class Stack:
         planes_p = wf3_p = None
         if mma == "planes3" and B % 16 == 0 and plan["wf3_total"]:
             planes, wf3, wbase = self._p3_prepare(plan, weights, with_backward, x.device)
-            # what the backward pass needs of this: the weight fragments.  The image arena of the forward activations (6 bytes per
-            # element) is NOT kept - nothing in sh_stack_backward reads it, the launches above are ordered on the stream, and the
-            # backward pass's own image arena can take the memory
-            p3 = (None, wf3, wbase)
+            # what the backward pass needs of this: the weight fragments - and, since round 6, the image arena of the forward
+            # activations (6 bytes per element): the three-plane weight gradient (csrc/wgrad_p3.hip) reads a step's gathered input
+            # through it.  SH_P3_WGRAD=0 (the exact weight-gradient kernels): not kept, as before.
+            p3 = (planes if (with_backward and _P3_WGRAD) else None, wf3, wbase)
             pl = (plan["pl_off"] + np.uint64(planes.data_ptr())) * plan["pl_mask"]
             wf = (plan["wf3_off"] + np.uint64(wf3.data_ptr() + wbase)) * plan["wf3_mask"]
             planes_p, wf3_p = pl.ctypes.data, wf.ctypes.data
@@ -432,8 +437,13 @@ class Stack:
         dW = plan["dW_off"] + fbase
         assert len(need_bias) == plan["npar"] == len(weights)
         db = (plan["db_off"] + fbase) * np.array([1 if nb else 0 for nb in need_bias], dtype=np.uint64)
-        gpl_p = wf3t_p = None
+        gpl_p = wf3t_p = inpl_p = None
         dpl = ctypes.c_void_p(0)
+        if mma == "planes3" and p3 is not None and p3[0] is not None:
+            # image of the INPUT of step i = image of the buffer step i - 1 wrote
+            inpl = np.zeros(n, dtype=np.uint64)
+            inpl[1:] = ((plan["pl_off"] + np.uint64(p3[0].data_ptr())) * plan["pl_mask"])[:n - 1]
+            inpl_p = inpl.ctypes.data
         if mma == "planes3" and p3 is not None:
             gimg = torch.empty(max(256, plan["gpl_total"]), dtype=torch.uint8, device=dev)
             gpl = (plan["gpl_off"] + np.uint64(gimg.data_ptr())) * plan["gpl_mask"]
@@ -445,7 +455,7 @@ class Stack:
             n, self._native_steps(), _lib.ptr(x), _LAYOUT_ID[in_layout], rows0, c0, B, acts.ctypes.data, _lib.ptr(g),
             _LAYOUT_ID[out_layout], self._ptr_array(weights), gin.ctypes.data, ctypes.c_void_p(int(wbase) + 4 * plan["dpre_last_off"]),
             wt.ctypes.data, ws.ctypes.data, plan["ws_bytes"].ctypes.data, dW.ctypes.data, db.ctypes.data, 1 if need_x_grad else 0,
-            _lib.mma_id(mma), gpl_p, dpl, wf3t_p, _lib.stream_ptr()), "sh_stack_backward")
+            _lib.mma_id(mma), gpl_p, dpl, wf3t_p, inpl_p, _lib.stream_ptr()), "sh_stack_backward")
         grads = {}
         for j, shp in enumerate(plan["shapes"]):
             if shp is None:

@@ -106,12 +106,13 @@ int main() {
                 wt[i] = alloc<float>((size_t)st[i].cin * S * st[i].cout);
             }
         void* gpl[4] = {nullptr, imgg, nullptr, nullptr};
+        const void* inpl[4] = {nullptr, nullptr, img0, nullptr};       // image of the input of step 2 = of the buffer steps 0 and 1 wrote
         if (dtype == SH_DTYPE_BF16)
             rc = sh_stack_backward_bf16(4, st, x, SH_DTYPE_BF16, 0, L0.n_in, L0.cin, B, outs, g, SH_DTYPE_F32, 1, W, gin, SH_DTYPE_BF16, dpre_last, wft, 0, ws,
                                         wsb, dW, db, 1, nullptr);
         else
             rc = sh_stack_backward(4, st, reinterpret_cast<const float*>(x), 0, L0.n_in, L0.cin, B, reinterpret_cast<const float* const*>(outs), g, 1, W,
-                                   reinterpret_cast<float* const*>(gin), dpre_last, wt, ws, wsb, dW, db, 1, mma, gpl, nullptr, wf3t, nullptr);
+                                   reinterpret_cast<float* const*>(gin), dpre_last, wt, ws, wsb, dW, db, 1, mma, gpl, nullptr, wf3t, inpl, nullptr);
         if (rc) { printf("backward rc=%d\n", rc); break; }
         for (int p = 0; p < 3; ++p) { free(W[p]); free(bias[p]); free(dW[p]); free(db[p]); }
         free(x); free(o0); free(o2); free(out); free(g); free(gx); free(g1); free(g2); free(g3); free(dpre_last);

@@ -131,6 +131,27 @@ int sh_spiral_conv_bwd_wgt_presum(const float* dpre, int64_t dp_sv, int64_t dp_s
     if (rc != 0 || sum_rows == 0) return rc;
     return sh_spmm_p3(sum_rowptr, sum_col, sum_val, dpre, dp_sv, dp_sb, sum_out, dp_sv, dp_sb, sum_out_planes, nullptr, 0, 0, 0, -1, B, sum_rows, Cout, st);
 }
+// three-plane weight gradient: the real shape rule; reads the two images, writes its slabs, the rider as above
+int sh_spiral_conv_bwd_wgt_p3_ok(int B, int R, int S, int Cin, int Cout) {
+    return B > 0 && B % 32 == 0 && R > 0 && S > 0 && (Cin == 16 || (Cin > 0 && Cin % 32 == 0)) && Cout > 0 && Cout % 32 == 0;
+}
+size_t sh_spiral_conv_bwd_wgt_p3_workspace(int B, int R, int S, int Cin, int Cout) {
+    return sh_spiral_conv_bwd_wgt_p3_ok(B, R, S, Cin, Cout) ? (size_t)8 * ((size_t)Cout * S * Cin + Cout) * 4 : 0;
+}
+size_t sh_p3_bytes(int rows, int B, int C);
+int sh_spiral_conv_bwd_wgt_p3_presum(const void* dpre_planes, const void* x_planes, const int32_t* table, void* ws, size_t ws_bytes, const float* dpre,
+                                     int64_t dp_sv, int64_t dp_sb, const int32_t* sum_rowptr, const int32_t* sum_col, const float* sum_val, float* sum_out,
+                                     void* sum_out_planes, int sum_rows, int B, int R, int S, int Cin, int Cout, sh_stream_t st) {
+    if (!sh_spiral_conv_bwd_wgt_p3_ok(B, R, S, Cin, Cout)) return SH_ERR_UNSUPPORTED;
+    int n_in = 0;
+    for (long i = 0; i < (long)R * S; ++i) n_in = table[i] + 1 > n_in ? table[i] + 1 : n_in;
+    touch_r(dpre_planes, sh_p3_bytes(R, B, Cout)); touch_r(x_planes, sh_p3_bytes(n_in, B, Cin));
+    if (ws_bytes < sh_spiral_conv_bwd_wgt_p3_workspace(B, R, S, Cin, Cout)) return SH_ERR_WORKSPACE;
+    touch_w(ws, ws_bytes);
+    log("bwd_wgt_p3 R=%d Cin=%d Cout=%d", R, Cin, Cout);
+    if (sum_rows == 0) return 0;
+    return sh_spmm_p3(sum_rowptr, sum_col, sum_val, dpre, dp_sv, dp_sb, sum_out, dp_sv, dp_sb, sum_out_planes, nullptr, 0, 0, 0, -1, B, sum_rows, Cout, st);
+}
 int sh_spiral_conv_bwd_wgt_bf16(const void* dpre, int dd, int64_t dp_sv, int64_t dp_sb, const void* x, int xd, int64_t x_sv, int64_t x_sb,
                                 const int32_t* table, void* ws, size_t ws_bytes, int B, int R, int S, int Cin, int Cout, sh_stream_t) {
     int n_in = 0;
@@ -200,6 +221,11 @@ static int reduce_common(const char* name, int n, const void* const* ws, float* 
 }
 int sh_spiral_conv_bwd_wgt_reduce_multi(int n, const void* const* ws, float* const* dW, float* const* db, const int* B, const int* R, const int* S,
                                         const int* Ci, const int* Co, sh_stream_t) { return reduce_common("reduce n=%d", n, ws, dW, db, S, Ci, Co); }
+int sh_spiral_conv_bwd_wgt_reduce_multi_kinds(int n, const void* const* ws, float* const* dW, float* const* db, const int* B, const int* R, const int* S,
+                                              const int* Ci, const int* Co, const int* kinds, sh_stream_t) {
+    for (int i = 0; i < n; ++i) if (kinds[i] < 0 || kinds[i] > 2) return SH_ERR_INVALID_ARG;
+    return reduce_common("reduce n=%d", n, ws, dW, db, S, Ci, Co);
+}
 int sh_spiral_conv_bwd_wgt_reduce_multi_bf16(int n, const void* const* ws, float* const* dW, float* const* db, const int* B, const int* R, const int* S,
                                              const int* Ci, const int* Co, sh_stream_t) { return reduce_common("reduce_bf16 n=%d", n, ws, dW, db, S, Ci, Co); }
 // ---- three-plane form: image sizes are the real formula (include/sh_kernels.h), the kernels touch the image ranges

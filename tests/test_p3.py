@@ -196,3 +196,65 @@ def test_latent_fc_bf16x3_error_against_float64(mnk, adversarial):
         assert err["exact"][k] <= 2e-5 * scale, (k, err["exact"][k], scale)
     print("FC %s %s: " % (mnk, "adversarial" if adversarial else "training-scale") +
           "  ".join("%s %.2e / %.2e" % (k, err["planes3"][k] / float(ref[k].abs().max()), err["exact"][k] / float(ref[k].abs().max())) for k in ref))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# round 6: the weight gradient in the three-plane form (csrc/wgrad_p3.hip; autograd of reference models.py:45, dW = dpre^T . gather(x))
+
+@pytest.mark.parametrize("tpl,B,n_taken", [("template6890.npz", 64, 6), ("template27554.npz", 32, 6)])
+@pytest.mark.parametrize("adversarial", [False, True])
+def test_three_plane_weight_gradient_error_against_float64(tpl, B, n_taken, adversarial):
+    """The same gate as the convs': max|dW - dW_f64| of the plane kernel <= 1.5 x that of the exact fp32 MFMA kernel, for every conv
+    layer of config 2 (batch 64: two batch pairs per vertex) and config 4 (27 554 vertices, spiral 18, batch 32: one), sums over
+    up to 441 024 (vertex, batch) rows; training-scale operands and adversarial ones (six decades of dynamic range).  dbias too."""
+    import wgrad_p3_probe
+    rows = list(wgrad_p3_probe.probe_layers(B, os.path.join(ROOT, "tests", "golden", tpl), adversarial, reps=1))
+    taken = [r for r in rows if r["ok"]]
+    assert len(taken) == n_taken, [(r["name"], r["ok"]) for r in rows]
+    bad = []
+    for r in taken:
+        for key in ("err", "errb"):
+            e = r[key]
+            assert e["exact"] < 5e-6, (r["name"], key, e)
+            if not e["p3"] <= 1.5 * e["exact"] + 1e-9:
+                bad.append((r["name"], key, e["p3"], e["exact"]))
+    assert not bad, bad
+
+
+def test_three_plane_weight_gradient_carries_the_presum_job_bitwise():
+    """sh_spiral_conv_bwd_wgt_p3_presum: the rows its tail workgroups write are sh_spmm's rows (and their image is the image of those
+    rows), bit for bit, and the slabs are those of the launch without a job."""
+    import p3_probe
+    from semantichuman_amd import _lib, ops
+    lib = _lib.load()
+    d = dev()
+    torch.manual_seed(5)
+    B, R, n_in, S, cin, cout, n_sum = 64, 301, 407, 7, 32, 32, 157
+    table = torch.randint(0, n_in, (R, S), dtype=torch.int32, device=d)
+    x = torch.randn(n_in, B, cin, device=d)
+    dp = torch.randn(R + n_sum, B, cout, device=d)
+    g = np.random.RandomState(1)
+    rowptr = np.concatenate([[0], np.cumsum(g.randint(1, 9, size=n_sum))]).astype(np.int32)      # 1..8 entries: both tail paths
+    col = g.randint(0, R, size=rowptr[-1]).astype(np.int32)
+    val = np.ones(rowptr[-1], dtype=np.float32)
+    m = tuple(torch.from_numpy(a).to(d) for a in (rowptr, col, val))
+    xi, di = p3_probe.to_p3(x), p3_probe.to_p3(dp[:R].contiguous())
+    assert lib.sh_spiral_conv_bwd_wgt_p3_ok(B, R, S, cin, cout)
+    nb = lib.sh_spiral_conv_bwd_wgt_p3_workspace(B, R, S, cin, cout)
+    ws0 = torch.zeros(nb // 4, dtype=torch.float32, device=d)
+    ws1 = torch.zeros_like(ws0)
+    _lib.check(lib.sh_spiral_conv_bwd_wgt_p3(_lib.ptr(di), _lib.ptr(xi), _lib.ptr(table), _lib.ptr(ws0), nb, B, R, S, cin, cout, _lib.stream_ptr()), "p3")
+    want = dp.clone()
+    ops.spmm(m, want, "vm", want[R:], "vm", n_sum)
+    for with_img in (False, True):
+        got = dp.clone()
+        img = torch.zeros(lib.sh_p3_bytes(n_sum, B, cout), dtype=torch.uint8, device=d) if with_img else None
+        ws1.zero_()
+        _lib.check(lib.sh_spiral_conv_bwd_wgt_p3_presum(_lib.ptr(di), _lib.ptr(xi), _lib.ptr(table), _lib.ptr(ws1), nb, _lib.ptr(got), B * cout, cout,
+                                                        _lib.ptr(m[0]), _lib.ptr(m[1]), _lib.ptr(m[2]), _lib.ptr(got[R:]), _lib.ptr(img), n_sum, B, R, S,
+                                                        cin, cout, _lib.stream_ptr()), "p3_presum")
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+        assert torch.equal(ws1, ws0)
+        if with_img:
+            assert torch.equal(img, p3_probe.to_p3(want[R:].contiguous()))
