@@ -351,7 +351,13 @@ SH_API int sh_vertex_l2(const float* a, const float* b, int B, int N1, int N, fl
  *   loss[0] = mean_{b,f} sum_{e in 3 edges} | |e_rec| / (|e_gt| + 1e-5) - 1 |
  * x_hat, x: contiguous [B][N1][3]; faces int32 [F][3].
  * bwd: corner lists (vptr [N1+1], vcorner [3F], entries f*3+k) give an atomic-free gradient
- *   grad[b,v,:] = gscale[0]/(B*F) * sum_{corners of v} d score / d x_hat[b,v,:] */
+ *   grad[b,v,:] = gscale[0]/(B*F) * sum_{corners of v} d score / d x_hat[b,v,:]
+ * STATED DEVIATION from the reference on one edge case (here and in sh_recon_loss_bwd): a RECONSTRUCTED edge of length exactly 0.
+ * The reference differentiates torch.sqrt(torch.sum(d ** 2)) (train_funcs.py:36-38) at d = 0: autograd multiplies the sqrt's
+ * infinite derivative by 2 d = 0 and every gradient of that batch entry downstream becomes NaN - the optimizer step then turns
+ * the whole model into NaN.  These kernels return the term's subgradient 0 for such an edge (`if (len > 0)`), so a collapsed
+ * face contributes its loss value (|0 / t - 1| = 1) and no gradient, and training continues.  Everywhere else (len > 0) the
+ * gradient is the reference's.  tests/test_gpu_parity.py::test_zero_length_reconstructed_edge pins both behaviours. */
 SH_API int sh_edge_ratio_loss_fwd(const float* x_hat, const float* x, const int32_t* faces, int B, int N1, int F,
                            float* loss, void* workspace, sh_stream_t stream);
 SH_API int sh_edge_ratio_loss_bwd(const float* x_hat, const float* x, const int32_t* faces,

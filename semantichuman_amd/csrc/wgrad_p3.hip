@@ -587,8 +587,13 @@ int sh_spiral_conv_bwd_wgt_p3_presum(const void* dpre_planes, const void* x_plan
     static const int dnt = sh_env_int("SH_WP3_DNT", 0, 0, 1);
     p.dnt = dnt;
     if (sum_rows > 0) {
-        // the pre-sum job: tail workgroups of this launch (SH_WP3_TAIL=1) when its rows take 16-byte accesses, else a launch of its own
-        static const int tail_on = sh_env_int("SH_WP3_TAIL", 1, 0, 1), tail_cap = sh_env_int("SH_WP3_TAIL_BLOCKS", 256, 1, 1 << 16);
+        // the pre-sum job: a launch of its own in front of this one (default), or tail workgroups of this launch (SH_WP3_TAIL=1).
+        // Measured (6890 vertices, batch 64, profiles/r06_wgrad_p3.txt): as tail workgroups the job costs MORE than its own launch -
+        // every workgroup of this launch is allotted the CU's whole LDS, so a tail workgroup only starts when a main one has left and
+        // then runs alone on its CU, four waves deep, on a chain of dependent loads (row pointer -> column -> rows): the five hosting
+        // launches 37 / 31 / 47 / 30 / 22 us -> 85 / 48 / 83 / 44 / 32, step 1.416 -> 1.483 ms.  The fp32 kernels host the job beside
+        // their one wave per SIMD (no LDS to speak of); this kernel cannot.
+        static const int tail_on = sh_env_int("SH_WP3_TAIL", 0, 0, 1), tail_cap = sh_env_int("SH_WP3_TAIL_BLOCKS", 256, 1, 1 << 16);
         const bool sum_vec = (Cout % 4 == 0) && (dp_sv % 4 == 0) && (dp_sb % 4 == 0) &&
                              ((reinterpret_cast<uintptr_t>(dpre) | reinterpret_cast<uintptr_t>(sum_out)) % 16 == 0);
         if (tail_on && sum_vec) {

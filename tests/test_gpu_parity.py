@@ -495,6 +495,58 @@ def test_fused_recon_loss_equals_separate_terms(golden_dir):
     close(a.grad, b.grad.cpu().numpy(), 1e-6, "fused loss gradient")
 
 
+def test_zero_length_reconstructed_edge(golden_dir):
+    """The one edge case of train_funcs.py:30-39 where the library deviates from the reference ON PURPOSE (include/sh_kernels.h,
+    DESIGN 4f): a reconstructed edge of length exactly 0.  Reference / oracle: d sqrt(sum(d^2)) at d = 0 is inf * 0 - the gradient
+    of that batch entry's vertices is NaN.  Library (both the separate edge-ratio kernels and the fused reconstruction loss): the
+    loss value is the reference's (|0 / t - 1| = 1 for the collapsed edge), the collapsed edge contributes NO gradient, every other
+    term's gradient is the reference's - checked against the oracle's gradient of the same loss with the collapsed edge's term left out."""
+    h = load_hierarchy(os.path.join(golden_dir, "small_ae.npz"))
+    rs = np.random.RandomState(5)
+    B, N1 = 3, h.sizes[0] + 1
+    x = torch.from_numpy(np.concatenate([rs.randn(B, N1 - 1, 3), np.zeros((B, 1, 3))], 1).astype(np.float32))
+    xh = x + 0.05 * torch.from_numpy(rs.randn(B, N1, 3).astype(np.float32))
+    xh[:, -1] = 0
+    f0 = np.asarray(h.faces)[0]
+    i, j = int(f0[0]), int(f0[1])
+    xh[1, j] = xh[1, i]                                             # batch entry 1: edge (i, j) of face 0 collapses in the reconstruction
+    # --- the reference's formulation (oracle): NaN gradient
+    xo = xh.clone().requires_grad_(True)
+    lo = ref_cpu.edge_ratio_loss(xo, x, h.faces)
+    lo.backward()
+    assert torch.isfinite(lo) and torch.isnan(xo.grad[1]).any() and torch.isfinite(xo.grad[0]).all()
+    # --- the oracle with the collapsed edges' terms left out of the graph: what every other term contributes
+    faces = torch.as_tensor(np.asarray(h.faces), dtype=torch.long)
+    xr = xh.clone().requires_grad_(True)
+    tot = 0.0
+    for a, b in ((0, 1), (1, 2), (0, 2)):
+        d = xr[:, faces[:, a]] - xr[:, faces[:, b]]
+        live = (d.detach() ** 2).sum(2) > 0
+        ln = torch.sqrt(torch.where(live[..., None], d, torch.ones_like(d)).pow(2).sum(2))
+        t = torch.sqrt(((x[:, faces[:, a]] - x[:, faces[:, b]]) ** 2).sum(2)) + 0.00001
+        tot = tot + torch.where(live, torch.abs(ln / t - 1), torch.ones_like(ln))      # a collapsed edge: |0 / t - 1| = 1, no gradient
+    lref = tot.mean(dim=1).mean()
+    lref.backward()
+    assert lref.item() == pytest.approx(lo.item(), rel=1e-6) and torch.isfinite(xr.grad).all()
+    # --- the library
+    d_ = dev()
+    ft = sh.FaceTables(h.faces, N1, d_)
+    xd = x.to(d_)
+    a = xh.to(d_).requires_grad_(True)
+    le = sh.edge_ratio_loss(a, xd, ft)
+    le.backward()
+    assert le.item() == pytest.approx(lo.item(), rel=2e-6)
+    assert torch.isfinite(a.grad).all()
+    close(a.grad, xr.grad, GRAD_TOL, "edge-ratio gradient with a collapsed edge")
+    b = xh.to(d_).requires_grad_(True)
+    total, parts = sh.recon_loss(b, xd, ft, 1.0)
+    total.backward()
+    l1 = xh.clone().requires_grad_(True)
+    torch.nn.functional.l1_loss(x, l1).backward()
+    assert torch.isfinite(b.grad).all()
+    close(b.grad, xr.grad + l1.grad, GRAD_TOL, "fused loss gradient with a collapsed edge")
+
+
 def test_c_abi_error_contract():
     """Bad calls return a negative status and leave a message in sh_last_error(); the Python wrappers turn that into
     RuntimeError - nothing fails silently and nothing falls back."""

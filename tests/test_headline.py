@@ -181,3 +181,91 @@ def test_the_benchs_own_step_vs_oracle(case, form):
     finally:
         _lib.profile_enable(False)
         _lib.set_f32_mma_mode(was)
+
+
+@pytest.mark.parametrize("form", ["exact", "planes3"])
+def test_replayed_graph_step_is_bitwise_the_eager_step(form, golden_dir):
+    """The launch path `bench.py` times - forward + fused L1/edge loss + backward + Adam captured into ONE hipGraph, the latent
+    FCs' update inside their weight-gradient kernels (optim.Adam.fuse_linear_weight_gradients), the batch copied into a fixed
+    input tensor before every replay - against the same three training steps (train_funcs.py:495-510) launched eagerly from the
+    same weights on the same batches: every parameter, both Adam moments and the step counts equal BIT FOR BIT, at the headline
+    size (6890 vertices, batch 64), in the exact form and in the three-plane form."""
+    import semantichuman_amd as sh
+    from semantichuman_amd import _lib, synthetic
+    dev = torch.device("cuda:0")
+    h = load_hierarchy(os.path.join(golden_dir, "template6890.npz"))
+    B, n_steps = 64, 3
+    data = torch.from_numpy(synthetic.synth_batch(h.verts, n_steps * B, seed=11)).to(dev)
+    ft = sh.FaceTables(h.faces, h.sizes[0] + 1, dev)
+    was = _lib.get_f32_mma_mode()
+    _lib.set_f32_mma_mode(form)
+    try:
+        torch.manual_seed(4)
+        m = sh.SpiralAutoencoder(FE, FD, 256, h.sizes, h.spiral_sizes, h.spirals, h.D, h.U, dev)
+        init = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        opt = sh.optim.Adam(m.parameters(), lr=LR, weight_decay=WD)
+        opt.fuse_linear_weight_gradients([m.fc_latent_enc, m.fc_latent_dec])
+        xin = torch.empty((B, h.sizes[0] + 1, 3), dtype=torch.float32, device=dev)
+        unit = torch.ones((), dtype=torch.float32, device=dev)
+
+        def one_step():
+            opt.zero_grad(set_to_none=True)
+            loss, _ = sh.recon_loss(m(xin)[0], xin, ft, EDGE_W)
+            loss.backward(unit)
+            opt.step()
+
+        def reset():
+            m.load_state_dict(init)
+            for st in opt.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+
+        def snapshot():
+            torch.cuda.synchronize()
+            out = {"p/" + n: q.detach().clone() for n, q in m.named_parameters()}
+            for n, q in m.named_parameters():
+                for k, v in opt.state[q].items():
+                    out["s/%s/%s" % (n, k)] = v.detach().clone()
+            return out
+        # --- eager
+        xin.copy_(data[:B])
+        one_step()                                   # creates the optimizer state; then back to the start
+        reset()
+        _lib.profile_enable(True)
+        for i in range(n_steps):
+            xin.copy_(data[i * B:(i + 1) * B])
+            one_step()
+        torch.cuda.synchronize()
+        names = [n for n, _, _ in _lib.profile_records_by_kernel()]
+        _lib.profile_enable(False)
+        assert sum(1 for n in names if n.startswith("linear_bwd_wgt_adam")) == 2 * n_steps, sorted(set(names))
+        if form == "planes3":
+            assert sum(1 for n in names if n.startswith("conv_p3")) == 14 * n_steps
+        eager = snapshot()
+        assert float(eager["s/fc_latent_enc.weight/step"]) == n_steps
+        # --- captured: warm-up on a side stream, capture one step, back to the start, three replays
+        reset()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                one_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            one_step()
+        reset()
+        for i in range(n_steps):
+            xin.copy_(data[i * B:(i + 1) * B])
+            graph.replay()
+        replayed = snapshot()
+        assert set(eager) == set(replayed)
+        diff = [k for k in eager if not torch.equal(eager[k], replayed[k])]
+        assert not diff, diff[:8]
+        assert not torch.equal(eager["p/fc_latent_dec.weight"], init["fc_latent_dec.weight"])       # it did train
+        opt.remove_fusion()
+    finally:
+        _lib.profile_enable(False)
+        _lib.set_f32_mma_mode(was)

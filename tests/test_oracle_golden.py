@@ -162,3 +162,35 @@ def test_sparse_resampling_form_equals_the_dense_one(small, golden_dir):
     torch.nn.functional.l1_loss(x2, yb).backward()
     for (name, pa), pb in zip(a.named_parameters(), b.parameters()):
         assert float((pa.grad - pb.grad).abs().max()) <= 1e-5 * float(pa.grad.abs().max()) + 1e-12, name
+
+
+def test_oracle_reproduces_the_references_nan_at_a_collapsed_edge(golden_dir):
+    """train_funcs.py:36-38 takes torch.sqrt(torch.sum(d ** 2)) of the RECONSTRUCTED edges: at a zero-length edge autograd gives
+    inf * 0 = NaN.  The oracle follows the reference there (the library does not: tests/test_gpu_parity.py::
+    test_zero_length_reconstructed_edge, include/sh_kernels.h) - pinned against the reference's own compute_score formula."""
+    import numpy as np
+    import torch
+    h = load_hierarchy(os.path.join(golden_dir, "small_ae.npz"))
+    rs = np.random.RandomState(5)
+    N1 = h.sizes[0] + 1
+    x = torch.from_numpy(rs.randn(2, N1, 3).astype(np.float32))
+    xh = (x + 0.05 * torch.from_numpy(rs.randn(2, N1, 3).astype(np.float32)))
+    f0 = np.asarray(h.faces)[0]
+    xh[1, int(f0[1])] = xh[1, int(f0[0])]
+    xo = xh.clone().requires_grad_(True)
+    lo = ref_cpu.edge_ratio_loss(xo, x, h.faces)
+    lo.backward()
+    # the reference's statement of the same score (train_funcs.py:30-39 over the batch, targets as get_target builds them)
+    faces = torch.as_tensor(np.asarray(h.faces), dtype=torch.long)
+    xr = xh.clone().requires_grad_(True)
+    tgt = [torch.sqrt(((x[:, faces[:, a]] - x[:, faces[:, b]]) ** 2).sum(2)) + 0.00001 for a, b in ((0, 1), (1, 2), (0, 2))]
+    A, Bv, C = xr[:, faces[:, 0]], xr[:, faces[:, 1]], xr[:, faces[:, 2]]
+    score = torch.abs(torch.sqrt(torch.sum((A - Bv) ** 2, dim=2)) / tgt[0] - 1)
+    score = score + torch.abs(torch.sqrt(torch.sum((Bv - C) ** 2, dim=2)) / tgt[1] - 1)
+    score = score + torch.abs(torch.sqrt(torch.sum((A - C) ** 2, dim=2)) / tgt[2] - 1)
+    lr = score.mean(dim=1).mean()
+    lr.backward()
+    assert lo.item() == pytest.approx(lr.item(), rel=1e-6)
+    assert torch.isnan(xr.grad[1]).any() and torch.isnan(xo.grad[1]).any()
+    assert torch.equal(torch.isnan(xo.grad), torch.isnan(xr.grad))
+    assert torch.isfinite(xo.grad[0]).all()

@@ -221,40 +221,13 @@ def test_three_plane_weight_gradient_error_against_float64(tpl, B, n_taken, adve
     assert not bad, bad
 
 
-def test_three_plane_weight_gradient_carries_the_presum_job_bitwise():
-    """sh_spiral_conv_bwd_wgt_p3_presum: the rows its tail workgroups write are sh_spmm's rows (and their image is the image of those
-    rows), bit for bit, and the slabs are those of the launch without a job."""
-    import p3_probe
-    from semantichuman_amd import _lib, ops
-    lib = _lib.load()
-    d = dev()
-    torch.manual_seed(5)
-    B, R, n_in, S, cin, cout, n_sum = 64, 301, 407, 7, 32, 32, 157
-    table = torch.randint(0, n_in, (R, S), dtype=torch.int32, device=d)
-    x = torch.randn(n_in, B, cin, device=d)
-    dp = torch.randn(R + n_sum, B, cout, device=d)
-    g = np.random.RandomState(1)
-    rowptr = np.concatenate([[0], np.cumsum(g.randint(1, 9, size=n_sum))]).astype(np.int32)      # 1..8 entries: both tail paths
-    col = g.randint(0, R, size=rowptr[-1]).astype(np.int32)
-    val = np.ones(rowptr[-1], dtype=np.float32)
-    m = tuple(torch.from_numpy(a).to(d) for a in (rowptr, col, val))
-    xi, di = p3_probe.to_p3(x), p3_probe.to_p3(dp[:R].contiguous())
-    assert lib.sh_spiral_conv_bwd_wgt_p3_ok(B, R, S, cin, cout)
-    nb = lib.sh_spiral_conv_bwd_wgt_p3_workspace(B, R, S, cin, cout)
-    ws0 = torch.zeros(nb // 4, dtype=torch.float32, device=d)
-    ws1 = torch.zeros_like(ws0)
-    _lib.check(lib.sh_spiral_conv_bwd_wgt_p3(_lib.ptr(di), _lib.ptr(xi), _lib.ptr(table), _lib.ptr(ws0), nb, B, R, S, cin, cout, _lib.stream_ptr()), "p3")
-    want = dp.clone()
-    ops.spmm(m, want, "vm", want[R:], "vm", n_sum)
-    for with_img in (False, True):
-        got = dp.clone()
-        img = torch.zeros(lib.sh_p3_bytes(n_sum, B, cout), dtype=torch.uint8, device=d) if with_img else None
-        ws1.zero_()
-        _lib.check(lib.sh_spiral_conv_bwd_wgt_p3_presum(_lib.ptr(di), _lib.ptr(xi), _lib.ptr(table), _lib.ptr(ws1), nb, _lib.ptr(got), B * cout, cout,
-                                                        _lib.ptr(m[0]), _lib.ptr(m[1]), _lib.ptr(m[2]), _lib.ptr(got[R:]), _lib.ptr(img), n_sum, B, R, S,
-                                                        cin, cout, _lib.stream_ptr()), "p3_presum")
-        torch.cuda.synchronize()
-        assert torch.equal(got, want)
-        assert torch.equal(ws1, ws0)
-        if with_img:
-            assert torch.equal(img, p3_probe.to_p3(want[R:].contiguous()))
+@pytest.mark.parametrize("tail", ["0", "1"])
+def test_three_plane_weight_gradient_carries_the_presum_job_bitwise(tail):
+    """sh_spiral_conv_bwd_wgt_p3_presum, with the job as a launch of its own in front (SH_WP3_TAIL=0, the default) and as tail
+    workgroups of the weight-gradient launch (SH_WP3_TAIL=1; read once per process, hence a child process): the rows written are
+    sh_spmm's rows (and their image is the image of those rows), bit for bit, and the slabs are those of the launch without a job."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "wgrad_p3_probe.py"), "--presum-check"], env=dict(os.environ, SH_WP3_TAIL=tail),
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and "PRESUM OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+    assert ("tail_blocks>0" in r.stdout) == (tail == "1"), r.stdout[-500:]

@@ -98,9 +98,55 @@ def probe_layers(B=64, tpl=None, adversarial=False, reps=1, seed=1, local_table=
         _lib.set_f32_mma_mode(was)
 
 
+def presum_check():
+    """sh_spiral_conv_bwd_wgt_p3_presum: rows and image of the pre-sum job are sh_spmm's, the slabs those of the launch without a job
+    (bitwise); prints which way the job ran (the library reads SH_WP3_TAIL once per process)."""
+    import numpy as np
+    lib = _lib.load()
+    d = torch.device("cuda:0")
+    torch.manual_seed(5)
+    B, R, n_in, S, cin, cout, n_sum = 64, 301, 407, 7, 32, 32, 157
+    table = torch.randint(0, n_in, (R, S), dtype=torch.int32, device=d)
+    x = torch.randn(n_in, B, cin, device=d)
+    dp = torch.randn(R + n_sum, B, cout, device=d)
+    g = np.random.RandomState(1)
+    rowptr = np.concatenate([[0], np.cumsum(g.randint(1, 9, size=n_sum))]).astype(np.int32)      # 1..8 entries: both tail paths
+    col = g.randint(0, R, size=rowptr[-1]).astype(np.int32)
+    val = np.ones(rowptr[-1], dtype=np.float32)
+    m = tuple(torch.from_numpy(a).to(d) for a in (rowptr, col, val))
+    xi, di = to_p3(x), to_p3(dp[:R].contiguous())
+    assert lib.sh_spiral_conv_bwd_wgt_p3_ok(B, R, S, cin, cout)
+    nb = lib.sh_spiral_conv_bwd_wgt_p3_workspace(B, R, S, cin, cout)
+    ws0 = torch.zeros(nb // 4, dtype=torch.float32, device=d)
+    ws1 = torch.zeros_like(ws0)
+    _lib.check(lib.sh_spiral_conv_bwd_wgt_p3(_lib.ptr(di), _lib.ptr(xi), _lib.ptr(table), _lib.ptr(ws0), nb, B, R, S, cin, cout, _lib.stream_ptr()), "p3")
+    want = dp.clone()
+    ops.spmm(m, want, "vm", want[R:], "vm", n_sum)
+    for with_img in (False, True):
+        got = dp.clone()
+        img = torch.zeros(lib.sh_p3_bytes(n_sum, B, cout), dtype=torch.uint8, device=d) if with_img else None
+        ws1.zero_()
+        _lib.profile_enable(True)
+        _lib.check(lib.sh_spiral_conv_bwd_wgt_p3_presum(_lib.ptr(di), _lib.ptr(xi), _lib.ptr(table), _lib.ptr(ws1), nb, _lib.ptr(got), B * cout, cout,
+                                                        _lib.ptr(m[0]), _lib.ptr(m[1]), _lib.ptr(m[2]), _lib.ptr(got[R:]), _lib.ptr(img), n_sum, B, R, S,
+                                                        cin, cout, _lib.stream_ptr()), "p3_presum")
+        torch.cuda.synchronize()
+        recs = _lib.profile_records()
+        _lib.profile_enable(False)
+        assert torch.equal(got, want), "rows differ from sh_spmm's"
+        assert torch.equal(ws1, ws0), "slabs differ from the launch without a job"
+        if with_img:
+            assert torch.equal(img, to_p3(want[R:].contiguous())), "image differs"
+        tail = any("wgrad_p3" in n and "presum=%d" % n_sum in n for n, _ in recs)
+        print("launches:", [n.split("|")[0] for n, _ in recs], "tail_blocks>0" if tail else "own launch")
+    print("PRESUM OK")
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     flags = [a for a in sys.argv[1:] if a.startswith("--")]
+    if "--presum-check" in flags:
+        return presum_check()
     B = int(args[0]) if args else 64
     tpl = args[1] if len(args) > 1 else None
     reps = 20
