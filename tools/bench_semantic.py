@@ -33,7 +33,30 @@ def voronoi_parts(v, k):
     return [np.sort(np.nonzero(owner == j)[0]) for j in range(k)]
 
 
-def run(batch=16, steps=50, graph=False, dev=None, warmup=10, torch_ops=False):
+def kernel_report(step, n_prof=3):
+    """Library kernels of `n_prof` eagerly launched iterations (the library's own per-launch HIP events): per kernel name
+    launches / iteration and us / iteration, sorted by time; plus the raw per-launch records of one iteration."""
+    from semantichuman_amd import _lib
+    torch.cuda.synchronize()
+    _lib.profile_enable(True)
+    for _ in range(n_prof):
+        step()
+    torch.cuda.synchronize()
+    recs = _lib.profile_records()
+    _lib.profile_enable(False)
+    agg = {}
+    for name, ms in recs:
+        k = name.split("|")[0]
+        a = agg.setdefault(k, [0, 0.0])
+        a[0] += 1
+        a[1] += ms
+    rows = [{"kernel": k, "launches_per_iteration": n / n_prof, "us_per_iteration": 1e3 * ms / n_prof} for k, (n, ms) in agg.items()]
+    rows.sort(key=lambda r: -r["us_per_iteration"])
+    per = len(recs) // n_prof
+    return rows, recs[:per], sum(r["us_per_iteration"] for r in rows)
+
+
+def run(batch=16, steps=50, graph=False, dev=None, warmup=10, torch_ops=False, report=False):
     """The measurement as a function (bench.py's `secondary` block calls it with graph=True)."""
     a = SimpleNamespace(batch=batch, steps=steps, graph=graph)
     dev = dev or torch.device("cuda:0")
@@ -106,10 +129,18 @@ def run(batch=16, steps=50, graph=False, dev=None, warmup=10, torch_ops=False):
         loss = out if out is not None else loss
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
-    return {"metric": "semantic training iteration (3 passes), 6890 vertices", "batch_per_pass": B, "steps": a.steps,
-            "launch": "hipGraph replay" if a.graph else "eager", "ms_per_iteration": 1e3 * dt, "meshes_per_s": 3 * B / dt,
-            "loss": float(loss.detach()), "dtype": "f32", "data": "synthetic (Voronoi parts, synthetic joint regressor)",
-            "parts": {n: int(len(p)) for n, p in list(fine.items())[:4]}}
+    res = {"metric": "semantic training iteration (3 passes), 6890 vertices", "batch_per_pass": B, "steps": a.steps,
+           "launch": "hipGraph replay" if a.graph else "eager", "ms_per_iteration": 1e3 * dt, "meshes_per_s": 3 * B / dt,
+           "loss": float(loss.detach()), "dtype": "f32", "data": "synthetic (Voronoi parts, synthetic joint regressor)",
+           "parts": {n: int(len(p)) for n, p in list(fine.items())[:4]}}
+    if report:
+        rows, one, tot = kernel_report(step)
+        res["library_kernel_us_per_iteration"] = tot
+        res["library_launches_per_iteration"] = len(one)
+        res["kernel_breakdown"] = rows[:10]
+        res["_records"] = one
+        res["_pair_loss"] = {"B": 3 * B, "part_sizes": [int(len(p)) for p in fine.values()]}
+    return res
 
 
 def main():
@@ -118,8 +149,21 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--graph", action="store_true", help="capture the iteration into a hipGraph and replay it")
     ap.add_argument("--torch-ops", action="store_true", help="list the tensor-library launches left in the iteration, by call site")
+    ap.add_argument("--layer-report", action="store_true", help="every library launch of one iteration (us), then the totals by kernel")
     a = ap.parse_args()
-    print(json.dumps(run(a.batch, a.steps, a.graph, torch_ops=a.torch_ops)))
+    res = run(a.batch, a.steps, a.graph, torch_ops=a.torch_ops, report=a.layer_report)
+    if a.layer_report:
+        print("%-52s %-52s %8s" % ("kernel", "shape", "us"))
+        for name, ms in res.pop("_records"):
+            k, _, shape = name.partition("|")
+            print("%-52s %-52s %8.1f" % (k.replace("_kernel", ""), shape, 1e3 * ms))
+        print("--- by kernel (launches / iteration, us / iteration)")
+        for r in res["kernel_breakdown"]:
+            print("%-52s %6.1f %9.1f" % (r["kernel"], r["launches_per_iteration"], r["us_per_iteration"]))
+        print("library kernels: %.1f us / iteration in %d launches (torch's own element-wise launches are not in this list)" %
+              (res["library_kernel_us_per_iteration"], res["library_launches_per_iteration"]))
+        res.pop("_pair_loss", None)
+    print(json.dumps(res))
 
 
 if __name__ == "__main__":
