@@ -1172,10 +1172,12 @@ def main():
     ap.add_argument("--adam-overlap", action="store_true", help="update the big parameters on a side stream underneath backward (measured: no gain, the GPU is already saturated)")
     ap.add_argument("--grad-comm", choices=["fp32", "bf16"], default="fp32",
                     help="N > 1: type of the two large gradient messages (bf16 halves the xGMI bytes; fp32 is the measured default)")
-    ap.add_argument("--shard-optimizer", action="store_true",
-                    help="N > 1, fp32: reduce-scatter the two latent FC gradients, update 1/N of each FC per rank, all-gather the weights "
-                         "(same xGMI bytes as the all-reduce, 1/N of Adam's HBM traffic); weights bitwise those of the all-reduce path "
-                         "(tests/test_parallel_gloo.py).  Off by default: no N > 1 hardware run has measured it")
+    ap.add_argument("--shard-optimizer", dest="shard_optimizer", action="store_true", default=None,
+                    help="N > 1: reduce-scatter the two latent FC gradients, update 1/N of each FC per rank, all-gather the weights "
+                         "(same xGMI bytes as the all-reduce, 1/N of Adam's HBM traffic and state); weights bitwise those of the all-reduce "
+                         "path, bf16 working copies kept current (tests/test_parallel_gloo.py).  Default: ON for --dtype bf16 (BASELINE "
+                         "configs[2], where Adam is the step's largest HBM stream), off for fp32 - no N > 1 hardware run has measured either")
+    ap.add_argument("--no-shard-optimizer", dest="shard_optimizer", action="store_false")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="arithmetic of the kernels: f32 = BASELINE configs[1] (the headline), bf16 = configs[2] (bf16 activations and "
                          "working weights, fp32 accumulation, fp32 master weights / gradients / Adam)")
@@ -1261,7 +1263,8 @@ def main():
         model.set_compute_dtype(torch.bfloat16)
     init_state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     ft = sh.FaceTables(h.faces, h.sizes[0] + 1, dev)
-    shard_opt = bool(args.shard_optimizer) and (world > 1 or force_reducer) and args.dtype == "f32" and not safe
+    want_shard = (args.dtype == "bf16") if args.shard_optimizer is None else bool(args.shard_optimizer)
+    shard_opt = want_shard and (world > 1 or force_reducer) and not safe
     reducer = GradientAllReducer(model, bucket_cap_mb=64.0, force_collectives=force_reducer, overlap=not safe,
                                  average_in_collective=not safe, shard_large=shard_opt,
                                  large_message_dtype=torch.bfloat16 if (args.grad_comm == "bf16" and not shard_opt) else None) \

@@ -150,20 +150,29 @@ class GradientAllReducer:
         slices (the slice leaves share the parameters' storage, so this rank's part is already in place)."""
         if not self.shard_large:
             return
+        from . import shadow
         for p, sh in self.shards.items():
-            flat = p.data.view(-1)
-            n = sh.numel()
-            if self._all_gather_into is not False:
-                try:
-                    dist.all_gather_into_tensor(flat, sh.data.clone() if flat.device.type == "cpu" else sh.data, group=self.group)
-                    self._all_gather_into = True
-                    continue
-                except (RuntimeError, NotImplementedError):
-                    if self._all_gather_into is True:
-                        raise
-                    self._all_gather_into = False
-            parts = [flat[r * n:(r + 1) * n] for r in range(self.world)]
-            dist.all_gather(parts, sh.data.clone(), group=self.group)
+            self._gather_one(p, sh)
+            # bf16 compute path: the optimizer updated the SLICE (a parameter of its own - it has no working copy), and the
+            # all-gather wrote the other ranks' slices through `p.data`, which torch's version counter does not see: the bf16
+            # working copy of the whole parameter is re-converted here, in place (one streaming pass; a captured graph keeps
+            # its address)
+            shadow.refresh(p)
+
+    def _gather_one(self, p, sh):
+        flat = p.data.view(-1)
+        n = sh.numel()
+        if self._all_gather_into is not False:
+            try:
+                dist.all_gather_into_tensor(flat, sh.data.clone() if flat.device.type == "cpu" else sh.data, group=self.group)
+                self._all_gather_into = True
+                return
+            except (RuntimeError, NotImplementedError):
+                if self._all_gather_into is True:
+                    raise
+                self._all_gather_into = False
+        parts = [flat[r * n:(r + 1) * n] for r in range(self.world)]
+        dist.all_gather(parts, sh.data.clone(), group=self.group)
 
     _all_gather_into = None
 

@@ -55,5 +55,17 @@ def lookup(param: torch.Tensor):
     return ent[1]
 
 
+def refresh(param: torch.Tensor) -> bool:
+    """Re-convert the registered copy of `param` IN PLACE, whatever its bookkeeping says - for a writer that changes the master
+    through a view torch's version counter does not see (parallel.GradientAllReducer.gather_weights: the all-gather lands in
+    `param.data`).  Returns False when the parameter has no copy (nothing reads it as bf16 yet)."""
+    ent = _entry(param)
+    if ent is None or ent[1].device != param.device or ent[1].shape != param.shape:
+        return False
+    ops.cast_bf16(param.detach().contiguous(), out=ent[1])
+    ent[2] = (param._version, param.data_ptr())
+    return True
+
+
 def drop(param: torch.Tensor):
     _REG.pop(id(param), None)

@@ -318,6 +318,14 @@ def _sharded_worker(rank, world, port, golden_dir, sharded, out_dir):
     from semantichuman_amd import synthetic
     from semantichuman_amd.parallel import GradientAllReducer, shard_batch
     m, h = _build(golden_dir)
+    # bf16 working copies of the large parameters (semantichuman_amd.shadow), as the bf16 compute path keeps them: on this CPU
+    # box the conversion kernel is replaced by torch's cast - what is under test is that the sharded update keeps the copies
+    # CURRENT (the optimizer only ever sees this rank's slice; the all-gather writes through `p.data`)
+    from semantichuman_amd import ops, shadow
+    ops.cast_bf16 = lambda src, out=None: (out.copy_(src.to(torch.bfloat16)) if out is not None else src.to(torch.bfloat16))
+    big = [p for p in m.parameters() if p.numel() * 4 >= 0.05 * 2 ** 20]
+    copies = [shadow.get(p) for p in big]
+    addrs = [c.data_ptr() for c in copies]
     red = GradientAllReducer(m, bucket_cap_mb=0.05, inplace_min_mb=0.05, shard_large=sharded)
     params = red.optimizer_params()
     if sharded:
@@ -336,6 +344,11 @@ def _sharded_worker(rank, world, port, golden_dir, sharded, out_dir):
         red.finish()
         opt.step()
         red.gather_weights()
+        if sharded:      # after every step the working copies are the bf16 image of the gathered weights, where they always were
+            assert len(big) >= 2
+            for p, c, a in zip(big, copies, addrs):
+                assert shadow.lookup(p) is c and c.data_ptr() == a
+                assert torch.equal(c, p.detach().to(torch.bfloat16))
     state_elems = sum(v.numel() for st in opt.state.values() for v in st.values() if torch.is_tensor(v))
     torch.save({"w": {k: v.clone() for k, v in m.state_dict().items()}, "state_elems": state_elems},
                os.path.join(out_dir, "s%d_r%d.pt" % (int(sharded), rank)))
@@ -345,7 +358,8 @@ def _sharded_worker(rank, world, port, golden_dir, sharded, out_dir):
 def test_sharded_update_of_the_large_parameters_is_bitwise_the_all_reduce_path(golden_dir, tmp_path):
     """VERDICT r3 item 9 (what the CPU can prove): the two latent FC gradients reduce-scattered, Adam on 1 / world of each FC,
     the updated slices all-gathered - after three steps every weight on every rank is BITWISE the weight of the all-reduce
-    path, with half the optimizer state per rank."""
+    path, with half the optimizer state per rank - and (round 6) the bf16 working copies the bf16 compute path keeps of those
+    parameters are current after every step, at their old addresses (asserted inside the workers)."""
     world = 2
     for sharded in (False, True):
         mp.spawn(_sharded_worker, args=(world, _free_port(), golden_dir, sharded, str(tmp_path)), nprocs=world, join=True)
