@@ -34,6 +34,7 @@ FD = [[128, 64, 32, 32, 16], [[], [], [], [], 3]]
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA dense peak
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
+PAIRDIST_VALU_INSTR_PER_PAIR = 170.0    # pairdist_fwd_kernel, thresholded weight mode: DESIGN 4c; re-measured in profiles/r06_pmc_sq_semantic.txt
 
 
 def f32_work_table(model, B):
@@ -177,7 +178,10 @@ def measured_traffic(kernel, workload):
     batch, dtype, arithmetic form), on THIS build of the kernel library (sh_build_id() of the loaded .so) and with the same
     SH_* switches; anything else yields (None, reason) instead of a silently wrong number."""
     from semantichuman_amd import _lib
-    name = "r05_pmc_traffic_%s.json" % workload
+    import glob
+    # the newest round's profile of this workload (profiles/rNN_pmc_traffic_<workload>.json); its stamp decides whether it is quoted
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic_%s.json" % workload)))
+    name = os.path.basename(cands[-1]) if cands else "r06_pmc_traffic_%s.json" % workload
     path = os.path.join(ROOT, "profiles", name)
     try:
         pmc = json.load(open(path))
@@ -537,9 +541,28 @@ def secondary_block(sh, h, B, dev, init_state, data, test, ft, cpu_l2_mm, args):
     def semantic_leg():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_semantic
-        r = bench_semantic.run(batch=16, steps=steps, graph=True, dev=dev, warmup=5)
+        r = bench_semantic.run(batch=16, steps=steps, graph=True, dev=dev, warmup=5, report=True)
         r["config"] = "semantic training iteration (SURVEY row f1): 3 passes x 16 meshes, all part losses, backward, Adam"
         r["f32_mma"] = _lib.get_f32_mma_mode()
+        r.pop("_records", None)
+        pl = r.pop("_pair_loss", None)
+        r["kernel_breakdown"] = r.get("kernel_breakdown", [])[:6]
+        # the dominant kernel of the iteration is the part pair-distance sweep (train_funcs.py:243-284, utils_SH.py:442-478): neither
+        # HBM- nor MFMA-bound but VALU / transcendental-bound - acosf, two square roots and three IEEE divisions per vertex pair.
+        # Its roof is the vector ALU's issue rate: 256 CUs x 4 SIMDs x 16 lanes per clock at 2.4 GHz; instructions per pair from the
+        # PMC pass of profiles/r06_pmc_sq_semantic.txt (SQ_INSTS_VALU of the launch / its pairs)
+        top = r["kernel_breakdown"][0] if r["kernel_breakdown"] else None
+        if top and pl and top["kernel"].startswith("pairdist_fwd"):
+            pairs = float(pl["B"]) / 3.0 * sum(n * (n - 1) for n in pl["part_sizes"])      # per launch: one pass's 16 meshes x ordered pairs of every part
+            per_launch_s = 1e-6 * top["us_per_iteration"] / max(1.0, top["launches_per_iteration"])
+            ipp = PAIRDIST_VALU_INSTR_PER_PAIR
+            peak = 256 * 4 * 16 * 2.4e9 / 1e12
+            ach = pairs * ipp / per_launch_s / 1e12
+            byt, why = measured_traffic("pairdist_fwd_kernel", "semantic_6890v_b48_f32_" + _lib.get_f32_mma_mode())
+            r["roofline"] = {"kernel": top["kernel"], "bound": "valu", "achieved": ach, "peak": peak, "unit": "T lane-op/s", "frac": ach / peak,
+                             "pairs_per_launch": pairs, "valu_instr_per_pair": ipp, "avg_launch_ms": 1e3 * per_launch_s,
+                             "traffic": byt, "traffic_note": why,
+                             "note": "vertex pairs x VALU instructions per pair / launch time against the vector ALU issue peak; not an HBM or MFMA kernel"}
         return r
 
     def other_f32_leg(other):
