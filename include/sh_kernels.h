@@ -686,18 +686,20 @@ SH_API int sh_spiral_conv_bwd_data_p3(const void* dprep, int dpre_zero_row, cons
  * what its forward plane conv gathered), dpre_planes = image of the pre-activation gradient (rows [0, R) are read) - six
  * bf16 partial products per fp32 product, fp32 accumulation, the arithmetic of sh_spiral_conv_fwd_p3.  Writes partial slabs
  * (dW and dbias) into workspace, in the layout and for the deferred reduction of sh_spiral_conv_bwd_wgt(dW == NULL):
- * sh_spiral_conv_bwd_wgt_reduce_multi_p3.  .._p3_ok: 1 when the kernel takes the shape (batch % 32 == 0, Cin 16 or a multiple
- * of 32, Cout a multiple of 32); otherwise the caller keeps sh_spiral_conv_bwd_wgt. */
+ * sh_spiral_conv_bwd_wgt_reduce_multi_kinds (kind 2).  .._p3_ok: 1 when the kernel takes the shape (batch % 16 == 0, Cin 16 or a
+ * multiple of 32, Cout a multiple of 32); otherwise the caller keeps sh_spiral_conv_bwd_wgt.  dpre_zero_row: a row of dpre that
+ * is all zero (the layer's dummy row), or -1 - needed only when R * (B / 16) is odd: the kernel sums pairs of 16-row units and
+ * completes an odd count with that row's (SH_ERR_UNSUPPORTED without one). */
 SH_API int sh_spiral_conv_bwd_wgt_p3_ok(int B, int R, int S, int Cin, int Cout);
 SH_API size_t sh_spiral_conv_bwd_wgt_p3_workspace(int B, int R, int S, int Cin, int Cout);
-SH_API int sh_spiral_conv_bwd_wgt_p3(const void* dpre_planes, const void* x_planes, const int32_t* table, void* workspace,
+SH_API int sh_spiral_conv_bwd_wgt_p3(const void* dpre_planes, int dpre_zero_row, const void* x_planes, const int32_t* table, void* workspace,
                                      size_t workspace_bytes, int B, int R, int S, int Cin, int Cout, sh_stream_t stream);
 /* The same launch also carrying a pre-sum job, as sh_spiral_conv_bwd_wgt_presum does for the fp32 kernels: sum_out[r] = sum_e
  * sum_val[e] * dpre[sum_col[e]] for r < sum_rows over the FP32 gradient rows dpre (element strides dp_sv, dp_sb; sum_out has the
  * same strides; sum_out_planes != NULL: also the image of those rows) - sh_spmm's sums bit for bit, run by tail workgroups of
  * the launch (or, for rows that do not take 16-byte accesses, by sh_spmm_p3 in front of it).  sum_rows == 0: no job. */
-SH_API int sh_spiral_conv_bwd_wgt_p3_presum(const void* dpre_planes, const void* x_planes, const int32_t* table, void* workspace,
-                                            size_t workspace_bytes, const float* dpre, int64_t dp_sv, int64_t dp_sb,
+SH_API int sh_spiral_conv_bwd_wgt_p3_presum(const void* dpre_planes, int dpre_zero_row, const void* x_planes, const int32_t* table,
+                                            void* workspace, size_t workspace_bytes, const float* dpre, int64_t dp_sv, int64_t dp_sb,
                                             const int32_t* sum_rowptr, const int32_t* sum_col, const float* sum_val, float* sum_out,
                                             void* sum_out_planes, int sum_rows, int B, int R, int S, int Cin, int Cout,
                                             sh_stream_t stream);

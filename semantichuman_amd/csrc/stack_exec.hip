@@ -261,7 +261,7 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
                 if (rc != SH_OK) return rc;
             }
             const bool p3w = p3 && p3_wgrad_on && i > 0 && in_planes && in_planes[i] && il.sb == s.cin && il.sv == (long)B * s.cin &&
-                             sh_spiral_conv_bwd_wgt_p3_ok(B, s.R, s.S, s.cin, s.cout) &&
+                             sh_spiral_conv_bwd_wgt_p3_ok(B, s.R, s.S, s.cin, s.cout) && (((long)s.R * (B / 16)) % 2 == 0 || s.zero_row >= 0) &&
                              workspace_bytes[i] >= sh_spiral_conv_bwd_wgt_p3_workspace(B, s.R, s.S, s.cin, s.cout);
             if (!thin) {
                 const sh_csr_ref& lm = s.n2 ? s.sum2 : s.sum1;
@@ -274,7 +274,7 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
                         if (rc != SH_OK) return rc;
                         cur_img_done = true;
                     }
-                    rc = sh_spiral_conv_bwd_wgt_p3_presum(cur_img, in_planes[i], s.table, workspace[i], workspace_bytes[i], cur, cl.sv, cl.sb,
+                    rc = sh_spiral_conv_bwd_wgt_p3_presum(cur_img, s.zero_row, in_planes[i], s.table, workspace[i], workspace_bytes[i], cur, cl.sv, cl.sb,
                                                           ln ? lm.rowptr : nullptr, ln ? lm.col : nullptr, ln ? lm.val : nullptr,
                                                           ln ? lout : nullptr, limg, ln, B, s.R, s.S, s.cin, s.cout, stream);
                 } else {

@@ -45,7 +45,10 @@ struct WP3Params {
     int B, R, S, Cin, Cout, K;
     int nxg;                                   // gathered 32-column groups: S * Cin / 32, or ceil(S / 2) for 16-channel images
     int n_qg, n_pt, sgx, nslab, n_items;       // sgx: workgroups (slabs) per XCD and tile
-    int xsplit, dnt;                           // xsplit: one batch pair per XCD; dnt: non-temporal dpre loads
+    int nbg;                                   // 16-batch groups per row (B / 16)
+    long n_units;                              // R * nbg (vertex, batch group) units; a stage = units 2 t and 2 t + 1
+    long zero_unit16;                          // dpre-image offset (16-byte units) of batch group 0 of an all-zero row: the partner of
+                                               // the last unit when n_units is odd (-1: none - the plan refuses an odd count)
     // tail job (sh_spiral_conv_bwd_wgt_p3_presum): workgroups n_items .. n_items + tail_blocks - 1 of the launch fill the pre-summed
     // rows the layer's backward-data pass reads through its transposed table - y[r] = sum_e val[e] dpre[col[e]] over the FP32
     // gradient rows, sh_spmm's arithmetic entry for entry (the rider of wgrad_stream_kernel, spiral_conv.hip)
@@ -157,13 +160,14 @@ __device__ __forceinline__ void wp_presum_tail(const WP3Params& p) {
     }
 }
 
-// Work assignment.  XCD x (= blockIdx & 7: workgroups are dealt round-robin) owns ONE batch pair (x % nbp, nbp = B / 32) and a
-// contiguous vertex range, and its C = 4 sgx waves per tile walk that range TOGETHER: wave c takes vertices lo + c, lo + c + C, ...
-// The kernel is a gather stream whose traffic beyond L2 is what it waits for (PMC: L2 hit rate 71 %, 157 MB fetched for 84 MB
-// of images at 3446 rows x 352 columns, ~4 TB/s of HBM / Infinity-Cache traffic under a 37-us launch), so what an XCD's 4 MiB L2
-// must hold between two uses of a gathered row decides: with this order it is the images of ~two rings of the mesh for ONE
-// batch pair (6 KiB per row) plus the dpre rows streamed past them in the meantime.  (A contiguous block of stages per wave
-// has every wave on a different part of the mesh; both batch pairs per XCD double the bytes between two uses.)
+// Work assignment.  The reduction rows are cut into UNITS of one vertex x one 16-batch group (one fragment per plane and channel
+// group); a STAGE is two consecutive units (2 t, 2 t + 1) - the 32 reduction rows of a matrix instruction; for batches that are
+// multiples of 32 both belong to one vertex, otherwise (16, 48, ...) a stage may pair two vertices: every unit brings its own
+// gather offsets, nothing else changes.  An odd unit count is completed by a unit of an all-zero dpre row (its products are 0).
+// XCD x (= blockIdx & 7: workgroups are dealt round-robin) owns a contiguous eighth of the stages and its C = 4 sgx waves per tile
+// walk it TOGETHER: wave c takes stages lo + c, lo + c + C, ... - at any moment the XCD gathers the neighbourhoods of a short run
+// of consecutive vertices.  (Measured, profiles/r06_wgrad_p3.txt: what this kernel waits for is the L2 -> CU gather itself, 11-15
+// TB/s of plane bytes; a perfectly local table, one batch pair per XCD, or non-temporal dpre loads change its time by < 2 %.)
 template <int QF, int PT, bool XC16>
 __global__ __launch_bounds__(256) void wgrad_p3_kernel(const WP3Params p) {
     static_assert(PT % 2 == 0, "dpre channels come in 32-channel fragments");
@@ -180,35 +184,32 @@ __global__ __launch_bounds__(256) void wgrad_p3_kernel(const WP3Params p) {
     const int qg = tile % p.n_qg, pt = tile / p.n_qg;
     const int sgroup = xcd * p.sgx + sgl;
     const int C = 4 * p.sgx, c = sgl * 4 + wave;
-    const int S = p.S, nbp = p.B >> 5;
-    // stage n of this wave = stage S0 + c + n C of the XCD's list.  xsplit (8 % nbp == 0): the XCD owns ONE batch pair
-    // (xcd % nbp) and a contiguous vertex range - its list is that range's vertices; otherwise (vertex, batch pair) pairs in order
-    const bool xsplit = p.xsplit != 0;
-    int S0, S1;
-    if (xsplit) { const int Gx = 8 / nbp, gx = xcd / nbp; S0 = (int)((long)gx * p.R / Gx); S1 = (int)((long)(gx + 1) * p.R / Gx); }
-    else { S0 = (int)((long)xcd * p.n_stages / 8); S1 = (int)((long)(xcd + 1) * p.n_stages / 8); }
+    const int S = p.S, nbg = p.nbg;
+    const int S0 = (int)((long)xcd * p.n_stages / 8), S1 = (int)((long)(xcd + 1) * p.n_stages / 8);
     const int nst = c < S1 - S0 ? (S1 - S0 - c + C - 1) / C : 0;
-    // this wave's source offsets -> LDS, all in 16-byte units (32 bits reach 64 GiB): per stage n (vertex v, batch pair bp)
-    //   Tl[n * NE + 0]         dpre:  v * d_vb + 2 bp * d_bgb
-    //   Tl[n * NE + 1 + k * H + hb]  gathered group k (16-channel images: its half hb): table[v][position] * x_vb + 2 bp * x_bgb +
-    //                          the offset of its 32-channel group       (groups past the end: a duplicate of the last, never stored)
-    // so a group's source address is ONE LDS read away and the loop holds no division
-    constexpr int H = XC16 ? 2 : 1, NE = 1 + QF * H;
+    // this wave's source offsets -> LDS, all in 16-byte units (32 bits reach 64 GiB): per stage n and unit h (0 / 1)
+    //   Tl[n * NE + h]                          dpre:  v * d_vb + bg * d_bgb   (the completing unit: the zero row's)
+    //   Tl[n * NE + 2 + 2 (k * H + hb) + h]     gathered group k (16-channel images: its half hb): table[v][position] * x_vb + bg * x_bgb +
+    //                                           the offset of its 32-channel group   (groups past the end: a duplicate, never stored)
+    // so a fragment's source address is ONE LDS read away and the loop holds no division
+    constexpr int H = XC16 ? 2 : 1, NE = 2 + 2 * QF * H;
     const int f0 = qg * QF;
     for (int i = lane; i < nst * NE; i += 64) {
-        const int n = i / NE, e = i - n * NE;
-        const int sn = S0 + c + n * C;
-        const int v = xsplit ? sn : sn / nbp, bp = xsplit ? xcd % nbp : sn - v * nbp;
+        const int n = i / NE, e = i - n * NE, hu = e & 1;
+        const long u = 2L * (S0 + c + n * C) + hu;
+        const bool pad = u >= p.n_units;                                    // only the very last unit of an odd count
+        const long uc = pad ? u - 1 : u;
+        const int v = (int)(uc / nbg), bg = (int)(uc - (long)v * nbg);
         unsigned val;
-        if (e == 0) {
-            val = (unsigned)v * (unsigned)(p.d_vb >> 4) + (unsigned)(2 * bp) * (unsigned)(p.d_bgb >> 4);
+        if (e < 2) {
+            val = pad ? (unsigned)p.zero_unit16 : (unsigned)v * (unsigned)(p.d_vb >> 4) + (unsigned)bg * (unsigned)(p.d_bgb >> 4);
         } else {
-            const int k = (e - 1) / H, hb = (e - 1) - k * H;
+            const int kk = (e - 2) >> 1, k = kk / H, hb = kk - k * H;
             const int f = f0 + k < p.nxg ? f0 + k : p.nxg - 1;
             int sp, off16;
             if (XC16) { sp = 2 * f + hb < S ? 2 * f + hb : S - 1; off16 = 0; }
             else { const int ncg = p.Cin >> 5; sp = f / ncg; off16 = (f - sp * ncg) * 192; }
-            val = (unsigned)p.table[(long)v * S + sp] * (unsigned)(p.x_vb >> 4) + (unsigned)(2 * bp) * (unsigned)(p.x_bgb >> 4) + (unsigned)off16;
+            val = (unsigned)p.table[(long)v * S + sp] * (unsigned)(p.x_vb >> 4) + (unsigned)bg * (unsigned)(p.x_bgb >> 4) + (unsigned)off16;
         }
         Tl[i] = (int)val;
     }
@@ -218,9 +219,6 @@ __global__ __launch_bounds__(256) void wgrad_p3_kernel(const WP3Params p) {
     typedef __attribute__((address_space(3))) char* lptr_t;
     auto dma16 = [](const char* gsrc, unsigned lds_dst) {
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory", "m0");
-    };
-    auto dma16nt = [](const char* gsrc, unsigned lds_dst) {                 // streamed once: do not displace the gathered rows in L2
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" : : "v"(gsrc), "s"(lds_dst) : "memory", "m0");
     };
     const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_t)ring);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // the offsets are in LDS
@@ -232,37 +230,38 @@ __global__ __launch_bounds__(256) void wgrad_p3_kernel(const WP3Params p) {
     auto issue = [&](auto JJ) {
         constexpr int jj = decltype(JJ)::value;
         const unsigned slot = ring_lds + (unsigned)((issued % G) * WP_GRP);
-        if constexpr (jj < NGD) {                                           // fragments (batch group 2 bp + bgi, plane pl) of 32 dpre channels
-            const unsigned o = (unsigned)__builtin_amdgcn_readfirstlane(Tl[iss_n * NE]);
-            const char* base = dbase + ((unsigned long)o << 4) + jj * 3072;
-            if (p.dnt) {
+        if constexpr (jj < NGD) {                                           // fragments (unit h, plane pl) of 32 dpre channels
 #pragma unroll
-                for (int bgi = 0; bgi < 2; ++bgi)
+            for (int h = 0; h < 2; ++h) {
+                const unsigned o = (unsigned)__builtin_amdgcn_readfirstlane(Tl[iss_n * NE + h]);
+                const char* base = dbase + ((unsigned long)o << 4) + jj * 3072;
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) dma16nt(base + bgi * p.d_bgb + pl * 1024, slot + (unsigned)((bgi * 3 + pl) * WP_BLK));
-            } else {
-#pragma unroll
-                for (int bgi = 0; bgi < 2; ++bgi)
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) dma16(base + bgi * p.d_bgb + pl * 1024, slot + (unsigned)((bgi * 3 + pl) * WP_BLK));
+                for (int pl = 0; pl < 3; ++pl) dma16(base + pl * 1024, slot + (unsigned)((h * 3 + pl) * WP_BLK));
             }
         } else {
             constexpr int k = jj - NGD;
-            if constexpr (XC16) {                                           // per half: 3072 contiguous bytes = (bg, plane) x 512
+            if constexpr (XC16) {
+                // per half hb: the two units' three 512-byte planes = six planes [lo h, lo m, lo l, hi h, hi m, hi l], two per
+                // instruction (lanes 0-31 the first, 32-63 the second; lane_off already carries the second plane's + 512):
+                // (lo h | lo m), (lo l | hi h), (hi m | hi l) - only the middle one takes its halves from different units
 #pragma unroll
                 for (int hb = 0; hb < 2; ++hb) {
-                    const unsigned o = (unsigned)__builtin_amdgcn_readfirstlane(Tl[iss_n * NE + 1 + k * 2 + hb]);
-                    const char* base = xbase + ((unsigned long)o << 4);
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) dma16(base + i * 1024, slot + (unsigned)((hb * 3 + i) * WP_BLK));
+                    const unsigned olo = (unsigned)__builtin_amdgcn_readfirstlane(Tl[iss_n * NE + 2 + 2 * (k * 2 + hb)]);
+                    const unsigned ohi = (unsigned)__builtin_amdgcn_readfirstlane(Tl[iss_n * NE + 2 + 2 * (k * 2 + hb) + 1]);
+                    const char* blo = xbase + ((unsigned long)olo << 4);
+                    const char* bhi = xbase + ((unsigned long)ohi << 4);
+                    dma16(blo, slot + (unsigned)((hb * 3 + 0) * WP_BLK));
+                    dma16(lane < 32 ? blo + 1024 : bhi - 512, slot + (unsigned)((hb * 3 + 1) * WP_BLK));
+                    dma16(bhi + 512, slot + (unsigned)((hb * 3 + 2) * WP_BLK));
                 }
             } else {
-                const unsigned o = (unsigned)__builtin_amdgcn_readfirstlane(Tl[iss_n * NE + 1 + k]);
-                const char* base = xbase + ((unsigned long)o << 4);
 #pragma unroll
-                for (int bgi = 0; bgi < 2; ++bgi)
+                for (int h = 0; h < 2; ++h) {
+                    const unsigned o = (unsigned)__builtin_amdgcn_readfirstlane(Tl[iss_n * NE + 2 + 2 * k + h]);
+                    const char* base = xbase + ((unsigned long)o << 4);
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) dma16(base + bgi * p.x_bgb + pl * 1024, slot + (unsigned)((bgi * 3 + pl) * WP_BLK));
+                    for (int pl = 0; pl < 3; ++pl) dma16(base + pl * 1024, slot + (unsigned)((h * 3 + pl) * WP_BLK));
+                }
             }
         }
         ++issued;
@@ -439,16 +438,17 @@ __global__ __launch_bounds__(256) void wgrad_p3_kernel(const WP3Params p) {
 // column groups per wave the kernel is built for (PT = 2: <= 16, PT = 4: <= 8: 256 accumulator registers)
 constexpr int WP_QF2[] = {4, 6, 8, 9, 11, 12, 16}, WP_QF4[] = {4, 6, 8};
 
-struct WP3Plan { int ok, qf, pt, xc16, nxg, n_qg, n_pt, sgx, nslab, xsplit; long n_stages; };
+struct WP3Plan { int ok, qf, pt, xc16, nxg, n_qg, n_pt, sgx, nslab; long n_stages, n_units; };
 WP3Plan plan_wp3(int B, int R, int S, int Cin, int Cout) {
     WP3Plan w{};
-    if (B <= 0 || B % 32 != 0 || R <= 0 || S <= 0) return w;
+    if (B <= 0 || B % 16 != 0 || R <= 0 || S <= 0) return w;
     if (!(Cin == 16 || Cin % 32 == 0) || Cout % 32 != 0) return w;
     w.xc16 = Cin == 16;
     w.nxg = w.xc16 ? (S + 1) / 2 : S * (Cin / 32);
     w.pt = Cout % 64 == 0 ? 4 : 2;
     w.n_pt = Cout / (16 * w.pt);
-    w.n_stages = (long)R * (B / 32);
+    w.n_units = (long)R * (B / 16);
+    w.n_stages = (w.n_units + 1) / 2;
     // Column groups per wave (QF), out of the widths the kernel is built for: one workgroup (160 KiB of LDS) per CU, so
     // 8 XCDs x tiles x sgx <= 256 workgroups; a wave's time is its stage count x the groups of a stage (dpre + QF gathered),
     // and with only a handful of stages per wave the rounding of that count decides (1724 rows x 16 groups: 3.4 stages of 17
@@ -458,10 +458,7 @@ WP3Plan plan_wp3(int B, int R, int S, int Cin, int Cout) {
     static const int slab_mb = sh_env_int("SH_WP3_SLAB_MB", 32, 1, 4096);
     static const int q_force = sh_env_int("SH_WP3_QF", 0, 0, 16);
     const long cap = (((long)slab_mb << 20) / ((long)Cout * S * Cin * 4)) / 8;
-    static const int xsplit_on = sh_env_int("SH_WP3_XSPLIT", 1, 0, 1);
-    const int nbp = B / 32;
-    w.xsplit = xsplit_on && 8 % nbp == 0;
-    const long per_xcd = w.xsplit ? ((long)R + 8 / nbp - 1) / (8 / nbp) : (w.n_stages + 7) / 8;
+    const long per_xcd = (w.n_stages + 7) / 8;
     const int ngd = w.pt / 2;
     long best = -1, sgx = 1;
     auto consider = [&](int q) {
@@ -474,7 +471,7 @@ WP3Plan plan_wp3(int B, int R, int S, int Cin, int Cout) {
         if (sg < 1) sg = 1;
         for (;; ++sg) {                                                         // a wave's source offsets must fit its LDS area
             const long nst = (per_xcd + 4 * sg - 1) / (4 * sg);
-            if (nst * (1 + q * (w.xc16 ? 2 : 1)) <= WP_TBL_INTS) break;
+            if (nst * (2 + 2 * q * (w.xc16 ? 2 : 1)) <= WP_TBL_INTS) break;
             if (sg > per_xcd) return;
         }
         const long rounds = (8 * tiles * sg + wg_target - 1) / wg_target;        // more workgroups than CUs: they run in turns
@@ -551,13 +548,13 @@ size_t sh_spiral_conv_bwd_wgt_p3_workspace(int B, int R, int S, int Cin, int Cou
     return (size_t)w.nslab * ((size_t)Cout * S * Cin + Cout) * sizeof(float);
 }
 
-int sh_spiral_conv_bwd_wgt_p3(const void* dpre_planes, const void* x_planes, const int32_t* table, void* workspace, size_t workspace_bytes,
-                              int B, int R, int S, int Cin, int Cout, sh_stream_t stream) {
-    return sh_spiral_conv_bwd_wgt_p3_presum(dpre_planes, x_planes, table, workspace, workspace_bytes, nullptr, 0, 0, nullptr, nullptr, nullptr,
-                                            nullptr, nullptr, 0, B, R, S, Cin, Cout, stream);
+int sh_spiral_conv_bwd_wgt_p3(const void* dpre_planes, int dpre_zero_row, const void* x_planes, const int32_t* table, void* workspace,
+                              size_t workspace_bytes, int B, int R, int S, int Cin, int Cout, sh_stream_t stream) {
+    return sh_spiral_conv_bwd_wgt_p3_presum(dpre_planes, dpre_zero_row, x_planes, table, workspace, workspace_bytes, nullptr, 0, 0, nullptr, nullptr,
+                                            nullptr, nullptr, nullptr, 0, B, R, S, Cin, Cout, stream);
 }
 
-int sh_spiral_conv_bwd_wgt_p3_presum(const void* dpre_planes, const void* x_planes, const int32_t* table, void* workspace,
+int sh_spiral_conv_bwd_wgt_p3_presum(const void* dpre_planes, int dpre_zero_row, const void* x_planes, const int32_t* table, void* workspace,
                                      size_t workspace_bytes, const float* dpre, int64_t dp_sv, int64_t dp_sb, const int32_t* sum_rowptr,
                                      const int32_t* sum_col, const float* sum_val, float* sum_out, void* sum_out_planes, int sum_rows, int B,
                                      int R, int S, int Cin, int Cout, sh_stream_t stream) {
@@ -566,8 +563,11 @@ int sh_spiral_conv_bwd_wgt_p3_presum(const void* dpre_planes, const void* x_plan
                "sh_spiral_conv_bwd_wgt_p3_presum: incomplete pre-sum job");
     const WP3Plan w = plan_wp3(B, R, S, Cin, Cout);
     SH_REQUIRE(w.ok, SH_ERR_UNSUPPORTED,
-               "sh_spiral_conv_bwd_wgt_p3: B=%d S=%d Cin=%d Cout=%d is not taken (batch %% 32 == 0; Cin 16 or %% 32 == 0; Cout %% 32 == 0)", B, S,
+               "sh_spiral_conv_bwd_wgt_p3: B=%d S=%d Cin=%d Cout=%d is not taken (batch %% 16 == 0; Cin 16 or %% 32 == 0; Cout %% 32 == 0)", B, S,
                Cin, Cout);
+    SH_REQUIRE(w.n_units % 2 == 0 || (dpre_zero_row >= 0 && dpre_zero_row < R), SH_ERR_UNSUPPORTED,
+               "sh_spiral_conv_bwd_wgt_p3: %d rows x %d batch groups is an odd number of units - name an all-zero row of dpre (dpre_zero_row)", R,
+               B / 16);
     SH_REQUIRE(workspace_bytes >= sh_spiral_conv_bwd_wgt_p3_workspace(B, R, S, Cin, Cout), SH_ERR_WORKSPACE,
                "sh_spiral_conv_bwd_wgt_p3: workspace too small");
     SH_REQUIRE(((reinterpret_cast<uintptr_t>(dpre_planes) | reinterpret_cast<uintptr_t>(x_planes) | reinterpret_cast<uintptr_t>(workspace)) & 15) == 0,
@@ -583,9 +583,8 @@ int sh_spiral_conv_bwd_wgt_p3_presum(const void* dpre_planes, const void* x_plan
     p.slab_stride = (long)Cout * p.K; p.bias_off = (long)w.nslab * p.slab_stride;
     p.nxg = w.nxg; p.n_qg = w.n_qg; p.n_pt = w.n_pt; p.sgx = w.sgx; p.nslab = w.nslab; p.n_stages = w.n_stages;
     p.n_items = w.n_qg * w.n_pt * w.nslab;
-    p.xsplit = w.xsplit;
-    static const int dnt = sh_env_int("SH_WP3_DNT", 0, 0, 1);
-    p.dnt = dnt;
+    p.nbg = nbg; p.n_units = w.n_units;
+    p.zero_unit16 = dpre_zero_row >= 0 ? (long)dpre_zero_row * (p.d_vb >> 4) : -1;
     if (sum_rows > 0) {
         // the pre-sum job: a launch of its own in front of this one (default), or tail workgroups of this launch (SH_WP3_TAIL=1).
         // Measured (6890 vertices, batch 64, profiles/r06_wgrad_p3.txt): as tail workgroups the job costs MORE than its own launch -

@@ -133,16 +133,17 @@ int sh_spiral_conv_bwd_wgt_presum(const float* dpre, int64_t dp_sv, int64_t dp_s
 }
 // three-plane weight gradient: the real shape rule; reads the two images, writes its slabs, the rider as above
 int sh_spiral_conv_bwd_wgt_p3_ok(int B, int R, int S, int Cin, int Cout) {
-    return B > 0 && B % 32 == 0 && R > 0 && S > 0 && (Cin == 16 || (Cin > 0 && Cin % 32 == 0)) && Cout > 0 && Cout % 32 == 0;
+    return B > 0 && B % 16 == 0 && R > 0 && S > 0 && (Cin == 16 || (Cin > 0 && Cin % 32 == 0)) && Cout > 0 && Cout % 32 == 0;
 }
 size_t sh_spiral_conv_bwd_wgt_p3_workspace(int B, int R, int S, int Cin, int Cout) {
     return sh_spiral_conv_bwd_wgt_p3_ok(B, R, S, Cin, Cout) ? (size_t)8 * ((size_t)Cout * S * Cin + Cout) * 4 : 0;
 }
 size_t sh_p3_bytes(int rows, int B, int C);
-int sh_spiral_conv_bwd_wgt_p3_presum(const void* dpre_planes, const void* x_planes, const int32_t* table, void* ws, size_t ws_bytes, const float* dpre,
+int sh_spiral_conv_bwd_wgt_p3_presum(const void* dpre_planes, int dpre_zero_row, const void* x_planes, const int32_t* table, void* ws, size_t ws_bytes, const float* dpre,
                                      int64_t dp_sv, int64_t dp_sb, const int32_t* sum_rowptr, const int32_t* sum_col, const float* sum_val, float* sum_out,
                                      void* sum_out_planes, int sum_rows, int B, int R, int S, int Cin, int Cout, sh_stream_t st) {
     if (!sh_spiral_conv_bwd_wgt_p3_ok(B, R, S, Cin, Cout)) return SH_ERR_UNSUPPORTED;
+    if (((long)R * (B / 16)) % 2 != 0 && !(dpre_zero_row >= 0 && dpre_zero_row < R)) return SH_ERR_UNSUPPORTED;
     int n_in = 0;
     for (long i = 0; i < (long)R * S; ++i) n_in = table[i] + 1 > n_in ? table[i] + 1 : n_in;
     touch_r(dpre_planes, sh_p3_bytes(R, B, Cout)); touch_r(x_planes, sh_p3_bytes(n_in, B, Cin));

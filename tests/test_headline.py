@@ -99,11 +99,11 @@ def test_full_training_step_vs_oracle(case, form, record_property):
             assert sum(1 for n in names if n.startswith("spmm_kernel<true, p3>")) >= 6      # re-sampling + U^T launches wrote images
             assert any(n.startswith("wfrag3_prep") for n in names)
             # round 6: the weight gradients of the layers between the 3-channel sides and the 16-channel level-0 layer run on the
-            # images too (csrc/wgrad_p3.hip; batches that are multiples of 32): six of the nine, the rest on the fp32 kernels
+            # images too (csrc/wgrad_p3.hip; any batch that has images, i.e. multiples of 16 - at batch 16 a stage pairs two vertices and
+            # the 863-row layers' odd unit count is completed by the dummy row): six of the nine, the rest on the fp32 kernels
             n_wp3 = sum(1 for n in names if n.startswith("wgrad_p3_kernel"))
-            assert n_wp3 == (6 if B % 32 == 0 else 0), (n_wp3, sorted(set(names)))
-            if B % 32 == 0:
-                assert sum(1 for n in names if n.startswith(("wgrad_stream", "wgrad_split3"))) == 2, sorted(set(names))
+            assert n_wp3 == 6, (n_wp3, sorted(set(names)))
+            assert sum(1 for n in names if n.startswith(("wgrad_stream", "wgrad_split3"))) == 2, sorted(set(names))
         else:
             assert n_p3 == 0 and not any("p3" in n for n in names), sorted(set(names))
         # ---- forward, loss

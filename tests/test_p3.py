@@ -201,12 +201,15 @@ def test_latent_fc_bf16x3_error_against_float64(mnk, adversarial):
 # ---------------------------------------------------------------------------------------------------------------------------
 # round 6: the weight gradient in the three-plane form (csrc/wgrad_p3.hip; autograd of reference models.py:45, dW = dpre^T . gather(x))
 
-@pytest.mark.parametrize("tpl,B,n_taken", [("template6890.npz", 64, 6), ("template27554.npz", 32, 6)])
+@pytest.mark.parametrize("tpl,B,n_taken", [("template6890.npz", 64, 6), ("template27554.npz", 32, 6), ("template6890.npz", 16, 6),
+                                           ("template6890.npz", 48, 6)])
 @pytest.mark.parametrize("adversarial", [False, True])
 def test_three_plane_weight_gradient_error_against_float64(tpl, B, n_taken, adversarial):
     """The same gate as the convs': max|dW - dW_f64| of the plane kernel <= 1.5 x that of the exact fp32 MFMA kernel, for every conv
     layer of config 2 (batch 64: two batch pairs per vertex) and config 4 (27 554 vertices, spiral 18, batch 32: one), sums over
-    up to 441 024 (vertex, batch) rows; training-scale operands and adversarial ones (six decades of dynamic range).  dbias too."""
+    up to 441 024 (vertex, batch) rows; training-scale operands and adversarial ones (six decades of dynamic range).  dbias too.
+    Batch 16 and 48 (the semantic loop's): a 32-row step pairs 16-row units of DIFFERENT vertices, and the layers with an odd
+    number of units (863 rows x 1 or 3 groups) are completed by the layer's all-zero dummy row."""
     import wgrad_p3_probe
     rows = list(wgrad_p3_probe.probe_layers(B, os.path.join(ROOT, "tests", "golden", tpl), adversarial, reps=1))
     taken = [r for r in rows if r["ok"]]

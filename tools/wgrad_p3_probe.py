@@ -24,14 +24,14 @@ import p3_probe                                                    # noqa: E402
 from p3_probe import FE, FD, rnd, timed, to_p3                     # noqa: E402
 
 
-def wgrad_p3(dp_img, x_img, table, B, R, S, cin, cout):
+def wgrad_p3(dp_img, x_img, table, B, R, S, cin, cout, zero_row=-1):
     """-> (dW [cout, S*cin], dbias [cout]) from the kernel's slabs, summed here in float64 (the probe checks the kernel's
     products; the shared slab reduction has its own tests)."""
     lib = _lib.load()
     nb = lib.sh_spiral_conv_bwd_wgt_p3_workspace(B, R, S, cin, cout)
     assert nb > 0
     ws = torch.zeros(nb // 4, dtype=torch.float32, device=table.device)
-    _lib.check(lib.sh_spiral_conv_bwd_wgt_p3(_lib.ptr(dp_img), _lib.ptr(x_img), _lib.ptr(table), _lib.ptr(ws), nb, B, R, S, cin, cout,
+    _lib.check(lib.sh_spiral_conv_bwd_wgt_p3(_lib.ptr(dp_img), zero_row, _lib.ptr(x_img), _lib.ptr(table), _lib.ptr(ws), nb, B, R, S, cin, cout,
                                              _lib.stream_ptr()), "sh_spiral_conv_bwd_wgt_p3")
     n = cout * S * cin
     nslab = nb // 4 // (n + cout)
@@ -86,7 +86,7 @@ def probe_layers(B=64, tpl=None, adversarial=False, reps=1, seed=1, local_table=
                     xi, di = to_p3(x), to_p3(dp)
 
                     def run_p3():
-                        out["p"] = wgrad_p3(di, xi, table, B, R, S, cin, cout)
+                        out["p"] = wgrad_p3(di, xi, table, B, R, S, cin, cout, st.zero_row)
                     rec["us"]["p3"] = timed(run_p3, reps)
                     dWs, dbs, _, _ = out["p"]
                     rec["err"]["p3"] = float((dWs.double().sum(0) - ref).abs().max()) / scale
@@ -119,7 +119,7 @@ def presum_check():
     nb = lib.sh_spiral_conv_bwd_wgt_p3_workspace(B, R, S, cin, cout)
     ws0 = torch.zeros(nb // 4, dtype=torch.float32, device=d)
     ws1 = torch.zeros_like(ws0)
-    _lib.check(lib.sh_spiral_conv_bwd_wgt_p3(_lib.ptr(di), _lib.ptr(xi), _lib.ptr(table), _lib.ptr(ws0), nb, B, R, S, cin, cout, _lib.stream_ptr()), "p3")
+    _lib.check(lib.sh_spiral_conv_bwd_wgt_p3(_lib.ptr(di), -1, _lib.ptr(xi), _lib.ptr(table), _lib.ptr(ws0), nb, B, R, S, cin, cout, _lib.stream_ptr()), "p3")
     want = dp.clone()
     ops.spmm(m, want, "vm", want[R:], "vm", n_sum)
     for with_img in (False, True):
@@ -127,7 +127,7 @@ def presum_check():
         img = torch.zeros(lib.sh_p3_bytes(n_sum, B, cout), dtype=torch.uint8, device=d) if with_img else None
         ws1.zero_()
         _lib.profile_enable(True)
-        _lib.check(lib.sh_spiral_conv_bwd_wgt_p3_presum(_lib.ptr(di), _lib.ptr(xi), _lib.ptr(table), _lib.ptr(ws1), nb, _lib.ptr(got), B * cout, cout,
+        _lib.check(lib.sh_spiral_conv_bwd_wgt_p3_presum(_lib.ptr(di), -1, _lib.ptr(xi), _lib.ptr(table), _lib.ptr(ws1), nb, _lib.ptr(got), B * cout, cout,
                                                         _lib.ptr(m[0]), _lib.ptr(m[1]), _lib.ptr(m[2]), _lib.ptr(got[R:]), _lib.ptr(img), n_sum, B, R, S,
                                                         cin, cout, _lib.stream_ptr()), "p3_presum")
         torch.cuda.synchronize()
