@@ -390,7 +390,10 @@ __global__ __launch_bounds__(256) void wgrad_p3_kernel(const WP3Params p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // the clamped tail loads still write this wave's LDS
     __syncthreads();                                                         // every wave is done with its ring: reuse it for the sum
 
-    // four waves -> one slab: passes of up to 32 tiles per wave (128 KiB for the four)
+    // four waves -> one slab: passes of up to 32 tiles per wave (128 KiB for the four).  (A form whose summing threads store whole
+    // runs of a channel's columns - 64 contiguous bytes per four threads instead of one 16-byte piece per channel row and lane -
+    // measured the same on one box, 18.4 / 19.5 / 27.3 / 45.6 / 29.1 / 37.9 against 18.3 / 19.2 / 27.1 / 45.1 / 29.0 / 38.2 us: the
+    // slab stores are not what the launch waits for.  Not kept.)
     constexpr int NT = QF * 2 * PT, TPP = 32, NPASS = (NT + TPP - 1) / TPP;
     float* red = reinterpret_cast<float*>(smem);
     float* slab = p.slab + (long)sgroup * p.slab_stride;
@@ -475,7 +478,10 @@ WP3Plan plan_wp3(int B, int R, int S, int Cin, int Cout) {
             if (sg > per_xcd) return;
         }
         const long rounds = (8 * tiles * sg + wg_target - 1) / wg_target;        // more workgroups than CUs: they run in turns
-        const long cost = rounds * ((per_xcd + 4 * sg - 1) / (4 * sg)) * (ngd + q);
+        // + the workgroup's epilogue (its 2 q pt accumulator tiles through LDS, summed over the four waves, stored as a slab): half a
+        // group's time per tile pair - calibrated on a sweep of forced widths (tools/exp/r06_wp3_qf_sweep.sh: 863 x 256 -> 64 and
+        // 432 x 512 -> 128 are 2.4 / 2.9 us faster with four column groups per wave than with eight; in units of half a group)
+        const long cost = 2 * rounds * ((per_xcd + 4 * sg - 1) / (4 * sg)) * (ngd + q) + (long)q * w.pt;
         if (best < 0 || cost < best || (cost == best && q > w.qf)) { best = cost; w.qf = q; w.n_qg = n_qg; sgx = sg; }
     };
     if (w.pt == 2) { for (int q : WP_QF2) consider(q); }
