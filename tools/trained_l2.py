@@ -12,8 +12,9 @@ held-out per-vertex L2 in mm (test_funcs.py:47-49) on 256 meshes none of the for
     python tools/trained_l2.py [--steps 2000] [--seeds 3] [--forms exact,planes3,bf16,oracle] [--out profiles/r06_trained_l2.json]
 
 Output: one JSON object - per form and seed the curve [(step, held-out L2 mm, training loss)], per form mean / min / max over the
-seeds at every evaluation point, and `verdict`: for each library form whether its final L2 lies inside the spread (min..max over
-seeds) of the oracle's, and its mean's relative distance to the oracle's mean.  Test infrastructure: the only thing that imports
+seeds at every evaluation point, the TAIL figure (each seed's mean over the evaluation points of the last fifth of the run: one late evaluation
+still moves by +-10 % from point to point) and `verdict`: for each library form whether its tail mean lies inside the spread
+(min..max over seeds) of the oracle's, and its relative distance to the oracle's mean.  Test infrastructure: the only thing that imports
 `oracle/` here is the reference leg."""
 from __future__ import annotations
 
@@ -110,7 +111,53 @@ def run_form(form, seed, sd0, h, data, test, steps, eval_every, dev):
     return curve
 
 
+TAIL_FRACTION = 0.8      # the "tail" figure averages the evaluation points at or after this fraction of the run
+
+
+def summarise(curves, forms, steps, seeds, eval_every, build):
+    """Per form: mean / min / max over the seeds at every evaluation point, and the TAIL figure - each seed's mean over its last
+    evaluation points of the last fifth of the run (a single evaluation late in training still moves by +-10 % from one point to the next: the model is
+    evaluated between two Adam steps at lr ~3e-4; the snapshot at the last step is reported too, the verdict uses the tail)."""
+    summary, tail = {}, {}
+    for f in forms:
+        pts = []
+        for k in range(len(curves[f][0])):
+            v = [c[k][1] for c in curves[f]]
+            pts.append({"step": curves[f][0][k][0], "mean_mm": float(np.mean(v)), "min_mm": float(np.min(v)), "max_mm": float(np.max(v))})
+        summary[f] = pts
+        sel = [k for k, q in enumerate(curves[f][0]) if q[0] >= TAIL_FRACTION * steps]
+        t = [float(np.mean([c[k][1] for k in sel])) for c in curves[f]]
+        tail[f] = {"steps": [curves[f][0][k][0] for k in sel], "per_seed_mm": t, "mean_mm": float(np.mean(t)), "min_mm": float(np.min(t)),
+                   "max_mm": float(np.max(t))}
+    verdict = {}
+    if "oracle" in forms:
+        o = tail["oracle"]
+        for f in forms:
+            if f == "oracle":
+                continue
+            e = tail[f]
+            verdict[f] = {"tail_mean_mm": e["mean_mm"], "oracle_tail_mean_mm": o["mean_mm"], "oracle_tail_spread_mm": [o["min_mm"], o["max_mm"]],
+                          "rel_diff_of_means": (e["mean_mm"] - o["mean_mm"]) / o["mean_mm"],
+                          "mean_inside_oracle_spread": bool(o["min_mm"] <= e["mean_mm"] <= o["max_mm"]),
+                          "last_step_mean_mm": summary[f][-1]["mean_mm"], "oracle_last_step_mean_mm": summary["oracle"][-1]["mean_mm"]}
+    return {"what": "held-out per-vertex L2 (mm, test_funcs.py:47-49) of the plain autoencoder trained with the reference's schedule "
+                    "(Adam 1e-3 / 5e-5, StepLR gamma 0.99 per 16-batch epoch, L1 + 1e-2 edge loss), 6890 vertices, batch 64, synthetic data",
+            "steps": steps, "seeds": seeds, "eval_every": eval_every, "build": build,
+            "forms": {"exact": "fp32 MFMA kernels", "planes3": "three-plane form of the fp32 products (the bench headline's form)",
+                      "bf16": "bf16 compute path (BASELINE config 3's per-GPU shard)",
+                      "oracle": "oracle/ref_cpu.py's pure-torch model on the GPU, torch.optim.Adam (no library kernel)"},
+            "tail": tail, "summary": summary, "verdict": verdict,
+            "curves": {f: [[[s_, l2, tl] for s_, l2, tl in c] for c in curves[f]] for f in forms}}
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--resummarise":      # recompute the statistics of an existing result file (no GPU)
+        d = json.load(open(sys.argv[2]))
+        curves = {f: [[tuple(q) for q in c] for c in cs] for f, cs in d["curves"].items()}
+        out = summarise(curves, list(curves), d["steps"], d["seeds"], d["eval_every"], d.get("build"))
+        json.dump(out, open(sys.argv[2], "w"), indent=1)
+        print(json.dumps({"tail": {f: out["tail"][f] for f in curves}, "verdict": out["verdict"]}))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--seeds", type=int, default=3)
@@ -139,36 +186,11 @@ def main():
                 torch.cuda.empty_cache()
     finally:
         _lib.set_f32_mma_mode(was)
-    summary = {}
-    for f in forms:
-        pts = []
-        for k in range(len(curves[f][0])):
-            v = [c[k][1] for c in curves[f]]
-            pts.append({"step": curves[f][0][k][0], "mean_mm": float(np.mean(v)), "min_mm": float(np.min(v)), "max_mm": float(np.max(v))})
-        summary[f] = pts
-    verdict = {}
-    if "oracle" in forms:
-        o = summary["oracle"][-1]
-        for f in forms:
-            if f == "oracle":
-                continue
-            e = summary[f][-1]
-            verdict[f] = {"final_mean_mm": e["mean_mm"], "oracle_final_mean_mm": o["mean_mm"], "oracle_spread_mm": [o["min_mm"], o["max_mm"]],
-                          "rel_diff_of_means": (e["mean_mm"] - o["mean_mm"]) / o["mean_mm"],
-                          "mean_inside_oracle_spread": bool(o["min_mm"] <= e["mean_mm"] <= o["max_mm"]),
-                          "every_seed_inside_oracle_spread": bool(o["min_mm"] <= e["min_mm"] and e["max_mm"] <= o["max_mm"])}
-    out = {"what": "held-out per-vertex L2 (mm, test_funcs.py:47-49) of the plain autoencoder trained with the reference's schedule "
-                   "(Adam 1e-3 / 5e-5, StepLR gamma 0.99 per 16-batch epoch, L1 + 1e-2 edge loss), 6890 vertices, batch 64, synthetic data",
-           "steps": args.steps, "seeds": args.seeds, "eval_every": args.eval_every, "build": _lib.build_id(),
-           "forms": {"exact": "fp32 MFMA kernels", "planes3": "three-plane form of the fp32 products (the bench headline's form)",
-                     "bf16": "bf16 compute path (BASELINE config 3's per-GPU shard)",
-                     "oracle": "oracle/ref_cpu.py's pure-torch model on the GPU, torch.optim.Adam (no library kernel)"},
-           "summary": summary, "verdict": verdict,
-           "curves": {f: [[[s, l2, tl] for s, l2, tl in c] for c in curves[f]] for f in forms}}
+    out = summarise(curves, forms, args.steps, args.seeds, args.eval_every, _lib.build_id())
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     with open(args.out, "w") as fh:
         json.dump(out, fh, indent=1)
-    print(json.dumps({"summary_final": {f: summary[f][-1] for f in forms}, "verdict": verdict}))
+    print(json.dumps({"tail": {f: out["tail"][f] for f in forms}, "verdict": out["verdict"]}))
 
 
 if __name__ == "__main__":
