@@ -675,11 +675,14 @@ SH_API int sh_spiral_conv_fwd_p3(const void* xp, const int32_t* table, const voi
 /* sh_spiral_conv_bwd_data_z with dpre given as its plane image dprep (dpre_zero_row >= 0: the all-zero row the "no source"
  * entries point at - their products are skipped, bitwise the same result).  dpre_f32 != NULL: only rows < n_image_rows of dprep
  * are valid; the rows behind them (the pre-summed rows the transposed table refers to) are read from the fp32 tensor
- * (element strides dp_sv, dp_sb) and split by the kernel - their producers then need not write images. */
+ * (element strides dp_sv, dp_sb) and split by the kernel - their producers then need not write images.  yprev_planes (round 6;
+ * may be NULL): the plane image of yprev ([n_in] rows x Cin channels) - the activation derivative is then evaluated from it
+ * (h + m + l is the fp32 value, bit for bit) instead of from the fp32 tensor, which the caller need not keep cache-warm. */
 SH_API int sh_spiral_conv_bwd_data_p3(const void* dprep, int dpre_zero_row, const float* dpre_f32, int64_t dp_sv, int64_t dp_sb,
                                       int n_image_rows, const int32_t* table_t, const void* wfrag3_t, float* dx, int64_t dx_sv,
-                                      int64_t dx_sb, void* dxp, const float* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev,
-                                      int zero_row, int B, int n_in, int S, int Cin, int Cout, sh_stream_t stream);
+                                      int64_t dx_sb, void* dxp, const float* yprev, int64_t yp_sv, int64_t yp_sb,
+                                      const void* yprev_planes, int act_prev, int zero_row, int B, int n_in, int S, int Cin, int Cout,
+                                      sh_stream_t stream);
 
 /* Weight gradient of a spiral conv in the three-plane form (csrc/wgrad_p3.hip, round 6; autograd of reference models.py:45,
  * dW = dpre^T . gather(x)): both operands given as their plane images - x_planes = image of the layer's input ([n_in] rows,

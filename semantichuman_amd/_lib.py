@@ -109,7 +109,7 @@ SIGNATURES = {
     "sh_act_backward_tr_img": (c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "sh_spmm_p3": (c_int, [_P, _P, _P, _P, _L, _L, _P, _L, _L, _P, _P, _L, _L, _I, _I, _I, _I, _I, _P]),
     "sh_spiral_conv_fwd_p3": (c_int, [_P, _P, _P, _P, _P, _L, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "sh_spiral_conv_bwd_data_p3": (c_int, [_P, _I, _P, _L, _L, _I, _P, _P, _P, _L, _L, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "sh_spiral_conv_bwd_data_p3": (c_int, [_P, _I, _P, _L, _L, _I, _P, _P, _P, _L, _L, _P, _P, _L, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sh_spiral_conv_bwd_wgt_p3_ok": (c_int, [_I, _I, _I, _I, _I]),
     "sh_spiral_conv_bwd_wgt_p3_workspace": (c_size_t, [_I, _I, _I, _I, _I]),
     "sh_spiral_conv_bwd_wgt_p3": (c_int, [_P, _I, _P, _P, _P, c_size_t, _I, _I, _I, _I, _I, _P]),

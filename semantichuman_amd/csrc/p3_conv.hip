@@ -42,6 +42,11 @@ struct P3Params {
     float* y; long y_sv, y_sb;                 // fp32 output, element strides of (row, batch entry); may be NULL
     char* yp; long yp_vb, yp_bgb;              // plane image of the output; may be NULL
     const float* yprev; long yv_sv, yv_sb;     // fp32 output of the layer that produced x (backward epilogue)
+    // ... or its plane image (same geometry as the image of this launch's output): h + m + l IS the fp32 value, and the image is
+    // what the layer's plane weight gradient has just streamed - the fp32 tensor was last touched in the forward pass (round 6:
+    // the two encoder backward-data launches behind a plane weight gradient ran 35 / 32 us on cold fp32 rows, 28 / 28 behind the
+    // exact kernels, which had gathered those very rows)
+    const char* yprev_img; long yvi_vb, yvi_bgb;
     int B, R, S, Cg, Nout, nks, nt_tot, ncg;
     int act, zero_row;
     int n_vg, n_tiles, nsplit;
@@ -63,6 +68,23 @@ struct P3Params {
 constexpr int p3_depth(int NT, int RT) {
     const int d = (P3_BUDGET - NT * RT * 4 - 12) / (RT * 12);
     return d < 2 ? 2 : d > P3_DCAP ? P3_DCAP : d;
+}
+
+// the quad (channels c0 .. c0 + 3 of row v, batch entry bs * 16 + r16) of a tensor from its plane image: (h + m) + l, exact
+__device__ __forceinline__ f32x4 p3_quad_from_image(const char* img, long vb, long bgb, int v, int bs, int r16, int c0, int nch) {
+    const bool o16 = nch == 16;
+    const char* src = img + (long)v * vb + (long)bs * bgb +
+                      (o16 ? ((c0 >> 3) * 16 + r16) * 16 : (c0 >> 5) * 3072 + (((c0 & 31) >> 3) * 16 + r16) * 16) + ((c0 >> 2) & 1) * 8;
+    const int opb = o16 ? 512 : 1024;
+    const u32x2 h = *reinterpret_cast<const u32x2*>(src), m = *reinterpret_cast<const u32x2*>(src + opb), l = *reinterpret_cast<const u32x2*>(src + 2 * opb);
+    f32x4 y;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        y[2 * i] = (__builtin_bit_cast(float, h[i] << 16) + __builtin_bit_cast(float, m[i] << 16)) + __builtin_bit_cast(float, l[i] << 16);
+        y[2 * i + 1] = (__builtin_bit_cast(float, h[i] & 0xFFFF0000u) + __builtin_bit_cast(float, m[i] & 0xFFFF0000u)) +
+                       __builtin_bit_cast(float, l[i] & 0xFFFF0000u);
+    }
+    return y;
 }
 
 template <int J, int D, class F>
@@ -278,6 +300,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(P3_WAVES_P
                 if (!BWD) {
                     if (p.bias) a += *reinterpret_cast<const f32x4*>(p.bias + c0);
                     a = sh_act_fwd4(a, p.act);
+                } else if (p.yprev_img) {
+                    const f32x4 yv = p3_quad_from_image(p.yprev_img, p.yvi_vb, p.yvi_bgb, v, bs, r16, c0, p.Nout);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[j] *= sh_act_grad_from_out(yv[j], p.act);
                 } else if (p.yprev) {
                     const f32x4 yv = *reinterpret_cast<const f32x4*>(p.yprev + (long)v * p.yv_sv + (long)b * p.yv_sb + c0);
 #pragma unroll
@@ -459,6 +485,10 @@ __global__ __launch_bounds__(1024 / RT) void conv_p3s_kernel(const P3Params p) {
                 if (!BWD) {
                     if (p.bias) a += *reinterpret_cast<const f32x4*>(p.bias + c0);
                     a = sh_act_fwd4(a, p.act);
+                } else if (p.yprev_img) {
+                    const f32x4 yv = p3_quad_from_image(p.yprev_img, p.yvi_vb, p.yvi_bgb, v, bs, r16, c0, p.Nout);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[j] *= sh_act_grad_from_out(yv[j], p.act);
                 } else if (p.yprev) {
                     const f32x4 yv = *reinterpret_cast<const f32x4*>(p.yprev + (long)v * p.yv_sv + (long)b * p.yv_sb + c0);
 #pragma unroll
@@ -797,8 +827,8 @@ int sh_spiral_conv_fwd_p3(const void* xp, const int32_t* table, const void* wfra
 
 int sh_spiral_conv_bwd_data_p3(const void* dprep, int dpre_zero_row, const float* dpre_f32, int64_t dp_sv, int64_t dp_sb, int n_image_rows,
                                const int32_t* table_t, const void* wfrag3_t, float* dx, int64_t dx_sv, int64_t dx_sb, void* dxp,
-                               const float* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row, int B, int n_in, int S, int Cin,
-                               int Cout, sh_stream_t stream) {
+                               const float* yprev, int64_t yp_sv, int64_t yp_sb, const void* yprev_planes, int act_prev, int zero_row, int B,
+                               int n_in, int S, int Cin, int Cout, sh_stream_t stream) {
     SH_REQUIRE(dprep && table_t && wfrag3_t, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_data_p3: null pointer");
     SH_REQUIRE(B > 0 && n_in > 0 && S > 0 && Cin > 0 && Cout > 0, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_data_p3: non-positive size");
     SH_REQUIRE(act_prev >= SH_ACT_IDENTITY && act_prev <= SH_ACT_TANH, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_data_p3: unknown activation");
@@ -806,6 +836,12 @@ int sh_spiral_conv_bwd_data_p3(const void* dprep, int dpre_zero_row, const float
     p.xp = static_cast<const char*>(dprep); p.table = table_t; p.wfrag = static_cast<const u32x4*>(wfrag3_t); p.bias = nullptr;
     p.y = dx; p.y_sv = dx_sv; p.y_sb = dx_sb; p.yp = static_cast<char*>(dxp);
     p.yprev = yprev; p.yv_sv = yp_sv; p.yv_sb = yp_sb;
+    if (yprev_planes) {
+        SH_REQUIRE(sh_p3_bytes(1, B, Cin) && (reinterpret_cast<uintptr_t>(yprev_planes) & 15) == 0, SH_ERR_UNSUPPORTED,
+                   "sh_spiral_conv_bwd_data_p3: B=%d Cin=%d has no plane image (yprev_planes)", B, Cin);
+        p.yprev_img = static_cast<const char*>(yprev_planes);
+        p.yvi_bgb = Cin == 16 ? 1536 : (long)(Cin / 32) * 3072; p.yvi_vb = p.yvi_bgb * (B / 16);
+    }
     p.B = B; p.R = n_in; p.S = S; p.Cg = Cout; p.Nout = Cin; p.act = act_prev; p.zero_row = zero_row;
     static const int skip_on = sh_env_int("SH_P3_SKIP", 1, 0, 1);
     p.skip_row = skip_on ? dpre_zero_row : -1;

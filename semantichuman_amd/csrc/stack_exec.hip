@@ -327,8 +327,12 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
                             if (rc != SH_OK) return rc;
                         }
                         const bool img_out = gi_img && gl.sb == s.cin && gl.sv == (long)B * s.cin && sh_p3_bytes(1, B, s.cin);
+                        // the activation to differentiate, from its image when the caller kept the forward images (SH_P3_YPREV_IMG=0: fp32)
+                        static const int yimg_on = sh_env_int("SH_P3_YPREV_IMG", 1, 0, 1);
+                        const void* yimg = (yimg_on && yprev && in_planes && in_planes[i] && yl.sb == s.cin && yl.sv == (long)B * s.cin &&
+                                            sh_p3_bytes(1, B, s.cin)) ? in_planes[i] : nullptr;
                         rc = sh_spiral_conv_bwd_data_p3(cur_img, s.zero_row, presum_img ? nullptr : cur, cl.sv, cl.sb, s.R, s.table_t, wfrag3_t[i], gi, gl.sv, gl.sb, img_out ? gi_img : nullptr, yprev, yl.sv,
-                                                        yl.sb, act_prev, zero_prev, B, s.n_in, s.S, s.cin, s.cout, stream);
+                                                        yl.sb, yimg, act_prev, zero_prev, B, s.n_in, s.S, s.cin, s.cout, stream);
                         gi_img_done = img_out;
                     } else {
                         // the "no source" entries of table_t point at this step's own dummy row of dpre (stack.py ConvStep.finalize),

@@ -253,15 +253,16 @@ int sh_spiral_conv_fwd_p3(const void* xp, const int32_t* table, const void* wfra
     return 0;
 }
 int sh_spiral_conv_bwd_data_p3(const void* dprep, int, const float* dpre_f32, int64_t dp_sv, int64_t dp_sb, int n_img, const int32_t* table_t, const void* wfrag3_t, float* dx, int64_t dx_sv, int64_t dx_sb, void* dxp,
-                               const float* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row, int B, int n_in, int S, int Cin, int Cout,
-                               sh_stream_t) {
+                               const float* yprev, int64_t yp_sv, int64_t yp_sb, const void* yprev_planes, int act_prev, int zero_row, int B, int n_in,
+                               int S, int Cin, int Cout, sh_stream_t) {
     int rows = 0;
     for (long i = 0; i < (long)n_in * S; ++i) rows = table_t[i] + 1 > rows ? table_t[i] + 1 : rows;
     touch_r(dprep, sh_p3_bytes(dpre_f32 ? (n_img < rows ? n_img : rows) : rows, B, Cout)); touch_r(wfrag3_t, sh_conv_wfrag3_bytes(S, Cout, Cin));
     if (dpre_f32) touch_r(dpre_f32, span(dp_sv, dp_sb, rows, B, Cout, 4));
     if (dx) touch_w(dx, span(dx_sv, dx_sb, n_in, B, Cin, 4));
     if (dxp) touch_w(dxp, sh_p3_bytes(n_in, B, Cin));
-    if (yprev) touch_r(yprev, span(yp_sv, yp_sb, n_in, B, Cin, 4));
+    if (yprev_planes) touch_r(yprev_planes, sh_p3_bytes(n_in, B, Cin));
+    else if (yprev) touch_r(yprev, span(yp_sv, yp_sb, n_in, B, Cin, 4));
     log("bwd_data_p3 n_in=%d Cin=%d Cout=%d", n_in, Cin, Cout);
     return 0;
 }

@@ -147,7 +147,7 @@ def probe_layers(B=64, tpl=None, directions=("fwd", "bwd"), adversarial=False, r
                                            "sh_spiral_conv_fwd_p3")
                             else:
                                 _lib.check(lib.sh_spiral_conv_bwd_data_p3(_lib.ptr(xp), zrow, _lib.ptr(x) if (F32ROWS and lib.sh_spiral_conv_p3_kind(B, S, Cg, Nout) == 1) else None, B * cout, cout, R, _lib.ptr(table_t), _lib.ptr(wf), _lib.ptr(y), B * Nout,
-                                                                          Nout, _lib.ptr(yp), None, 0, 0, 0, -1, B, n_in, S, cin, cout,
+                                                                          Nout, _lib.ptr(yp), None, 0, 0, None, 0, -1, B, n_in, S, cin, cout,
                                                                           _lib.stream_ptr()), "sh_spiral_conv_bwd_data_p3")
                         rec["us"]["planes3"] = timed(run_p3, reps)
                         rec["err"]["planes3"] = float((y.double() - ref).abs().max()) / scale
