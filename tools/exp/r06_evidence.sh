@@ -75,7 +75,7 @@ for d in f32 bf16; do
   rm -rf $O/tr_$d
 done
 # trained-model matched L2
-timeout 1500 python tools/trained_l2.py --out $P/r06_trained_l2.json 2>/dev/null | grep -v "Consider\|curve.append" > $P/r06_trained_l2.log.txt
+timeout 2000 python tools/trained_l2.py --seeds 5 --eval-every 100 --out $P/r06_trained_l2.json 2>/dev/null | grep -v "Consider\|curve.append" > $P/r06_trained_l2.log.txt
 ls $P | grep r06 | head -80
 python - <<'PY'
 import json,glob
