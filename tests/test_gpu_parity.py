@@ -586,6 +586,29 @@ def test_c_abi_error_contract():
     steps[0].cin = 4
     assert lib.sh_stack_forward(1, steps, _lib.ptr(x), 1, 9, 4, 2, wp, None, outs, 1, 0, None, None, 1, st) == -1
     assert b"output buffer" in lib.sh_last_error()
+    # round 6, the three-plane weight gradient: a shape it does not take, a workspace that is too small, an odd number of 16-row
+    # units without a zero row to complete it, an unknown plan kind in the deferred reduction
+    img = torch.zeros(1 << 20, dtype=torch.uint8, device=d)
+    t7 = torch.zeros((7, 3), dtype=torch.int32, device=d)
+    assert lib.sh_spiral_conv_bwd_wgt_p3_ok(20, 7, 3, 32, 32) == 0 and lib.sh_spiral_conv_bwd_wgt_p3_workspace(20, 7, 3, 32, 32) == 0
+    assert lib.sh_spiral_conv_bwd_wgt_p3(_lib.ptr(img), -1, _lib.ptr(img), _lib.ptr(t7), _lib.ptr(img), ctypes.c_size_t(1 << 20), 20, 7, 3, 32, 32, st) == -2
+    assert b"not taken" in lib.sh_last_error()
+    need3 = lib.sh_spiral_conv_bwd_wgt_p3_workspace(16, 7, 3, 32, 32)
+    assert need3 > 0 and lib.sh_spiral_conv_bwd_wgt_p3_ok(16, 7, 3, 32, 32) == 1
+    assert lib.sh_spiral_conv_bwd_wgt_p3(_lib.ptr(img), 6, _lib.ptr(img), _lib.ptr(t7), _lib.ptr(img), ctypes.c_size_t(16), 16, 7, 3, 32, 32, st) == -3
+    assert lib.sh_spiral_conv_bwd_wgt_p3(_lib.ptr(img), -1, _lib.ptr(img), _lib.ptr(t7), _lib.ptr(img), ctypes.c_size_t(1 << 30), 16, 7, 3, 32, 32, st) == -2
+    assert b"odd number of units" in lib.sh_last_error()
+    ws3 = torch.zeros(need3, dtype=torch.uint8, device=d)
+    assert lib.sh_spiral_conv_bwd_wgt_p3(_lib.ptr(img), 6, _lib.ptr(img), _lib.ptr(t7), _lib.ptr(ws3), ctypes.c_size_t(need3), 16, 7, 3, 32, 32, st) == 0
+    one = lambda v, ct: (ct * 1)(v)      # noqa: E731
+    dW3 = torch.zeros((32, 96), device=d)
+    kinds_bad = one(3, ctypes.c_int)
+    args = [one(ws3.data_ptr(), ctypes.c_void_p), one(dW3.data_ptr(), ctypes.c_void_p), one(0, ctypes.c_void_p)] + \
+        [one(v, ctypes.c_int) for v in (16, 7, 3, 32, 32)]
+    assert lib.sh_spiral_conv_bwd_wgt_reduce_multi_kinds(1, *[ctypes.cast(a, ctypes.c_void_p) for a in args], ctypes.cast(kinds_bad, ctypes.c_void_p), st) == -1
+    assert b"plan kind" in lib.sh_last_error()
+    assert lib.sh_spiral_conv_bwd_wgt_reduce_multi_kinds(1, *[ctypes.cast(a, ctypes.c_void_p) for a in args], ctypes.cast(one(2, ctypes.c_int), ctypes.c_void_p), st) == 0
+    torch.cuda.synchronize()
     # the typed wrappers raise
     with pytest.raises(RuntimeError, match="status -2"):             # a spiral longer than the kernels' 64-entry table lines
         ops.spiral_conv_fwd(x, "bm", torch.zeros((9, 65), dtype=torch.int32, device=d), torch.zeros((8, 65 * 4), device=d), None,

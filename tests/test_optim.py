@@ -373,3 +373,55 @@ def test_fused_update_registration_rules():
     opt.zero_grad(set_to_none=True)
     linear.latent_linear(x, fc.weight, fc.bias).sum().backward()
     assert fc.weight.grad is not None
+
+
+@pytest.mark.gpu
+def test_fused_update_registry_lifetime_and_second_backward():
+    """ADVICE r5 (both medium findings).  The registry of fused updates holds parameter and optimizer WEAKLY: an optimizer that
+    dies takes its registrations along; another `optim.Adam` built over a fused parameter releases the old optimizer's
+    registration (with a warning) instead of leaving it to update the weight during backward with its own moments; and a SECOND
+    backward through a fused layer before `step()` - gradient accumulation - raises instead of applying a second update with the
+    same bias-correction step."""
+    import gc
+    import warnings
+    from semantichuman_amd import linear
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    fc = torch.nn.Linear(256, 128).to(dev)
+    x = torch.randn(32, 256, device=dev)
+    key = fc.weight.data_ptr()
+    # --- a second backward before step()
+    opt = sh.optim.Adam(fc.parameters(), lr=1e-3)
+    opt.fuse_linear_weight_gradients([fc])
+    linear.latent_linear(x, fc.weight, fc.bias).sum().backward()
+    with pytest.raises(RuntimeError, match="second backward"):
+        linear.latent_linear(x, fc.weight, fc.bias).sum().backward()
+    opt.step()
+    assert float(opt.state[fc.weight]["step"]) == 1.0
+    opt.zero_grad(set_to_none=True)
+    linear.latent_linear(x, fc.weight, fc.bias).sum().backward()            # the next step is fine again
+    opt.step()
+    assert float(opt.state[fc.weight]["step"]) == 2.0
+    # --- another optimizer over the same parameter: the old registration is released, the weight takes the ordinary path
+    opt.zero_grad(set_to_none=True)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        opt2 = sh.optim.Adam(fc.parameters(), lr=1e-3)
+    assert any("registration is removed" in str(w.message) for w in rec)
+    assert key not in linear._FUSED_UPDATE and not opt._fused
+    w0 = fc.weight.detach().clone()
+    linear.latent_linear(x, fc.weight, fc.bias).sum().backward()
+    assert fc.weight.grad is not None and torch.equal(fc.weight.detach(), w0)      # nobody touched the weight during backward
+    opt2.step()
+    assert not torch.equal(fc.weight.detach(), w0) and float(opt2.state[fc.weight]["step"]) == 1.0
+    assert float(opt.state[fc.weight]["step"]) == 2.0                              # the old optimizer's state did not move
+    # --- an optimizer that dies takes its registration along
+    opt2.zero_grad(set_to_none=True)
+    opt3 = sh.optim.Adam(fc.parameters(), lr=1e-3)
+    opt3.fuse_linear_weight_gradients([fc])
+    assert key in linear._FUSED_UPDATE
+    del opt3
+    gc.collect()
+    w1 = fc.weight.detach().clone()
+    linear.latent_linear(x, fc.weight, fc.bias).sum().backward()
+    assert key not in linear._FUSED_UPDATE and fc.weight.grad is not None and torch.equal(fc.weight.detach(), w1)
