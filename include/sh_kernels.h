@@ -233,6 +233,14 @@ typedef struct sh_stack_step {
      * next step reads Z = [x ; M x] (m_cols + m_rows rows) through a table composed with the row map, outs[i] must equal
      * outs[i-1], and mt is the transpose of [I ; M] (m_cols x (m_cols + m_rows)), so the backward pass is the plain one. */
     int extend;
+    /* conv, optional (round 6; NULL / 0 = none): the step's backward-data sources as RAGGED lists instead of table_t + pre-summed
+     * rows - rag_rows [n_in][rag_L]: for input row u its sources (rows of the pre-activation gradient, all < R), rag_pos [n_in][rag_L]:
+     * the spiral position whose weight multiplies each, -1 behind a row's last source (rag_rows then holds any valid row).  A step
+     * that has them and whose backward-data pass runs on planes with a resident weight (sh_spiral_conv_p3_rag_ok) takes
+     * sh_spiral_conv_bwd_data_p3_rag and needs neither its pre-sum launches nor the extra rows filled. */
+    const int32_t* rag_rows;
+    const int32_t* rag_pos;
+    int rag_L;
 } sh_stack_step;
 
 /* outs[i]: output of step i, vertex-major, except outs[n_steps-1] which has layout out_layout.
@@ -683,6 +691,17 @@ SH_API int sh_spiral_conv_bwd_data_p3(const void* dprep, int dpre_zero_row, cons
                                       int64_t dx_sb, void* dxp, const float* yprev, int64_t yp_sv, int64_t yp_sb,
                                       const void* yprev_planes, int act_prev, int zero_row, int B, int n_in, int S, int Cin, int Cout,
                                       sh_stream_t stream);
+
+/* sh_spiral_conv_bwd_data_p3 over RAGGED source lists (round 6; csrc/p3_conv.hip conv_p3r_kernel): dx[u] = act'(yprev[u]) x
+ * sum_j dpre[rag_rows[u][j]] . W_{rag_pos[u][j]} over the entries with rag_pos >= 0 - no transposed table, no "no source" slots,
+ * no pre-summed rows: the sums over several sources of one (row, position) are formed by the matrix pipe (linearity).  Every
+ * source is a row of the image dprep.  sh_spiral_conv_p3_rag_ok: resident three-plane weight with at most four channel tiles per
+ * workgroup, gathered channels (Cg = the layer's Cout) a multiple of 32, lists of at most 64 entries. */
+SH_API int sh_spiral_conv_p3_rag_ok(int B, int S, int Cg, int Nout, int rag_L);
+SH_API int sh_spiral_conv_bwd_data_p3_rag(const void* dprep, const int32_t* rag_rows, const int32_t* rag_pos, int rag_L, const void* wfrag3_t,
+                                          float* dx, int64_t dx_sv, int64_t dx_sb, void* dxp, const float* yprev, int64_t yp_sv,
+                                          int64_t yp_sb, const void* yprev_planes, int act_prev, int zero_row, int B, int n_in, int S,
+                                          int Cin, int Cout, sh_stream_t stream);
 
 /* Weight gradient of a spiral conv in the three-plane form (csrc/wgrad_p3.hip, round 6; autograd of reference models.py:45,
  * dW = dpre^T . gather(x)): both operands given as their plane images - x_planes = image of the layer's input ([n_in] rows,

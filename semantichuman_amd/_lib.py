@@ -110,6 +110,8 @@ SIGNATURES = {
     "sh_spmm_p3": (c_int, [_P, _P, _P, _P, _L, _L, _P, _L, _L, _P, _P, _L, _L, _I, _I, _I, _I, _I, _P]),
     "sh_spiral_conv_fwd_p3": (c_int, [_P, _P, _P, _P, _P, _L, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sh_spiral_conv_bwd_data_p3": (c_int, [_P, _I, _P, _L, _L, _I, _P, _P, _P, _L, _L, _P, _P, _L, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "sh_spiral_conv_p3_rag_ok": (c_int, [_I, _I, _I, _I, _I]),
+    "sh_spiral_conv_bwd_data_p3_rag": (c_int, [_P, _P, _P, _I, _P, _P, _L, _L, _P, _P, _L, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sh_spiral_conv_bwd_wgt_p3_ok": (c_int, [_I, _I, _I, _I, _I]),
     "sh_spiral_conv_bwd_wgt_p3_workspace": (c_size_t, [_I, _I, _I, _I, _I]),
     "sh_spiral_conv_bwd_wgt_p3": (c_int, [_P, _I, _P, _P, _P, c_size_t, _I, _I, _I, _I, _I, _P]),
@@ -128,7 +130,8 @@ class StackStep(ctypes.Structure):                     # sh_stack_step (include/
     _fields_ = [("kind", c_int), ("param", c_int), ("table", c_void_p), ("table_t", c_void_p),
                 ("R", c_int), ("S", c_int), ("n_in", c_int), ("cin", c_int), ("cout", c_int), ("act", c_int), ("zero_row", c_int),
                 ("n1", c_int), ("n2", c_int), ("sum1", CsrRef), ("sum2", CsrRef), ("m", CsrRef), ("mt", CsrRef),
-                ("m_rows", c_int), ("m_cols", c_int), ("extend", c_int)]
+                ("m_rows", c_int), ("m_cols", c_int), ("extend", c_int),
+                ("rag_rows", c_void_p), ("rag_pos", c_void_p), ("rag_L", c_int)]
 
 
 _lib = None

@@ -47,6 +47,9 @@ struct P3Params {
     // the two encoder backward-data launches behind a plane weight gradient ran 35 / 32 us on cold fp32 rows, 28 / 28 behind the
     // exact kernels, which had gathered those very rows)
     const char* yprev_img; long yvi_vb, yvi_bgb;
+    // ragged backward-data (conv_p3r_kernel): per output row its sources as a LIST - rag_rows [R][rag_L] rows of the gathered image,
+    // rag_pos [R][rag_L] the spiral position whose weight multiplies each (-1: padding behind the row's last source)
+    const int* rag_rows; const int* rag_pos; int rag_L;
     int B, R, S, Cg, Nout, nks, nt_tot, ncg;
     int act, zero_row;
     int n_vg, n_tiles, nsplit;
@@ -326,6 +329,151 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(P3_WAVES_P
         }
 #pragma unroll
         for (int m = 0; m < RT; ++m) tv[m] = tvn[m];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward-data over RAGGED source lists (round 6).  The dense transposed table has one slot per (input row, spiral position):
+// a slot nobody reads from points at the zero row (8 233 of 37 906 slots at 3446 rows x 11 positions, MORE THAN HALF on the
+// down-sampling levels - their loads are issued all the same), a slot several output rows read through points at an extra row
+// that a pre-sum launch has to fill first (4 495 rows there: an 18-us launch and, for the fp32-only form of those rows, a split
+// inside the conv).  The number of SOURCES of an input row, however, is on average the spiral length or half of it and never
+// much more (mean 10.1, max 15 there; mean 5.1, max 11 on a down-sampling level): a list of (source row, position) pairs per
+// input row - every source an IMAGE row, the sums formed by the matrix pipe by linearity, W_s (a + b) = W_s a + W_s b - is
+// shorter than the dense line, has no empty slots and needs no pre-summed rows.  One vertex x 16 batch entries per wave item
+// (two vertices could not share weight-fragment reads: their positions differ step by step), resident weight, !C16.
+template <int NT, int NP>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(P3_WAVES_PER_EU, 8))) void conv_p3r_kernel(const P3Params p) {
+    constexpr int D = p3_depth(NT, 1);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const u32x4* Wl = reinterpret_cast<const u32x4*>(smem);       // [nks][NT][3][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+    const int nwg_x = ((int)gridDim.x - xcd + 7) >> 3;
+    const int slice = li % p.nsplit, lj = li / p.nsplit;
+    const int ngrp = nwg_x / p.nsplit;
+    const int q8 = p.n_tiles >> 3, r8 = p.n_tiles & 7;
+    const int t_begin = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int t_end = t_begin + (xcd < r8 ? q8 + 1 : q8);
+    const int stride = ngrp * nw;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int Lp = p.rag_L, ll = lane < Lp ? lane : Lp - 1;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const unsigned rowmul = (unsigned)(p.x_vb >> 4);
+    // the list of an item's vertex: lane j holds source j (row pre-multiplied by the image's row stride in 16-byte units) and its position
+    auto load_list = [&](int t, int& rows, int& pos) {
+        const int tt = t < t_end ? t : (t_end > 0 ? t_end - 1 : 0);
+        const int v = tt % p.n_vg;
+        rows = (int)((unsigned)p.rag_rows[(long)v * Lp + ll] * rowmul);
+        pos = lane < Lp ? p.rag_pos[(long)v * Lp + ll] : -1;
+    };
+    int t = t_begin + lj * nw + wave;
+    int tv, tp, tvn, tpn;
+    load_list(t, tv, tp);
+    {
+        typedef __attribute__((address_space(3))) char* lptr_t;
+        const unsigned wl_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_t)smem);
+        const int nfrag = p.nks * NT * 3;
+        for (int f = __builtin_amdgcn_readfirstlane(wave); f < nfrag; f += nw) {
+            const int pl = f % 3, n = (f / 3) % NT, ks = f / (3 * NT);
+            const char* src = reinterpret_cast<const char*>(p.wfrag + (((long)ks * p.nt_tot + slice * NT + n) * 3 + pl) * 64 + lane);
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(__builtin_amdgcn_readfirstlane(wl_lds + (unsigned)f * 1024u)) : "memory", "m0");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    for (; t < t_end; t += stride) {
+        load_list(t + stride, tvn, tpn);
+        const int bs = t / p.n_vg, v = t - bs * p.n_vg;
+        const char* xl = p.xp + (long)bs * p.x_bgb + lane * 16;
+        const int L = __builtin_popcountll(__builtin_amdgcn_ballot_w64(tp >= 0));      // sources of this vertex (uniform)
+        const int nks = L * p.ncg;
+        int lj2 = 0, lc = 0;                               // running load position: list entry, channel group (uniform)
+        u32x4 ring[D][3];
+        auto issue = [&](u32x4 (&a)[3]) {
+            const int j = lj2 < L ? lj2 : (L > 0 ? L - 1 : 0);      // past the end: the last entry again (never multiplied)
+            const int row = __builtin_amdgcn_readlane(tv, j);
+            const char* src = xl + (long)((unsigned long)(unsigned)row << 4) + (long)lc * 3072;
+            a[0] = *reinterpret_cast<const u32x4*>(src);
+            a[1] = *reinterpret_cast<const u32x4*>(src + 1024);
+            a[2] = *reinterpret_cast<const u32x4*>(src + 2048);
+            if (++lc >= p.ncg) { lc = 0; ++lj2; }
+        };
+        f32x4 acc[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n] = zero4;
+        int cj = 0, cc = 0;                                // entry / channel group of the k-step being multiplied (uniform)
+        auto compute = [&](u32x4 (&a)[3]) {
+            const int s = __builtin_amdgcn_readlane(tp, cj);
+            const u32x4* wk = Wl + ((long)(s * p.ncg + cc) * NT) * 192 + lane;
+            if (++cc >= p.ncg) { cc = 0; ++cj; }
+            const bf16x8 xh = *reinterpret_cast<const bf16x8*>(&a[0]), xm = *reinterpret_cast<const bf16x8*>(&a[1]),
+                         xl2 = *reinterpret_cast<const bf16x8*>(&a[2]);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const u32x4 r0 = wk[n * 192], r1 = wk[n * 192 + 64], r2 = wk[n * 192 + 128];
+                const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&r0), wm = *reinterpret_cast<const bf16x8*>(&r1),
+                             wl = *reinterpret_cast<const bf16x8*>(&r2);
+                f32x4 c = acc[n];
+                if constexpr (NP == 9) {
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xl2, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xm, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xl2, c, 0, 0, 0);
+                }
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl2, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, c, 0, 0, 0);
+                acc[n] = c;
+            }
+        };
+#pragma unroll
+        for (int d = 0; d < D - 1; ++d) issue(ring[d]);
+        auto step = [&](auto J, int ks) {
+            constexpr int j = decltype(J)::value;
+            issue(ring[(j + D - 1) % D]);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(ring[j]);
+        };
+        for (int ks = 0; ks < nks; ks += D)
+            if (!p3_ring_steps<0, D>(ks, nks, step)) break;
+
+        // ---- epilogue: lane holds channels c0..c0+3 (c0 = 16 n + 4 kq) of row (v, bs * 16 + r16)
+        const int b = bs * 16 + r16;
+        if (v < p.R && b < p.B) {
+            const bool zero = v == p.zero_row;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int c0 = (slice * NT + n) * 16 + kq * 4;
+                if (c0 >= p.Nout) continue;
+                f32x4 a = acc[n];
+                if (p.yprev_img) {
+                    const f32x4 yv = p3_quad_from_image(p.yprev_img, p.yvi_vb, p.yvi_bgb, v, bs, r16, c0, p.Nout);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[j] *= sh_act_grad_from_out(yv[j], p.act);
+                } else if (p.yprev) {
+                    const f32x4 yv = *reinterpret_cast<const f32x4*>(p.yprev + (long)v * p.yv_sv + (long)b * p.yv_sb + c0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[j] *= sh_act_grad_from_out(yv[j], p.act);
+                }
+                if (zero) a = zero4;
+                if (p.y) *reinterpret_cast<f32x4*>(p.y + (long)v * p.y_sv + (long)b * p.y_sb + c0) = a;
+                if (p.yp) {
+                    u32x2 h, mm, l;
+                    sh_split3_quad(a, h, mm, l);
+                    const bool o16 = p.Nout == 16;
+                    char* dst = p.yp + (long)v * p.yp_vb + (long)bs * p.yp_bgb +
+                                (o16 ? ((c0 >> 3) * 16 + r16) * 16 : (c0 >> 5) * 3072 + (((c0 & 31) >> 3) * 16 + r16) * 16) + (kq & 1) * 8;
+                    const int opb = o16 ? 512 : 1024;
+                    *reinterpret_cast<u32x2*>(dst) = h;
+                    *reinterpret_cast<u32x2*>(dst + opb) = mm;
+                    *reinterpret_cast<u32x2*>(dst + 2 * opb) = l;
+                }
+            }
+        }
+        tv = tvn; tp = tpn;
     }
 }
 
@@ -694,6 +842,41 @@ int launch_p3(P3Params& p, hipStream_t st) {
     return SH_OK;
 }
 
+template <int NT, int NP>
+int launch_p3r(P3Params& p, hipStream_t st) {
+    auto kern = conv_p3r_kernel<NT, NP>;
+    const size_t smem = (size_t)p.nks * NT * 3072;
+    static size_t attr_set = 0;
+    if (smem > 65536 && smem > attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            (void)hipGetLastError();
+            sh_set_error("conv_p3r: cannot raise the dynamic LDS limit to %zu bytes", smem);
+            return SH_ERR_LAUNCH;
+        }
+        attr_set = 160 * 1024;
+    }
+    p.n_vg = p.R;
+    const long tiles = (long)p.n_vg * (p.B / 16);
+    SH_REQUIRE(tiles < (1L << 30), SH_ERR_UNSUPPORTED, "conv_p3r: %ld work items", tiles);
+    p.n_tiles = (int)tiles;
+    const int per_cu = smem <= 36 * 1024 ? 4 : smem <= 76 * 1024 ? 2 : 1;
+    static const int waves_cu = sh_env_int("SH_P3_WAVES_CU", 4 * P3_WAVES_PER_EU, 16, 32);
+    int nw = waves_cu / per_cu;
+    if (nw > 16) nw = 16;
+    while (nw > 4 && (nw & 1) == 0 && (long)p3_num_cus() * per_cu * (nw >> 1) >= tiles * p.nsplit) nw >>= 1;
+    long groups = (tiles + nw - 1) / nw;
+    const long cap = (long)p3_num_cus() * per_cu / p.nsplit;
+    if (groups > cap) groups = cap;
+    if (groups < 8) groups = 8;
+    groups = (groups + 7) / 8 * 8;
+    const int grid = (int)groups * p.nsplit;
+    ShProfScope ps(st, "conv_p3r_kernel<%d, %d>|R=%d B=%d K=%d N=%d grid=%dx%d L=%d", NT, NP, p.R, p.B, p.S * p.Cg, p.Nout, grid, nw * 64, p.rag_L);
+    SH_LAUNCH_PS(ps, kern, dim3(grid), dim3(nw * 64), smem, st, p);
+    SH_CHECK_LAUNCH("conv_p3r");
+    g_p3_launches.fetch_add(1, std::memory_order_relaxed);
+    return SH_OK;
+}
+
 template <bool C16, bool BWD, int NP, bool F32R = false>
 int dispatch_p3_nt(P3Params& p, int nt, hipStream_t st) {
     const long tiles16 = (long)p.R * (p.B / 16);
@@ -852,6 +1035,55 @@ int sh_spiral_conv_bwd_data_p3(const void* dprep, int dpre_zero_row, const float
         p.xf = dpre_f32; p.xf_sv = dp_sv; p.xf_sb = dp_sb; p.n_img = n_image_rows;
     }
     return dispatch_p3<true>(p, static_cast<hipStream_t>(stream));
+}
+
+int sh_spiral_conv_p3_rag_ok(int B, int S, int Cg, int Nout, int rag_L) {
+    return p3_shape_ok(B, S, Cg, Nout) && p3_resident_ok(S, Cg, Nout) && p3_geom(S, Cg, Nout).nt <= 4 && Cg % 32 == 0 && rag_L > 0 && rag_L <= 64;
+}
+
+int sh_spiral_conv_bwd_data_p3_rag(const void* dprep, const int32_t* rag_rows, const int32_t* rag_pos, int rag_L, const void* wfrag3_t, float* dx,
+                                   int64_t dx_sv, int64_t dx_sb, void* dxp, const float* yprev, int64_t yp_sv, int64_t yp_sb,
+                                   const void* yprev_planes, int act_prev, int zero_row, int B, int n_in, int S, int Cin, int Cout,
+                                   sh_stream_t stream) {
+    SH_REQUIRE(dprep && rag_rows && rag_pos && wfrag3_t, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_data_p3_rag: null pointer");
+    SH_REQUIRE(B > 0 && n_in > 0 && S > 0 && Cin > 0 && Cout > 0, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_data_p3_rag: non-positive size");
+    SH_REQUIRE(act_prev >= SH_ACT_IDENTITY && act_prev <= SH_ACT_TANH, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_data_p3_rag: unknown activation");
+    SH_REQUIRE(sh_spiral_conv_p3_rag_ok(B, S, Cout, Cin, rag_L), SH_ERR_UNSUPPORTED,
+               "sh_spiral_conv_bwd_data_p3_rag: B=%d S=%d gathered channels=%d output channels=%d lists of %d is not taken (resident three-plane "
+               "weight, gathered channels %% 32 == 0, lists of at most 64 sources)", B, S, Cout, Cin, rag_L);
+    P3Params p{};
+    p.xp = static_cast<const char*>(dprep); p.wfrag = static_cast<const u32x4*>(wfrag3_t);
+    p.y = dx; p.y_sv = dx_sv; p.y_sb = dx_sb; p.yp = static_cast<char*>(dxp);
+    p.yprev = yprev; p.yv_sv = yp_sv; p.yv_sb = yp_sb;
+    p.B = B; p.R = n_in; p.S = S; p.Cg = Cout; p.Nout = Cin; p.act = act_prev; p.zero_row = zero_row;
+    p.rag_rows = rag_rows; p.rag_pos = rag_pos; p.rag_L = rag_L;
+    if (yprev_planes) {
+        SH_REQUIRE(sh_p3_bytes(1, B, Cin) && (reinterpret_cast<uintptr_t>(yprev_planes) & 15) == 0, SH_ERR_UNSUPPORTED,
+                   "sh_spiral_conv_bwd_data_p3_rag: B=%d Cin=%d has no plane image (yprev_planes)", B, Cin);
+        p.yprev_img = static_cast<const char*>(yprev_planes);
+        p.yvi_bgb = Cin == 16 ? 1536 : (long)(Cin / 32) * 3072; p.yvi_vb = p.yvi_bgb * (B / 16);
+    }
+    const P3Geom g = p3_geom(p.S, p.Cg, p.Nout);
+    p.nks = g.nks; p.nt_tot = g.nt_tot; p.nsplit = g.nsplit; p.ncg = p.Cg / 32;
+    const int nbg = B / 16;
+    p.x_bgb = (long)p.ncg * 3072; p.x_vb = p.x_bgb * nbg;
+    if (p.yp) {
+        SH_REQUIRE(p.Nout == 16 || p.Nout % 32 == 0, SH_ERR_UNSUPPORTED, "conv_p3r: a plane image has 16 or a multiple of 32 channels (%d)", p.Nout);
+        p.yp_bgb = p.Nout == 16 ? 1536 : (long)(p.Nout / 32) * 3072; p.yp_vb = p.yp_bgb * nbg;
+    }
+    SH_REQUIRE(p.y || p.yp, SH_ERR_INVALID_ARG, "conv_p3r: no output");
+    SH_REQUIRE(((reinterpret_cast<uintptr_t>(p.xp) | reinterpret_cast<uintptr_t>(p.yp) | reinterpret_cast<uintptr_t>(p.y) | reinterpret_cast<uintptr_t>(p.yprev)) & 15) == 0 &&
+               ((p.y_sv | p.y_sb | p.yv_sv | p.yv_sb) & 3) == 0, SH_ERR_INVALID_ARG, "conv_p3r: tensors must be 16-byte aligned with strides %% 4 == 0");
+    static const int np = sh_env_int("SH_P3_NP", 6, 6, 9);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nt = g.nt;
+#define SH_P3R_CASE(N) (np == 9 ? launch_p3r<N, 9>(p, st) : launch_p3r<N, 6>(p, st))
+    if (nt == 1) return SH_P3R_CASE(1);
+    if (nt == 2) return SH_P3R_CASE(2);
+    if (nt == 4) return SH_P3R_CASE(4);
+#undef SH_P3R_CASE
+    sh_set_error("conv_p3r: %d channel tiles per workgroup is not built", nt);
+    return SH_ERR_UNSUPPORTED;
 }
 
 }  // extern "C"

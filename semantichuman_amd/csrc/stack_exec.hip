@@ -242,9 +242,13 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
             const bool thin = want_in && s.table_t && s.R == s.n_in && il.sb == s.cin && il.sv == (long)B * s.cin && cl.sb == s.cout &&
                               cl.sv == (long)B * s.cout && sh_spiral_conv_bwd_wgt_thin_ok(B, s.n_in, s.S, s.cin, s.cout, SH_DTYPE_F32);
             const bool p3 = !thin && cur_img && cl.sb == s.cout && cl.sv == (long)B * s.cout;
+            // backward-data over ragged source lists (round 6): every source an image row, no pre-summed rows - neither the launches
+            // that fill them nor the rider in the weight gradient (SH_P3_RAGGED=0: the dense table with its pre-sums)
+            static const int rag_on = sh_env_int("SH_P3_RAGGED", 1, 0, 1);
+            const bool rag = p3 && rag_on && want_in && s.rag_rows && s.rag_pos && sh_spiral_conv_p3_rag_ok(B, s.S, s.cout, s.cin, s.rag_L);
             // the last pre-sum level of this layer rides in the weight-gradient launch (sh_spiral_conv_bwd_wgt_presum); an
             // earlier level (very long lists: two levels) runs first, on its own
-            const bool ride = !thin && want_in && s.table_t && (s.n1 || s.n2);
+            const bool ride = !thin && !rag && want_in && s.table_t && (s.n1 || s.n2);
             // SH_P3_PRESUM_IMG=1: the riders / pre-sum launches write the image of their rows; default 0: they stay plain and the
             // backward-data kernel splits those rows itself from the fp32 buffer (they are ~6 % of what it gathers)
             // pre-summed rows: imaged by their producers (the riders / pre-sum launches), or - LDS-resident plane kernel and at
@@ -293,12 +297,12 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
                 SH_REQUIRE(s.table_t, SH_ERR_INVALID_ARG, "sh_stack_backward: step %d has no transposed table", i);
                 float* mut = const_cast<float*>(cur);          // the extra rows behind the R real ones of this step's own buffer
                 char* pimg = pimg0;
-                if (s.n1 && !ride) {
+                if (s.n1 && !ride && !rag) {
                     rc = sh_spmm_p3(s.sum1.rowptr, s.sum1.col, s.sum1.val, cur, cl.sv, cl.sb, mut + (long)s.R * cl.sv, cl.sv, cl.sb,
                                     pimg ? pimg + sh_p3_bytes(s.R, B, s.cout) : nullptr, nullptr, 0, 0, 0, -1, B, s.n1, s.cout, stream);
                     if (rc != SH_OK) return rc;
                 }
-                if (s.n2 && !ride) {
+                if (s.n2 && !ride && !rag) {
                     rc = sh_spmm_p3(s.sum2.rowptr, s.sum2.col, s.sum2.val, cur, cl.sv, cl.sb, mut + (long)(s.R + s.n1) * cl.sv,
                                     cl.sv, cl.sb, pimg ? pimg + sh_p3_bytes(s.R + s.n1, B, s.cout) : nullptr, nullptr, 0, 0, 0, -1, B, s.n2,
                                     s.cout, stream);
@@ -331,6 +335,10 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
                         static const int yimg_on = sh_env_int("SH_P3_YPREV_IMG", 1, 0, 1);
                         const void* yimg = (yimg_on && yprev && in_planes && in_planes[i] && yl.sb == s.cin && yl.sv == (long)B * s.cin &&
                                             sh_p3_bytes(1, B, s.cin)) ? in_planes[i] : nullptr;
+                        if (rag)
+                            rc = sh_spiral_conv_bwd_data_p3_rag(cur_img, s.rag_rows, s.rag_pos, s.rag_L, wfrag3_t[i], gi, gl.sv, gl.sb, img_out ? gi_img : nullptr,
+                                                                yprev, yl.sv, yl.sb, yimg, act_prev, zero_prev, B, s.n_in, s.S, s.cin, s.cout, stream);
+                        else
                         rc = sh_spiral_conv_bwd_data_p3(cur_img, s.zero_row, presum_img ? nullptr : cur, cl.sv, cl.sb, s.R, s.table_t, wfrag3_t[i], gi, gl.sv, gl.sb, img_out ? gi_img : nullptr, yprev, yl.sv,
                                                         yl.sb, yimg, act_prev, zero_prev, B, s.n_in, s.S, s.cin, s.cout, stream);
                         gi_img_done = img_out;

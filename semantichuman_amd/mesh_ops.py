@@ -220,6 +220,35 @@ def transpose_table_dense(table: np.ndarray, n_in: int, none_row: int, skip_row:
     return TransposedTable(tt.reshape(n_in, S), csr1, csr2, n1, n2)
 
 
+def transpose_table_ragged(table: np.ndarray, n_in: int, none_row: int, skip_row: int = -1, max_len: int = 64):
+    """The sources of every input row as a LIST (round 6; csrc/p3_conv.hip conv_p3r_kernel): for input row u all (output row r,
+    position s) pairs with table[r, s] == u, ordered by s, then r.  Returns (rows int32 [n_in, L], pos int32 [n_in, L]) with L the
+    longest list and pos == -1 (rows == none_row) behind a row's last source, or None when a list is longer than `max_len` (a
+    dummy row with hundreds of readers whose gradient is needed: such a layer keeps the dense table and its pre-summed rows).
+    The number of sources of a row is about the spiral length, or half of it on a down-sampling level, and never much more: the
+    list form has no empty slots (8 233 of 37 906 dense slots at 3446 rows x 11 positions, more than half of them on the
+    down-sampling levels) and needs no pre-summed rows (4 495 there)."""
+    R, S = table.shape
+    gl = transpose_table(table, n_in, skip_row=skip_row)
+    per_slot = np.diff(gl.ptr).reshape(n_in, S)
+    length = per_slot.sum(axis=1)
+    L = int(length.max()) if length.size else 0
+    if L == 0:
+        L = 1
+    if L > max_len:
+        return None
+    rows = np.full((n_in, L), none_row, dtype=np.int32)
+    pos = np.full((n_in, L), -1, dtype=np.int32)
+    # gl.src is ordered by (u, s) and, inside a slot, by increasing source row (stable sort): exactly the list order wanted
+    start = gl.ptr[:-1].reshape(n_in, S)[:, 0]
+    slot_pos = np.repeat(np.tile(np.arange(S, dtype=np.int32), n_in), per_slot.ravel())
+    u_of = np.repeat(np.arange(n_in), length)
+    j_of = np.arange(gl.src.size) - np.repeat(start, length)
+    rows[u_of, j_of] = gl.src
+    pos[u_of, j_of] = slot_pos
+    return rows, pos
+
+
 # ----------------------------------------------------------------------------- U (up-sampling)
 def _closest_point_barycentric(p, a, b, c):
     """Closest point to p on triangles (a,b,c) (all [M,3]); returns barycentric

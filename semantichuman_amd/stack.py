@@ -42,6 +42,7 @@ _LAYOUT_ID = {"vm": 0, "bm": 1}
 # the library's own switch (csrc/stack_exec.hip reads it once): with the exact weight-gradient kernels nothing reads the forward
 # images during the backward pass, so they are not kept
 _P3_WGRAD = os.environ.get("SH_P3_WGRAD", "1").strip() != "0"
+_P3_RAGGED = os.environ.get("SH_P3_RAGGED", "1").strip() != "0"
 _ALIGN = 64                       # floats: every carved buffer starts 256-byte aligned (16-byte vector accesses)
 
 
@@ -94,10 +95,16 @@ class ConvStep:
         self.tt = mesh_ops.transpose_table_dense(self.table, self.n_in, none_row=self.zero_row,
                                                  skip_row=dummy if self.dead_dummy_grad else -1)
         self.n_extra = self.tt.n_extra
+        # the same sources as ragged lists (round 6): the plane backward-data kernel of a layer with a resident weight walks them
+        # instead of the dense table and needs no pre-summed rows (SH_P3_RAGGED=0, or a list longer than 64: the dense form)
+        self.rag = mesh_ops.transpose_table_ragged(self.table, self.n_in, none_row=self.zero_row,
+                                                   skip_row=dummy if self.dead_dummy_grad else -1) if _P3_RAGGED else None
         return self
 
     def to(self, device):
         self.dev = {"table": _dev(self.table, device), "table_t": _dev(self.tt.table_t, device)}
+        if getattr(self, "rag", None) is not None:
+            self.dev["rag_rows"], self.dev["rag_pos"] = _dev(self.rag[0], device), _dev(self.rag[1], device)
         if self.tt.csr1 is not None:
             self.dev["sum1"] = _csr_dev(self.tt.csr1, device)
         if self.tt.csr2 is not None:
@@ -239,6 +246,8 @@ class Stack:
                 for name, ref in (("sum1", e.sum1), ("sum2", e.sum2)):
                     if name in st.dev:
                         ref.rowptr, ref.col, ref.val = (P(t) for t in st.dev[name])
+                if "rag_rows" in st.dev:
+                    e.rag_rows, e.rag_pos, e.rag_L = P(st.dev["rag_rows"]), P(st.dev["rag_pos"]), int(st.dev["rag_rows"].shape[1])
             else:
                 e.kind, e.param = 1, -1
                 e.m.rowptr, e.m.col, e.m.val = (P(t) for t in st.dev["m"])

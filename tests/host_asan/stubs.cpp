@@ -266,5 +266,19 @@ int sh_spiral_conv_bwd_data_p3(const void* dprep, int, const float* dpre_f32, in
     log("bwd_data_p3 n_in=%d Cin=%d Cout=%d", n_in, Cin, Cout);
     return 0;
 }
+int sh_spiral_conv_p3_rag_ok(int B, int S, int Cg, int Nout, int rag_L) { return sh_spiral_conv_p3_ok(B, S, Cg, Nout) && Cg % 32 == 0 && rag_L > 0 && rag_L <= 64; }
+int sh_spiral_conv_bwd_data_p3_rag(const void* dprep, const int32_t* rag_rows, const int32_t* rag_pos, int rag_L, const void* wfrag3_t, float* dx, int64_t dx_sv,
+                                   int64_t dx_sb, void* dxp, const float* yprev, int64_t yp_sv, int64_t yp_sb, const void* yprev_planes, int act_prev, int zero_row,
+                                   int B, int n_in, int S, int Cin, int Cout, sh_stream_t) {
+    int rows = 0;
+    for (long i = 0; i < (long)n_in * rag_L; ++i) { rows = rag_rows[i] + 1 > rows ? rag_rows[i] + 1 : rows; if (rag_pos[i] >= S) return SH_ERR_INVALID_ARG; }
+    touch_r(dprep, sh_p3_bytes(rows, B, Cout)); touch_r(wfrag3_t, sh_conv_wfrag3_bytes(S, Cout, Cin));
+    if (dx) touch_w(dx, span(dx_sv, dx_sb, n_in, B, Cin, 4));
+    if (dxp) touch_w(dxp, sh_p3_bytes(n_in, B, Cin));
+    if (yprev_planes) touch_r(yprev_planes, sh_p3_bytes(n_in, B, Cin));
+    else if (yprev) touch_r(yprev, span(yp_sv, yp_sb, n_in, B, Cin, 4));
+    log("bwd_data_p3_rag n_in=%d Cin=%d L=%d", n_in, Cin, rag_L);
+    return 0;
+}
 }  // extern "C"
 bool sh_mma_mode_valid(int mode) { return mode >= 0 && mode <= 2; }

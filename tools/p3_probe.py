@@ -151,6 +151,26 @@ def probe_layers(B=64, tpl=None, directions=("fwd", "bwd"), adversarial=False, r
                                                                           _lib.stream_ptr()), "sh_spiral_conv_bwd_data_p3")
                         rec["us"]["planes3"] = timed(run_p3, reps)
                         rec["err"]["planes3"] = float((y.double() - ref).abs().max()) / scale
+                        # round 6: the same backward-data pass over ragged source lists (no dense table, no pre-summed rows)
+                        if bwd and getattr(st, "rag", None) is not None and lib.sh_spiral_conv_p3_rag_ok(B, S, Cg, Nout, int(st.rag[0].shape[1])):
+                            rr, rp = st.dev["rag_rows"], st.dev["rag_pos"]
+                            # reference of the ragged form = the dense one when the extra rows hold the pre-sums: build it from the lists
+                            ref_r = torch.zeros((rows_out, B, Nout), dtype=torch.float64, device=dev)
+                            for j in range(rr.shape[1]):
+                                ok_j = (rp[:, j] >= 0)
+                                for s_ in range(S):
+                                    sel = ok_j & (rp[:, j] == s_)
+                                    if bool(sel.any()):
+                                        ref_r[sel] += x64[rr[sel, j].long()] @ w64[:, s_, :]
+                            y.zero_()
+
+                            def run_rag():
+                                _lib.check(lib.sh_spiral_conv_bwd_data_p3_rag(_lib.ptr(xp), _lib.ptr(rr), _lib.ptr(rp), int(rr.shape[1]), _lib.ptr(wf), _lib.ptr(y),
+                                                                              B * Nout, Nout, _lib.ptr(yp), None, 0, 0, None, 0, -1, B, n_in, S, cin, cout,
+                                                                              _lib.stream_ptr()), "sh_spiral_conv_bwd_data_p3_rag")
+                            rec["us"]["planes3_rag"] = timed(run_rag, reps)
+                            rec["err"]["planes3_rag"] = float((y.double() - ref_r).abs().max()) / float(ref_r.abs().max())
+                            rec["rag_L"] = int(rr.shape[1])
                         rec["us_to_p3"] = timed(lambda: to_p3(x), reps)
                         rec["img_ok"] = None if yp is None else bool(torch.equal(to_p3(y), yp))
                     yield rec
@@ -176,8 +196,9 @@ def main():
             t3 = "%6.1f (+%.1f)%s" % (r["us"]["planes3"], r["us_to_p3"], "" if r["img_ok"] is None else " img=" + ("ok" if r["img_ok"] else "MISMATCH"))
         else:
             p3s, t3 = "   -   ", "  -"
-        print("%-34s %.2e %.2e %-9s   %6.1f %6.1f %s" % (r["name"], r["err"]["exact"], r["err"]["split3"], p3s, r["us"]["exact"],
-                                                         r["us"]["split3"], t3), flush=True)
+        rag = "   ragged lists (L %d): err %.2e, %6.1f us" % (r["rag_L"], r["err"]["planes3_rag"], r["us"]["planes3_rag"]) if "planes3_rag" in r["us"] else ""
+        print("%-34s %.2e %.2e %-9s   %6.1f %6.1f %s%s" % (r["name"], r["err"]["exact"], r["err"]["split3"], p3s, r["us"]["exact"],
+                                                           r["us"]["split3"], t3, rag), flush=True)
 
 
 if __name__ == "__main__":
