@@ -101,6 +101,18 @@ def test_full_training_step_vs_oracle(case, form, record_property):
             # round 6: the weight gradients of the layers between the 3-channel sides and the 16-channel level-0 layer run on the
             # images too (csrc/wgrad_p3.hip; any batch that has images, i.e. multiples of 16 - at batch 16 a stage pairs two vertices and
             # the 863-row layers' odd unit count is completed by the dummy row): six of the nine, the rest on the fp32 kernels
+            # ... and the backward-data pass of the four layers with a resident weight walks ragged source lists: no pre-sum launch
+            # of theirs is left (the two streamed-weight layers and the level-0 layers keep the dense table)
+            lib = _lib.load()
+            n_rag = 0
+            for stack in (m._enc_stack, m._dec_stack):
+                for i, st in enumerate(stack.steps):
+                    first = stack is m._enc_stack and i == 0                    # no backward-data pass
+                    if st.kind == "conv" and not first and getattr(st, "rag", None) is not None and \
+                            lib.sh_spiral_conv_p3_rag_ok(B, st.S, st.cout, st.cin, int(st.rag[0].shape[1])):
+                        n_rag += 1
+            assert n_rag == (4 if case["tpl"] == "template6890.npz" else n_rag) and n_rag >= 2
+            assert sum(1 for n in names if n.startswith("conv_p3r_kernel")) == n_rag, (n_rag, sorted(set(names)))
             n_wp3 = sum(1 for n in names if n.startswith("wgrad_p3_kernel"))
             assert n_wp3 == 6, (n_wp3, sorted(set(names)))
             assert sum(1 for n in names if n.startswith(("wgrad_stream", "wgrad_split3"))) == 2, sorted(set(names))

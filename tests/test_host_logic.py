@@ -357,3 +357,43 @@ def test_checkpoint_with_pickled_objects_needs_trust_pickle(tmp_path):
     with pytest.raises(RuntimeError, match="trust_pickle"):
         train_funcs.load_checkpoint(str(p), torch.nn.Linear(2, 2))
     assert train_funcs.load_checkpoint(str(p), torch.nn.Linear(2, 2), trust_pickle=True) == 5
+
+
+def test_ragged_source_lists_are_the_dense_transposed_table_with_its_presums():
+    """mesh_ops.transpose_table_ragged (round 6; the plane backward-data kernel's list form): for every input row exactly the
+    (output row, position) pairs that read it - ordered by position, then row; the dead dummy row empty; padding marked -1 -
+    and a backward-data pass evaluated over the lists equals the one over the dense transposed table with its pre-summed rows."""
+    import numpy as np
+    from semantichuman_amd import mesh_ops
+    rs = np.random.RandomState(3)
+    R, S, n_in, Co, Ci = 61, 5, 43, 4, 3
+    table = rs.randint(0, n_in, size=(R, S)).astype(np.int32)
+    table[:, 3] = n_in - 1                                    # a dummy row with R readers at one position
+    for skip in (-1, n_in - 1):
+        rag = mesh_ops.transpose_table_ragged(table, n_in, none_row=R - 1, skip_row=skip, max_len=200)
+        assert rag is not None
+        rows, pos = rag
+        for u in range(n_in):
+            want = [] if u == skip else [(r, s) for s in range(S) for r in range(R) if table[r, s] == u]
+            got = [(int(rows[u, j]), int(pos[u, j])) for j in range(rows.shape[1]) if pos[u, j] >= 0]
+            assert want == got, u
+            assert (pos[u, len(got):] == -1).all() and (rows[u, len(got):] == R - 1).all()
+        # the numbers: dx[u] = sum_j dpre[rows[u, j]] @ W[pos[u, j]]  ==  sum_s dpre_ext[table_t[u, s]] @ W[s]
+        tt = mesh_ops.transpose_table_dense(table, n_in, none_row=R - 1, skip_row=skip)
+        dpre = rs.randn(R, Co)
+        dpre[R - 1] = 0                                        # the "no source" row
+        W = rs.randn(S, Co, Ci)
+        ext = np.concatenate([dpre, np.zeros((tt.n_extra, Co))])
+        if tt.csr1 is not None:
+            for k in range(tt.n1):
+                ext[R + k] = ext[tt.csr1.col[tt.csr1.rowptr[k]:tt.csr1.rowptr[k + 1]]].sum(0)
+        if tt.csr2 is not None:
+            for k in range(tt.n2):
+                ext[R + tt.n1 + k] = ext[tt.csr2.col[tt.csr2.rowptr[k]:tt.csr2.rowptr[k + 1]]].sum(0)
+        dense = sum(ext[tt.table_t[:, s]] @ W[s] for s in range(S))
+        lists = np.zeros((n_in, Ci))
+        for j in range(rows.shape[1]):
+            ok = pos[:, j] >= 0
+            lists[ok] += np.einsum("uc,uci->ui", dpre[rows[ok, j]], W[pos[ok, j]])
+        assert np.allclose(dense, lists, rtol=1e-12, atol=1e-12)
+    assert mesh_ops.transpose_table_ragged(table, n_in, none_row=R - 1, skip_row=-1, max_len=16) is None      # the long list: dense form

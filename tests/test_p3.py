@@ -69,7 +69,12 @@ def test_error_of_the_split_forms_against_float64(adversarial):
                 bad.append((r["name"], form, e[form], e["exact"]))
         assert r["img_ok"] in (True, None), r["name"]
         assert e["exact"] < 5e-6, (r["name"], e)                    # the exact form itself is at fp32 level on these sums
+        # round 6: backward-data over ragged source lists (conv_p3r_kernel) - its own float64 reference (the sums over a list's
+        # sources are formed by the matrix pipe instead of by a pre-sum launch), the same gate
+        if "planes3_rag" in e and not e["planes3_rag"] <= 1.5 * e["exact"] + 1e-9:
+            bad.append((r["name"], "planes3_rag", e["planes3_rag"], e["exact"]))
     assert not bad, bad
+    assert sum(1 for r in rows if "planes3_rag" in r["err"]) == 4, [r["name"] for r in rows if "planes3_rag" in r["err"]]
 
 
 def test_nine_products_are_not_needed():
