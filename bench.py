@@ -143,10 +143,12 @@ def parse_tag(name, shape):
     fam = name.split("<")[0]
     if fam in ("wgrad_bf16_dma_kernel", "wgrad_thin_kernel"):       # the other two forms of the bf16 weight gradient
         fam = "wgrad_bf16_kernel"
-    if fam not in ("conv_bf16_kernel", "wgrad_bf16_kernel"):
+    if fam not in ("conv_bf16_kernel", "conv_bf16r_kernel", "wgrad_bf16_kernel"):
         return None
     f = dict(kv.split("=") for kv in shape.split() if "=" in kv)
     try:
+        if fam == "conv_bf16r_kernel":                               # backward-data over ragged source lists: <NT>
+            return ("conv_bf16_kernel", True, int(f["R"]), int(f["S"]), int(f["Cg"]), int(f["N"]))
         if fam == "conv_bf16_kernel":
             bwd = name.split("<")[1].split(",")[3].strip() == "true"
             return (fam, bwd, int(f["R"]), int(f["S"]), int(f["Cg"]), int(f["N"]))

@@ -703,6 +703,17 @@ SH_API int sh_spiral_conv_bwd_data_p3_rag(const void* dprep, const int32_t* rag_
                                           int64_t yp_sb, const void* yprev_planes, int act_prev, int zero_row, int B, int n_in, int S,
                                           int Cin, int Cout, sh_stream_t stream);
 
+/* The same over bf16 tensors (csrc/bf16_conv.hip conv_bf16r_kernel; the ragged sibling of sh_spiral_conv_bwd_data_bf16): dpre and dx
+ * bf16 (element strides), wfrag_t the transposed bf16 fragments of sh_conv_wfrag_prep_multi, yprev bf16 or NULL.  The sums over
+ * several sources of one (row, position) are formed in fp32 by the matrix pipe, where the dense form reads pre-summed rows that
+ * were rounded to bf16 once more.  .._rag_ok: gathered channels (the layer's Cout) a multiple of 32, output channels a multiple
+ * of 4, lists of at most 64 entries, a weight slice that fits LDS. */
+SH_API int sh_spiral_conv_bf16_rag_ok(int B, int S, int Cg, int Nout, int rag_L);
+SH_API int sh_spiral_conv_bwd_data_bf16_rag(const void* dpre, int64_t dp_sv, int64_t dp_sb, const int32_t* rag_rows, const int32_t* rag_pos,
+                                            int rag_L, const void* wfrag_t, void* dx, int64_t dx_sv, int64_t dx_sb, const void* yprev,
+                                            int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row, int B, int n_in, int S, int Cin,
+                                            int Cout, sh_stream_t stream);
+
 /* Weight gradient of a spiral conv in the three-plane form (csrc/wgrad_p3.hip, round 6; autograd of reference models.py:45,
  * dW = dpre^T . gather(x)): both operands given as their plane images - x_planes = image of the layer's input ([n_in] rows,
  * what its forward plane conv gathered), dpre_planes = image of the pre-activation gradient (rows [0, R) are read) - six

@@ -111,6 +111,8 @@ SIGNATURES = {
     "sh_spiral_conv_fwd_p3": (c_int, [_P, _P, _P, _P, _P, _L, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sh_spiral_conv_bwd_data_p3": (c_int, [_P, _I, _P, _L, _L, _I, _P, _P, _P, _L, _L, _P, _P, _L, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sh_spiral_conv_p3_rag_ok": (c_int, [_I, _I, _I, _I, _I]),
+    "sh_spiral_conv_bf16_rag_ok": (c_int, [_I, _I, _I, _I, _I]),
+    "sh_spiral_conv_bwd_data_bf16_rag": (c_int, [_P, _L, _L, _P, _P, _I, _P, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sh_spiral_conv_bwd_data_p3_rag": (c_int, [_P, _P, _P, _I, _P, _P, _L, _L, _P, _P, _L, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sh_spiral_conv_bwd_wgt_p3_ok": (c_int, [_I, _I, _I, _I, _I]),
     "sh_spiral_conv_bwd_wgt_p3_workspace": (c_size_t, [_I, _I, _I, _I, _I]),

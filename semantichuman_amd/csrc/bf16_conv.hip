@@ -53,6 +53,9 @@ struct BCParams {
     int B, R, S, Cg, Nout, nks, nt_tot;
     int act, zero_row;
     int n_vg, n_tiles, nsplit;
+    // ragged backward-data (conv_bf16r_kernel): per output row its sources as a LIST - rag_rows [R][rag_L] rows of x, rag_pos [R][rag_L]
+    // the spiral position whose weight multiplies each (-1 behind the last source); ncg = Cg / 32
+    const int* rag_rows; const int* rag_pos; int rag_L, ncg;
 };
 
 struct __attribute__((packed, aligned(4))) bc_f3 { float a, b, c; };
@@ -294,6 +297,125 @@ __global__ __launch_bounds__(1024) void conv_bf16_kernel(const BCParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Backward-data over RAGGED source lists (round 6; the bf16 sibling of p3_conv.hip's conv_p3r_kernel).  The dense transposed
+// table has one slot per (input row, spiral position): a slot nobody reads from points at the zero row (more than half of the
+// slots on the down-sampling levels - their loads are issued all the same), a slot several output rows read through points at an
+// extra row that a pre-sum launch (spmm_bf16: eight launches of a backward pass here, ~55 us of a 0.9-ms step) has to fill first.
+// A list of (source row, position) pairs per input row has neither: every source is a real row of dpre and the sums are formed by
+// the matrix pipe (linearity) - in fp32, where the pre-summed rows were rounded to bf16 once more.  One vertex x 16 batch entries
+// per wave item (two vertices could not share weight-fragment reads: their positions differ step by step), line-wise loads as in
+// BC_C32C (lane l: piece l & 3 of batch row l >> 2), gathered channels % 32 == 0, bf16 on both sides.
+template <int NT>
+__global__ __launch_bounds__(1024) void conv_bf16r_kernel(const BCParams p) {
+    constexpr int D = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const u32x4* Wl = reinterpret_cast<const u32x4*>(smem);       // [nks][NT][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+    const int nwg_x = ((int)gridDim.x - xcd + 7) >> 3;
+    const int slice = li % p.nsplit, lj = li / p.nsplit;
+    const int ngrp = nwg_x / p.nsplit;
+    const int q8 = p.n_tiles >> 3, r8 = p.n_tiles & 7;
+    const int t_begin = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int t_end = t_begin + (xcd < r8 ? q8 + 1 : q8);
+    const int stride = ngrp * nw;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int Lp = p.rag_L, ll = lane < Lp ? lane : Lp - 1;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const unsigned rowmul = (unsigned)(p.x_rb >> 4);
+    // the list of an item's vertex: lane j holds source j (row pre-multiplied by the row stride in 16-byte units) and its position
+    auto load_list = [&](int t, int& rows, int& pos) {
+        const int tt = t < t_end ? t : (t_end > 0 ? t_end - 1 : 0);
+        const int v = tt % p.n_vg;
+        rows = (int)((unsigned)p.rag_rows[(long)v * Lp + ll] * rowmul);
+        pos = lane < Lp ? p.rag_pos[(long)v * Lp + ll] : -1;
+    };
+    int t = t_begin + lj * nw + wave;
+    int tv, tp, tvn, tpn;
+    load_list(t, tv, tp);
+    {
+        typedef __attribute__((address_space(3))) char* lptr_t;
+        const unsigned wl_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_t)smem);
+        const int nfrag = p.nks * NT;
+        for (int f = __builtin_amdgcn_readfirstlane(wave); f < nfrag; f += nw) {
+            const int n = f % NT, ks = f / NT;
+            const char* src = reinterpret_cast<const char*>(p.wfrag + ((long)ks * p.nt_tot + slice * NT + n) * 64 + lane);
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(__builtin_amdgcn_readfirstlane(wl_lds + (unsigned)f * 1024u)) : "memory", "m0");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    const int perm = (4 * r16 + kq) << 2;                  // the MFMA operand of lane (r, kq) is the piece lane 4 r + kq loaded
+    for (; t < t_end; t += stride) {
+        load_list(t + stride, tvn, tpn);
+        const int bs = t / p.n_vg, v = t - bs * p.n_vg;
+        const int b0 = bs * 16;
+        const int bl_co = b0 + (lane >> 2) < p.B ? b0 + (lane >> 2) : p.B - 1;
+        const char* xl = p.x + (long)bl_co * p.x_bb + (lane & 3) * 16;
+        const int L = __builtin_popcountll(__builtin_amdgcn_ballot_w64(tp >= 0));      // sources of this vertex (uniform)
+        const int nks = L * p.ncg;
+        int lj2 = 0, lc = 0;                               // running load position: list entry, channel group (uniform)
+        u32x4 ring[D];
+        auto issue = [&](u32x4& a) {
+            const int j = lj2 < L ? lj2 : (L > 0 ? L - 1 : 0);      // past the end: the last entry again (never multiplied)
+            const int row = __builtin_amdgcn_readlane(tv, j);
+            a = *reinterpret_cast<const u32x4*>(xl + (long)((unsigned long)(unsigned)row << 4) + (long)lc * 64);
+            if (++lc >= p.ncg) { lc = 0; ++lj2; }
+        };
+        f32x4 acc[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n] = zero4;
+        int cj = 0, cc = 0;                                // entry / channel group of the k-step being multiplied (uniform)
+        auto compute = [&](const u32x4& a) {
+            const int s = __builtin_amdgcn_readlane(tp, cj);
+            const u32x4* wk = Wl + ((long)(s * p.ncg + cc) * NT) * 64 + lane;
+            if (++cc >= p.ncg) { cc = 0; ++cj; }
+            u32x4 g4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g4[j] = (unsigned)__builtin_amdgcn_ds_bpermute(perm, (int)a[j]);
+            const bf16x8 g = *reinterpret_cast<const bf16x8*>(&g4);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const u32x4 wraw = wk[n * 64];
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&wraw), g, acc[n], 0, 0, 0);
+            }
+        };
+#pragma unroll
+        for (int d = 0; d < D - 1; ++d) issue(ring[d]);
+        auto step = [&](auto J, int ks) {
+            constexpr int j = decltype(J)::value;
+            issue(ring[(j + D - 1) % D]);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(ring[j]);
+        };
+        for (int ks = 0; ks < nks; ks += D)
+            if (!bc_ring_steps<0, D>(ks, nks, step)) break;
+
+        // ---- epilogue: lane holds channels c0..c0+3 (c0 = 16 n + 4 kq) of row (v, b0 + r16)
+        const int b = b0 + r16;
+        if (v < p.R && b < p.B) {
+            char* yrow = p.y + (long)v * p.y_rb + (long)b * p.y_bb;
+            const char* yp = p.yprev ? p.yprev + (long)v * p.yp_rb + (long)b * p.yp_bb : nullptr;
+            const bool zero = v == p.zero_row;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int c0 = (slice * NT + n) * 16 + kq * 4;
+                if (c0 >= p.Nout) continue;
+                f32x4 a = acc[n];
+                if (yp) {
+                    const f32x4 yv = sh_from_bf16x4(*reinterpret_cast<const bf16x4*>(yp + 2 * c0));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[j] *= sh_act_grad_from_out(yv[j], p.act);
+                }
+                if (zero) a = zero4;
+                *reinterpret_cast<bf16x4*>(yrow + 2 * c0) = sh_to_bf16x4(a);
+            }
+        }
+        tv = tvn; tp = tpn;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // fp32 master weight -> fragment-ordered bf16 working copy (one launch for all layers of a stack).
 //   transpose == 0 (forward):        W'[row = co][k = (s, ci)] = W[co][s*Cin + ci]            Cg = Cin,  Nout = Cout
 //   transpose == 1 (backward-data):  W'[row = ci][k = (s, co)] = W[co][s*Cin + ci]            Cg = Cout, Nout = Cin
@@ -376,6 +498,46 @@ int launch_bc(BCParams& p, hipStream_t st) {
     SH_LAUNCH_PS(ps, kern, dim3(grid), dim3(nw * 64), smem, st, p);
     SH_CHECK_LAUNCH("conv_bf16");
     return SH_OK;
+}
+
+template <int NT>
+int launch_bcr(BCParams& p, hipStream_t st) {
+    auto kern = conv_bf16r_kernel<NT>;
+    const size_t smem = (size_t)p.nks * NT * 1024;
+    static size_t attr_set = 0;
+    if (smem > 65536 && smem > attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            (void)hipGetLastError();
+            sh_set_error("conv_bf16r: cannot raise the dynamic LDS limit to %zu bytes", smem);
+            return SH_ERR_LAUNCH;
+        }
+        attr_set = 160 * 1024;
+    }
+    p.n_vg = p.R;
+    const long tiles = (long)p.R * sh_cdiv(p.B, 16);
+    SH_REQUIRE(tiles < (1L << 30), SH_ERR_UNSUPPORTED, "conv_bf16r: %ld work items", tiles);
+    p.n_tiles = (int)tiles;
+    const int per_cu = smem <= 36 * 1024 ? 4 : smem <= 76 * 1024 ? 2 : 1;
+    int nw = 16 / per_cu;
+    while (nw > 4 && (long)num_cus() * per_cu * (nw >> 1) >= tiles * p.nsplit) nw >>= 1;
+    long groups = (tiles + nw - 1) / nw;
+    const long cap = (long)num_cus() * per_cu / p.nsplit;
+    if (groups > cap) groups = cap;
+    if (groups < 8) groups = 8;
+    groups = (groups + 7) / 8 * 8;
+    const int grid = (int)groups * p.nsplit;
+    ShProfScope ps(st, "conv_bf16r_kernel<%d>|R=%d B=%d S=%d Cg=%d N=%d grid=%dx%d L=%d", NT, p.R, p.B, p.S, p.Cg, p.Nout, grid, nw * 64, p.rag_L);
+    SH_LAUNCH_PS(ps, kern, dim3(grid), dim3(nw * 64), smem, st, p);
+    SH_CHECK_LAUNCH("conv_bf16r");
+    return SH_OK;
+}
+
+// channel tiles per workgroup of the ragged form: the whole (slice of the) weight resident, as dispatch_bc_nt
+inline int bcr_nt(int nks, int nt_tot, int* nsplit) {
+    int nt = nt_tot > 8 ? 8 : nt_tot, ns = nt_tot / nt;
+    while (nt > 1 && (long)nks * nt > 128) { nt >>= 1; ns <<= 1; }
+    *nsplit = ns;
+    return nt;
 }
 
 template <int MODE, bool BWD, bool OUTF32>
@@ -506,6 +668,51 @@ int sh_spiral_conv_bwd_data_bf16(const void* dpre, int dp_dtype, int64_t dp_sv, 
     p.yprev = static_cast<const char*>(yprev); p.yp_rb = yp_sv * 2; p.yp_bb = yp_sb * 2;
     p.B = B; p.R = n_in; p.S = S; p.Cg = Cout; p.Nout = Cin; p.act = act_prev; p.zero_row = zero_row;
     return dispatch_bc<true>(p, dp_dtype == SH_DTYPE_F32, dx_dtype == SH_DTYPE_F32, static_cast<hipStream_t>(stream));
+}
+
+int sh_spiral_conv_bf16_rag_ok(int B, int S, int Cg, int Nout, int rag_L) {
+    if (B <= 0 || S <= 0 || S > 64 || Cg <= 0 || Cg % 32 != 0 || Nout <= 0 || Nout % 4 != 0 || rag_L <= 0 || rag_L > 64) return 0;
+    const ShFragGeom g = sh_frag_geom(S, Cg, Nout);
+    if (g.nt_tot > 8 && g.nt_tot % 8 != 0) return 0;
+    int ns;
+    const int nt = bcr_nt(g.nks, g.nt_tot, &ns);
+    return (nt == 1 || nt == 2 || nt == 4 || nt == 8) && nt * ns == g.nt_tot && (long)g.nks * nt <= 150;
+}
+
+int sh_spiral_conv_bwd_data_bf16_rag(const void* dpre, int64_t dp_sv, int64_t dp_sb, const int32_t* rag_rows, const int32_t* rag_pos,
+                                     int rag_L, const void* wfrag_t, void* dx, int64_t dx_sv, int64_t dx_sb, const void* yprev,
+                                     int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row, int B, int n_in, int S, int Cin, int Cout,
+                                     sh_stream_t stream) {
+    SH_REQUIRE(dpre && rag_rows && rag_pos && wfrag_t && dx, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_data_bf16_rag: null pointer");
+    SH_REQUIRE(B > 0 && n_in > 0 && S > 0 && Cin > 0 && Cout > 0, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_data_bf16_rag: non-positive size");
+    SH_REQUIRE(act_prev >= SH_ACT_IDENTITY && act_prev <= SH_ACT_TANH, SH_ERR_INVALID_ARG, "sh_spiral_conv_bwd_data_bf16_rag: unknown activation");
+    SH_REQUIRE(sh_spiral_conv_bf16_rag_ok(B, S, Cout, Cin, rag_L), SH_ERR_UNSUPPORTED,
+               "sh_spiral_conv_bwd_data_bf16_rag: B=%d S=%d gathered channels=%d output channels=%d lists of %d is not taken (gathered "
+               "channels %% 32 == 0, output channels %% 4 == 0, lists of at most 64 sources)", B, S, Cout, Cin, rag_L);
+    BCParams p{};
+    p.x = static_cast<const char*>(dpre); p.x_rb = dp_sv * 2; p.x_bb = dp_sb * 2;
+    p.wfrag = static_cast<const u32x4*>(wfrag_t);
+    p.y = static_cast<char*>(dx); p.y_rb = dx_sv * 2; p.y_bb = dx_sb * 2;
+    p.yprev = static_cast<const char*>(yprev); p.yp_rb = yp_sv * 2; p.yp_bb = yp_sb * 2;
+    p.B = B; p.R = n_in; p.S = S; p.Cg = Cout; p.Nout = Cin; p.act = act_prev; p.zero_row = zero_row;
+    p.rag_rows = rag_rows; p.rag_pos = rag_pos; p.rag_L = rag_L; p.ncg = Cout / 32;
+    const ShFragGeom g = sh_frag_geom(S, Cout, Cin);
+    p.nks = g.nks; p.nt_tot = g.nt_tot;
+    SH_REQUIRE(((reinterpret_cast<uintptr_t>(p.x) | (uintptr_t)p.x_rb | (uintptr_t)p.x_bb) & 15) == 0, SH_ERR_INVALID_ARG,
+               "sh_spiral_conv_bwd_data_bf16_rag: gathered tensor must be 16-byte aligned with 16-byte-multiple strides");
+    SH_REQUIRE(((reinterpret_cast<uintptr_t>(p.y) | (uintptr_t)p.y_rb | (uintptr_t)p.y_bb) & 7) == 0 &&
+               (!p.yprev || ((reinterpret_cast<uintptr_t>(p.yprev) | (uintptr_t)p.yp_rb | (uintptr_t)p.yp_bb) & 7) == 0),
+               SH_ERR_UNSUPPORTED, "sh_spiral_conv_bwd_data_bf16_rag: bf16 rows must be 8-byte aligned");
+    SH_REQUIRE((unsigned long)n_in * (unsigned long)(p.x_rb >> 4) < (1UL << 32), SH_ERR_UNSUPPORTED,
+               "sh_spiral_conv_bwd_data_bf16_rag: gathered tensor too large for 32-bit piece offsets");
+    const int nt = bcr_nt(p.nks, p.nt_tot, &p.nsplit);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (nt) {
+        case 1: return launch_bcr<1>(p, st);
+        case 2: return launch_bcr<2>(p, st);
+        case 4: return launch_bcr<4>(p, st);
+        default: return launch_bcr<8>(p, st);
+    }
 }
 
 }  // extern "C"

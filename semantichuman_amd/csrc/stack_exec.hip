@@ -513,11 +513,16 @@ int sh_stack_backward_bf16(int n_steps, const sh_stack_step* steps, const void* 
             ++njobs;
             if (want_in) {
                 SH_REQUIRE(s.table_t, SH_ERR_INVALID_ARG, "sh_stack_backward_bf16: step %d has no transposed table", i);
+                // backward-data over ragged source lists (round 6): every source a real row of dpre - neither the pre-sum launches nor
+                // the empty slots of the dense transposed table (SH_BF16_RAGGED=0: the dense form)
+                static const int rag_on = sh_env_int("SH_BF16_RAGGED", 1, 0, 1);
+                const bool rag = rag_on && !thin && cd == SH_DTYPE_BF16 && gd == SH_DTYPE_BF16 && s.rag_rows && s.rag_pos &&
+                                 sh_spiral_conv_bf16_rag_ok(B, s.S, s.cout, s.cin, s.rag_L);
                 char* mut = static_cast<char*>(const_cast<void*>(cur));      // extra rows behind the R real ones of this step's buffer
                 const long rb = cl.sv * esz_of(cd);
                 for (int lev = 0; lev < 2; ++lev) {
                     const int n = lev == 0 ? s.n1 : s.n2;
-                    if (!n) continue;
+                    if (!n || rag) continue;
                     const sh_csr_ref& m = lev == 0 ? s.sum1 : s.sum2;
                     void* dst = mut + (long)(s.R + (lev == 0 ? 0 : s.n1)) * rb;
                     if (cd == SH_DTYPE_F32)
@@ -535,9 +540,12 @@ int sh_stack_backward_bf16(int n_steps, const sh_stack_step* steps, const void* 
                                                      SH_DTYPE_BF16, stream);
                     if (rc != SH_OK) return rc;
                 }
-                if (!thin_dx)
-                rc = sh_spiral_conv_bwd_data_bf16(cur, cd, cl.sv, cl.sb, s.table_t, wfrag_t[i], gi, gd, gl.sv, gl.sb, yprev, yl.sv, yl.sb,
-                                                  act_prev, zero_prev, B, s.n_in, s.S, s.cin, s.cout, stream);
+                if (rag)
+                    rc = sh_spiral_conv_bwd_data_bf16_rag(cur, cl.sv, cl.sb, s.rag_rows, s.rag_pos, s.rag_L, wfrag_t[i], gi, gl.sv, gl.sb, yprev, yl.sv,
+                                                          yl.sb, act_prev, zero_prev, B, s.n_in, s.S, s.cin, s.cout, stream);
+                else if (!thin_dx)
+                    rc = sh_spiral_conv_bwd_data_bf16(cur, cd, cl.sv, cl.sb, s.table_t, wfrag_t[i], gi, gd, gl.sv, gl.sb, yprev, yl.sv, yl.sb,
+                                                      act_prev, zero_prev, B, s.n_in, s.S, s.cin, s.cout, stream);
                 if (rc != SH_OK) return rc;
             }
         } else if (want_in) {

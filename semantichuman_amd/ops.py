@@ -449,6 +449,28 @@ def spiral_conv_bwd_data_bf16(dpre, dp_layout, table_t, wfrag_t, dx, dx_layout, 
                                                    Cin, Cout, stream_ptr()), "sh_spiral_conv_bwd_data_bf16")
 
 
+def spiral_conv_bf16_rag_ok(B, S, Cg, Nout, rag_L) -> bool:
+    return bool(_lib.load().sh_spiral_conv_bf16_rag_ok(B, S, Cg, Nout, rag_L))
+
+
+def spiral_conv_bwd_data_bf16_rag(dpre, dp_layout, rag_rows, rag_pos, wfrag_t, dx, dx_layout, yprev, yp_layout, act_prev, zero_row, n_in, S,
+                                  Cin, Cout):
+    """Backward-data over ragged source lists (mesh_ops.transpose_table_ragged): bf16 on both sides, no pre-summed rows."""
+    B, _, C1, dsv, dsb = _dims(dpre, dp_layout, (torch.bfloat16,))
+    B2, Rx, C2, xsv, xsb = _dims(dx, dx_layout, (torch.bfloat16,))
+    assert B == B2 and C1 == Cout and C2 == Cin and Rx >= n_in and rag_rows.shape == rag_pos.shape and rag_rows.shape[0] == n_in
+    assert rag_rows.dtype == torch.int32 and rag_pos.dtype == torch.int32 and rag_rows.is_contiguous() and rag_pos.is_contiguous()
+    _check_index_range(dpre)
+    if yprev is not None:
+        _, _, C3, ysv, ysb = _dims(yprev, yp_layout, (torch.bfloat16,))
+        assert C3 == Cin
+    else:
+        ysv = ysb = 0
+    check(_lib.load().sh_spiral_conv_bwd_data_bf16_rag(ptr(dpre), dsv, dsb, ptr(rag_rows), ptr(rag_pos), int(rag_rows.shape[1]), ptr(wfrag_t),
+                                                       ptr(dx), xsv, xsb, ptr(yprev), ysv, ysb, act_prev, zero_row, B, n_in, S, Cin, Cout,
+                                                       stream_ptr()), "sh_spiral_conv_bwd_data_bf16_rag")
+
+
 def spiral_conv_bwd_wgt_bf16(dpre, dp_layout, x, x_layout, table, R, S, Cin, Cout, want_bias=True):
     """-> (dW fp32 [Cout, S*Cin], dbias fp32 [Cout] or None)"""
     import ctypes

@@ -197,6 +197,18 @@ int sh_spiral_conv_bwd_data_bf16(const void* dpre, int dd, int64_t dp_sv, int64_
     return bwd_data_common("bwd_data_bf16 n_in=%d Cin=%d Cout=%d", dpre, dd == SH_DTYPE_BF16 ? 2 : 4, dp_sv, dp_sb, table_t, dx, xd == SH_DTYPE_BF16 ? 2 : 4,
                            dx_sv, dx_sb, yprev, yp_sv, yp_sb, B, n_in, S, Cin, Cout);
 }
+int sh_spiral_conv_bf16_rag_ok(int B, int S, int Cg, int Nout, int rag_L) { return B > 0 && S <= 64 && Cg % 32 == 0 && Nout % 4 == 0 && rag_L > 0 && rag_L <= 64; }
+int sh_spiral_conv_bwd_data_bf16_rag(const void* dpre, int64_t dp_sv, int64_t dp_sb, const int32_t* rag_rows, const int32_t* rag_pos, int rag_L, const void* wfrag_t,
+                                     void* dx, int64_t dx_sv, int64_t dx_sb, const void* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row, int B,
+                                     int n_in, int S, int Cin, int Cout, sh_stream_t) {
+    int rows = 0;
+    for (long i = 0; i < (long)n_in * rag_L; ++i) { rows = rag_rows[i] + 1 > rows ? rag_rows[i] + 1 : rows; if (rag_pos[i] >= S) return SH_ERR_INVALID_ARG; }
+    touch_r(dpre, span(dp_sv, dp_sb, rows, B, Cout, 2)); touch_r(wfrag_t, sh_conv_wfrag_bytes(S, Cout, Cin));
+    touch_w(dx, span(dx_sv, dx_sb, n_in, B, Cin, 2));
+    if (yprev) touch_r(yprev, span(yp_sv, yp_sb, n_in, B, Cin, 2));
+    log("bwd_data_bf16_rag n_in=%d Cin=%d L=%d", n_in, Cin, rag_L);
+    return 0;
+}
 int sh_weight_transpose_multi(int n, const float* const* w, float* const* wt, const int* S, const int* Ci, const int* Co, sh_stream_t) {
     for (int i = 0; i < n; ++i) { touch_r(w[i], (size_t)S[i] * Ci[i] * Co[i] * 4); touch_w(wt[i], (size_t)S[i] * Ci[i] * Co[i] * 4); }
     log("weight_transpose n=%d", n);

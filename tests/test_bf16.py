@@ -97,6 +97,24 @@ def test_conv_fwd_and_bwd_data_bf16(shape, layouts):
     err = float((gdx.double() - torch.from_numpy(ref_dx)).abs().max())
     assert err <= ULP * float(np.abs(ref_dx).max()) + 1e-6, (err, np.abs(ref_dx).max())
 
+    # round 6: the same gradient over ragged source lists (conv_bf16r_kernel) - no pre-summed rows, so the reference is the float64
+    # gradient of the UNROUNDED sums (the sums are formed in fp32 by the matrix pipe)
+    rag = mesh_ops.transpose_table_ragged(table, n_in, none_row=R - 1, skip_row=-1)
+    if rag is not None and ops.spiral_conv_bf16_rag_ok(B, S, Cout, Cin, rag[0].shape[1]):
+        ref_r = emulate.conv_bwd_data(ext, tt.table_t, W.double().numpy(), Cin) * emulate.DACT[a](yprev.double().numpy())
+        ref_r[n_in - 1] = 0
+        dpr = (dpre if lo == "vm" else dpre.permute(1, 0, 2).contiguous()).to(dev(), torch.bfloat16)
+        dxr = torch.full_like(dx, float("nan"))
+        ops.spiral_conv_bwd_data_bf16_rag(dpr, lo, torch.from_numpy(rag[0]).to(dev()), torch.from_numpy(rag[1]).to(dev()), wft, dxr, li, ypd, "vm",
+                                          a, n_in - 1, n_in, S, Cin, Cout)
+        gr = dxr.float().cpu()
+        gr = gr if li == "vm" else gr.permute(1, 0, 2)
+        assert torch.isfinite(gr).all()
+        err = float((gr.double() - torch.from_numpy(ref_r)).abs().max())
+        assert err <= ULP * float(np.abs(ref_r).max()) + 1e-6, (err, np.abs(ref_r).max())
+    else:
+        assert Cout % 32 != 0, "the ragged form takes every layer that gathers a multiple of 32 channels"
+
 
 @pytest.mark.parametrize("B,N,S,Cout", [(16, 60, 10, 16), (5, 37, 9, 16), (64, 50, 3, 16)])
 def test_conv_bf16_three_channel_fp32_sides(B, N, S, Cout):
@@ -507,12 +525,17 @@ def test_bf16_step_runs_the_intended_kernels():
     assert len(fam.get("wgrad_bf16_dma_kernel", [])) == 7                  # every bf16 x bf16 weight gradient
     assert len(fam.get("wgrad_bf16_kernel", [])) == 1                      # only the fp32 3-channel input side is staged
     conv = fam.get("conv_bf16_kernel", [])
-    assert len(conv) == 16                                                  # 9 forward + 7 backward-data (dec4's rides in the thin launch)
-    # line-wise loads (BC_C32C, round 3) on every layer that gathers a multiple of 32 bf16 channels: 6 forward + 6 backward-data
-    assert sum(1 for n, _ in conv if n.split(",")[2].strip() == "4") == 12
+    # 9 forward + 7 backward-data (dec4's rides in the thin launch); round 6: the 6 backward-data layers that gather a multiple of
+    # 32 channels walk ragged source lists (conv_bf16r_kernel) and need no pre-sum launch
+    assert len(fam.get("conv_bf16r_kernel", [])) == 6
+    assert len(conv) == 10
+    # line-wise loads (BC_C32C, round 3) on every forward layer that gathers a multiple of 32 bf16 channels
+    assert sum(1 for n, _ in conv if n.split(",")[2].strip() == "4") == 6
     assert sum(1 for n, _ in conv if n.split(",")[2].strip() in ("0", "3")) == 0      # no plain / full-line gathers left
     up = [t for _, t in fam.get("spmm_bf16_kernel", []) if "rows=3445 " in t or "rows=1722 " in t or "rows=861 " in t]
     assert len(up) == 3                                                     # folded up-sampling: only the blended rows
+    # what is left of spmm_bf16: 4 down-sampling + 3 up-sampling forward, their 7 transposes, the pre-sum of the one dense layer
+    assert len(fam.get("spmm_bf16_kernel", [])) <= 15, [t for _, t in fam.get("spmm_bf16_kernel", [])]
 
 
 def test_model_bf16_with_second_convs_per_level():
