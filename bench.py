@@ -90,6 +90,8 @@ def parse_tag_f32(name, shape):
             return ("bwd" if targs[3] == "true" else "fwd", int(f["R"]), int(f["K"]), int(f["N"]))
         if fam == "conv_p3r_kernel":                       # three-plane backward-data over ragged source lists: <NT, NP>
             return ("bwd", int(f["R"]), int(f["K"]), int(f["N"]))
+        if fam == "conv_p3g_kernel":                       # three-plane form over grouped lists: <NT, G, BWD, NP>
+            return ("bwd" if targs[2] == "true" else "fwd", int(f["R"]), int(f["K"]), int(f["N"]))
         if fam == "conv_p3s_kernel":                       # three-plane form, streamed weight: <RT, BWD, NP>
             return ("bwd" if targs[1] == "true" else "fwd", int(f["R"]), int(f["K"]), int(f["N"]))
         if fam == "conv_out3_linewise_kernel":             # forward of the <= 3-channel last layer on the VALU

@@ -241,6 +241,16 @@ typedef struct sh_stack_step {
     const int32_t* rag_rows;
     const int32_t* rag_pos;
     int rag_L;
+    /* conv, optional (round 6; NULL / 0 = none): GROUPED lists - output rows whose source lists overlap share one list of the union
+     * (mesh_ops.group_lists; sh_spiral_conv_p3_grp).  fg_*: the forward pass (groups of rows of the step's output, sources = rows of
+     * its input, built from `table`); bg_*: the backward-data pass (groups of rows of the step's input, sources = rows of the
+     * pre-activation gradient, built from the ragged lists).  x_rows [n][L] rows of the gathered tensor; x_pos [n][L] one byte per
+     * member: the spiral position that member reads the row at, 0xFF = it does not (0xFFFFFFFF behind the group's last entry);
+     * x_out [n][4] the members' output rows (-1: none; at most sh_spiral_conv_p3_grp_members() of them).  A step that has them and
+     * whose pass runs on planes with a resident weight (sh_spiral_conv_p3_grp_ok) takes the grouped kernel: every row of a group's
+     * union is gathered once (SH_P3_GROUPED=0: the one-row lists / the table). */
+    const int32_t* fg_rows; const uint32_t* fg_pos; const int32_t* fg_out; int fg_n, fg_L;
+    const int32_t* bg_rows; const uint32_t* bg_pos; const int32_t* bg_out; int bg_n, bg_L;
 } sh_stack_step;
 
 /* outs[i]: output of step i, vertex-major, except outs[n_steps-1] which has layout out_layout.
@@ -252,7 +262,11 @@ typedef struct sh_stack_step {
  * image and whose shape sh_spiral_conv_p3_ok() takes runs sh_spiral_conv_fwd_p3; images are written by their producers.
  * keep_fp32: 1 = every step writes its fp32 output (a backward pass reads them); 0 = forward only: rows that the next plane
  * conv gathers through their image alone are written as the image alone (outs[i] of such a step is then partly or wholly
- * unwritten; the last step's output is always fp32). */
+ * unwritten; the last step's output is always fp32); 2 (round 6) = training on the images: the same rows, where the BACKWARD
+ * pass of the conv that gathers them leaves their fp32 form unread as well - its weight gradient runs on the two images
+ * (sh_spiral_conv_bwd_wgt_p3) and the activation derivative is evaluated from the image.  What is known of that from the steps
+ * alone decides (shapes, tables, the switches SH_P3_BWD / SH_P3_WGRAD / SH_P3_YPREV_IMG / SH_P3_DROP_FP32); the caller of 2 owes
+ * sh_stack_backward the plane buffers (gin_planes, wfrag3_t, in_planes, plane-sized workspaces) and acts_fp32 == 2. */
 SH_API int sh_stack_forward(int n_steps, const sh_stack_step* steps, const float* x, int x_layout, int rows0, int c0, int B,
                             const float* const* weights, const float* const* biases, float* const* outs, int out_layout,
                             int mma_mode, void* const* planes, const void* const* wfrag3, int keep_fp32, sh_stream_t stream);
@@ -271,13 +285,17 @@ SH_API int sh_stack_forward(int n_steps, const sh_stack_step* steps, const float
  * of conv step i - what sh_stack_forward wrote to planes[i - 1], kept alive by the caller - or NULL; with it, the image of its
  * gradient rows and a workspace of at least sh_spiral_conv_bwd_wgt_p3_workspace() bytes, a step whose shape
  * sh_spiral_conv_bwd_wgt_p3_ok() takes computes its WEIGHT gradient from the two images (sh_spiral_conv_bwd_wgt_p3_presum)
- * instead of from the fp32 tensors (sh_spiral_conv_bwd_wgt_presum). */
+ * instead of from the fp32 tensors (sh_spiral_conv_bwd_wgt_presum).  acts_fp32: the keep_fp32 sh_stack_forward ran with (1 or
+ * 2).  With 2 a step whose input was left as its image alone must run on the images: SH_ERR_INVALID_ARG when the buffers given
+ * do not allow it (never a read of unwritten rows); and the gradient rows this pass itself hands from step to step are written
+ * as their image alone where the step that takes them reads nothing else (ragged source lists or a table without
+ * multiplicities, plane weight gradient). */
 SH_API int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, int x_layout, int rows0, int c0, int B,
                              const float* const* acts, const float* g, int out_layout, const float* const* weights,
                              float* const* gin, float* dpre_last, float* const* weight_t, void* const* workspace,
                              const size_t* workspace_bytes, float* const* dW, float* const* dbias, int need_x_grad,
                              int mma_mode, void* const* gin_planes, void* dpre_last_planes, const void* const* wfrag3_t,
-                             const void* const* in_planes, sh_stream_t stream);
+                             const void* const* in_planes, int acts_fp32, sh_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense layers with one tiny and one huge dimension: the latent nn.Linear pair fc_latent_enc /
@@ -702,6 +720,25 @@ SH_API int sh_spiral_conv_bwd_data_p3_rag(const void* dprep, const int32_t* rag_
                                           float* dx, int64_t dx_sv, int64_t dx_sb, void* dxp, const float* yprev, int64_t yp_sv,
                                           int64_t yp_sb, const void* yprev_planes, int act_prev, int zero_row, int B, int n_in, int S,
                                           int Cin, int Cout, sh_stream_t stream);
+
+/* Plane conv over GROUPED lists (csrc/p3_conv.hip conv_p3g_kernel, round 6): up to four output rows whose source lists overlap form a
+ * group and share ONE list of the union of their sources - y[g_out[k][m]] = sum over the entries j of group k that member m reads
+ * (byte m of g_pos[k][j] != 0xFF) of x[g_rows[k][j]] . W_{that byte} - so every row of the union is gathered once where the
+ * one-row kernels (sh_spiral_conv_fwd_p3 through the table, sh_spiral_conv_bwd_data_p3_rag through ragged lists) gather it once
+ * per member; matrix work and results' arithmetic are theirs (the order of a row's partial sums follows the group's list).
+ * backward == 0: the forward pass (x = image of the layer input, wfrag3 = forward fragments, bias, activation `act`, masked
+ * zero_row; Cg = the layer's Cin, Nout = its Cout, R = its output rows); backward == 1: backward-data (x = image of the
+ * pre-activation gradient, wfrag3 = transposed fragments, the derivative of activation `act` at yprev / yprev_planes - the fp32
+ * tensor or the image of the layer input - or neither; Cg = the layer's Cout, Nout = its Cin, R = its input rows).  y and / or yp
+ * (the image of the result) are written.  .._grp_ok: resident three-plane weight with at most four channel tiles per workgroup,
+ * Cg % 32 == 0, lists of at most 64 entries; .._grp_members: how many members per group the kernel of this shape takes (4 or 2;
+ * 0 = shape not taken) - g_out always has four slots per group. */
+SH_API int sh_spiral_conv_p3_grp_ok(int B, int S, int Cg, int Nout, int g_L);
+SH_API int sh_spiral_conv_p3_grp_members(int B, int S, int Cg, int Nout);
+SH_API int sh_spiral_conv_p3_grp(const void* xp, const int32_t* g_rows, const uint32_t* g_pos, const int32_t* g_out, int n_groups, int g_L,
+                                 const void* wfrag3, const float* bias, float* y, int64_t y_sv, int64_t y_sb, void* yp, const float* yprev,
+                                 int64_t yp_sv, int64_t yp_sb, const void* yprev_planes, int act, int zero_row, int backward, int B, int R,
+                                 int S, int Cg, int Nout, sh_stream_t stream);
 
 /* The same over bf16 tensors (csrc/bf16_conv.hip conv_bf16r_kernel; the ragged sibling of sh_spiral_conv_bwd_data_bf16): dpre and dx
  * bf16 (element strides), wfrag_t the transposed bf16 fragments of sh_conv_wfrag_prep_multi, yprev bf16 or NULL.  The sums over

@@ -38,7 +38,7 @@ SIGNATURES = {
     "sh_act_backward_tr": (c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "sh_spmm": (c_int, [_P, _P, _P, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _P]),
     "sh_stack_forward": (c_int, [_I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _I, _P]),
-    "sh_stack_backward": (c_int, [_I, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "sh_stack_backward": (c_int, [_I, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P]),
     "sh_linear_workspace": (c_size_t, [_I, _I, _I]),
     "sh_linear_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, c_size_t, _I, _P]),
     "sh_linear_bwd_data": (c_int, [_P, _P, _P, _I, _I, _I, _P, c_size_t, _I, _P]),
@@ -112,6 +112,9 @@ SIGNATURES = {
     "sh_spiral_conv_bwd_data_p3": (c_int, [_P, _I, _P, _L, _L, _I, _P, _P, _P, _L, _L, _P, _P, _L, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sh_spiral_conv_p3_rag_ok": (c_int, [_I, _I, _I, _I, _I]),
     "sh_spiral_conv_bf16_rag_ok": (c_int, [_I, _I, _I, _I, _I]),
+    "sh_spiral_conv_p3_grp_ok": (c_int, [_I, _I, _I, _I, _I]),
+    "sh_spiral_conv_p3_grp_members": (c_int, [_I, _I, _I, _I]),
+    "sh_spiral_conv_p3_grp": (c_int, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _L, _L, _P, _P, _L, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sh_spiral_conv_bwd_data_bf16_rag": (c_int, [_P, _L, _L, _P, _P, _I, _P, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sh_spiral_conv_bwd_data_p3_rag": (c_int, [_P, _P, _P, _I, _P, _P, _L, _L, _P, _P, _L, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sh_spiral_conv_bwd_wgt_p3_ok": (c_int, [_I, _I, _I, _I, _I]),
@@ -133,7 +136,9 @@ class StackStep(ctypes.Structure):                     # sh_stack_step (include/
                 ("R", c_int), ("S", c_int), ("n_in", c_int), ("cin", c_int), ("cout", c_int), ("act", c_int), ("zero_row", c_int),
                 ("n1", c_int), ("n2", c_int), ("sum1", CsrRef), ("sum2", CsrRef), ("m", CsrRef), ("mt", CsrRef),
                 ("m_rows", c_int), ("m_cols", c_int), ("extend", c_int),
-                ("rag_rows", c_void_p), ("rag_pos", c_void_p), ("rag_L", c_int)]
+                ("rag_rows", c_void_p), ("rag_pos", c_void_p), ("rag_L", c_int),
+                ("fg_rows", c_void_p), ("fg_pos", c_void_p), ("fg_out", c_void_p), ("fg_n", c_int), ("fg_L", c_int),
+                ("bg_rows", c_void_p), ("bg_pos", c_void_p), ("bg_out", c_void_p), ("bg_n", c_int), ("bg_L", c_int)]
 
 
 _lib = None

@@ -50,6 +50,10 @@ struct P3Params {
     // ragged backward-data (conv_p3r_kernel): per output row its sources as a LIST - rag_rows [R][rag_L] rows of the gathered image,
     // rag_pos [R][rag_L] the spiral position whose weight multiplies each (-1: padding behind the row's last source)
     const int* rag_rows; const int* rag_pos; int rag_L;
+    // grouped lists (conv_p3g_kernel): g_rows [n_grp][g_L] rows of the gathered image, g_pos [n_grp][g_L] one position byte per member of
+    // the group (0xFF: this member does not read the row; 0xFFFFFFFF behind the group's last entry), g_out [n_grp][4] the members'
+    // output rows (-1: none)
+    const int* g_rows; const unsigned* g_pos; const int* g_out; int g_L, n_grp;
     int B, R, S, Cg, Nout, nks, nt_tot, ncg;
     int act, zero_row;
     int n_vg, n_tiles, nsplit;
@@ -478,6 +482,166 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(P3_WAVES_P
 }
 
 // ------------------------------------------------------------------------------------------
+// GROUPED lists (round 6): the plane convs with a resident weight are paced by the L2 -> CU gather (14-17 TB/s of plane bytes; section 4f
+// of DESIGN.md), and most of what they gather they gather again: neighbouring vertices' spirals overlap - a row is read once per spiral
+// that contains it, ~S times per launch and batch group.  Here a wave item is a GROUP of up to four output rows chosen on the host for
+// overlapping lists (mesh_ops.group_lists: greedy matching on shared rows, twice) and the list of the group is the UNION of its
+// members' rows: every row is loaded once (three 1-KiB plane fragments per 32 channels, as before) and multiplied once per member
+// that reads it, with that member's position's weight fragments, into that member's accumulators.  Matrix work and weight-fragment
+// reads are those of the one-vertex kernels; the gathered bytes fall by the overlap (measured on the 6890-vertex template: lists
+// of 10-11 per row -> unions of ~21-25 per four rows).  Forward (bias, activation) and backward-data over ragged sources (activation
+// derivative from the image or the fp32 tensor of the producing layer) share the kernel.
+template <int NT, int G, bool BWD, int NP>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(P3_WAVES_PER_EU, 8))) void conv_p3g_kernel(const P3Params p) {
+    constexpr int D = p3_depth(NT * G, 1) < 3 ? 3 : p3_depth(NT * G, 1);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const u32x4* Wl = reinterpret_cast<const u32x4*>(smem);       // [nks][NT][3][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+    const int nwg_x = ((int)gridDim.x - xcd + 7) >> 3;
+    const int slice = li % p.nsplit, lj = li / p.nsplit;
+    const int ngrp = nwg_x / p.nsplit;
+    const int q8 = p.n_tiles >> 3, r8 = p.n_tiles & 7;
+    const int t_begin = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int t_end = t_begin + (xcd < r8 ? q8 + 1 : q8);
+    const int stride = ngrp * nw;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int Lp = p.g_L, ll = lane < Lp ? lane : Lp - 1;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const unsigned rowmul = (unsigned)(p.x_vb >> 4);
+    // the list of an item's group: lane j holds entry j (row pre-multiplied by the image's row stride in 16-byte units) and its positions
+    auto load_list = [&](int t, int& rows, unsigned& pos) {
+        const int tt = t < t_end ? t : (t_end > 0 ? t_end - 1 : 0);
+        const int g = tt % p.n_vg;
+        rows = (int)((unsigned)p.g_rows[(long)g * Lp + ll] * rowmul);
+        pos = lane < Lp ? p.g_pos[(long)g * Lp + ll] : 0xFFFFFFFFu;
+    };
+    int t = t_begin + lj * nw + wave;
+    int tv, tvn;
+    unsigned tp, tpn;
+    load_list(t, tv, tp);
+    {
+        typedef __attribute__((address_space(3))) char* lptr_t;
+        const unsigned wl_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_t)smem);
+        const int nfrag = p.nks * NT * 3;
+        for (int f = __builtin_amdgcn_readfirstlane(wave); f < nfrag; f += nw) {
+            const int pl = f % 3, n = (f / 3) % NT, ks = f / (3 * NT);
+            const char* src = reinterpret_cast<const char*>(p.wfrag + (((long)ks * p.nt_tot + slice * NT + n) * 3 + pl) * 64 + lane);
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(__builtin_amdgcn_readfirstlane(wl_lds + (unsigned)f * 1024u)) : "memory", "m0");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    for (; t < t_end; t += stride) {
+        load_list(t + stride, tvn, tpn);
+        const int bs = t / p.n_vg, grp = t - bs * p.n_vg;
+        const char* xl = p.xp + (long)bs * p.x_bgb + lane * 16;
+        const int L = __builtin_popcountll(__builtin_amdgcn_ballot_w64(tp != 0xFFFFFFFFu));      // entries of this group (uniform)
+        const int nks = L * p.ncg;
+        int lj2 = 0, lc = 0;                               // running load position: list entry, channel group (uniform)
+        u32x4 ring[D][3];
+        auto issue = [&](u32x4 (&a)[3]) {
+            const int j = lj2 < L ? lj2 : (L > 0 ? L - 1 : 0);      // past the end: the last entry again (never multiplied)
+            const int row = __builtin_amdgcn_readlane(tv, j);
+            const char* src = xl + (long)((unsigned long)(unsigned)row << 4) + (long)lc * 3072;
+            a[0] = *reinterpret_cast<const u32x4*>(src);
+            a[1] = *reinterpret_cast<const u32x4*>(src + 1024);
+            a[2] = *reinterpret_cast<const u32x4*>(src + 2048);
+            if (++lc >= p.ncg) { lc = 0; ++lj2; }
+        };
+        f32x4 acc[G][NT];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[g][n] = zero4;
+        int cj = 0, cc = 0;                                // entry / channel group of the k-step being multiplied (uniform)
+        auto compute = [&](u32x4 (&a)[3]) {
+            const unsigned pk = (unsigned)__builtin_amdgcn_readlane((int)tp, cj);
+            const int ccw = cc;
+            if (++cc >= p.ncg) { cc = 0; ++cj; }
+            const bf16x8 xh = *reinterpret_cast<const bf16x8*>(&a[0]), xm = *reinterpret_cast<const bf16x8*>(&a[1]),
+                         xl2 = *reinterpret_cast<const bf16x8*>(&a[2]);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int s = (int)((pk >> (8 * g)) & 0xFFu);
+                if (s == 0xFF) continue;                   // (uniform) this member does not read the row
+                const u32x4* wk = Wl + ((long)(s * p.ncg + ccw) * NT) * 192 + lane;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const u32x4 r0 = wk[n * 192], r1 = wk[n * 192 + 64], r2 = wk[n * 192 + 128];
+                    const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&r0), wm = *reinterpret_cast<const bf16x8*>(&r1),
+                                 wl = *reinterpret_cast<const bf16x8*>(&r2);
+                    f32x4 c = acc[g][n];
+                    if constexpr (NP == 9) {
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xl2, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xm, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xl2, c, 0, 0, 0);
+                    }
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl2, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, c, 0, 0, 0);
+                    acc[g][n] = c;
+                }
+            }
+        };
+#pragma unroll
+        for (int d = 0; d < D - 1; ++d) issue(ring[d]);
+        auto step = [&](auto J, int ks) {
+            constexpr int j = decltype(J)::value;
+            issue(ring[(j + D - 1) % D]);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(ring[j]);
+        };
+        for (int ks = 0; ks < nks; ks += D)
+            if (!p3_ring_steps<0, D>(ks, nks, step)) break;
+
+        // ---- epilogue: per member, lane holds channels c0..c0+3 (c0 = 16 n + 4 kq) of row (v, bs * 16 + r16)
+        const int b = bs * 16 + r16;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int v = p.g_out[(long)grp * 4 + g];      // (uniform)
+            if (v < 0 || v >= p.R || b >= p.B) continue;
+            const bool zero = v == p.zero_row;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int c0 = (slice * NT + n) * 16 + kq * 4;
+                if (c0 >= p.Nout) continue;
+                f32x4 a = acc[g][n];
+                if (!BWD) {
+                    if (p.bias) a += *reinterpret_cast<const f32x4*>(p.bias + c0);
+                    a = sh_act_fwd4(a, p.act);
+                } else if (p.yprev_img) {
+                    const f32x4 yv = p3_quad_from_image(p.yprev_img, p.yvi_vb, p.yvi_bgb, v, bs, r16, c0, p.Nout);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[j] *= sh_act_grad_from_out(yv[j], p.act);
+                } else if (p.yprev) {
+                    const f32x4 yv = *reinterpret_cast<const f32x4*>(p.yprev + (long)v * p.yv_sv + (long)b * p.yv_sb + c0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[j] *= sh_act_grad_from_out(yv[j], p.act);
+                }
+                if (zero) a = zero4;
+                if (p.y) *reinterpret_cast<f32x4*>(p.y + (long)v * p.y_sv + (long)b * p.y_sb + c0) = a;
+                if (p.yp) {
+                    u32x2 h, mm, l;
+                    sh_split3_quad(a, h, mm, l);
+                    const bool o16 = p.Nout == 16;
+                    char* dst = p.yp + (long)v * p.yp_vb + (long)bs * p.yp_bgb +
+                                (o16 ? ((c0 >> 3) * 16 + r16) * 16 : (c0 >> 5) * 3072 + (((c0 & 31) >> 3) * 16 + r16) * 16) + (kq & 1) * 8;
+                    const int opb = o16 ? 512 : 1024;
+                    *reinterpret_cast<u32x2*>(dst) = h;
+                    *reinterpret_cast<u32x2*>(dst + opb) = mm;
+                    *reinterpret_cast<u32x2*>(dst + 2 * opb) = l;
+                }
+            }
+        }
+        tv = tvn; tp = tpn;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Weight-STREAMING form for layers whose three-plane weight does not fit LDS (the coarsest level: 512 x 128 and 1024 x 64
 // weights = 384 KiB of planes).  Same gather stream per wave (D = 4 k-steps of plane loads in flight, continuous over the whole
 // K loop), but the weight passes through LDS in chunks of KC = 4 k-steps x 4 channel tiles (48 KiB, double-buffered): the 16
@@ -792,8 +956,8 @@ int launch_p3s(P3Params& p, hipStream_t st) {
     if (groups < 8) groups = 8;
     groups = (groups + 7) / 8 * 8;
     const int grid = (int)groups * p.nsplit;
-    ShProfScope ps(st, "conv_p3s_kernel<%d, %s, %d, %d>|R=%d B=%d K=%d N=%d grid=%dx%d", RT, BWD ? "true" : "false", NP, NT, p.R, p.B,
-                   p.S * p.Cg, p.Nout, grid, WAVES * 64);
+    ShProfScope ps(st, "conv_p3s_kernel<%d, %s, %d, %d>|R=%d B=%d K=%d N=%d grid=%dx%d f32=%d", RT, BWD ? "true" : "false", NP, NT, p.R, p.B,
+                   p.S * p.Cg, p.Nout, grid, WAVES * 64, p.y ? 1 : 0);
     SH_LAUNCH_PS(ps, kern, dim3(grid), dim3(WAVES * 64), smem, st, p);
     SH_CHECK_LAUNCH("conv_p3s");
     g_p3_launches.fetch_add(1, std::memory_order_relaxed);
@@ -834,8 +998,8 @@ int launch_p3(P3Params& p, hipStream_t st) {
     if (groups < 8) groups = 8;
     groups = (groups + 7) / 8 * 8;
     const int grid = (int)groups * p.nsplit;
-    ShProfScope ps(st, "conv_p3_kernel<%d, %d, %s, %s, %d, %s>|R=%d B=%d K=%d N=%d grid=%dx%d", NT, RT, C16 ? "true" : "false",
-                   BWD ? "true" : "false", NP, F32R ? "true" : "false", p.R, p.B, p.S * p.Cg, p.Nout, grid, nw * 64);
+    ShProfScope ps(st, "conv_p3_kernel<%d, %d, %s, %s, %d, %s>|R=%d B=%d K=%d N=%d grid=%dx%d f32=%d", NT, RT, C16 ? "true" : "false",
+                   BWD ? "true" : "false", NP, F32R ? "true" : "false", p.R, p.B, p.S * p.Cg, p.Nout, grid, nw * 64, p.y ? 1 : 0);
     SH_LAUNCH_PS(ps, kern, dim3(grid), dim3(nw * 64), smem, st, p);
     SH_CHECK_LAUNCH("conv_p3");
     g_p3_launches.fetch_add(1, std::memory_order_relaxed);
@@ -870,9 +1034,45 @@ int launch_p3r(P3Params& p, hipStream_t st) {
     if (groups < 8) groups = 8;
     groups = (groups + 7) / 8 * 8;
     const int grid = (int)groups * p.nsplit;
-    ShProfScope ps(st, "conv_p3r_kernel<%d, %d>|R=%d B=%d K=%d N=%d grid=%dx%d L=%d", NT, NP, p.R, p.B, p.S * p.Cg, p.Nout, grid, nw * 64, p.rag_L);
+    ShProfScope ps(st, "conv_p3r_kernel<%d, %d>|R=%d B=%d K=%d N=%d grid=%dx%d L=%d f32=%d", NT, NP, p.R, p.B, p.S * p.Cg, p.Nout, grid, nw * 64, p.rag_L, p.y ? 1 : 0);
     SH_LAUNCH_PS(ps, kern, dim3(grid), dim3(nw * 64), smem, st, p);
     SH_CHECK_LAUNCH("conv_p3r");
+    g_p3_launches.fetch_add(1, std::memory_order_relaxed);
+    return SH_OK;
+}
+
+template <int NT, int G, bool BWD, int NP>
+int launch_p3g(P3Params& p, hipStream_t st) {
+    auto kern = conv_p3g_kernel<NT, G, BWD, NP>;
+    const size_t smem = (size_t)p.nks * NT * 3072;
+    static size_t attr_set = 0;
+    if (smem > 65536 && smem > attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            (void)hipGetLastError();
+            sh_set_error("conv_p3g: cannot raise the dynamic LDS limit to %zu bytes", smem);
+            return SH_ERR_LAUNCH;
+        }
+        attr_set = 160 * 1024;
+    }
+    p.n_vg = p.n_grp;
+    const long tiles = (long)p.n_grp * (p.B / 16);
+    SH_REQUIRE(tiles < (1L << 30), SH_ERR_UNSUPPORTED, "conv_p3g: %ld work items", tiles);
+    p.n_tiles = (int)tiles;
+    const int per_cu = smem <= 36 * 1024 ? 4 : smem <= 76 * 1024 ? 2 : 1;
+    static const int waves_cu = sh_env_int("SH_P3_WAVES_CU", 4 * P3_WAVES_PER_EU, 16, 32);
+    int nw = waves_cu / per_cu;
+    if (nw > 16) nw = 16;
+    while (nw > 4 && (nw & 1) == 0 && (long)p3_num_cus() * per_cu * (nw >> 1) >= tiles * p.nsplit) nw >>= 1;
+    long groups = (tiles + nw - 1) / nw;
+    const long cap = (long)p3_num_cus() * per_cu / p.nsplit;
+    if (groups > cap) groups = cap;
+    if (groups < 8) groups = 8;
+    groups = (groups + 7) / 8 * 8;
+    const int grid = (int)groups * p.nsplit;
+    ShProfScope ps(st, "conv_p3g_kernel<%d, %d, %s, %d>|R=%d B=%d K=%d N=%d grid=%dx%d groups=%d L=%d f32=%d", NT, G, BWD ? "true" : "false", NP,
+                   p.R, p.B, p.S * p.Cg, p.Nout, grid, nw * 64, p.n_grp, p.g_L, p.y ? 1 : 0);
+    SH_LAUNCH_PS(ps, kern, dim3(grid), dim3(nw * 64), smem, st, p);
+    SH_CHECK_LAUNCH("conv_p3g");
     g_p3_launches.fetch_add(1, std::memory_order_relaxed);
     return SH_OK;
 }
@@ -1083,6 +1283,66 @@ int sh_spiral_conv_bwd_data_p3_rag(const void* dprep, const int32_t* rag_rows, c
     if (nt == 4) return SH_P3R_CASE(4);
 #undef SH_P3R_CASE
     sh_set_error("conv_p3r: %d channel tiles per workgroup is not built", nt);
+    return SH_ERR_UNSUPPORTED;
+}
+
+int sh_spiral_conv_p3_grp_ok(int B, int S, int Cg, int Nout, int g_L) {
+    return p3_shape_ok(B, S, Cg, Nout) && p3_resident_ok(S, Cg, Nout) && p3_geom(S, Cg, Nout).nt <= 4 && Cg % 32 == 0 && S < 255 && g_L > 0 && g_L <= 64;
+}
+
+// members per group the kernel of this shape is built for (the host groups accordingly): four while their accumulators leave room
+// for the load ring (<= 2 channel tiles per workgroup), two with four tiles; 0: the shape is not taken
+int sh_spiral_conv_p3_grp_members(int B, int S, int Cg, int Nout) {
+    if (!sh_spiral_conv_p3_grp_ok(B, S, Cg, Nout, 1)) return 0;
+    return p3_geom(S, Cg, Nout).nt <= 2 ? 4 : 2;
+}
+
+int sh_spiral_conv_p3_grp(const void* xp, const int32_t* g_rows, const uint32_t* g_pos, const int32_t* g_out, int n_groups, int g_L,
+                          const void* wfrag3, const float* bias, float* y, int64_t y_sv, int64_t y_sb, void* yp, const float* yprev,
+                          int64_t yp_sv, int64_t yp_sb, const void* yprev_planes, int act, int zero_row, int backward, int B, int R, int S,
+                          int Cg, int Nout, sh_stream_t stream) {
+    SH_REQUIRE(xp && g_rows && g_pos && g_out && wfrag3, SH_ERR_INVALID_ARG, "sh_spiral_conv_p3_grp: null pointer");
+    SH_REQUIRE(B > 0 && R > 0 && S > 0 && Cg > 0 && Nout > 0 && n_groups > 0, SH_ERR_INVALID_ARG, "sh_spiral_conv_p3_grp: non-positive size");
+    SH_REQUIRE(act >= SH_ACT_IDENTITY && act <= SH_ACT_TANH, SH_ERR_INVALID_ARG, "sh_spiral_conv_p3_grp: unknown activation");
+    SH_REQUIRE(sh_spiral_conv_p3_grp_ok(B, S, Cg, Nout, g_L), SH_ERR_UNSUPPORTED,
+               "sh_spiral_conv_p3_grp: B=%d S=%d gathered channels=%d output channels=%d lists of %d is not taken (resident three-plane weight, "
+               "gathered channels %% 32 == 0, lists of at most 64 rows)", B, S, Cg, Nout, g_L);
+    SH_REQUIRE(backward || !(yprev || yprev_planes), SH_ERR_INVALID_ARG, "sh_spiral_conv_p3_grp: yprev belongs to the backward form");
+    P3Params p{};
+    p.xp = static_cast<const char*>(xp); p.wfrag = static_cast<const u32x4*>(wfrag3); p.bias = backward ? nullptr : bias;
+    p.y = y; p.y_sv = y_sv; p.y_sb = y_sb; p.yp = static_cast<char*>(yp);
+    p.yprev = yprev; p.yv_sv = yp_sv; p.yv_sb = yp_sb;
+    p.B = B; p.R = R; p.S = S; p.Cg = Cg; p.Nout = Nout; p.act = act; p.zero_row = zero_row;
+    p.g_rows = g_rows; p.g_pos = g_pos; p.g_out = g_out; p.g_L = g_L; p.n_grp = n_groups;
+    if (yprev_planes) {
+        SH_REQUIRE(sh_p3_bytes(1, B, Nout) && (reinterpret_cast<uintptr_t>(yprev_planes) & 15) == 0, SH_ERR_UNSUPPORTED,
+                   "sh_spiral_conv_p3_grp: B=%d channels=%d has no plane image (yprev_planes)", B, Nout);
+        p.yprev_img = static_cast<const char*>(yprev_planes);
+        p.yvi_bgb = Nout == 16 ? 1536 : (long)(Nout / 32) * 3072; p.yvi_vb = p.yvi_bgb * (B / 16);
+    }
+    const P3Geom g = p3_geom(p.S, p.Cg, p.Nout);
+    p.nks = g.nks; p.nt_tot = g.nt_tot; p.nsplit = g.nsplit; p.ncg = p.Cg / 32;
+    const int nbg = B / 16;
+    p.x_bgb = (long)p.ncg * 3072; p.x_vb = p.x_bgb * nbg;
+    if (p.yp) {
+        SH_REQUIRE(p.Nout == 16 || p.Nout % 32 == 0, SH_ERR_UNSUPPORTED, "conv_p3g: a plane image has 16 or a multiple of 32 channels (%d)", p.Nout);
+        p.yp_bgb = p.Nout == 16 ? 1536 : (long)(p.Nout / 32) * 3072; p.yp_vb = p.yp_bgb * nbg;
+    }
+    SH_REQUIRE(p.y || p.yp, SH_ERR_INVALID_ARG, "conv_p3g: no output");
+    SH_REQUIRE(((reinterpret_cast<uintptr_t>(p.xp) | reinterpret_cast<uintptr_t>(p.yp) | reinterpret_cast<uintptr_t>(p.y) | reinterpret_cast<uintptr_t>(p.yprev) |
+                 reinterpret_cast<uintptr_t>(p.bias)) & 15) == 0 && ((p.y_sv | p.y_sb | p.yv_sv | p.yv_sb) & 3) == 0, SH_ERR_INVALID_ARG,
+               "conv_p3g: tensors must be 16-byte aligned with strides %% 4 == 0");
+    static const int np = sh_env_int("SH_P3_NP", 6, 6, 9);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nt = g.nt;
+    // four members per group while their accumulators leave room for the load ring (<= 2 channel tiles), two beyond
+#define SH_P3G_CASE(N, GG) (backward ? (np == 9 ? launch_p3g<N, GG, true, 9>(p, st) : launch_p3g<N, GG, true, 6>(p, st)) \
+                                     : (np == 9 ? launch_p3g<N, GG, false, 9>(p, st) : launch_p3g<N, GG, false, 6>(p, st)))
+    if (nt == 1) return SH_P3G_CASE(1, 4);
+    if (nt == 2) return SH_P3G_CASE(2, 4);
+    if (nt == 4) return SH_P3G_CASE(4, 2);
+#undef SH_P3G_CASE
+    sh_set_error("conv_p3g: %d channel tiles per workgroup is not built", nt);
     return SH_ERR_UNSUPPORTED;
 }
 

@@ -402,7 +402,7 @@ int sh_spmm_p3(const int32_t* rowptr, const int32_t* col, const float* val, cons
         SH_REQUIRE(vec && y_sb == C && y_sv == (int64_t)B * C && sh_p3_bytes(1, B, C) && (reinterpret_cast<uintptr_t>(y_planes) & 15) == 0, SH_ERR_UNSUPPORTED,
                    "sh_spmm_p3: B=%d C=%d has no plane image (vertex-major y; B %% 16 == 0; C == 16 or C %% 32 == 0; 16-byte aligned tensors)", B, C);
         const long bgb = C == 16 ? 1536 : (long)(C / 32) * 3072;
-        ShProfScope ps(st, "spmm_kernel<true, p3>|rows=%d B=%d C=%d", rows, B, C);
+        ShProfScope ps(st, "spmm_kernel<true, p3>|rows=%d B=%d C=%d f32=%d", rows, B, C, y ? 1 : 0);
         // measured (profiles/r05_spmm_x8.txt): the eight-channel form wins on wide rows (C = 128: 396 -> 286 us at batch 1024, 19.1 -> 18.1
         // at 64; C = 64 at batch 1024: 156 -> 138) and loses 1-7 % on the 32-channel levels: 0 = never, 1 = that rule, 2 = always
         static const int x8_mode = sh_env_int("SH_SPMM_P3X8", 1, 0, 2);

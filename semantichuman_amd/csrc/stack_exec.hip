@@ -79,6 +79,31 @@ inline bool p3_fwd(const P3Ctx& c, int i, bool in_vm) {
     return c.mode == SH_MMA_PLANES3 && s.kind == 0 && i > 0 && in_vm && c.planes && c.planes[i - 1] && c.wfrag3 && c.wfrag3[i] &&
            p3_step_shape_ok(c.B, s);
 }
+// Training on the plane images (round 6, keep_fp32 == 2): does the BACKWARD pass of conv step j leave the fp32 rows of the step's
+// gathered input (acts[j - 1]) unread?  Yes when its weight gradient runs on the images (wgrad_p3.hip) and the activation
+// derivative its backward-data pass applies is evaluated from the image.  This is the part of sh_stack_backward's decisions that is
+// known from the steps alone; sh_stack_forward drops fp32 rows by it and sh_stack_backward, told so (acts_fp32 == 2), refuses to
+// run such a step in any other form.
+inline bool bwd_plane_static(const sh_stack_step* st, int j, int B) {
+    static const int on = sh_env_int("SH_P3_BWD", 1, 0, 1) && sh_env_int("SH_P3_WGRAD", 1, 0, 1) && sh_env_int("SH_P3_YPREV_IMG", 1, 0, 1) &&
+                          sh_env_int("SH_P3_DROP_FP32", 1, 0, 1);
+    const sh_stack_step& s = st[j];
+    if (!on || j == 0 || s.kind != 0 || !s.table_t) return false;
+    if (!sh_spiral_conv_p3_ok(B, s.S, s.cout, s.cin)) return false;                  // its backward-data pass gathers the image of dpre
+    if (s.R == s.n_in && sh_spiral_conv_bwd_wgt_thin_ok(B, s.n_in, s.S, s.cin, s.cout, SH_DTYPE_F32)) return false;
+    if (!sh_spiral_conv_bwd_wgt_p3_ok(B, s.R, s.S, s.cin, s.cout)) return false;
+    if (((long)s.R * (B / 16)) % 2 != 0 && s.zero_row < 0) return false;
+    return sh_p3_bytes(1, B, s.cin) != 0;
+}
+// ... and does it leave the fp32 rows of its pre-activation gradient (what the step behind it writes to gin[j + 1]) unread?  When,
+// besides, no pre-sum launch or rider reads them: ragged source lists, or a table without multiplicities.
+inline bool bwd_grad_plane_static(const sh_stack_step* st, int j, int B) {
+    static const int rag_on = sh_env_int("SH_P3_RAGGED", 1, 0, 1);
+    const sh_stack_step& s = st[j];
+    if (!bwd_plane_static(st, j, B)) return false;
+    const bool rag = rag_on && s.rag_rows && s.rag_pos && sh_spiral_conv_p3_rag_ok(B, s.S, s.cout, s.cin, s.rag_L);
+    return rag || (s.n1 == 0 && s.n2 == 0);
+}
 // the conv step that gathers the buffer step i writes (through a folded up-sampling that appends to it), or -1
 inline int consumer_conv(const P3Ctx& c, int i) {
     int j = i + 1;
@@ -98,6 +123,7 @@ int sh_stack_forward(int n_steps, const sh_stack_step* steps, const float* x, in
     if (B > 0 && (rc = check_tensor_sizes(n_steps, steps, rows0, c0, B, "sh_stack_forward")) != SH_OK) return rc;
     SH_REQUIRE(x && weights && outs && B > 0, SH_ERR_INVALID_ARG, "sh_stack_forward: null pointer or empty batch");
     SH_REQUIRE(sh_mma_mode_valid(mma_mode), SH_ERR_INVALID_ARG, "sh_stack_forward: unknown mma_mode %d", mma_mode);
+    SH_REQUIRE(keep_fp32 >= 0 && keep_fp32 <= 2, SH_ERR_INVALID_ARG, "sh_stack_forward: keep_fp32 = %d (0, 1 or 2)", keep_fp32);
     const P3Ctx pc{n_steps, B, mma_mode, steps, planes, wfrag3};
     const float* cur = x;
     Lay cl = lay(x_layout, rows0, B, c0);
@@ -114,10 +140,19 @@ int sh_stack_forward(int n_steps, const sh_stack_step* steps, const float* x, in
         // forward only (keep_fp32 == 0: no backward pass will read this pass's activations): rows that are gathered through
         // their plane image alone are written as the image alone - a re-sampling step in front of a plane conv, a plane conv
         // directly in front of another (6 instead of 10 bytes per element; BASELINE config 5's decode)
-        const bool img_only = !keep_fp32 && img && cons >= 0 && p3_fwd(pc, cons, true);
+        // training on the images (keep_fp32 == 2): the same rows, when the backward pass of the consumer leaves them unread too
+        const bool img_only = (keep_fp32 == 0 || (keep_fp32 == 2 && cons >= 0 && bwd_plane_static(steps, cons, B))) && img && cons >= 0 &&
+                              p3_fwd(pc, cons, true);
         if (s.kind == 0) {
             if (p3_fwd(pc, i, cl.sb == c && cl.sv == (long)B * c)) {
                 const bool direct = img_only && cons == i + 1;      // (through a folded up-sampling the fp32 rows feed the blend)
+                // grouped lists (round 6): output rows with overlapping spirals share one list of the union - every row gathered once
+                static const int grp_on = sh_env_int("SH_P3_GROUPED", 1, 0, 1);
+                if (grp_on && s.fg_rows && s.fg_pos && s.fg_out && s.fg_n > 0 && sh_spiral_conv_p3_grp_ok(B, s.S, s.cin, s.cout, s.fg_L))
+                    rc = sh_spiral_conv_p3_grp(planes[i - 1], s.fg_rows, s.fg_pos, s.fg_out, s.fg_n, s.fg_L, wfrag3[i], biases ? biases[s.param] : nullptr,
+                                               direct ? nullptr : outs[i], ol.sv, ol.sb, img, nullptr, 0, 0, nullptr, s.act, s.zero_row, 0, B, s.R, s.S,
+                                               s.cin, s.cout, stream);
+                else
                 rc = sh_spiral_conv_fwd_p3(planes[i - 1], s.table, wfrag3[i], biases ? biases[s.param] : nullptr, direct ? nullptr : outs[i], ol.sv,
                                            ol.sb, img, B, s.R, s.S, s.cin, s.cout, s.act, s.zero_row, stream);
             } else {
@@ -146,13 +181,16 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
                       float* const* gin, float* dpre_last, float* const* weight_t, void* const* workspace,
                       const size_t* workspace_bytes, float* const* dW, float* const* dbias, int need_x_grad, int mma_mode,
                       void* const* gin_planes, void* dpre_last_planes, const void* const* wfrag3_t, const void* const* in_planes,
-                      sh_stream_t stream) {
+                      int acts_fp32, sh_stream_t stream) {
     int rc = check_steps(n_steps, steps, c0, "sh_stack_backward");
     if (rc != SH_OK) return rc;
     if (B > 0 && (rc = check_tensor_sizes(n_steps, steps, rows0, c0, B, "sh_stack_backward")) != SH_OK) return rc;
     SH_REQUIRE(x && acts && g && weights && gin && dW && B > 0, SH_ERR_INVALID_ARG, "sh_stack_backward: null pointer or empty batch");
     SH_REQUIRE(n_steps <= 64, SH_ERR_UNSUPPORTED, "sh_stack_backward: more than 64 steps");
     SH_REQUIRE(sh_mma_mode_valid(mma_mode), SH_ERR_INVALID_ARG, "sh_stack_backward: unknown mma_mode %d", mma_mode);
+    SH_REQUIRE(acts_fp32 == 1 || (acts_fp32 == 2 && mma_mode == SH_MMA_PLANES3 && in_planes), SH_ERR_INVALID_ARG,
+               "sh_stack_backward: acts_fp32 = %d (1: every activation has its fp32 rows; 2, three-plane form with in_planes: the forward pass "
+               "ran with keep_fp32 == 2)", acts_fp32);
     const int last = n_steps - 1;
     int cin_of[64];                                            // channels entering step i
     {
@@ -267,6 +305,12 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
             const bool p3w = p3 && p3_wgrad_on && i > 0 && in_planes && in_planes[i] && il.sb == s.cin && il.sv == (long)B * s.cin &&
                              sh_spiral_conv_bwd_wgt_p3_ok(B, s.R, s.S, s.cin, s.cout) && (((long)s.R * (B / 16)) % 2 == 0 || s.zero_row >= 0) &&
                              workspace_bytes[i] >= sh_spiral_conv_bwd_wgt_p3_workspace(B, s.R, s.S, s.cin, s.cout);
+            // the forward pass left the fp32 rows of this step's input unwritten (keep_fp32 == 2) when this much was known from the
+            // steps alone: then the step must run on the images, whatever the buffers the caller gave this pass
+            const bool in_dropped = acts_fp32 == 2 && bwd_plane_static(steps, i, B);
+            SH_REQUIRE(!in_dropped || (p3w && (!yprev || (in_planes[i] && yl.sb == s.cin && yl.sv == (long)B * s.cin))), SH_ERR_INVALID_ARG,
+                       "sh_stack_backward: step %d: the forward pass kept only the image of its input (keep_fp32 == 2) but this pass cannot run "
+                       "the step on images (gin_planes / wfrag3_t / in_planes / workspace of sh_spiral_conv_bwd_wgt_p3_workspace bytes)", i);
             if (!thin) {
                 const sh_csr_ref& lm = s.n2 ? s.sum2 : s.sum1;
                 const int ln = ride ? (s.n2 ? s.n2 : s.n1) : 0;
@@ -331,15 +375,22 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
                             if (rc != SH_OK) return rc;
                         }
                         const bool img_out = gi_img && gl.sb == s.cin && gl.sv == (long)B * s.cin && sh_p3_bytes(1, B, s.cin);
+                        // the step that takes this gradient reads it through the image alone (acts_fp32 == 2 holds it to that): image only
+                        float* gi_f = (acts_fp32 == 2 && img_out && i > 0 && bwd_grad_plane_static(steps, i - 1, B)) ? nullptr : gi;
                         // the activation to differentiate, from its image when the caller kept the forward images (SH_P3_YPREV_IMG=0: fp32)
                         static const int yimg_on = sh_env_int("SH_P3_YPREV_IMG", 1, 0, 1);
                         const void* yimg = (yimg_on && yprev && in_planes && in_planes[i] && yl.sb == s.cin && yl.sv == (long)B * s.cin &&
                                             sh_p3_bytes(1, B, s.cin)) ? in_planes[i] : nullptr;
-                        if (rag)
-                            rc = sh_spiral_conv_bwd_data_p3_rag(cur_img, s.rag_rows, s.rag_pos, s.rag_L, wfrag3_t[i], gi, gl.sv, gl.sb, img_out ? gi_img : nullptr,
+                        static const int grp_on = sh_env_int("SH_P3_GROUPED", 1, 0, 1);
+                        if (rag && grp_on && s.bg_rows && s.bg_pos && s.bg_out && s.bg_n > 0 && sh_spiral_conv_p3_grp_ok(B, s.S, s.cout, s.cin, s.bg_L))
+                            rc = sh_spiral_conv_p3_grp(cur_img, s.bg_rows, s.bg_pos, s.bg_out, s.bg_n, s.bg_L, wfrag3_t[i], nullptr, gi_f, gl.sv, gl.sb,
+                                                       img_out ? gi_img : nullptr, yprev, yl.sv, yl.sb, yimg, act_prev, zero_prev, 1, B, s.n_in, s.S, s.cout,
+                                                       s.cin, stream);
+                        else if (rag)
+                            rc = sh_spiral_conv_bwd_data_p3_rag(cur_img, s.rag_rows, s.rag_pos, s.rag_L, wfrag3_t[i], gi_f, gl.sv, gl.sb, img_out ? gi_img : nullptr,
                                                                 yprev, yl.sv, yl.sb, yimg, act_prev, zero_prev, B, s.n_in, s.S, s.cin, s.cout, stream);
                         else
-                        rc = sh_spiral_conv_bwd_data_p3(cur_img, s.zero_row, presum_img ? nullptr : cur, cl.sv, cl.sb, s.R, s.table_t, wfrag3_t[i], gi, gl.sv, gl.sb, img_out ? gi_img : nullptr, yprev, yl.sv,
+                        rc = sh_spiral_conv_bwd_data_p3(cur_img, s.zero_row, presum_img ? nullptr : cur, cl.sv, cl.sb, s.R, s.table_t, wfrag3_t[i], gi_f, gl.sv, gl.sb, img_out ? gi_img : nullptr, yprev, yl.sv,
                                                         yl.sb, yimg, act_prev, zero_prev, B, s.n_in, s.S, s.cin, s.cout, stream);
                         gi_img_done = img_out;
                     } else {
@@ -354,7 +405,8 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
         } else if (want_in) {
             SH_REQUIRE(s.mt.rowptr && s.mt.col && s.mt.val, SH_ERR_INVALID_ARG, "sh_stack_backward: step %d has no transposed matrix", i);
             const bool img_out = gi_img && gl.sb == cin_of[i] && gl.sv == (long)B * cin_of[i] && sh_p3_bytes(1, B, cin_of[i]);
-            rc = sh_spmm_p3(s.mt.rowptr, s.mt.col, s.mt.val, cur, cl.sv, cl.sb, gi, gl.sv, gl.sb, img_out ? gi_img : nullptr, yprev, yl.sv, yl.sb,
+            float* gi_f = (acts_fp32 == 2 && img_out && i > 0 && bwd_grad_plane_static(steps, i - 1, B)) ? nullptr : gi;
+            rc = sh_spmm_p3(s.mt.rowptr, s.mt.col, s.mt.val, cur, cl.sv, cl.sb, gi_f, gl.sv, gl.sb, img_out ? gi_img : nullptr, yprev, yl.sv, yl.sb,
                             act_prev, zero_prev, B, s.m_cols, cin_of[i], stream);
             if (rc != SH_OK) return rc;
             gi_img_done = img_out;

@@ -249,6 +249,134 @@ def transpose_table_ragged(table: np.ndarray, n_in: int, none_row: int, skip_row
     return rows, pos
 
 
+def _match_by_overlap(sets, weight_pairs, cap_len, can_merge):
+    """Greedy maximum-weight matching: `weight_pairs` = (a, b, w) arrays over nodes with row sets `sets`; pairs are taken in order of
+    decreasing shared rows (ties: smaller indices first - deterministic) when both ends are free, `can_merge(a, b)` holds and the
+    union stays within `cap_len` rows.  -> list of merged node lists."""
+    a, b, w = weight_pairs
+    order = np.lexsort((b, a, -w))
+    taken = np.zeros(len(sets), dtype=bool)
+    out = []
+    for k in order:
+        i, j = int(a[k]), int(b[k])
+        if taken[i] or taken[j] or not can_merge(i, j):
+            continue
+        if len(sets[i] | sets[j]) > cap_len:
+            continue
+        taken[i] = taken[j] = True
+        out.append((i, j))
+    out.extend((i,) for i in range(len(sets)) if not taken[i])
+    return out
+
+
+def _shared_row_pairs(owner_of_entry, row_of_entry, n_nodes, max_readers=64):
+    """(a, b, shared rows) for every pair of nodes a < b that read a common row; rows with more than `max_readers` readers (a
+    dummy row) say nothing about locality and are left out."""
+    key = np.unique(row_of_entry.astype(np.int64) * n_nodes + owner_of_entry.astype(np.int64))       # one entry per (row, node)
+    rows, nodes = key // n_nodes, key % n_nodes
+    start = np.flatnonzero(np.r_[True, rows[1:] != rows[:-1]])
+    cnt = np.diff(np.r_[start, rows.size])
+    ok = np.repeat(cnt <= max_readers, cnt)
+    rows, nodes = rows[ok], nodes[ok]
+    pa, pb = [], []
+    for d in range(1, int(min(cnt.max() if cnt.size else 0, max_readers))):
+        same = rows[d:] == rows[:-d]
+        pa.append(nodes[:-d][same])
+        pb.append(nodes[d:][same])
+    if not pa:
+        return np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.int64)
+    pa, pb = np.concatenate(pa), np.concatenate(pb)
+    pk, w = np.unique(pa * n_nodes + pb, return_counts=True)
+    return pk // n_nodes, pk % n_nodes, w
+
+
+def group_lists(rows: np.ndarray, pos: np.ndarray, members: int = 4, max_len: int = 64):
+    """Group output rows whose source lists overlap (round 6; csrc/p3_conv.hip conv_p3g_kernel).  `rows`, `pos` int32 [n, L]: per output
+    row its sources (row of the gathered tensor, spiral position; pos == -1 behind the last one) - a forward gather table with
+    pos = 0..S-1, or the ragged lists of `transpose_table_ragged`.  Neighbouring vertices' spirals share most of their rows; a group
+    of up to `members` (2 or 4) output rows lists the UNION once.  Returns
+        g_rows int32  [n_groups, Lg]     rows of the gathered tensor (padding: the group's first row)
+        g_pos  uint32 [n_groups, Lg]     one byte per member: the position that member reads the row at, 0xFF = it does not
+                                         (0xFFFFFFFF behind the group's last entry)
+        g_out  int32  [n_groups, 4]      the members' output rows (-1: none)
+    or None when a single list is longer than `max_len` or a position does not fit a byte.  Grouping: greedy matching on the number
+    of shared rows (pairs first, then pairs of pairs), unions capped at `max_len` entries; deterministic.  A member that reads one
+    row at two positions gets a second entry for it."""
+    assert members in (2, 4) and rows.shape == pos.shape
+    import hashlib
+    key = (hashlib.sha1(np.ascontiguousarray(rows).tobytes() + np.ascontiguousarray(pos).tobytes()).hexdigest(), rows.shape, members, max_len)
+    if key not in _GROUP_CACHE:                           # (the same mesh hierarchy is built many times per process: models, tests)
+        if len(_GROUP_CACHE) > 256:
+            _GROUP_CACHE.clear()
+        _GROUP_CACHE[key] = _group_lists(rows, pos, members, max_len)
+    return _GROUP_CACHE[key]
+
+
+_GROUP_CACHE: dict = {}
+
+
+def _group_lists(rows, pos, members, max_len):
+    n, L = rows.shape
+    valid = pos >= 0
+    if n == 0 or int(valid.sum(axis=1).max()) > max_len or (pos.max() if pos.size else 0) >= 255:
+        return None
+    owner = np.repeat(np.arange(n), L)[valid.ravel()]
+    rr = rows.ravel()[valid.ravel()]
+    sets = [set() for _ in range(n)]
+    for o, r in zip(owner.tolist(), rr.tolist()):
+        sets[o].add(r)
+    # a member reading one row twice needs that many entries of the group: count multiplicities in the cap through list lengths
+    length = valid.sum(axis=1)
+    slack = [int(length[i]) - len(sets[i]) for i in range(n)]
+    pairs = _match_by_overlap(sets, _shared_row_pairs(owner, rr, n), max_len, lambda i, j: slack[i] == 0 and slack[j] == 0 or
+                              len(sets[i] | sets[j]) + slack[i] + slack[j] <= max_len)
+    groups = pairs
+    if members == 4:
+        psets = [set().union(*(sets[i] for i in g)) for g in pairs]
+        pslack = [sum(slack[i] for i in g) for g in pairs]
+        node_of = np.empty(n, dtype=np.int64)
+        for k, g in enumerate(pairs):
+            for i in g:
+                node_of[i] = k
+        quads = _match_by_overlap(psets, _shared_row_pairs(node_of[owner], rr, len(pairs)), max_len,
+                                  lambda a, b: len(psets[a] | psets[b]) + pslack[a] + pslack[b] <= max_len)
+        groups = [tuple(i for k in q for i in pairs[k]) for q in quads]
+    groups.sort(key=lambda g: g[0])                       # launch order follows the rows' order (neighbouring groups share rows in L2)
+    ent = []
+    for g in groups:
+        by_row = {}
+        for m, i in enumerate(g):
+            for r, q in zip(rows[i][valid[i]].tolist(), pos[i][valid[i]].tolist()):
+                slots = by_row.setdefault(r, [])
+                for e in slots:                            # the first entry of this row that member m has not used yet
+                    if e[m] == 0xFF:
+                        e[m] = q
+                        break
+                else:
+                    e = [0xFF] * 4
+                    e[m] = q
+                    slots.append(e)
+        # entries ordered by the smallest position that reads them, then row: every member meets its positions in ascending order
+        # as far as the union allows
+        flat = [(min(x for x in e if x != 0xFF), r, e) for r, slots in by_row.items() for e in slots]
+        flat.sort(key=lambda t: (t[0], t[1]))
+        ent.append(flat)
+    Lg = max(len(f) for f in ent)
+    if Lg > max_len:
+        return None
+    ng = len(groups)
+    g_rows = np.zeros((ng, Lg), dtype=np.int32)
+    g_pos = np.full((ng, Lg), 0xFFFFFFFF, dtype=np.uint32)
+    g_out = np.full((ng, 4), -1, dtype=np.int32)
+    for k, (g, flat) in enumerate(zip(groups, ent)):
+        g_out[k, :len(g)] = g
+        g_rows[k, :] = flat[0][1] if flat else 0
+        for j, (_, r, e) in enumerate(flat):
+            g_rows[k, j] = r
+            g_pos[k, j] = e[0] | (e[1] << 8) | (e[2] << 16) | (e[3] << 24)
+    return g_rows, g_pos, g_out
+
+
 # ----------------------------------------------------------------------------- U (up-sampling)
 def _closest_point_barycentric(p, a, b, c):
     """Closest point to p on triangles (a,b,c) (all [M,3]); returns barycentric

@@ -43,6 +43,11 @@ _LAYOUT_ID = {"vm": 0, "bm": 1}
 # images during the backward pass, so they are not kept
 _P3_WGRAD = os.environ.get("SH_P3_WGRAD", "1").strip() != "0"
 _P3_RAGGED = os.environ.get("SH_P3_RAGGED", "1").strip() != "0"
+# Test switch: fill the activation / gradient arenas with NaN when they are allocated.  A training pass on the images (keep_fp32 == 2)
+# leaves fp32 rows unwritten; a kernel that read one would otherwise see whatever the allocator's block held before - possibly the same
+# rows of an earlier, identical step.
+DEBUG_POISON = os.environ.get("SH_DEBUG_POISON", "0").strip() == "1"
+_P3_GROUPED = os.environ.get("SH_P3_GROUPED", "1").strip() != "0"
 _ALIGN = 64                       # floats: every carved buffer starts 256-byte aligned (16-byte vector accesses)
 
 
@@ -99,12 +104,29 @@ class ConvStep:
         # instead of the dense table and needs no pre-summed rows (SH_P3_RAGGED=0, or a list longer than 64: the dense form)
         self.rag = mesh_ops.transpose_table_ragged(self.table, self.n_in, none_row=self.zero_row,
                                                    skip_row=dummy if self.dead_dummy_grad else -1) if _P3_RAGGED else None
+        # grouped lists (round 6): output rows with overlapping source lists share one list of the union, for the plane kernels with a
+        # resident weight (csrc/p3_conv.hip conv_p3g_kernel) - forward from the table, backward-data from the ragged lists; how many
+        # members a group takes is the kernel's (registers: 4 with <= 2 channel tiles, else 2).  SH_P3_GROUPED=0: none
+        self.fgrp = self.bgrp = None
+        if _P3_GROUPED:
+            lib = _lib.load()
+            m = lib.sh_spiral_conv_p3_grp_members(16, self.S, self.cin, self.cout)
+            if m:
+                pos = np.ascontiguousarray(np.broadcast_to(np.arange(self.S, dtype=np.int32), self.table.shape))
+                self.fgrp = mesh_ops.group_lists(self.table, pos, members=m)
+            m = lib.sh_spiral_conv_p3_grp_members(16, self.S, self.cout, self.cin)
+            if m and self.rag is not None:
+                self.bgrp = mesh_ops.group_lists(self.rag[0], self.rag[1], members=m)
         return self
 
     def to(self, device):
         self.dev = {"table": _dev(self.table, device), "table_t": _dev(self.tt.table_t, device)}
         if getattr(self, "rag", None) is not None:
             self.dev["rag_rows"], self.dev["rag_pos"] = _dev(self.rag[0], device), _dev(self.rag[1], device)
+        for key in ("fgrp", "bgrp"):
+            g = getattr(self, key, None)
+            if g is not None:
+                self.dev[key] = (_dev(g[0], device), _dev(g[1].view(np.int32), device), _dev(g[2], device))
         if self.tt.csr1 is not None:
             self.dev["sum1"] = _csr_dev(self.tt.csr1, device)
         if self.tt.csr2 is not None:
@@ -248,6 +270,12 @@ class Stack:
                         ref.rowptr, ref.col, ref.val = (P(t) for t in st.dev[name])
                 if "rag_rows" in st.dev:
                     e.rag_rows, e.rag_pos, e.rag_L = P(st.dev["rag_rows"]), P(st.dev["rag_pos"]), int(st.dev["rag_rows"].shape[1])
+                if "fgrp" in st.dev:
+                    r, q, o = st.dev["fgrp"]
+                    e.fg_rows, e.fg_pos, e.fg_out, e.fg_n, e.fg_L = P(r), P(q), P(o), int(r.shape[0]), int(r.shape[1])
+                if "bgrp" in st.dev:
+                    r, q, o = st.dev["bgrp"]
+                    e.bg_rows, e.bg_pos, e.bg_out, e.bg_n, e.bg_L = P(r), P(q), P(o), int(r.shape[0]), int(r.shape[1])
             else:
                 e.kind, e.param = 1, -1
                 e.m.rowptr, e.m.col, e.m.val = (P(t) for t in st.dev["m"])
@@ -404,10 +432,13 @@ class Stack:
         plan = self._plan(B, c0)
         n = len(self.steps)
         arena = torch.empty(max(1, plan["f_total"]), dtype=torch.float32, device=x.device)
+        if DEBUG_POISON:
+            arena.fill_(float("nan"))
         out = ops.alloc(B, plan["out_rows"][-1], plan["out_ch"][-1], out_layout, x.device)
         outs = plan["f_off"] + np.uint64(arena.data_ptr())
         outs[n - 1] = out.data_ptr()
         p3 = None
+        keep = 1 if with_backward else 0
         planes_p = wf3_p = None
         if mma == "planes3" and B % 16 == 0 and plan["wf3_total"]:
             planes, wf3, wbase = self._p3_prepare(plan, weights, with_backward, x.device)
@@ -415,13 +446,16 @@ class Stack:
             # activations (6 bytes per element): the three-plane weight gradient (csrc/wgrad_p3.hip) reads a step's gathered input
             # through it.  SH_P3_WGRAD=0 (the exact weight-gradient kernels): not kept, as before.
             p3 = (planes if (with_backward and _P3_WGRAD) else None, wf3, wbase)
+            # ... and with the images kept, the fp32 rows that neither pass reads are not written (sh_stack_forward keep_fp32 == 2;
+            # SH_P3_DROP_FP32=0: every row, as before)
+            if p3[0] is not None:
+                keep = 2
             pl = (plan["pl_off"] + np.uint64(planes.data_ptr())) * plan["pl_mask"]
             wf = (plan["wf3_off"] + np.uint64(wf3.data_ptr() + wbase)) * plan["wf3_mask"]
             planes_p, wf3_p = pl.ctypes.data, wf.ctypes.data
         _lib.check(_lib.load().sh_stack_forward(n, self._native_steps(), _lib.ptr(x), _LAYOUT_ID[in_layout], rows0, c0, B,
                                                 self._ptr_array(weights), self._ptr_array(biases), outs.ctypes.data,
-                                                _LAYOUT_ID[out_layout], _lib.mma_id(mma), planes_p, wf3_p, 1 if with_backward else 0,
-                                                _lib.stream_ptr()),
+                                                _LAYOUT_ID[out_layout], _lib.mma_id(mma), planes_p, wf3_p, keep, _lib.stream_ptr()),
                    "sh_stack_forward")
         return out, arena, p3
 
@@ -434,6 +468,8 @@ class Stack:
         n = len(self.steps)
         dev = x.device
         work = torch.empty(max(1, plan["b_total"]), dtype=torch.float32, device=dev)
+        if DEBUG_POISON:
+            work.fill_(float("nan"))
         flat = torch.empty(max(1, plan["p_total"]), dtype=torch.float32, device=dev)
         gx = ops.alloc(B, rows0, c0, in_layout, dev) if need_x_grad else None
         acts = plan["f_off"] + np.uint64(arena.data_ptr())
@@ -464,7 +500,7 @@ class Stack:
             n, self._native_steps(), _lib.ptr(x), _LAYOUT_ID[in_layout], rows0, c0, B, acts.ctypes.data, _lib.ptr(g),
             _LAYOUT_ID[out_layout], self._ptr_array(weights), gin.ctypes.data, ctypes.c_void_p(int(wbase) + 4 * plan["dpre_last_off"]),
             wt.ctypes.data, ws.ctypes.data, plan["ws_bytes"].ctypes.data, dW.ctypes.data, db.ctypes.data, 1 if need_x_grad else 0,
-            _lib.mma_id(mma), gpl_p, dpl, wf3t_p, inpl_p, _lib.stream_ptr()), "sh_stack_backward")
+            _lib.mma_id(mma), gpl_p, dpl, wf3t_p, inpl_p, 2 if inpl_p is not None else 1, _lib.stream_ptr()), "sh_stack_backward")
         grads = {}
         for j, shp in enumerate(plan["shapes"]):
             if shp is None:

@@ -112,7 +112,7 @@ int main() {
                                         wsb, dW, db, 1, nullptr);
         else
             rc = sh_stack_backward(4, st, reinterpret_cast<const float*>(x), 0, L0.n_in, L0.cin, B, reinterpret_cast<const float* const*>(outs), g, 1, W,
-                                   reinterpret_cast<float* const*>(gin), dpre_last, wt, ws, wsb, dW, db, 1, mma, gpl, nullptr, wf3t, inpl, nullptr);
+                                   reinterpret_cast<float* const*>(gin), dpre_last, wt, ws, wsb, dW, db, 1, mma, gpl, nullptr, wf3t, inpl, 1, nullptr);
         if (rc) { printf("backward rc=%d\n", rc); break; }
         for (int p = 0; p < 3; ++p) { free(W[p]); free(bias[p]); free(dW[p]); free(db[p]); }
         free(x); free(o0); free(o2); free(out); free(g); free(gx); free(g1); free(g2); free(g3); free(dpre_last);

@@ -197,6 +197,26 @@ int sh_spiral_conv_bwd_data_bf16(const void* dpre, int dd, int64_t dp_sv, int64_
     return bwd_data_common("bwd_data_bf16 n_in=%d Cin=%d Cout=%d", dpre, dd == SH_DTYPE_BF16 ? 2 : 4, dp_sv, dp_sb, table_t, dx, xd == SH_DTYPE_BF16 ? 2 : 4,
                            dx_sv, dx_sb, yprev, yp_sv, yp_sb, B, n_in, S, Cin, Cout);
 }
+int sh_spiral_conv_p3_grp_ok(int B, int S, int Cg, int Nout, int g_L) { return sh_spiral_conv_p3_ok(B, S, Cg, Nout) && Cg % 32 == 0 && g_L > 0 && g_L <= 64; }
+int sh_spiral_conv_p3_grp_members(int B, int S, int Cg, int Nout) { return sh_spiral_conv_p3_grp_ok(B, S, Cg, Nout, 1) ? (Nout <= 32 ? 4 : 2) : 0; }
+int sh_spiral_conv_p3_grp(const void* xp, const int32_t* g_rows, const uint32_t* g_pos, const int32_t* g_out, int n_groups, int g_L, const void* wfrag3, const float* bias,
+                          float* y, int64_t y_sv, int64_t y_sb, void* yp, const float* yprev, int64_t yp_sv, int64_t yp_sb, const void* yprev_planes, int act, int zero_row,
+                          int backward, int B, int R, int S, int Cg, int Nout, sh_stream_t) {
+    int rows = 0;
+    for (long i = 0; i < (long)n_groups * g_L; ++i) {
+        rows = g_rows[i] + 1 > rows ? g_rows[i] + 1 : rows;
+        for (int m = 0; m < 4; ++m) { const unsigned q = (g_pos[i] >> (8 * m)) & 0xFF; if (q != 0xFF && (int)q >= S) return SH_ERR_INVALID_ARG; }
+    }
+    for (long i = 0; i < (long)n_groups * 4; ++i) if (g_out[i] >= R) return SH_ERR_INVALID_ARG;
+    touch_r(xp, sh_p3_bytes(rows, B, Cg)); touch_r(wfrag3, sh_conv_wfrag3_bytes(S, Cg, Nout));
+    if (bias) touch_r(bias, (size_t)Nout * 4);
+    if (y) touch_w(y, span(y_sv, y_sb, R, B, Nout, 4));
+    if (yp) touch_w(yp, sh_p3_bytes(R, B, Nout));
+    if (yprev_planes) touch_r(yprev_planes, sh_p3_bytes(R, B, Nout));
+    else if (yprev) touch_r(yprev, span(yp_sv, yp_sb, R, B, Nout, 4));
+    log("conv_p3_grp R=%d N=%d bwd=%d", R, Nout, backward);
+    return 0;
+}
 int sh_spiral_conv_bf16_rag_ok(int B, int S, int Cg, int Nout, int rag_L) { return B > 0 && S <= 64 && Cg % 32 == 0 && Nout % 4 == 0 && rag_L > 0 && rag_L <= 64; }
 int sh_spiral_conv_bwd_data_bf16_rag(const void* dpre, int64_t dp_sv, int64_t dp_sb, const int32_t* rag_rows, const int32_t* rag_pos, int rag_L, const void* wfrag_t,
                                      void* dx, int64_t dx_sv, int64_t dx_sb, const void* yprev, int64_t yp_sv, int64_t yp_sb, int act_prev, int zero_row, int B,

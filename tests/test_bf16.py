@@ -99,8 +99,11 @@ def test_conv_fwd_and_bwd_data_bf16(shape, layouts):
 
     # round 6: the same gradient over ragged source lists (conv_bf16r_kernel) - no pre-summed rows, so the reference is the float64
     # gradient of the UNROUNDED sums (the sums are formed in fp32 by the matrix pipe)
-    rag = mesh_ops.transpose_table_ragged(table, n_in, none_row=R - 1, skip_row=-1)
-    if rag is not None and ops.spiral_conv_bf16_rag_ok(B, S, Cout, Cin, rag[0].shape[1]):
+    # (the input's dummy row - read through every padding entry, a list of dozens of sources - is masked in dx: skipped, as the stacks do
+    # where that gradient is dead; a list longer than 64 sources keeps the dense form)
+    rag = mesh_ops.transpose_table_ragged(table, n_in, none_row=R - 1, skip_row=n_in - 1)
+    assert rag is not None
+    if ops.spiral_conv_bf16_rag_ok(B, S, Cout, Cin, rag[0].shape[1]):
         ref_r = emulate.conv_bwd_data(ext, tt.table_t, W.double().numpy(), Cin) * emulate.DACT[a](yprev.double().numpy())
         ref_r[n_in - 1] = 0
         dpr = (dpre if lo == "vm" else dpre.permute(1, 0, 2).contiguous()).to(dev(), torch.bfloat16)
@@ -525,17 +528,18 @@ def test_bf16_step_runs_the_intended_kernels():
     assert len(fam.get("wgrad_bf16_dma_kernel", [])) == 7                  # every bf16 x bf16 weight gradient
     assert len(fam.get("wgrad_bf16_kernel", [])) == 1                      # only the fp32 3-channel input side is staged
     conv = fam.get("conv_bf16_kernel", [])
-    # 9 forward + 7 backward-data (dec4's rides in the thin launch); round 6: the 6 backward-data layers that gather a multiple of
-    # 32 channels walk ragged source lists (conv_bf16r_kernel) and need no pre-sum launch
-    assert len(fam.get("conv_bf16r_kernel", [])) == 6
-    assert len(conv) == 10
-    # line-wise loads (BC_C32C, round 3) on every forward layer that gathers a multiple of 32 bf16 channels
-    assert sum(1 for n, _ in conv if n.split(",")[2].strip() == "4") == 6
+    # 9 forward + 7 backward-data (dec4's rides in the thin launch); round 6: 5 of the 6 backward-data layers that gather a multiple
+    # of 32 channels walk ragged source lists (conv_bf16r_kernel) and need no pre-sum launch - dec0 keeps the dense table: its input's
+    # dummy row carries a live gradient (the latent FC writes that row) and is read through every padding entry, a list of ~1100
+    assert len(fam.get("conv_bf16r_kernel", [])) == 5
+    assert len(conv) == 11
+    # line-wise loads (BC_C32C, round 3) on every other layer that gathers a multiple of 32 bf16 channels: 6 forward + dec0's backward
+    assert sum(1 for n, _ in conv if n.split(",")[2].strip() == "4") == 7
     assert sum(1 for n, _ in conv if n.split(",")[2].strip() in ("0", "3")) == 0      # no plain / full-line gathers left
     up = [t for _, t in fam.get("spmm_bf16_kernel", []) if "rows=3445 " in t or "rows=1722 " in t or "rows=861 " in t]
     assert len(up) == 3                                                     # folded up-sampling: only the blended rows
     # what is left of spmm_bf16: 4 down-sampling + 3 up-sampling forward, their 7 transposes, the pre-sum of the one dense layer
-    assert len(fam.get("spmm_bf16_kernel", [])) <= 15, [t for _, t in fam.get("spmm_bf16_kernel", [])]
+    assert len(fam.get("spmm_bf16_kernel", [])) == 11, [t for _, t in fam.get("spmm_bf16_kernel", [])]      # 4 + 4 re-sampling, 3 pre-sums (dec3, dec0 x 2)
 
 
 def test_model_bf16_with_second_convs_per_level():

@@ -397,3 +397,71 @@ def test_ragged_source_lists_are_the_dense_transposed_table_with_its_presums():
             lists[ok] += np.einsum("uc,uci->ui", dpre[rows[ok, j]], W[pos[ok, j]])
         assert np.allclose(dense, lists, rtol=1e-12, atol=1e-12)
     assert mesh_ops.transpose_table_ragged(table, n_in, none_row=R - 1, skip_row=-1, max_len=16) is None      # the long list: dense form
+
+
+def test_grouped_lists_cover_every_source_exactly_once():
+    """mesh_ops.group_lists (round 6; csrc/p3_conv.hip conv_p3g_kernel): every output row is a member of exactly one group; the
+    entries of a group that a member reads are exactly that row's (source row, position) list - multiplicities included - and an
+    evaluation over the groups equals the one over the one-row lists; unions stay within the cap; on a real hierarchy the union is
+    markedly shorter than the members' lists together (what the kernel's gather shrinks by)."""
+    import os
+    import numpy as np
+    from semantichuman_amd import mesh_ops
+    from semantichuman_amd.hierarchy import load_hierarchy
+    rs = np.random.RandomState(5)
+
+    def check(rows, pos, members, max_len=64):
+        g = mesh_ops.group_lists(rows, pos, members=members, max_len=max_len)
+        assert g is not None
+        g_rows, g_pos, g_out = g
+        n = rows.shape[0]
+        seen = np.zeros(n, dtype=int)
+        x = rs.randn(int(rows.max()) + 1, 3)
+        W = rs.randn(int(pos.max()) + 1, 3, 2)
+        ref = np.zeros((n, 2))
+        for i in range(n):
+            for r, q in zip(rows[i], pos[i]):
+                if q >= 0:
+                    ref[i] += x[r] @ W[q]
+        got = np.zeros((n, 2))
+        for k in range(g_rows.shape[0]):
+            mem = [int(v) for v in g_out[k] if v >= 0]
+            assert 1 <= len(mem) <= members and (g_out[k, len(mem):] == -1).all()
+            n_ent = int((g_pos[k] != 0xFFFFFFFF).sum())
+            assert n_ent <= max_len and (g_pos[k, n_ent:] == 0xFFFFFFFF).all() and (g_pos[k, :n_ent] != 0xFFFFFFFF).all()
+            for m, i in enumerate(mem):
+                seen[i] += 1
+                mine = sorted((int(g_rows[k, j]), int((g_pos[k, j] >> (8 * m)) & 0xFF)) for j in range(n_ent) if (g_pos[k, j] >> (8 * m)) & 0xFF != 0xFF)
+                want = sorted((int(r), int(q)) for r, q in zip(rows[i], pos[i]) if q >= 0)
+                assert mine == want, (k, m, i)
+                for j in range(n_ent):
+                    q = (int(g_pos[k, j]) >> (8 * m)) & 0xFF
+                    if q != 0xFF:
+                        got[i] += x[g_rows[k, j]] @ W[q]
+            for m in range(len(mem), 4):
+                assert all((int(g_pos[k, j]) >> (8 * m)) & 0xFF == 0xFF for j in range(n_ent))
+        assert (seen == 1).all()
+        assert np.allclose(got, ref, rtol=1e-12, atol=1e-12)
+        return g
+
+    # random lists: ragged lengths, a row read at two positions by one member, a row with very many readers
+    n, L = 57, 9
+    rows = rs.randint(0, 40, size=(n, L)).astype(np.int32)
+    pos = np.tile(np.arange(L, dtype=np.int32), (n, 1))
+    pos[rs.rand(n, L) < 0.2] = -1
+    rows[:, 4] = 39
+    rows[3, 0] = rows[3, 1]
+    for members in (2, 4):
+        check(rows, pos, members)
+        check(rows, pos, members, max_len=12)               # a tight cap: groups stay smaller
+    assert mesh_ops.group_lists(rows, pos, members=4, max_len=4) is None       # a single list longer than the cap
+    # a real hierarchy: forward tables of every level and the ragged backward lists of one
+    h = load_hierarchy(os.path.join(os.path.dirname(__file__), "golden", "template6890.npz"))
+    for lvl in (1, 3):
+        t = mesh_ops.spirals_to_table(h.spirals[lvl])
+        p = np.ascontiguousarray(np.broadcast_to(np.arange(t.shape[1], dtype=np.int32), t.shape))
+        g_rows, g_pos, g_out = check(t, p, 4)
+        assert int((g_pos != 0xFFFFFFFF).sum()) * 1.6 < t.size, ((g_pos != 0xFFFFFFFF).sum(), t.size)
+    t = mesh_ops.spirals_to_table(h.spirals[2])
+    rag = mesh_ops.transpose_table_ragged(t, t.shape[0], none_row=t.shape[0] - 1, skip_row=t.shape[0] - 1)
+    check(rag[0], rag[1], 2)

@@ -73,8 +73,14 @@ def test_error_of_the_split_forms_against_float64(adversarial):
         # sources are formed by the matrix pipe instead of by a pre-sum launch), the same gate
         if "planes3_rag" in e and not e["planes3_rag"] <= 1.5 * e["exact"] + 1e-9:
             bad.append((r["name"], "planes3_rag", e["planes3_rag"], e["exact"]))
+        # ... and over GROUPED lists (conv_p3g_kernel: rows with overlapping lists share one list of the union), both directions
+        if "planes3_grp" in e:
+            if not e["planes3_grp"] <= 1.5 * e["exact"] + 1e-9:
+                bad.append((r["name"], "planes3_grp", e["planes3_grp"], e["exact"]))
+            assert r["grp_img_ok"] in (True, None), r["name"]
     assert not bad, bad
     assert sum(1 for r in rows if "planes3_rag" in r["err"]) == 4, [r["name"] for r in rows if "planes3_rag" in r["err"]]
+    assert sum(1 for r in rows if "planes3_grp" in r["err"]) == 8, [r["name"] for r in rows if "planes3_grp" in r["err"]]      # 4 forward, 4 backward
 
 
 def test_nine_products_are_not_needed():
@@ -239,3 +245,24 @@ def test_three_plane_weight_gradient_carries_the_presum_job_bitwise(tail):
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0 and "PRESUM OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
     assert ("tail_blocks>0" in r.stdout) == (tail == "1"), r.stdout[-500:]
+
+
+@pytest.mark.parametrize("tpl,B", [("template6890.npz", 64), ("template27554.npz", 32), ("template6890.npz", 48)])
+def test_training_on_the_images_leaves_unread_fp32_rows_unwritten_and_changes_nothing(tpl, B):
+    """sh_stack_forward(keep_fp32 == 2) / sh_stack_backward(acts_fp32 == 2) (round 6): fp32 rows that neither pass reads - the gathered
+    input of a conv whose forward, weight gradient and activation derivative all run on its plane image; gradient rows handed to a
+    step that reads them through their image alone - are not written.  One training step with the arenas poisoned with NaN
+    (tools/drop_fp32_check.py; a read of an unwritten row would surface as NaN, not as the row of an earlier step): loss,
+    reconstruction and every parameter gradient equal, BIT FOR BIT, those of SH_P3_DROP_FP32=0 where every row is written.  The
+    switch is read once per process: two child processes."""
+    import subprocess
+    out = {}
+    for drop in ("1", "0"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "drop_fp32_check.py"), os.path.join(ROOT, "tests", "golden", tpl), str(B)],
+                           env=dict(os.environ, SH_P3_DROP_FP32=drop), capture_output=True, text=True, timeout=900, cwd=ROOT)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("DIGEST ")]
+        assert r.returncode == 0 and lines, (r.stdout[-2000:], r.stderr[-3000:])
+        out[drop] = lines[-1]
+        n_img = int([l for l in r.stdout.splitlines() if l.startswith("IMAGE_ONLY ")][-1].split()[1])
+        assert (n_img >= 8) if drop == "1" else (n_img == 0), (drop, n_img)      # at least: 3 encoder convs, 3 up-sampling steps, 2 gradient hand-overs
+    assert out["1"] == out["0"]

@@ -171,6 +171,24 @@ def probe_layers(B=64, tpl=None, directions=("fwd", "bwd"), adversarial=False, r
                             rec["us"]["planes3_rag"] = timed(run_rag, reps)
                             rec["err"]["planes3_rag"] = float((y.double() - ref_r).abs().max()) / float(ref_r.abs().max())
                             rec["rag_L"] = int(rr.shape[1])
+                        # round 6: GROUPED lists (conv_p3g_kernel): rows with overlapping lists share the union - forward from the table,
+                        # backward-data from the ragged lists; same float64 references, image of the result checked like the others'
+                        grp = st.dev.get("bgrp" if bwd else "fgrp")
+                        if grp is not None and lib.sh_spiral_conv_p3_grp_ok(B, S, Cg, Nout, int(grp[0].shape[1])):
+                            g_r, g_p, g_o = grp
+                            ref_g = ref_r if bwd else ref
+                            y.zero_()
+                            ypg = torch.empty(nimg, dtype=torch.uint8, device=dev) if nimg else None
+
+                            def run_grp():
+                                _lib.check(lib.sh_spiral_conv_p3_grp(_lib.ptr(xp), _lib.ptr(g_r), _lib.ptr(g_p), _lib.ptr(g_o), int(g_r.shape[0]), int(g_r.shape[1]),
+                                                                     _lib.ptr(wf), None if bwd else _lib.ptr(bias), _lib.ptr(y), B * Nout, Nout, _lib.ptr(ypg), None, 0, 0,
+                                                                     None, 0, -1, 1 if bwd else 0, B, rows_out, S, Cg, Nout, _lib.stream_ptr()),
+                                           "sh_spiral_conv_p3_grp")
+                            rec["us"]["planes3_grp"] = timed(run_grp, reps)
+                            rec["err"]["planes3_grp"] = float((y.double() - ref_g).abs().max()) / float(ref_g.abs().max())
+                            rec["grp"] = (int(g_r.shape[0]), int(g_r.shape[1]), int((g_p.view(torch.int32) != -1).sum()))
+                            rec["grp_img_ok"] = None if ypg is None else bool(torch.equal(to_p3(y), ypg))
                         rec["us_to_p3"] = timed(lambda: to_p3(x), reps)
                         rec["img_ok"] = None if yp is None else bool(torch.equal(to_p3(y), yp))
                     yield rec
@@ -197,6 +215,9 @@ def main():
         else:
             p3s, t3 = "   -   ", "  -"
         rag = "   ragged lists (L %d): err %.2e, %6.1f us" % (r["rag_L"], r["err"]["planes3_rag"], r["us"]["planes3_rag"]) if "planes3_rag" in r["us"] else ""
+        if "planes3_grp" in r["us"]:
+            rag += "   grouped (%d groups, L %d, %d entries): err %.2e, %6.1f us%s" % (r["grp"] + (r["err"]["planes3_grp"], r["us"]["planes3_grp"],
+                                                                                        "" if r["grp_img_ok"] in (True, None) else " img=MISMATCH"))
         print("%-34s %.2e %.2e %-9s   %6.1f %6.1f %s%s" % (r["name"], r["err"]["exact"], r["err"]["split3"], p3s, r["us"]["exact"],
                                                            r["us"]["split3"], t3, rag), flush=True)
 
