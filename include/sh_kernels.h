@@ -735,6 +735,9 @@ SH_API int sh_spiral_conv_bwd_data_p3_rag(const void* dprep, const int32_t* rag_
  * 0 = shape not taken) - g_out always has four slots per group. */
 SH_API int sh_spiral_conv_p3_grp_ok(int B, int S, int Cg, int Nout, int g_L);
 SH_API int sh_spiral_conv_p3_grp_members(int B, int S, int Cg, int Nout);
+/* 1 when the launch has enough groups x batch groups to fill the chip with its coarser work items (the sequencers' rule for taking
+ * the grouped form; SH_P3_GRP_MIN_ITEMS_PER_CU, default 12). */
+SH_API int sh_spiral_conv_p3_grp_pays(int B, int n_groups);
 SH_API int sh_spiral_conv_p3_grp(const void* xp, const int32_t* g_rows, const uint32_t* g_pos, const int32_t* g_out, int n_groups, int g_L,
                                  const void* wfrag3, const float* bias, float* y, int64_t y_sv, int64_t y_sb, void* yp, const float* yprev,
                                  int64_t yp_sv, int64_t yp_sb, const void* yprev_planes, int act, int zero_row, int backward, int B, int R,

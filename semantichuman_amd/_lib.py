@@ -114,6 +114,7 @@ SIGNATURES = {
     "sh_spiral_conv_bf16_rag_ok": (c_int, [_I, _I, _I, _I, _I]),
     "sh_spiral_conv_p3_grp_ok": (c_int, [_I, _I, _I, _I, _I]),
     "sh_spiral_conv_p3_grp_members": (c_int, [_I, _I, _I, _I]),
+    "sh_spiral_conv_p3_grp_pays": (c_int, [_I, _I]),
     "sh_spiral_conv_p3_grp": (c_int, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _L, _L, _P, _P, _L, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sh_spiral_conv_bwd_data_bf16_rag": (c_int, [_P, _L, _L, _P, _P, _I, _P, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sh_spiral_conv_bwd_data_p3_rag": (c_int, [_P, _P, _P, _I, _P, _P, _L, _L, _P, _P, _L, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -1297,6 +1297,14 @@ int sh_spiral_conv_p3_grp_members(int B, int S, int Cg, int Nout) {
     return p3_geom(S, Cg, Nout).nt <= 2 ? 4 : 2;
 }
 
+// does grouping pay for this launch?  Measured (profiles/r06_kernel_experiments.txt item 12, 6890 vertices x 64): a group is one wave
+// item of up to four rows - with fewer than ~one item per resident wave the launch loses more to its coarser, uneven items than the
+// halved gather brings (449-493 groups x 4 batch groups: +2.3 ... +4.0 us; 886-1760 x 4: -0.8 ... -8.2 us).
+int sh_spiral_conv_p3_grp_pays(int B, int n_groups) {
+    static const int min_per_cu = sh_env_int("SH_P3_GRP_MIN_ITEMS_PER_CU", 12, 0, 1 << 20);
+    return B >= 16 && (long)n_groups * (B / 16) >= (long)min_per_cu * p3_num_cus();
+}
+
 int sh_spiral_conv_p3_grp(const void* xp, const int32_t* g_rows, const uint32_t* g_pos, const int32_t* g_out, int n_groups, int g_L,
                           const void* wfrag3, const float* bias, float* y, int64_t y_sv, int64_t y_sb, void* yp, const float* yprev,
                           int64_t yp_sv, int64_t yp_sb, const void* yprev_planes, int act, int zero_row, int backward, int B, int R, int S,

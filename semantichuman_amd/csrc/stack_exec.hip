@@ -148,7 +148,8 @@ int sh_stack_forward(int n_steps, const sh_stack_step* steps, const float* x, in
                 const bool direct = img_only && cons == i + 1;      // (through a folded up-sampling the fp32 rows feed the blend)
                 // grouped lists (round 6): output rows with overlapping spirals share one list of the union - every row gathered once
                 static const int grp_on = sh_env_int("SH_P3_GROUPED", 1, 0, 1);
-                if (grp_on && s.fg_rows && s.fg_pos && s.fg_out && s.fg_n > 0 && sh_spiral_conv_p3_grp_ok(B, s.S, s.cin, s.cout, s.fg_L))
+                if (grp_on && s.fg_rows && s.fg_pos && s.fg_out && s.fg_n > 0 && sh_spiral_conv_p3_grp_ok(B, s.S, s.cin, s.cout, s.fg_L) &&
+                    sh_spiral_conv_p3_grp_pays(B, s.fg_n))
                     rc = sh_spiral_conv_p3_grp(planes[i - 1], s.fg_rows, s.fg_pos, s.fg_out, s.fg_n, s.fg_L, wfrag3[i], biases ? biases[s.param] : nullptr,
                                                direct ? nullptr : outs[i], ol.sv, ol.sb, img, nullptr, 0, 0, nullptr, s.act, s.zero_row, 0, B, s.R, s.S,
                                                s.cin, s.cout, stream);
@@ -382,7 +383,8 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
                         const void* yimg = (yimg_on && yprev && in_planes && in_planes[i] && yl.sb == s.cin && yl.sv == (long)B * s.cin &&
                                             sh_p3_bytes(1, B, s.cin)) ? in_planes[i] : nullptr;
                         static const int grp_on = sh_env_int("SH_P3_GROUPED", 1, 0, 1);
-                        if (rag && grp_on && s.bg_rows && s.bg_pos && s.bg_out && s.bg_n > 0 && sh_spiral_conv_p3_grp_ok(B, s.S, s.cout, s.cin, s.bg_L))
+                        if (rag && grp_on && s.bg_rows && s.bg_pos && s.bg_out && s.bg_n > 0 && sh_spiral_conv_p3_grp_ok(B, s.S, s.cout, s.cin, s.bg_L) &&
+                            sh_spiral_conv_p3_grp_pays(B, s.bg_n))
                             rc = sh_spiral_conv_p3_grp(cur_img, s.bg_rows, s.bg_pos, s.bg_out, s.bg_n, s.bg_L, wfrag3_t[i], nullptr, gi_f, gl.sv, gl.sb,
                                                        img_out ? gi_img : nullptr, yprev, yl.sv, yl.sb, yimg, act_prev, zero_prev, 1, B, s.n_in, s.S, s.cout,
                                                        s.cin, stream);

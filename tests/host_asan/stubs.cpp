@@ -198,6 +198,7 @@ int sh_spiral_conv_bwd_data_bf16(const void* dpre, int dd, int64_t dp_sv, int64_
                            dx_sv, dx_sb, yprev, yp_sv, yp_sb, B, n_in, S, Cin, Cout);
 }
 int sh_spiral_conv_p3_grp_ok(int B, int S, int Cg, int Nout, int g_L) { return sh_spiral_conv_p3_ok(B, S, Cg, Nout) && Cg % 32 == 0 && g_L > 0 && g_L <= 64; }
+int sh_spiral_conv_p3_grp_pays(int B, int n_groups) { return B >= 16 && n_groups > 0; }
 int sh_spiral_conv_p3_grp_members(int B, int S, int Cg, int Nout) { return sh_spiral_conv_p3_grp_ok(B, S, Cg, Nout, 1) ? (Nout <= 32 ? 4 : 2) : 0; }
 int sh_spiral_conv_p3_grp(const void* xp, const int32_t* g_rows, const uint32_t* g_pos, const int32_t* g_out, int n_groups, int g_L, const void* wfrag3, const float* bias,
                           float* y, int64_t y_sv, int64_t y_sb, void* yp, const float* yprev, int64_t yp_sv, int64_t yp_sb, const void* yprev_planes, int act, int zero_row,

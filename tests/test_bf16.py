@@ -449,9 +449,13 @@ def test_captured_bf16_step_survives_load_state_dict():
 def test_matched_l2_bf16_vs_fp32_training():
     """Config 3's acceptance: 'matched L2' on the trained metric.  30 training steps (batch 16, L1 + 1e-2 edge loss, Adam)
     from the same weights on the same batches, bf16 path vs fp32 path; held-out per-vertex L2 within 5 %.
-    (30 steps from a random init end in the steep part of the descent, L2 ~ 90 mm: across this round's kernel revisions -
-    which only re-associate fp32 sums - the gap read 0.9 % to 2.7 %; the bound leaves room for that, not for a wrong kernel:
-    one dropped spiral tap or a stale working copy of a weight moves the figure by tens of per cent.)"""
+    30 steps from a random init end in the steep part of the descent (L2 ~ 90 mm) where ONE evaluation of ONE trajectory moves by
+    several per cent when an fp32 sum is merely re-associated: across the kernel revisions of rounds 2-6 the single-point gap read
+    0.9 % ... 2.7 %, then 6.6 % when the bf16 backward-data pass went to ragged lists - whose gradients are as close to the fp32
+    step's as the dense form's (tools/exp/bf16_grad_err.py: summed relative error 0.1140 against 0.1140 at batch 16, 0.1101 /
+    0.1096 at 64).  So the figure compared is a mean: two seeds, evaluations after steps 24, 26, 28 and 30.  The bound leaves room
+    for re-association, not for a wrong kernel: one dropped spiral tap or a stale working copy of a weight moves the figure by tens
+    of per cent.  (The statement on a TRAINED model is tools/trained_l2.py: 2000 steps, 5 seeds, profiles/r06_trained_l2.json.)"""
     from semantichuman_amd import synthetic
     h = load_hierarchy(os.path.join(GOLDEN, "template6890.npz"))
     data = torch.from_numpy(synthetic.synth_batch(h.verts, 16 * 6, seed=100)).to(dev())
@@ -459,18 +463,23 @@ def test_matched_l2_bf16_vs_fp32_training():
     ft = sh.FaceTables(h.faces, h.sizes[0] + 1, dev())
     out = {}
     for dt in (torch.float32, torch.bfloat16):
-        torch.manual_seed(2)
-        m = sh.SpiralAutoencoder(FE, FD, 256, h.sizes, h.spiral_sizes, h.spirals, h.D, h.U, dev()).set_compute_dtype(dt)
-        opt = sh.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-5)
-        for i in range(30):
-            xb = data[(i % 6) * 16:(i % 6 + 1) * 16]
-            opt.zero_grad()
-            loss, _ = sh.recon_loss(m(xb)[0], xb, ft, 1e-2)
-            loss.backward()
-            opt.step()
-        with torch.no_grad():
-            out[dt] = float(sh.vertex_l2_mm(m(test)[0], test))
-    assert abs(out[torch.bfloat16] - out[torch.float32]) <= 5e-2 * out[torch.float32], out
+        vals = []
+        for seed in (2, 3):
+            torch.manual_seed(seed)
+            m = sh.SpiralAutoencoder(FE, FD, 256, h.sizes, h.spiral_sizes, h.spirals, h.D, h.U, dev()).set_compute_dtype(dt)
+            opt = sh.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-5)
+            for i in range(30):
+                xb = data[(i % 6) * 16:(i % 6 + 1) * 16]
+                opt.zero_grad()
+                loss, _ = sh.recon_loss(m(xb)[0], xb, ft, 1e-2)
+                loss.backward()
+                opt.step()
+                if i + 1 in (24, 26, 28, 30):
+                    with torch.no_grad():
+                        vals.append(float(sh.vertex_l2_mm(m(test)[0], test)))
+        out[dt] = (sum(vals) / len(vals), vals)
+    a, b = out[torch.float32][0], out[torch.bfloat16][0]
+    assert abs(b - a) <= 5e-2 * a, out
 
 
 @pytest.mark.parametrize("name,B", [("small_ae.npz", 1), ("small_ae.npz", 5), ("small_ae.npz", 32), ("small_ae.npz", 96),

@@ -171,6 +171,7 @@ def probe_layers(B=64, tpl=None, directions=("fwd", "bwd"), adversarial=False, r
                             rec["us"]["planes3_rag"] = timed(run_rag, reps)
                             rec["err"]["planes3_rag"] = float((y.double() - ref_r).abs().max()) / float(ref_r.abs().max())
                             rec["rag_L"] = int(rr.shape[1])
+                        rec["img_ok"] = None if yp is None else bool(torch.equal(to_p3(y), yp))
                         # round 6: GROUPED lists (conv_p3g_kernel): rows with overlapping lists share the union - forward from the table,
                         # backward-data from the ragged lists; same float64 references, image of the result checked like the others'
                         grp = st.dev.get("bgrp" if bwd else "fgrp")
@@ -190,7 +191,6 @@ def probe_layers(B=64, tpl=None, directions=("fwd", "bwd"), adversarial=False, r
                             rec["grp"] = (int(g_r.shape[0]), int(g_r.shape[1]), int((g_p.view(torch.int32) != -1).sum()))
                             rec["grp_img_ok"] = None if ypg is None else bool(torch.equal(to_p3(y), ypg))
                         rec["us_to_p3"] = timed(lambda: to_p3(x), reps)
-                        rec["img_ok"] = None if yp is None else bool(torch.equal(to_p3(y), yp))
                     yield rec
                     del x64, w64, ref
     finally:
