@@ -108,6 +108,12 @@ __device__ __forceinline__ bool p3_ring_steps(int ks, int nks, F&& f) {
 #ifndef P3_WAVES_PER_EU
 #define P3_WAVES_PER_EU 4
 #endif
+// Diagnostic builds only (tools/exp/r06_p3_ablate.sh; never the shipped library): what of a k-step is left in conv_p3_kernel -
+// 1: no gathered loads (operands from registers), 2: the loads alone (no weight reads, no MFMAs), 3: loads + weight-fragment reads from
+// LDS, no MFMAs, 4: loads + MFMAs with weight fragments from registers (no LDS reads).  Results are garbage; times tell what bounds it.
+#ifndef P3_ABLATE
+#define P3_ABLATE 0
+#endif
 template <int NT, int RT, bool C16, bool BWD, int NP, bool F32R = false>      // F32R: rows >= n_img are read as fp32 and split here
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(P3_WAVES_PER_EU, 8))) void conv_p3_kernel(const P3Params p) {
     constexpr int D = p3_depth(NT, RT);
@@ -178,9 +184,13 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(P3_WAVES_P
                     const char* src = f32row ? reinterpret_cast<const char*>(p.xf + (long)row * p.xf_sv + (long)(bs * 16 + r16) * p.xf_sb + lc * 32 + kq * 8)
                                              : xl + (F32R ? (long)row * p.x_vb : (long)((unsigned long)(unsigned)row << 4)) + (long)lc * 3072;
                     const int o1 = f32row ? 16 : PB, o2 = f32row ? 0 : 2 * PB;
+                    if constexpr (P3_ABLATE == 1) {
+                        a[m][0] = a[m][1] = a[m][2] = (u32x4){(unsigned)row, (unsigned)lane, (unsigned)lc, 0x3f803f80u};
+                    } else {
                     a[m][0] = *reinterpret_cast<const u32x4*>(src);
                     a[m][1] = *reinterpret_cast<const u32x4*>(src + o1);
                     a[m][2] = *reinterpret_cast<const u32x4*>(src + o2);
+                    }
                 }
                 if (++lc >= p.ncg) { lc = 0; ++ls; }
             } else {
@@ -253,10 +263,25 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(P3_WAVES_P
                     }
                 }
             }
+            if constexpr (P3_ABLATE == 2) {
+#pragma unroll
+                for (int m = 0; m < RT; ++m) acc[m][0][0] += __builtin_bit_cast(float, a[m][0][0] ^ a[m][1][1] ^ a[m][2][2]);
+                return;
+            }
             const u32x4* wk = Wl + ((long)ks * NT) * 192 + lane;
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-                const u32x4 r0 = wk[n * 192], r1 = wk[n * 192 + 64], r2 = wk[n * 192 + 128];
+                u32x4 r0, r1, r2;
+                if constexpr (P3_ABLATE == 4) {
+                    r0 = (u32x4){(unsigned)lane, 0x3f803f80u, (unsigned)n, 1u}; r1 = r0; r2 = r0;
+                } else {
+                    r0 = wk[n * 192]; r1 = wk[n * 192 + 64]; r2 = wk[n * 192 + 128];
+                }
+                if constexpr (P3_ABLATE == 3) {
+#pragma unroll
+                    for (int m = 0; m < RT; ++m) acc[m][n][0] += __builtin_bit_cast(float, r0[0] ^ r1[1] ^ r2[2] ^ a[m][0][0] ^ a[m][1][1] ^ a[m][2][2]);
+                    continue;
+                }
                 const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&r0), wm = *reinterpret_cast<const bf16x8*>(&r1),
                              wl = *reinterpret_cast<const bf16x8*>(&r2);
 #pragma unroll

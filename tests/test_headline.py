@@ -119,7 +119,7 @@ def test_full_training_step_vs_oracle(case, form, record_property):
             # (where the launch has enough groups to fill the chip: sh_spiral_conv_p3_grp_pays)
             n_fg = sum(1 for stack in (m._enc_stack, m._dec_stack) for st in stack.steps if st.kind == "conv" and getattr(st, "fgrp", None) is not None
                        and lib.sh_spiral_conv_p3_grp_pays(B, int(st.fgrp[0].shape[0])))
-            assert n_fg >= 2 and sum(1 for n in names if n.startswith("conv_p3g_kernel") and ", false," in n) == n_fg, (n_fg, sorted(set(names)))
+            assert (n_fg >= 2 or B < 64) and sum(1 for n in names if n.startswith("conv_p3g_kernel") and ", false," in n) == n_fg, (n_fg, sorted(set(names)))
             n_wp3 = sum(1 for n in names if n.startswith("wgrad_p3_kernel"))
             assert n_wp3 == 6, (n_wp3, sorted(set(names)))
             assert sum(1 for n in names if n.startswith(("wgrad_stream", "wgrad_split3"))) == 2, sorted(set(names))
