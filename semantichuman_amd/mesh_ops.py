@@ -316,24 +316,6 @@ _GROUP_CACHE: dict = {}
 
 
 def _group_lists(rows, pos, members, max_len):
-    """Two passes: group under the kernel's cap, then once more under a cap of 1.15 x the mean union (never below the longest single
-    list).  A launch at training batch sizes has about one group per resident wave, so it takes as long as its LONGEST group: the few
-    unions far above the mean (33 entries against a mean of 23 at 3446 rows x 11) are split again - a few per cent more entries, the
-    longest item a quarter shorter."""
-    g = _group_once(rows, pos, members, max_len)
-    if g is None:
-        return None
-    n_ent = (g[1] != 0xFFFFFFFF).sum(axis=1)
-    longest_single = int((pos >= 0).sum(axis=1).max())
-    cap = max(longest_single, int(np.ceil(1.15 * float(n_ent.mean()))))
-    if cap < int(n_ent.max()):
-        g2 = _group_once(rows, pos, members, cap)
-        if g2 is not None:
-            return g2
-    return g
-
-
-def _group_once(rows, pos, members, max_len):
     n, L = rows.shape
     valid = pos >= 0
     if n == 0 or int(valid.sum(axis=1).max()) > max_len or (pos.max() if pos.size else 0) >= 255:
