@@ -39,9 +39,15 @@ timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_f32.json 2>$O/bench
 timeout 600 python bench.py --steps 20 --warmup 5 --dtype bf16 > $O/bench_bf16.json 2>$O/bench_bf16.err
 timeout 600 python bench.py --steps 20 --warmup 5 --f32-mma exact --no-secondary > $O/bench_f32_exact.json 2>$O/bench_f32_exact.err
 SH_P3_WGRAD=0 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-roofline > $O/bench_f32_exact_wgrad.json 2>/dev/null
+# the same box with round 5's launches (exact weight gradients with their riders, dense transposed tables, one-row lists, every fp32 row written) ...
+SH_P3_WGRAD=0 SH_P3_RAGGED=0 SH_P3_GROUPED=0 SH_P3_DROP_FP32=0 SH_P3_YPREV_IMG=0 timeout 600 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-secondary --no-roofline > $O/bench_f32_round5_launches.json 2>/dev/null
+# ... and this round's, measured the same way (100 steps); bf16 with the dense backward-data tables next to the ragged default
+timeout 600 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-secondary --no-roofline > $O/bench_f32_100steps.json 2>/dev/null
+SH_BF16_RAGGED=0 timeout 600 python bench.py --steps 100 --warmup 10 --dtype bf16 --no-cpu-baseline --no-secondary --no-roofline > $O/bench_bf16_dense_tables.json 2>/dev/null
+timeout 600 python bench.py --steps 100 --warmup 10 --dtype bf16 --no-cpu-baseline --no-secondary --no-roofline > $O/bench_bf16_100steps.json 2>/dev/null
 SH_BENCH_FORCE_REDUCER=1 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-roofline > $O/bench_reducer_graph_f32.json 2>$O/bench_reducer_graph_f32.err
 SH_BENCH_FORCE_REDUCER=1 timeout 600 python bench.py --steps 20 --warmup 5 --dtype bf16 --no-cpu-baseline --no-secondary --no-roofline > $O/bench_reducer_graph_bf16_sharded.json 2>$O/bench_reducer_graph_bf16_sharded.err
-for f in bench_f32 bench_bf16 bench_f32_exact bench_f32_exact_wgrad bench_reducer_graph_f32 bench_reducer_graph_bf16_sharded; do grep "^{" $O/$f.json | tail -1 > $P/r06_$f.json; done
+for f in bench_f32 bench_bf16 bench_f32_exact bench_f32_exact_wgrad bench_f32_round5_launches bench_f32_100steps bench_bf16_dense_tables bench_bf16_100steps bench_reducer_graph_f32 bench_reducer_graph_bf16_sharded; do grep "^{" $O/$f.json | tail -1 > $P/r06_$f.json; done
 # layer reports
 SH_F32_MMA=exact timeout 300 python tools/layer_report.py 64 > $P/r06_layer_report_f32_exact.txt 2>/dev/null
 SH_F32_MMA=planes3 timeout 300 python tools/layer_report.py 64 > $P/r06_layer_report_f32_planes3.txt 2>/dev/null
