@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 P=profiles
 timeout 2400 python -m pytest tests -q -m gpu -rs > $O/tests_all.txt 2>&1
 grep -n "passed\|failed\|FAILED" $O/tests_all.txt | tail -6
-(grep -E "passed|failed" $O/tests_all.txt | tail -2; grep -E "^SKIPPED" $O/tests_all.txt | sed 's/SKIPPED \[[0-9]*\] //' | sort | uniq -c | sort -rn | head -12) > $P/r06_gpu_tests.txt
+(grep -E "^=* ?[0-9]+ (passed|failed)" $O/tests_all.txt | tail -2; grep -E "^SKIPPED" $O/tests_all.txt | sed 's/SKIPPED \[[0-9]*\] //' | sort | uniq -c | sort -rn | head -12) > $P/r06_gpu_tests.txt
 timeout 900 python -m pytest tests/test_headline.py tests/test_p3.py -q -m gpu -s -k "full_training or latent_fc or replayed" 2>&1 | grep -h "^FC\|template\|passed\|failed" > $P/r06_headline_and_fc_gate.txt
 pmc() {  # tag, env assignment or "-", command...
   tag=$1; envs=$2; shift 2
