@@ -731,7 +731,7 @@ SH_API int sh_spiral_conv_bwd_data_p3_rag(const void* dprep, const int32_t* rag_
  * pre-activation gradient, wfrag3 = transposed fragments, the derivative of activation `act` at yprev / yprev_planes - the fp32
  * tensor or the image of the layer input - or neither; Cg = the layer's Cout, Nout = its Cin, R = its input rows).  y and / or yp
  * (the image of the result) are written.  .._grp_ok: resident three-plane weight with at most four channel tiles per workgroup,
- * Cg % 32 == 0, lists of at most 64 entries; .._grp_members: how many members per group the kernel of this shape takes (4 or 2;
+ * Cg a multiple of 32, or 16 with at most two channel tiles (a k-step then spans two list entries), lists of at most 64 entries; .._grp_members: how many members per group the kernel of this shape takes (4 or 2;
  * 0 = shape not taken) - g_out always has four slots per group. */
 SH_API int sh_spiral_conv_p3_grp_ok(int B, int S, int Cg, int Nout, int g_L);
 SH_API int sh_spiral_conv_p3_grp_members(int B, int S, int Cg, int Nout);

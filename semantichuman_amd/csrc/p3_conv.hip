@@ -516,9 +516,15 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(P3_WAVES_P
 // reads are those of the one-vertex kernels; the gathered bytes fall by the overlap (measured on the 6890-vertex template: lists
 // of 10-11 per row -> unions of ~21-25 per four rows).  Forward (bias, activation) and backward-data over ragged sources (activation
 // derivative from the image or the fp32 tensor of the producing layer) share the kernel.
-template <int NT, int G, bool BWD, int NP>
+// C16: the gathered tensor has 16 channels (image fragments of 1536 bytes: two 8-channel pieces per batch entry and plane) and a k-step
+// spans TWO list entries - lanes kq < 2 hold the first entry's row, lanes kq >= 2 the second's.  A member reads the two entries at two
+// unrelated positions, so its weight operand is put together per lane: lane (r, kq) takes piece r + 16 (2 (pos & 1) + (kq & 1)) of
+// weight fragment pos >> 1, pos = the position of its half's entry; a member that reads only one of the two entries multiplies the
+// other half of the operand as zeros.
+template <int NT, int G, bool BWD, int NP, bool C16 = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(P3_WAVES_PER_EU, 8))) void conv_p3g_kernel(const P3Params p) {
     constexpr int D = p3_depth(NT * G, 1) < 3 ? 3 : p3_depth(NT * G, 1);
+    constexpr int PB = C16 ? 512 : 1024;                   // bytes between the planes of a gathered fragment
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const u32x4* Wl = reinterpret_cast<const u32x4*>(smem);       // [nks][NT][3][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
@@ -560,19 +566,25 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(P3_WAVES_P
     for (; t < t_end; t += stride) {
         load_list(t + stride, tvn, tpn);
         const int bs = t / p.n_vg, grp = t - bs * p.n_vg;
-        const char* xl = p.xp + (long)bs * p.x_bgb + lane * 16;
+        const char* xl = p.xp + (long)bs * p.x_bgb + (C16 ? ((kq & 1) * 16 + r16) * 16 : lane * 16);
         const int L = __builtin_popcountll(__builtin_amdgcn_ballot_w64(tp != 0xFFFFFFFFu));      // entries of this group (uniform)
-        const int nks = L * p.ncg;
+        const int nks = C16 ? (L + 1) >> 1 : L * p.ncg;
         int lj2 = 0, lc = 0;                               // running load position: list entry, channel group (uniform)
         u32x4 ring[D][3];
         auto issue = [&](u32x4 (&a)[3]) {
             const int j = lj2 < L ? lj2 : (L > 0 ? L - 1 : 0);      // past the end: the last entry again (never multiplied)
-            const int row = __builtin_amdgcn_readlane(tv, j);
-            const char* src = xl + (long)((unsigned long)(unsigned)row << 4) + (long)lc * 3072;
+            int row = __builtin_amdgcn_readlane(tv, j);
+            if constexpr (C16) {
+                const int j1 = lj2 + 1 < L ? lj2 + 1 : j;
+                const int row1 = __builtin_amdgcn_readlane(tv, j1);
+                row = (kq & 2) ? row1 : row;
+            }
+            const char* src = xl + (long)((unsigned long)(unsigned)row << 4) + (C16 ? 0L : (long)lc * 3072);
             a[0] = *reinterpret_cast<const u32x4*>(src);
-            a[1] = *reinterpret_cast<const u32x4*>(src + 1024);
-            a[2] = *reinterpret_cast<const u32x4*>(src + 2048);
-            if (++lc >= p.ncg) { lc = 0; ++lj2; }
+            a[1] = *reinterpret_cast<const u32x4*>(src + PB);
+            a[2] = *reinterpret_cast<const u32x4*>(src + 2 * PB);
+            if constexpr (C16) lj2 += 2;
+            else if (++lc >= p.ncg) { lc = 0; ++lj2; }
         };
         f32x4 acc[G][NT];
 #pragma unroll
@@ -582,15 +594,35 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(P3_WAVES_P
         int cj = 0, cc = 0;                                // entry / channel group of the k-step being multiplied (uniform)
         auto compute = [&](u32x4 (&a)[3]) {
             const unsigned pk = (unsigned)__builtin_amdgcn_readlane((int)tp, cj);
+            unsigned pk1 = 0xFFFFFFFFu;                    // C16: the positions of the k-step's second entry
             const int ccw = cc;
-            if (++cc >= p.ncg) { cc = 0; ++cj; }
-            const bf16x8 xh = *reinterpret_cast<const bf16x8*>(&a[0]), xm = *reinterpret_cast<const bf16x8*>(&a[1]),
-                         xl2 = *reinterpret_cast<const bf16x8*>(&a[2]);
+            if constexpr (C16) {
+                if (cj + 1 < L) pk1 = (unsigned)__builtin_amdgcn_readlane((int)tp, cj + 1);
+                cj += 2;
+            } else if (++cc >= p.ncg) { cc = 0; ++cj; }
+            bf16x8 xh = *reinterpret_cast<const bf16x8*>(&a[0]), xm = *reinterpret_cast<const bf16x8*>(&a[1]),
+                   xl2 = *reinterpret_cast<const bf16x8*>(&a[2]);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const int s = (int)((pk >> (8 * g)) & 0xFFu);
-                if (s == 0xFF) continue;                   // (uniform) this member does not read the row
-                const u32x4* wk = Wl + ((long)(s * p.ncg + ccw) * NT) * 192 + lane;
+                const u32x4* wk;
+                if constexpr (C16) {
+                    const int s1 = (int)((pk1 >> (8 * g)) & 0xFFu);
+                    if (s == 0xFF && s1 == 0xFF) continue;             // (uniform) this member reads neither entry
+                    const int q = (kq & 2) ? (s1 == 0xFF ? 0 : s1) : (s == 0xFF ? 0 : s);      // this lane's half: its entry's position
+                    wk = Wl + ((long)(q >> 1) * NT) * 192 + (r16 + 16 * (2 * (q & 1) + (kq & 1)));
+                    if (s == 0xFF || s1 == 0xFF) {                     // (uniform) one entry only: the other half of the operand is zero
+                        const bool dead = (kq & 2) ? s1 == 0xFF : s == 0xFF;
+                        const u32x4 z = {0u, 0u, 0u, 0u};
+                        const u32x4 h4 = dead ? z : a[0], m4 = dead ? z : a[1], l4 = dead ? z : a[2];
+                        xh = *reinterpret_cast<const bf16x8*>(&h4); xm = *reinterpret_cast<const bf16x8*>(&m4); xl2 = *reinterpret_cast<const bf16x8*>(&l4);
+                    } else {
+                        xh = *reinterpret_cast<const bf16x8*>(&a[0]); xm = *reinterpret_cast<const bf16x8*>(&a[1]); xl2 = *reinterpret_cast<const bf16x8*>(&a[2]);
+                    }
+                } else {
+                    if (s == 0xFF) continue;               // (uniform) this member does not read the row
+                    wk = Wl + ((long)(s * p.ncg + ccw) * NT) * 192 + lane;
+                }
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
                     const u32x4 r0 = wk[n * 192], r1 = wk[n * 192 + 64], r2 = wk[n * 192 + 128];
@@ -1066,9 +1098,9 @@ int launch_p3r(P3Params& p, hipStream_t st) {
     return SH_OK;
 }
 
-template <int NT, int G, bool BWD, int NP>
+template <int NT, int G, bool BWD, int NP, bool C16 = false>
 int launch_p3g(P3Params& p, hipStream_t st) {
-    auto kern = conv_p3g_kernel<NT, G, BWD, NP>;
+    auto kern = conv_p3g_kernel<NT, G, BWD, NP, C16>;
     const size_t smem = (size_t)p.nks * NT * 3072;
     static size_t attr_set = 0;
     if (smem > 65536 && smem > attr_set) {
@@ -1094,8 +1126,8 @@ int launch_p3g(P3Params& p, hipStream_t st) {
     if (groups < 8) groups = 8;
     groups = (groups + 7) / 8 * 8;
     const int grid = (int)groups * p.nsplit;
-    ShProfScope ps(st, "conv_p3g_kernel<%d, %d, %s, %d>|R=%d B=%d K=%d N=%d grid=%dx%d groups=%d L=%d f32=%d", NT, G, BWD ? "true" : "false", NP,
-                   p.R, p.B, p.S * p.Cg, p.Nout, grid, nw * 64, p.n_grp, p.g_L, p.y ? 1 : 0);
+    ShProfScope ps(st, "conv_p3g_kernel<%d, %d, %s, %d, %s>|R=%d B=%d K=%d N=%d grid=%dx%d groups=%d L=%d f32=%d", NT, G, BWD ? "true" : "false", NP,
+                   C16 ? "true" : "false", p.R, p.B, p.S * p.Cg, p.Nout, grid, nw * 64, p.n_grp, p.g_L, p.y ? 1 : 0);
     SH_LAUNCH_PS(ps, kern, dim3(grid), dim3(nw * 64), smem, st, p);
     SH_CHECK_LAUNCH("conv_p3g");
     g_p3_launches.fetch_add(1, std::memory_order_relaxed);
@@ -1312,7 +1344,9 @@ int sh_spiral_conv_bwd_data_p3_rag(const void* dprep, const int32_t* rag_rows, c
 }
 
 int sh_spiral_conv_p3_grp_ok(int B, int S, int Cg, int Nout, int g_L) {
-    return p3_shape_ok(B, S, Cg, Nout) && p3_resident_ok(S, Cg, Nout) && p3_geom(S, Cg, Nout).nt <= 4 && Cg % 32 == 0 && S < 255 && g_L > 0 && g_L <= 64;
+    static const int c16_on = sh_env_int("SH_P3_GRP_C16", 1, 0, 1);
+    if (!(Cg % 32 == 0 || (Cg == 16 && c16_on && p3_geom(S, Cg, Nout).nt <= 2))) return 0;
+    return p3_shape_ok(B, S, Cg, Nout) && p3_resident_ok(S, Cg, Nout) && p3_geom(S, Cg, Nout).nt <= 4 && S < 255 && g_L > 0 && g_L <= 64;
 }
 
 // members per group the kernel of this shape is built for (the host groups accordingly): four while their accumulators leave room
@@ -1339,7 +1373,7 @@ int sh_spiral_conv_p3_grp(const void* xp, const int32_t* g_rows, const uint32_t*
     SH_REQUIRE(act >= SH_ACT_IDENTITY && act <= SH_ACT_TANH, SH_ERR_INVALID_ARG, "sh_spiral_conv_p3_grp: unknown activation");
     SH_REQUIRE(sh_spiral_conv_p3_grp_ok(B, S, Cg, Nout, g_L), SH_ERR_UNSUPPORTED,
                "sh_spiral_conv_p3_grp: B=%d S=%d gathered channels=%d output channels=%d lists of %d is not taken (resident three-plane weight, "
-               "gathered channels %% 32 == 0, lists of at most 64 rows)", B, S, Cg, Nout, g_L);
+               "gathered channels 16 or %% 32 == 0, lists of at most 64 rows)", B, S, Cg, Nout, g_L);
     SH_REQUIRE(backward || !(yprev || yprev_planes), SH_ERR_INVALID_ARG, "sh_spiral_conv_p3_grp: yprev belongs to the backward form");
     P3Params p{};
     p.xp = static_cast<const char*>(xp); p.wfrag = static_cast<const u32x4*>(wfrag3); p.bias = backward ? nullptr : bias;
@@ -1356,7 +1390,8 @@ int sh_spiral_conv_p3_grp(const void* xp, const int32_t* g_rows, const uint32_t*
     const P3Geom g = p3_geom(p.S, p.Cg, p.Nout);
     p.nks = g.nks; p.nt_tot = g.nt_tot; p.nsplit = g.nsplit; p.ncg = p.Cg / 32;
     const int nbg = B / 16;
-    p.x_bgb = (long)p.ncg * 3072; p.x_vb = p.x_bgb * nbg;
+    const bool c16 = Cg == 16;
+    p.x_bgb = c16 ? 1536 : (long)p.ncg * 3072; p.x_vb = p.x_bgb * nbg;
     if (p.yp) {
         SH_REQUIRE(p.Nout == 16 || p.Nout % 32 == 0, SH_ERR_UNSUPPORTED, "conv_p3g: a plane image has 16 or a multiple of 32 channels (%d)", p.Nout);
         p.yp_bgb = p.Nout == 16 ? 1536 : (long)(p.Nout / 32) * 3072; p.yp_vb = p.yp_bgb * nbg;
@@ -1371,6 +1406,11 @@ int sh_spiral_conv_p3_grp(const void* xp, const int32_t* g_rows, const uint32_t*
     // four members per group while their accumulators leave room for the load ring (<= 2 channel tiles), two beyond
 #define SH_P3G_CASE(N, GG) (backward ? (np == 9 ? launch_p3g<N, GG, true, 9>(p, st) : launch_p3g<N, GG, true, 6>(p, st)) \
                                      : (np == 9 ? launch_p3g<N, GG, false, 9>(p, st) : launch_p3g<N, GG, false, 6>(p, st)))
+#define SH_P3G_CASE16(N) (backward ? (np == 9 ? launch_p3g<N, 4, true, 9, true>(p, st) : launch_p3g<N, 4, true, 6, true>(p, st)) \
+                                   : (np == 9 ? launch_p3g<N, 4, false, 9, true>(p, st) : launch_p3g<N, 4, false, 6, true>(p, st)))
+    if (c16 && nt == 1) return SH_P3G_CASE16(1);
+    if (c16 && nt == 2) return SH_P3G_CASE16(2);
+#undef SH_P3G_CASE16
     if (nt == 1) return SH_P3G_CASE(1, 4);
     if (nt == 2) return SH_P3G_CASE(2, 4);
     if (nt == 4) return SH_P3G_CASE(4, 2);

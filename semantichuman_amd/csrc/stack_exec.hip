@@ -284,7 +284,12 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
             // backward-data over ragged source lists (round 6): every source an image row, no pre-summed rows - neither the launches
             // that fill them nor the rider in the weight gradient (SH_P3_RAGGED=0: the dense table with its pre-sums)
             static const int rag_on = sh_env_int("SH_P3_RAGGED", 1, 0, 1);
-            const bool rag = p3 && rag_on && want_in && s.rag_rows && s.rag_pos && sh_spiral_conv_p3_rag_ok(B, s.S, s.cout, s.cin, s.rag_L);
+            static const int grp_on = sh_env_int("SH_P3_GROUPED", 1, 0, 1);
+            // ... as GROUPS of input rows sharing one list where the launch has groups enough (also the layers that gather 16 channels,
+            // which the one-row list kernel does not take)
+            const bool grp_b = p3 && rag_on && grp_on && want_in && s.bg_rows && s.bg_pos && s.bg_out && s.bg_n > 0 &&
+                               sh_spiral_conv_p3_grp_ok(B, s.S, s.cout, s.cin, s.bg_L) && sh_spiral_conv_p3_grp_pays(B, s.bg_n);
+            const bool rag = grp_b || (p3 && rag_on && want_in && s.rag_rows && s.rag_pos && sh_spiral_conv_p3_rag_ok(B, s.S, s.cout, s.cin, s.rag_L));
             // the last pre-sum level of this layer rides in the weight-gradient launch (sh_spiral_conv_bwd_wgt_presum); an
             // earlier level (very long lists: two levels) runs first, on its own
             const bool ride = !thin && !rag && want_in && s.table_t && (s.n1 || s.n2);
@@ -382,9 +387,7 @@ int sh_stack_backward(int n_steps, const sh_stack_step* steps, const float* x, i
                         static const int yimg_on = sh_env_int("SH_P3_YPREV_IMG", 1, 0, 1);
                         const void* yimg = (yimg_on && yprev && in_planes && in_planes[i] && yl.sb == s.cin && yl.sv == (long)B * s.cin &&
                                             sh_p3_bytes(1, B, s.cin)) ? in_planes[i] : nullptr;
-                        static const int grp_on = sh_env_int("SH_P3_GROUPED", 1, 0, 1);
-                        if (rag && grp_on && s.bg_rows && s.bg_pos && s.bg_out && s.bg_n > 0 && sh_spiral_conv_p3_grp_ok(B, s.S, s.cout, s.cin, s.bg_L) &&
-                            sh_spiral_conv_p3_grp_pays(B, s.bg_n))
+                        if (grp_b)
                             rc = sh_spiral_conv_p3_grp(cur_img, s.bg_rows, s.bg_pos, s.bg_out, s.bg_n, s.bg_L, wfrag3_t[i], nullptr, gi_f, gl.sv, gl.sb,
                                                        img_out ? gi_img : nullptr, yprev, yl.sv, yl.sb, yimg, act_prev, zero_prev, 1, B, s.n_in, s.S, s.cout,
                                                        s.cin, stream);

@@ -80,7 +80,8 @@ def test_error_of_the_split_forms_against_float64(adversarial):
             assert r["grp_img_ok"] in (True, None), r["name"]
     assert not bad, bad
     assert sum(1 for r in rows if "planes3_rag" in r["err"]) == 4, [r["name"] for r in rows if "planes3_rag" in r["err"]]
-    assert sum(1 for r in rows if "planes3_grp" in r["err"]) == 8, [r["name"] for r in rows if "planes3_grp" in r["err"]]      # 4 forward, 4 backward
+    # 5 forward (enc2 gathers 16 channels), 5 backward (the level-0 layer's gradient has 16)
+    assert sum(1 for r in rows if "planes3_grp" in r["err"]) == 10, [r["name"] for r in rows if "planes3_grp" in r["err"]]
 
 
 def test_nine_products_are_not_needed():

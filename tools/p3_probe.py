@@ -152,9 +152,10 @@ def probe_layers(B=64, tpl=None, directions=("fwd", "bwd"), adversarial=False, r
                         rec["us"]["planes3"] = timed(run_p3, reps)
                         rec["err"]["planes3"] = float((y.double() - ref).abs().max()) / scale
                         # round 6: the same backward-data pass over ragged source lists (no dense table, no pre-summed rows)
-                        if bwd and getattr(st, "rag", None) is not None and lib.sh_spiral_conv_p3_rag_ok(B, S, Cg, Nout, int(st.rag[0].shape[1])):
+                        ref_r = None
+                        if bwd and getattr(st, "rag", None) is not None:
                             rr, rp = st.dev["rag_rows"], st.dev["rag_pos"]
-                            # reference of the ragged form = the dense one when the extra rows hold the pre-sums: build it from the lists
+                            # reference of the list forms = the dense one when the extra rows hold the pre-sums: build it from the lists
                             ref_r = torch.zeros((rows_out, B, Nout), dtype=torch.float64, device=dev)
                             for j in range(rr.shape[1]):
                                 ok_j = (rp[:, j] >= 0)
@@ -162,6 +163,7 @@ def probe_layers(B=64, tpl=None, directions=("fwd", "bwd"), adversarial=False, r
                                     sel = ok_j & (rp[:, j] == s_)
                                     if bool(sel.any()):
                                         ref_r[sel] += x64[rr[sel, j].long()] @ w64[:, s_, :]
+                        if ref_r is not None and lib.sh_spiral_conv_p3_rag_ok(B, S, Cg, Nout, int(st.rag[0].shape[1])):
                             y.zero_()
 
                             def run_rag():
@@ -175,7 +177,7 @@ def probe_layers(B=64, tpl=None, directions=("fwd", "bwd"), adversarial=False, r
                         # round 6: GROUPED lists (conv_p3g_kernel): rows with overlapping lists share the union - forward from the table,
                         # backward-data from the ragged lists; same float64 references, image of the result checked like the others'
                         grp = st.dev.get("bgrp" if bwd else "fgrp")
-                        if grp is not None and lib.sh_spiral_conv_p3_grp_ok(B, S, Cg, Nout, int(grp[0].shape[1])):
+                        if grp is not None and lib.sh_spiral_conv_p3_grp_ok(B, S, Cg, Nout, int(grp[0].shape[1])) and (not bwd or ref_r is not None):
                             g_r, g_p, g_o = grp
                             ref_g = ref_r if bwd else ref
                             y.zero_()
