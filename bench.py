@@ -775,7 +775,9 @@ def roofline_f32(recs, model, B, nprof, verts):
         elif "gbps_algorithmic" in k:
             base.update({"bound": "hbm", "achieved": k["gbps_algorithmic"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": k["gbps_algorithmic"] / PEAK_HBM_GBS,
-                         "note": "algorithmic bytes (outputs written once + distinct inputs read once, fp32) of its launches / their HIP-event time"})
+                         "note": "algorithmic bytes (outputs written once + distinct inputs read once, fp32) of its launches / their HIP-event time" +
+                                 ("; these launches write the 6-byte plane image of their rows (and the 4-byte fp32 row only where a later kernel still reads it), "
+                                  "which the fp32 count does not include: traffic / algorithmic ~ 2 is the data format, not re-reads" if "p3" in k["kernel"] else "")})
             if "tflops" in k:
                 base.update({"mfma_tflops": k["tflops"], "mfma_frac_of_f32_peak": k["tflops"] / PEAK_F32_MFMA_TFLOPS})
         else:
