@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 6: grouped lists after the balancing pass (unions capped at 1.15 x their mean): per-layer times standalone, in the step with the
+# round 6: grouped lists, the "enough items" rule against every layer grouped (written for a balancing pass of group_lists - unions capped at 1.15 x
+# their mean - that was measured and dropped: item 14 of the record; what it re-runs today is the comparison of the rule): per-layer times standalone, in the step with the
 # "enough items" rule and with every layer grouped, step time A/B
 O=gpurun_out/r06grp4; rm -rf $O; mkdir -p $O
 timeout 600 python tools/p3_probe.py 64 --both > $O/p3_probe.txt 2>&1; grep -E "grouped" $O/p3_probe.txt | awk '{print $1,$2,$3,$4,"p3",$11; for(i=1;i<=NF;i++) if($i=="grouped"||$i=="lists") printf "   %s ... %s %s\n", $i, $(NF-1), $NF}' | cut -c1-200
